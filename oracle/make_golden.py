@@ -1,0 +1,290 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference) on CPU.
+
+Runs only in the build container (the reference never travels).  Container-only shims,
+none of which touch arithmetic:
+  * `skimage` stub module (util/util.py:9 imports it at module top; not installed);
+  * `scale_factor` passed as an int subclass whose `/` floor-divides -- the reference is
+    Python-2 code (models/networks.py:127-129, :808-811 compute sigma = scale_factor / 2);
+  * `--which_model_netG fcgan` (README's `deconv` alias is rejected by define_G);
+  * noise tensors are injected (Tensor.normal_ is patched to pop from a numpy-seeded queue
+    for the latent shape) so the vectors do not depend on torch's RNG stream.
+
+Usage:  python oracle/make_golden.py            (writes tests/golden/)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+sys.path.insert(0, REF)
+
+import sgan_oracle as O  # noqa: E402  (only for the numpy-seeded init helpers / configs)
+
+for name in ("skimage", "skimage.measure"):
+    if name not in sys.modules:
+        sys.modules[name] = types.ModuleType(name)
+sys.modules["skimage"].measure = sys.modules["skimage.measure"]
+
+import models.networks as RN  # noqa: E402
+
+
+class Py2Int(int):
+    """int whose true-division floor-divides (Python-2 semantics the reference relies on)."""
+    def __truediv__(self, other):
+        return Py2Int(int(self) // int(other))
+
+    def __rmul__(self, other):
+        return Py2Int(int(other) * int(self))
+
+    def __mul__(self, other):
+        return Py2Int(int(self) * int(other))
+
+    def __add__(self, other):
+        return Py2Int(int(self) + int(other))
+
+    __radd__ = __add__
+
+
+def to_np(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
+
+
+def ref_define_D(input_nc, ndf, n_layers, scale_factor, use_sigmoid=True):
+    sf = Py2Int(scale_factor) if scale_factor > 1 else scale_factor
+    return RN.define_D(input_nc, ndf, "n_layers", n_layers_D=n_layers, norm="instance",
+                       use_sigmoid=use_sigmoid, scale_factor=sf, gpu_ids=[])
+
+
+def ref_define_G(input_nc, ngf, n_layers, noise_nc):
+    return RN.define_G(input_nc, 0, ngf, "fcgan", "instance", False, n_layers_G=n_layers,
+                       use_fcn=True, noise_nc=noise_nc, gpu_ids=[])
+
+
+def load_sd(net, sd):
+    net.load_state_dict({k: v.detach().clone() for k, v in sd.items()})
+
+
+# ---------------------------------------------------------------------------------------
+def golden_gauss():
+    arrs = {}
+    for s in (2, 4):
+        for nc in (2, 3):
+            d = ref_define_D(nc, 8, 3, s)
+            arrs[f"s{s}_nc{nc}"] = d.gauss_filter[0].weight.detach().numpy()
+            arrs[f"s{s}_nc{nc}_pad"] = np.asarray(d.gauss_filter[0].padding)
+    save("gauss.npz", **arrs)
+
+
+def golden_g_small():
+    ngf, nl, nz, out_nc, zs = 8, 5, 8, 2, 2
+    sd = O.init_fcgan_g(11, nz, out_nc, ngf, nl)
+    g = ref_define_G(out_nc, ngf, nl, nz)
+    load_sd(g, sd)
+    z = O.np_normal(101, (1, nz, zs, zs)).requires_grad_(True)
+    r = O.np_normal(102, (1, out_nc, zs * 64, zs * 64))
+    # raw conv outputs via hooks (ConvTranspose2d modules only)
+    taps = {}
+    convs = [m for m in g.model if m.__class__.__name__ == "ConvTranspose2d"]
+    for i, m in enumerate(convs):
+        m.register_forward_hook(lambda mod, inp, out, i=i: taps.__setitem__(f"conv{i}", out.detach().numpy().copy()))
+    y = g.forward(z)
+    loss = (y * r).sum()
+    loss.backward()
+    arrs = {"y": y.detach().numpy(), "dz": z.grad.numpy(), "loss": np.float64(loss.item())}
+    for k, p in g.named_parameters():
+        arrs["grad/" + k] = p.grad.numpy()
+    for k, v in g.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            arrs["buf/" + k] = v.numpy()
+    for k, v in taps.items():
+        if k in ("conv0", "conv5"):
+            arrs["tap/" + k] = v
+    save("fcgan_g_small.npz", **arrs)
+
+
+def golden_d_small():
+    ndf, nl, nc, hw = 8, 3, 2, 128
+    for s in (1, 2, 4):
+        sd = O.init_nlayer_d(20 + s, nc, ndf, nl, s)
+        d = ref_define_D(nc, ndf, nl, s)
+        load_sd(d, sd)
+        x = O.np_uniform(200 + s, (1, nc, hw, hw)).requires_grad_(True)
+        crit = RN.GANLoss(use_lsgan=False)
+        p = d.forward(x)
+        l_real = crit(p, True)
+        l_fake = crit(d.forward(x), False)
+        loss = l_real * 0.7 + l_fake * 0.3
+        loss.backward()
+        arrs = {"p": p.detach().numpy(), "l_real": np.float64(l_real.item()),
+                "l_fake": np.float64(l_fake.item()), "dx": x.grad.numpy()}
+        for k, prm in d.named_parameters():
+            if k.startswith("model."):
+                arrs["grad/" + k] = prm.grad.numpy()
+        save(f"nlayer_d_small_s{s}.npz", **arrs)
+    # n_layers=4 (cgan's second D), 3 input channels, lsgan head as well
+    sd = O.init_nlayer_d(29, 3, ndf, 4, 1)
+    d = ref_define_D(3, ndf, 4, 1, use_sigmoid=False)
+    load_sd(d, sd)
+    x = O.np_uniform(209, (1, 3, hw, hw)).requires_grad_(True)
+    crit = RN.GANLoss(use_lsgan=True)
+    p = d.forward(x)
+    loss = crit(p, True)
+    loss.backward()
+    arrs = {"p": p.detach().numpy(), "loss": np.float64(loss.item()), "dx": x.grad.numpy()}
+    for k, prm in d.named_parameters():
+        arrs["grad/" + k] = prm.grad.numpy()
+    save("nlayer_d_small_n4_lsgan.npz", **arrs)
+
+
+class NoiseInjector:
+    """Patch torch.Tensor.normal_ so latents of `shape` come from a numpy-seeded queue."""
+    def __init__(self, shape, seed0):
+        self.shape, self.seed, self.n = tuple(shape), seed0, 0
+        self._orig = torch.Tensor.normal_
+
+    def __enter__(self):
+        inj = self
+
+        def patched(t, mean=0.0, std=1.0, *a, **k):
+            if tuple(t.shape) == inj.shape and mean == 0 and std == 1:
+                t.copy_(O.np_normal(inj.seed + inj.n, inj.shape))
+                inj.n += 1
+                return t
+            return inj._orig(t, mean, std, *a, **k)
+        torch.Tensor.normal_ = patched
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.normal_ = self._orig
+
+
+def build_ref_fcgan(cfg: O.FCGANConfig, seed: int, tmpdir: str):
+    from options.train_options import TrainOptions
+    from models.fcgan_model import FCGANModel
+    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "fcgan", "--which_direction", "A",
+            "--dataset_mode", "single", "--fineSize", str(cfg.fineSize), "--batchSize", "1",
+            "--input_nc", str(cfg.input_nc), "--which_model_netG", "fcgan", "--n_layers_G", str(cfg.n_layers_G),
+            "--ngf", str(cfg.ngf), "--which_model_netD", "n_layers", "--n_layers_D", *map(str, cfg.n_layers_D),
+            "--ndf", str(cfg.ndf), "--scale_factor", *map(str, cfg.scale_factor),
+            "--lambda_D", *map(str, cfg.lambda_D), "--noise_nc", str(cfg.noise_nc), "--noiseSize", str(cfg.noiseSize),
+            "--norm", "instance", "--no_dropout", "--n_update_G", str(cfg.n_update_G), "--no_lsgan",
+            "--which_channel", "rg", "--gpu_ids", "-1", "--display_id", "0", "--checkpoints_dir", tmpdir,
+            "--pool_size", str(cfg.pool_size)]
+    old = sys.argv
+    sys.argv = argv
+    try:
+        opt = TrainOptions().parse()
+    finally:
+        sys.argv = old
+    opt.scale_factor = [Py2Int(s) if s > 1 else s for s in opt.scale_factor]
+    model = FCGANModel()
+    model.initialize(opt)
+    # numpy-seeded weights (same as FCGANOracle(seed))
+    load_sd(model.netG, O.init_fcgan_g(seed + 1, cfg.noise_nc, cfg.input_nc, cfg.ngf, cfg.n_layers_G))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D, cfg.scale_factor)):
+        load_sd(model.netD[i], O.init_nlayer_d(seed + 2 + i, cfg.input_nc, cfg.ndf, nl, sf))
+    return model
+
+
+def grad_sample_idx(n, k=512):
+    """Indices of the elementwise-checked sample of a flattened gradient (shared with tests)."""
+    return np.unique(np.linspace(0, n - 1, num=min(n, k)).astype(np.int64))
+
+
+def capture_grads(arrs, prefix, net):
+    for k, p in net.named_parameters():
+        if p.grad is None or not k.startswith("model."):
+            continue
+        gflat = p.grad.detach().reshape(-1)
+        arrs[f"{prefix}/summary/{k}"] = np.asarray(O.tensor_summary(gflat))
+        arrs[f"{prefix}/sample/{k}"] = gflat[torch.from_numpy(grad_sample_idx(gflat.numel()))].numpy()
+
+
+def golden_step(name, cfg: O.FCGANConfig, seed: int, nsteps: int, full_params: bool):
+    """Step 1 is driven through the reference model's own methods in optimize_parameters' order
+    (models/fcgan_model.py:178-193) so that pre-Adam quantities can be captured; steps 2.. call
+    optimize_parameters() itself."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        zshape = (1, cfg.noise_nc, cfg.noiseSize, cfg.noiseSize)
+        with NoiseInjector(zshape, 5000) as inj:
+            # fixed_noiseA/B draws in initialize() also pop from the queue (2 draws)
+            model = build_ref_fcgan(cfg, seed, tmp)
+            arrs = {"n_init_noise_draws": np.int64(inj.n)}
+            losses = []
+            for step in range(nsteps):
+                real3 = O.np_uniform(7000 + step, (1, 3, cfg.fineSize, cfg.fineSize))
+                model.set_input({"A": real3, "A_paths": ["synthetic"]})
+                if step > 0:
+                    model.optimize_parameters()
+                else:
+                    assert cfg.n_update_D == 1
+                    model.forward()
+                    fake1 = model.fake.detach()
+                    arrs["step1/fake_summary"] = np.asarray(O.tensor_summary(fake1))
+                    arrs["step1/fake_crop"] = fake1[:, :, :64, :64].numpy().copy()
+                    model.optimizer_D.zero_grad()
+                    model.backward_D()
+                    for i, d in enumerate(model.netD):
+                        capture_grads(arrs, f"step1/gradD_{i}", d)
+                    arrs["step1/loss_D"] = np.asarray([float(model.loss_D_real), float(model.loss_D_fake)])
+                    model.optimizer_D.step()
+                    for it in range(cfg.n_update_G):
+                        model.optimizer_G.zero_grad()
+                        model.backward_G()
+                        if it == 0:
+                            capture_grads(arrs, "step1/gradG", model.netG)
+                            arrs["step1/loss_G"] = np.float64(float(model.loss_G))
+                        model.optimizer_G.step()
+                        if cfg.n_update_G > 1:
+                            model.sample_noise()
+                losses.append([float(model.loss_G), float(model.loss_D_real), float(model.loss_D_fake)])
+            arrs["losses"] = np.asarray(losses, dtype=np.float64)
+            arrs["n_noise_draws"] = np.int64(inj.n)
+        nets = {"G": model.netG}
+        for i, d in enumerate(model.netD):
+            nets[f"D_{i}"] = d
+        for label, net in nets.items():
+            for k, v in net.state_dict().items():
+                if not v.is_floating_point():
+                    arrs[f"buf/{label}/{k}"] = v.numpy()
+                    continue
+                if full_params:
+                    arrs[f"param/{label}/{k}"] = v.numpy()
+                arrs[f"summary/{label}/{k}"] = np.asarray(O.tensor_summary(v))
+        fake = model.fake.detach()
+        arrs["fake_crop"] = fake[:, :, :64, :64].numpy() if not full_params else fake.numpy()
+        arrs["fake_summary"] = np.asarray(O.tensor_summary(fake))
+        save(name, **arrs)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    golden_gauss()
+    golden_g_small()
+    golden_d_small()
+    small = O.FCGANConfig(ngf=8, ndf=8, noiseSize=2, n_update_G=2)
+    golden_step("fcgan_step_small.npz", small, seed=0, nsteps=3, full_params=True)
+    full = O.FCGANConfig()  # README config: 512x512, ngf=ndf=32, n_update_G=2
+    golden_step("fcgan_step_full.npz", full, seed=0, nsteps=3, full_params=False)
+    full1 = O.FCGANConfig(n_update_G=1)
+    golden_step("fcgan_step_full_nug1.npz", full1, seed=0, nsteps=2, full_params=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,429 @@
+"""CPU oracle for the supervised-gan conv G/D training hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain-PyTorch fp32 *restatement* of the
+reference's algorithm for the path BASELINE.json names.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the
+product path (`supervised-gan_amd/`) never does and fails loudly without its HIP
+library.
+
+Parity status: PINNED.  `oracle/make_golden.py` imports the real reference from
+/root/reference in the build container, runs it on numpy-seeded weights/inputs and
+commits the results under tests/golden/; tests/test_oracle_golden.py checks every
+function here against those vectors.
+
+All arithmetic is fp32 on CPU, autograd supplies the backward exactly as it does in
+the reference (the reference has no hand-written backward either).
+
+Reference map (paths relative to /root/reference):
+  matlab_style_gauss2D / init_gauss_filters   models/networks.py:22-40
+  weights_init                                models/networks.py:13-19
+  FCGANGenerator                              models/networks.py:493-540
+  NLayerDiscriminator                         models/networks.py:798-847
+  define_D gaussian init (py2 int division)   models/networks.py:124-129
+  GANLoss                                     models/networks.py:152-185
+  WeightedL1Loss                              models/networks.py:205-214
+  FCGANModel step recipe                      models/fcgan_model.py:124-193
+  Adam hyper-parameters                       models/fcgan_model.py:98-109, options/train_options.py:16-17
+  ImagePool                                   util/image_pool.py:6-42
+  LR schedule                                 models/fcgan_model.py:228-236
+"""
+from __future__ import annotations
+
+import math
+import random
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+IN_EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------------
+# deterministic, platform-independent tensors (numpy legacy RandomState is stable)
+# ----------------------------------------------------------------------------------
+def np_normal(seed: int, shape, mean=0.0, std=1.0) -> torch.Tensor:
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy((rs.standard_normal(size=tuple(shape)) * std + mean).astype(np.float32))
+
+
+def np_uniform(seed: int, shape, lo=-1.0, hi=1.0) -> torch.Tensor:
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy(rs.uniform(lo, hi, size=tuple(shape)).astype(np.float32))
+
+
+# ----------------------------------------------------------------------------------
+# Gaussian pre-filter (models/networks.py:22-40)
+# ----------------------------------------------------------------------------------
+def gauss2d(kw: int, sigma: float) -> np.ndarray:
+    """fspecial('gaussian') restated: models/networks.py:22-33."""
+    m = (kw - 1.0) / 2.0
+    y, x = np.ogrid[-m:m + 1, -m:m + 1]
+    h = np.exp(-(x * x + y * y) / (2.0 * sigma * sigma))
+    h[h < np.finfo(h.dtype).eps * h.max()] = 0
+    s = h.sum()
+    if s != 0:
+        h /= s
+    return h
+
+
+def gauss_filter_weight(nc: int, scale_factor: int) -> torch.Tensor:
+    """Dense block-diagonal [nc,nc,k,k] weight; sigma = scale_factor // 2 (the
+    reference is Python-2 code: models/networks.py:127-129, :808-811)."""
+    sigma = scale_factor // 2
+    kw = 4 * sigma + 1
+    w = np.zeros((nc, nc, kw, kw))
+    g = gauss2d(kw, sigma)
+    for i in range(nc):
+        w[i, i] = g
+    return torch.from_numpy(w.astype(np.float32))
+
+
+# ----------------------------------------------------------------------------------
+# parameter construction with the reference's key names / shapes / init distributions
+# ----------------------------------------------------------------------------------
+def fcgan_g_channels(ngf: int, n_layers: int):
+    """Channel plan of FCGANGenerator (models/networks.py:499-530)."""
+    mults = [min(2 ** (n_layers - 1), 8)]
+    for n in range(1, n_layers):
+        mults.append(min(2 ** (n_layers - n - 1), 8))
+    return [ngf * m for m in mults]
+
+
+def init_fcgan_g(seed: int, noise_nc: int, out_nc: int, ngf: int = 32, n_layers: int = 5) -> "OrderedDict[str, torch.Tensor]":
+    """state_dict of FCGANGenerator(use_fcn=True) with numpy-seeded values drawn from the
+    reference's init distributions (weights_init: conv N(0,.02), BN gamma N(1,.02), beta 0;
+    conv biases U(+-1/sqrt(fan_in)) = torch default for ConvTranspose2d: fan_in = Cout*k*k)."""
+    ch = fcgan_g_channels(ngf, n_layers)
+    sd = OrderedDict()
+    s = seed * 1000
+    cin = noise_nc
+    idx = 0
+    for li, cout in enumerate(ch):
+        sd[f"model.{idx}.weight"] = np_normal(s, (cin, cout, 4, 4), 0.0, 0.02); s += 1
+        if li > 0:
+            bound = 1.0 / math.sqrt(cout * 16)
+            sd[f"model.{idx}.bias"] = np_uniform(s, (cout,), -bound, bound); s += 1
+        sd[f"model.{idx + 1}.weight"] = np_normal(s, (cout,), 1.0, 0.02); s += 1
+        sd[f"model.{idx + 1}.bias"] = torch.zeros(cout)
+        sd[f"model.{idx + 1}.running_mean"] = torch.zeros(cout)
+        sd[f"model.{idx + 1}.running_var"] = torch.ones(cout)
+        sd[f"model.{idx + 1}.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+        cin = cout
+        idx += 3
+    sd[f"model.{idx}.weight"] = np_normal(s, (cin, out_nc, 4, 4), 0.0, 0.02)
+    return sd
+
+
+def nlayer_d_plan(input_nc: int, ndf: int, n_layers: int):
+    """[(idx, cin, cout, stride, has_norm)] of NLayerDiscriminator.model convs
+    (models/networks.py:814-835); final logits conv last."""
+    plan = [(0, input_nc, ndf, 2, False)]
+    nf = 1
+    idx = 2
+    for n in range(1, n_layers):
+        nf_prev, nf = nf, min(2 ** n, 8)
+        plan.append((idx, ndf * nf_prev, ndf * nf, 2, True)); idx += 3
+    nf_prev, nf = nf, min(2 ** n_layers, 8)
+    plan.append((idx, ndf * nf_prev, ndf * nf, 1, True)); idx += 3
+    plan.append((idx, ndf * nf, 1, 1, False))
+    return plan
+
+
+def init_nlayer_d(seed: int, input_nc: int, ndf: int = 32, n_layers: int = 3, scale_factor: int = 1) -> "OrderedDict[str, torch.Tensor]":
+    sd = OrderedDict()
+    s = seed * 1000
+    if scale_factor > 1:
+        sd["gauss_filter.0.weight"] = gauss_filter_weight(input_nc, scale_factor)
+    for idx, cin, cout, _stride, _norm in nlayer_d_plan(input_nc, ndf, n_layers):
+        sd[f"model.{idx}.weight"] = np_normal(s, (cout, cin, 4, 4), 0.0, 0.02); s += 1
+        bound = 1.0 / math.sqrt(cin * 16)
+        sd[f"model.{idx}.bias"] = np_uniform(s, (cout,), -bound, bound); s += 1
+    return sd
+
+
+# ----------------------------------------------------------------------------------
+# network forwards (functional; autograd gives the backward)
+# ----------------------------------------------------------------------------------
+def fcgan_g_forward(sd, z, n_layers: int = 5, update_running: bool = True, tanh: bool = True,
+                    taps: dict | None = None):
+    """FCGANGenerator.forward (models/networks.py:535-540), BatchNorm always in train mode
+    (the reference never calls .eval()).  `taps` (optional dict) receives raw conv outputs."""
+    x = z
+    idx = 0
+    for li in range(n_layers):
+        x = F.conv_transpose2d(x, sd[f"model.{idx}.weight"], sd.get(f"model.{idx}.bias"), stride=2, padding=1)
+        if taps is not None:
+            taps[f"conv{li}"] = x
+        rm = sd[f"model.{idx + 1}.running_mean"] if update_running else None
+        rv = sd[f"model.{idx + 1}.running_var"] if update_running else None
+        x = F.batch_norm(x, rm, rv, sd[f"model.{idx + 1}.weight"], sd[f"model.{idx + 1}.bias"],
+                         training=True, momentum=BN_MOMENTUM, eps=BN_EPS)
+        if update_running and f"model.{idx + 1}.num_batches_tracked" in sd:
+            sd[f"model.{idx + 1}.num_batches_tracked"] += 1
+        x = F.relu(x)
+        idx += 3
+    x = F.conv_transpose2d(x, sd[f"model.{idx}.weight"], None, stride=2, padding=1)
+    if taps is not None:
+        taps[f"conv{n_layers}"] = x
+    return torch.tanh(x) if tanh else x
+
+
+def gauss_down(x, w, scale_factor: int):
+    """gauss_filter = Conv2d(k=4s+1, pad=2s, no bias) then AvgPool2d(kernel 1, stride s)
+    (models/networks.py:807-813)."""
+    sigma = scale_factor // 2
+    y = F.conv2d(x, w, None, stride=1, padding=2 * sigma)
+    return F.avg_pool2d(y, kernel_size=1, stride=scale_factor)
+
+
+def nlayer_d_forward(sd, x, n_layers: int = 3, scale_factor: int = 1, use_sigmoid: bool = True,
+                     taps: dict | None = None):
+    """NLayerDiscriminator.forward with InstanceNorm2d(affine=False) (models/networks.py:841-847)."""
+    if scale_factor > 1:
+        x = gauss_down(x, sd["gauss_filter.0.weight"], scale_factor)
+    input_nc = x.shape[1]
+    ndf = sd["model.0.weight"].shape[0]
+    for li, (idx, _cin, _cout, stride, has_norm) in enumerate(nlayer_d_plan(input_nc, ndf, n_layers)):
+        x = F.conv2d(x, sd[f"model.{idx}.weight"], sd[f"model.{idx}.bias"], stride=stride, padding=2)
+        if taps is not None:
+            taps[f"conv{li}"] = x
+        last = li == n_layers + 1
+        if has_norm:
+            x = F.instance_norm(x, eps=IN_EPS)
+        if not last:
+            x = F.leaky_relu(x, 0.2)
+    return torch.sigmoid(x) if use_sigmoid else x
+
+
+def gan_loss(pred, target_is_real: bool, use_lsgan: bool = False):
+    """GANLoss.__call__ (models/networks.py:183-185): BCELoss / MSELoss vs a constant map."""
+    t = torch.full_like(pred, 1.0 if target_is_real else 0.0)
+    return F.mse_loss(pred, t) if use_lsgan else F.binary_cross_entropy(pred, t)
+
+
+def weighted_l1(x, y, w=None):
+    """WeightedL1Loss (models/networks.py:209-214)."""
+    z = torch.abs(x - y)
+    if w is not None:
+        z = z * w
+    return z.mean()
+
+
+# ----------------------------------------------------------------------------------
+# Adam (torch.optim.Adam default form) restated with explicit tensor ops
+# ----------------------------------------------------------------------------------
+class Adam:
+    def __init__(self, params, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8):
+        self.params = list(params)
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        bc1 = 1.0 - self.b1 ** self.t
+        bc2 = 1.0 - self.b2 ** self.t
+        step_size = self.lr / bc1
+        for p, m, v in zip(self.params, self.m, self.v):
+            if p.grad is None:
+                continue
+            g = p.grad
+            m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+            denom = (v.sqrt() / math.sqrt(bc2)).add_(self.eps)
+            p.addcdiv_(m, denom, value=-step_size)
+
+
+# ----------------------------------------------------------------------------------
+# ImagePool (util/image_pool.py:6-33), python `random` driven like the reference
+# ----------------------------------------------------------------------------------
+class ImagePool:
+    def __init__(self, pool_size=50, reject=0.5):
+        self.pool_size, self.reject = pool_size, reject
+        self.num_imgs, self.images = 0, []
+
+    def query(self, images):
+        if self.pool_size == 0:
+            return images
+        out = []
+        for image in images.detach():
+            image = image.unsqueeze(0)
+            if self.num_imgs < self.pool_size:
+                self.num_imgs += 1
+                self.images.append(image)
+                out.append(image)
+            else:
+                p = random.uniform(0, 1)
+                if p > self.reject:
+                    rid = random.randint(0, self.pool_size - 1)
+                    tmp = self.images[rid].clone()
+                    self.images[rid] = image
+                    out.append(tmp)
+                else:
+                    out.append(image)
+        return torch.cat(out, 0)
+
+
+# ----------------------------------------------------------------------------------
+# the fcgan training step (models/fcgan_model.py:124-193)
+# ----------------------------------------------------------------------------------
+class FCGANConfig:
+    """README fcgan flags (README.md:33)."""
+    def __init__(self, input_nc=2, ngf=32, ndf=32, n_layers_G=5, n_layers_D=(3, 3, 3), scale_factor=(1, 2, 4),
+                 lambda_D=(0.5, 0.4, 0.1), noise_nc=8, noiseSize=8, n_update_D=1, n_update_G=2,
+                 lr=2e-4, beta1=0.5, pool_size=50, no_lsgan=True, no_logD_trick=False, batchSize=1):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+    @property
+    def fineSize(self):
+        return self.noiseSize * 2 ** (self.n_layers_G + 1)
+
+
+class FCGANOracle:
+    """FCGANModel restated (initialize :32-116, forward :124-128, backward_D :146-163,
+    backward_G :165-176, optimize_parameters :178-193)."""
+
+    def __init__(self, cfg: FCGANConfig, seed: int = 0):
+        self.cfg = cfg
+        self.G = init_fcgan_g(seed + 1, cfg.noise_nc, cfg.input_nc, cfg.ngf, cfg.n_layers_G)
+        self.D = [init_nlayer_d(seed + 2 + i, cfg.input_nc, cfg.ndf, nl, sf)
+                  for i, (nl, sf) in enumerate(zip(cfg.n_layers_D, cfg.scale_factor))]
+        for k, v in self.G.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+        for d in self.D:
+            for k, v in d.items():
+                if v.is_floating_point():
+                    v.requires_grad_(True)      # gauss_filter weights require grad in the reference too
+        g_params = [v for k, v in self.G.items() if v.requires_grad]
+        d_params = [v for d in self.D for k, v in d.items() if k.startswith("model.")]
+        self.opt_G = Adam(g_params, cfg.lr, cfg.beta1)
+        self.opt_D = Adam(d_params, cfg.lr, cfg.beta1)
+        self.pool = ImagePool(cfg.pool_size)
+        self.noise_iter = None  # set by caller: iterator yielding z tensors
+
+    def _z(self):
+        return next(self.noise_iter)
+
+    def forward(self):
+        self.noise = self._z()
+        self.fake = fcgan_g_forward(self.G, self.noise, self.cfg.n_layers_G)
+
+    def _d(self, i, x):
+        c = self.cfg
+        return nlayer_d_forward(self.D[i], x, c.n_layers_D[i], c.scale_factor[i], use_sigmoid=c.no_lsgan)
+
+    def backward_D(self):
+        c = self.cfg
+        fake = self.pool.query(self.fake)
+        self.loss_D_fake = sum(gan_loss(self._d(i, fake.detach()), False, not c.no_lsgan) for i in range(len(self.D)))
+        self.loss_D_real = sum(gan_loss(self._d(i, self.real), True, not c.no_lsgan) for i in range(len(self.D)))
+        self.loss_D = (self.loss_D_fake + self.loss_D_real) * 0.5
+        self.loss_D.backward()
+
+    def backward_G(self):
+        c = self.cfg
+        loss = 0
+        for i, lam in enumerate(c.lambda_D):
+            pred = self._d(i, self.fake)
+            if not c.no_logD_trick:
+                loss = loss + gan_loss(pred, True, not c.no_lsgan) * lam
+            else:
+                loss = loss - gan_loss(pred, False, not c.no_lsgan) * lam
+        self.loss_G = loss
+        self.loss_G.backward()
+
+    def _zero_all_D_grads(self):
+        for d in self.D:
+            for v in d.values():
+                v.grad = None
+
+    def optimize_parameters(self, real):
+        c = self.cfg
+        self.real = real
+        self.forward()
+        for _ in range(c.n_update_D):
+            self.opt_D.zero_grad()
+            self.backward_D()
+            self.opt_D.step()
+            if c.n_update_D > 1:
+                self.forward()
+        for _ in range(c.n_update_G):
+            self.opt_G.zero_grad()
+            self.backward_G()
+            self.opt_G.step()
+            if c.n_update_G > 1:
+                self.forward()
+
+    def step1_with_captures(self, real):
+        """First training step in optimize_parameters' order with the pre-Adam quantities captured
+        (same capture points as oracle/make_golden.py::golden_step)."""
+        c = self.cfg
+        assert c.n_update_D == 1
+        cap = {}
+        self.real = real
+        self.forward()
+        cap["fake"] = self.fake.detach().clone()
+        self.opt_D.zero_grad()
+        self.backward_D()
+        cap["gradD"] = [{k: v.grad.detach().clone() for k, v in d.items() if k.startswith("model.")} for d in self.D]
+        cap["loss_D"] = [float(self.loss_D_real.detach()), float(self.loss_D_fake.detach())]
+        self.opt_D.step()
+        for it in range(c.n_update_G):
+            self.opt_G.zero_grad()
+            self.backward_G()
+            if it == 0:
+                cap["gradG"] = {k: v.grad.detach().clone() for k, v in self.G.items() if v.grad is not None}
+                cap["loss_G"] = float(self.loss_G.detach())
+            self.opt_G.step()
+            if c.n_update_G > 1:
+                self.forward()
+        return cap
+
+    def losses(self):
+        return {"G_GAN": float(self.loss_G.detach()), "D_real": float(self.loss_D_real.detach()),
+                "D_fake": float(self.loss_D_fake.detach())}
+
+
+def norm_cancelled_keys_g(n_layers: int = 5):
+    """Keys of FCGANGenerator whose values are numerically UNDETERMINED in the reference itself:
+    conv biases that feed a BatchNorm (analytically-zero gradient => Adam turns rounding noise into
+    +-lr steps) and the running_mean of that BatchNorm (tracks the bias).  Two CPU runs of the
+    reference with different thread counts already disagree on these by ~lr per Adam step."""
+    keys = set()
+    for li in range(1, n_layers):
+        keys.add(f"model.{3 * li}.bias")
+        keys.add(f"model.{3 * li + 1}.running_mean")
+    return keys
+
+
+def norm_cancelled_keys_d(input_nc: int, ndf: int, n_layers: int):
+    return {f"model.{idx}.bias" for idx, _ci, _co, _s, has_norm in nlayer_d_plan(input_nc, ndf, n_layers) if has_norm}
+
+
+def grad_sample_idx(n: int, k: int = 512):
+    """Indices of the elementwise-checked sample of a flattened gradient (same as make_golden.py)."""
+    return np.unique(np.linspace(0, n - 1, num=min(n, k)).astype(np.int64))
+
+
+def tensor_summary(t: torch.Tensor):
+    t = t.detach().double()
+    return [float(t.mean()), float(t.abs().max()), float(t.norm())]
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """The parity statistic of SURVEY 8d: max|a-b| / (max|b| + 1e-12)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))

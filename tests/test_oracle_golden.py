@@ -1,0 +1,171 @@
+"""Pin the CPU oracle (oracle/sgan_oracle.py) against vectors produced by the real reference
+(oracle/make_golden.py).  CPU-only; no GPU, no /root/reference needed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sgan_oracle as O
+
+TOL = 1e-3   # north-star tolerance: max|a-b| / max|b|, fp32
+TIGHT = 2e-5  # what two fp32 CPU runs of the same math actually achieve
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _t(a):
+    return a.detach() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))
+
+
+def rel(a, b):
+    return O.rel_err(_t(a), _t(b))
+
+
+def test_gauss_filters(golden_dir):
+    g = load(golden_dir, "gauss.npz")
+    for s in (2, 4):
+        for nc in (2, 3):
+            w = O.gauss_filter_weight(nc, s).numpy()
+            assert w.shape == g[f"s{s}_nc{nc}"].shape
+            assert np.abs(w - g[f"s{s}_nc{nc}"]).max() < 1e-7
+            assert tuple(g[f"s{s}_nc{nc}_pad"]) == (2 * (s // 2),) * 2
+            assert w.shape[-1] == 4 * (s // 2) + 1
+
+
+def test_fcgan_g_small(golden_dir):
+    g = load(golden_dir, "fcgan_g_small.npz")
+    sd = O.init_fcgan_g(11, 8, 2, 8, 5)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    z = O.np_normal(101, (1, 8, 2, 2)).requires_grad_(True)
+    r = O.np_normal(102, (1, 2, 128, 128))
+    taps = {}
+    y = O.fcgan_g_forward(sd, z, 5, taps=taps)
+    (y * r).sum().backward()
+    assert rel(y, g["y"]) < TIGHT
+    assert rel(taps["conv0"], g["tap/conv0"]) < TIGHT
+    assert rel(taps["conv5"], g["tap/conv5"]) < TIGHT
+    assert rel(z.grad, g["dz"]) < TIGHT
+    for k in g.files:
+        if k.startswith("grad/"):
+            name = k[5:]
+            # conv biases in front of BatchNorm have analytically-zero gradient: compare on the
+            # scale of the weight gradient of the same layer instead of their own (noise) scale
+            if name.endswith(".bias") and name.replace(".bias", ".weight") in sd and sd[name.replace(".bias", ".weight")].dim() == 4:
+                scale = np.abs(g["grad/" + name.replace(".bias", ".weight")]).max()
+                assert np.abs(sd[name].grad.numpy() - g[k]).max() < TOL * scale
+            else:
+                assert rel(sd[name].grad, g[k]) < TIGHT * 10, name
+        if k.startswith("buf/"):
+            name = k[4:]
+            assert rel(sd[name].double(), g[k].astype(np.float64)) < TIGHT, name
+
+
+@pytest.mark.parametrize("s", [1, 2, 4])
+def test_nlayer_d_small(golden_dir, s):
+    g = load(golden_dir, f"nlayer_d_small_s{s}.npz")
+    sd = O.init_nlayer_d(20 + s, 2, 8, 3, s)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = O.np_uniform(200 + s, (1, 2, 128, 128)).requires_grad_(True)
+    p = O.nlayer_d_forward(sd, x, 3, s, True)
+    l_real = O.gan_loss(p, True)
+    l_fake = O.gan_loss(O.nlayer_d_forward(sd, x, 3, s, True), False)
+    (l_real * 0.7 + l_fake * 0.3).backward()
+    assert p.shape == g["p"].shape
+    assert rel(p, g["p"]) < TIGHT
+    assert abs(float(l_real.detach()) - float(g["l_real"])) < 1e-5
+    assert abs(float(l_fake.detach()) - float(g["l_fake"])) < 1e-5
+    assert rel(x.grad, g["dx"]) < TIGHT * 10
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith(".weight"):
+            assert rel(sd[k[5:]].grad, g[k]) < TIGHT * 10, k
+
+
+def test_nlayer_d_n4_lsgan(golden_dir):
+    g = load(golden_dir, "nlayer_d_small_n4_lsgan.npz")
+    sd = O.init_nlayer_d(29, 3, 8, 4, 1)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = O.np_uniform(209, (1, 3, 128, 128)).requires_grad_(True)
+    p = O.nlayer_d_forward(sd, x, 4, 1, False)
+    loss = O.gan_loss(p, True, use_lsgan=True)
+    loss.backward()
+    assert rel(p, g["p"]) < TIGHT
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    assert rel(x.grad, g["dx"]) < TIGHT * 10
+    assert rel(sd["model.0.weight"].grad, g["grad/model.0.weight"]) < TIGHT * 10
+
+
+def make_oracle(cfg, n_init_draws):
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    m = O.FCGANOracle(cfg, seed=0)
+    zshape = (1, cfg.noise_nc, cfg.noiseSize, cfg.noiseSize)
+
+    def zs():
+        i = n_init_draws
+        while True:
+            yield O.np_normal(5000 + i, zshape)
+            i += 1
+    m.noise_iter = zs()
+    return m
+
+
+def real_batch(cfg, step):
+    return O.np_uniform(7000 + step, (1, 3, cfg.fineSize, cfg.fineSize))[:, :2].contiguous()
+
+
+def check_grad(name, grad, g, prefix, scale_key=None, tol=TOL):
+    """grad vs golden summary + strided sample; error measured against max|grad| of the tensor
+    (or of `scale_key`'s tensor for analytically-zero gradients)."""
+    ref_sum = g[f"{prefix}/summary/{name}"]
+    ref_smp = g[f"{prefix}/sample/{name}"]
+    scale = g[f"{prefix}/summary/{scale_key}"][1] if scale_key else ref_sum[1]
+    flat = grad.detach().reshape(-1)
+    smp = flat[torch.from_numpy(O.grad_sample_idx(flat.numel()))].double().numpy()
+    assert np.abs(smp - ref_smp).max() <= tol * scale + 1e-12, (prefix, name, np.abs(smp - ref_smp).max(), scale)
+    if not scale_key:
+        s = O.tensor_summary(flat)
+        assert abs(s[1] - ref_sum[1]) <= tol * scale, (prefix, name, s, ref_sum)
+        assert abs(s[2] - ref_sum[2]) <= tol * ref_sum[2] + 1e-12, (prefix, name, s, ref_sum)
+
+
+def check_step1(cap, g, cfg, tol=TOL):
+    assert rel(cap["fake"][:, :, :64, :64], g["step1/fake_crop"]) < tol
+    fs = O.tensor_summary(cap["fake"])
+    assert abs(fs[2] - g["step1/fake_summary"][2]) <= tol * g["step1/fake_summary"][2]
+    assert np.abs(np.asarray(cap["loss_D"]) - g["step1/loss_D"]).max() < tol
+    assert abs(cap["loss_G"] - float(g["step1/loss_G"])) < tol
+    for i, gd in enumerate(cap["gradD"]):
+        undet = O.norm_cancelled_keys_d(cfg.input_nc, cfg.ndf, cfg.n_layers_D[i])
+        for k, v in gd.items():
+            check_grad(k, v, g, f"step1/gradD_{i}", k.replace(".bias", ".weight") if k in undet else None, tol)
+    undet = O.norm_cancelled_keys_g(cfg.n_layers_G)
+    for k, v in cap["gradG"].items():
+        check_grad(k, v, g, "step1/gradG", k.replace(".bias", ".weight") if k in undet else None, tol)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("fcgan_step_small.npz", dict(ngf=8, ndf=8, noiseSize=2, n_update_G=2)),
+    ("fcgan_step_full.npz", dict(n_update_G=2)),          # BASELINE configs[0]: README fcgan @512x512 on CPU
+    ("fcgan_step_full_nug1.npz", dict(n_update_G=1)),
+])
+def test_fcgan_step(golden_dir, name, kw):
+    """Step 1 (pre-Adam: fake, losses, every gradient) is the strict gate; the multi-step trajectory is
+    only compared through the losses because the reference's own trajectory is chaotic (Adam's first
+    steps are sign(g): a 1-thread and an 8-thread CPU run of the reference math already differ by 1e-2
+    in `fake` after one update -- see DESIGN.md 'What parity means')."""
+    g = load(golden_dir, name)
+    cfg = O.FCGANConfig(**kw)
+    m = make_oracle(cfg, int(g["n_init_noise_draws"]))
+    cap = m.step1_with_captures(real_batch(cfg, 0))
+    check_step1(cap, g, cfg, tol=1e-4)
+    losses = [list(m.losses().values())]
+    for step in range(1, g["losses"].shape[0]):
+        m.optimize_parameters(real_batch(cfg, step))
+        losses.append(list(m.losses().values()))
+    assert np.abs(np.asarray(losses) - g["losses"]).max() < 1e-3, (losses, g["losses"])

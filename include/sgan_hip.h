@@ -1,0 +1,186 @@
+/*
+ * sgan_hip.h -- C ABI of libsgan_hip.so: hand-written CDNA4 (gfx950) kernels for the conv
+ * generator / discriminator training hot path of phymhan/supervised-gan.
+ *
+ * The reference has no FFI: its hot path is the stock torch.nn modules built in
+ * models/networks.py.  Each entry point below replaces the ATen operator family that one of
+ * those modules resolves to; the citation names the reference line that instantiates it.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - tensors are NHWC, batch 1, fp32; the channel count `C` passed here is the STORED count,
+ *     a multiple of 4 (logical channels are zero-padded up: 1,2,3 -> 4); `*_ld` is the element
+ *     stride between pixels (>= C: lets a tensor be a channel slice of a wider concat buffer);
+ *   - conv weights ("master layout") are [kh*kw][Cout][Cin] with Cout,Cin the STORED counts, for
+ *     Conv2d and ConvTranspose2d alike (the Python side exposes them to state_dict() as strided
+ *     views with the reference's logical shapes [Cout,Cin,kh,kw] / [Cin,Cout,kh,kw]);
+ *   - per-channel statistics are double[2*C]: sum then sum-of-squares, accumulated with atomics
+ *     into a buffer the caller zeroed;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - no entry point allocates, frees or synchronises: safe inside hipGraph capture;
+ *   - return value: 0 = ok, <0 = error (see sgan_last_error()); nothing throws across the ABI.
+ */
+#ifndef SGAN_HIP_H
+#define SGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGAN_OK 0
+#define SGAN_ERR_INVALID (-1)
+#define SGAN_ERR_UNSUPPORTED (-2)
+#define SGAN_ERR_HIP (-3)
+
+/* activation codes */
+#define SGAN_ACT_NONE 0
+#define SGAN_ACT_RELU 1
+#define SGAN_ACT_LRELU 2
+#define SGAN_ACT_TANH 3
+
+/* conv kinds */
+#define SGAN_CONV 0  /* nn.Conv2d            */
+#define SGAN_CONVT 1 /* nn.ConvTranspose2d   */
+
+/* Per-channel normalisation + activation applied to a tensor as it is READ by a kernel
+ * ("normalise-on-load").  y = act( gamma * (x - mean) * rstd + beta ), mean/rstd derived in-kernel
+ * from `stats` (biased variance, eps inside the sqrt).  stats == NULL: no normalisation, only act.
+ * Replaces nn.InstanceNorm2d(affine=False) (models/networks.py:46-47), nn.BatchNorm2d in train
+ * mode with batch 1 (models/networks.py:87,507,517), nn.ReLU / nn.LeakyReLU(0.2)
+ * (models/networks.py:508,525,816,826,833). */
+typedef struct sgan_norm_desc {
+    const double* stats; /* [2*C] sum, sumsq of the tensor being read, or NULL */
+    const float* gamma;  /* [C] or NULL (=1) */
+    const float* beta;   /* [C] or NULL (=0) */
+    int32_t count;       /* H*W of the tensor being read (statistics population) */
+    float eps;
+    int32_t act;         /* SGAN_ACT_NONE / RELU / LRELU */
+    float slope;         /* LeakyReLU slope */
+} sgan_norm_desc;
+
+/* Geometry of one Conv2d / ConvTranspose2d layer (square kernel, symmetric stride/pad). */
+typedef struct sgan_conv_desc {
+    int32_t kind;   /* SGAN_CONV or SGAN_CONVT */
+    int32_t k, stride, pad;
+    int32_t Hin, Win, Cin;    /* forward input  (stored channels) */
+    int32_t Hout, Wout, Cout; /* forward output (stored channels) */
+} sgan_conv_desc;
+
+const char* sgan_version(void);
+const char* sgan_last_error(void);
+
+/* ---- Conv2d / ConvTranspose2d: forward ------------------------------------------------------
+ * out = conv(act(norm(in)), w) + bias ; optionally out = tanh(out) ; optionally accumulates the
+ * per-channel sum / sumsq of the (pre-tanh) result into out_stats.
+ * Replaces: nn.ConvTranspose2d k4 s2 p1 (models/networks.py:502,516,523,529),
+ *           nn.Conv2d k4 s2 p2 / k4 s1 p2 (models/networks.py:815,824,831,835),
+ *           nn.Conv2d k4 s2 p1 (models/networks.py:356,385), nn.Conv2d k3 s1 p1 (:686,752,774),
+ *           nn.Tanh (models/networks.py:540). */
+int sgan_conv_fwd(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
+                  const float* w, const float* bias, float* out, int32_t out_ld, int32_t out_act,
+                  double* out_stats, void* stream);
+
+/* ---- backward-data ---------------------------------------------------------------------------
+ * din = conv_bwd_data(dout, w), then multiplied by act'(norm(x)) of the forward tensor `x` at the
+ * same positions (x_norm describes how the forward consumer read x; x == NULL: plain dgrad).
+ * With x_norm->stats != NULL it also accumulates the two InstanceNorm/BatchNorm backward sums
+ * bwd_sums[0..C) = sum(dY), bwd_sums[C..2C) = sum(dY * xhat) (caller-zeroed).  The result is dY
+ * (gradient w.r.t. the normalised-affine value); sgan_norm_bwd_apply() turns it into dX.
+ * Replaces: convolution_backward (input grad) + LeakyReLU/ReLU backward of the autograd graph
+ * built by FCGANModel.backward_D / backward_G (models/fcgan_model.py:146-176). */
+int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32_t dout_ld, const float* w,
+                    float* din, int32_t din_ld, const float* x, int32_t x_ld, const sgan_norm_desc* x_norm,
+                    double* bwd_sums, void* stream);
+
+/* ---- backward-weight ---------------------------------------------------------------------------
+ * dw += act(norm(in))^T (x) dout over all pixels (master layout), dbias += sum_pixels dout.
+ * Accumulates (atomics) into caller-owned gradient buffers.
+ * Replaces: convolution_backward (weight / bias grad). */
+int sgan_conv_wgrad(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
+                    const float* dout, int32_t dout_ld, float* dw, float* dbias, void* stream);
+
+/* ---- InstanceNorm / BatchNorm(batch 1) backward, in place ------------------------------------
+ * dy[p][c] <- gamma_c * rstd_c * ( dy - s1_c/M - xhat * s2_c/M ), xhat = (x - mean_c) * rstd_c.
+ * dgamma += s2, dbeta += s1 when non-NULL.  M = npix.
+ * Replaces: native_batch_norm_backward of nn.InstanceNorm2d / nn.BatchNorm2d. */
+int sgan_norm_bwd_apply(float* dy, int32_t dy_ld, const float* x, int32_t x_ld, int32_t npix, int32_t C,
+                        const sgan_norm_desc* x_norm, const double* bwd_sums, float* dgamma, float* dbeta,
+                        void* stream);
+
+/* ---- BatchNorm running statistics (momentum update, unbiased variance), n layers per launch --
+ * Replaces the running_mean / running_var side effect of nn.BatchNorm2d.forward in train mode. */
+typedef struct sgan_bn_running_desc {
+    const double* stats;
+    float* running_mean;
+    float* running_var;
+    int64_t* num_batches_tracked; /* device int64 incremented by one, or NULL */
+    int32_t C;
+    int32_t count; /* H*W */
+} sgan_bn_running_desc;
+int sgan_bn_running_update(const sgan_bn_running_desc* layers, int32_t n, float momentum, void* stream);
+
+/* ---- Gaussian pre-filter + stride pick of the multi-scale discriminators ----------------------
+ * out[y][x][c] = sum_{ky,kx} g[c][ky][kx] * in[y*s + ky - pad][x*s + kx - pad][c], where g is read
+ * from the diagonal of the reference's dense [C,C,k,k] weight (w_diag_stride = element stride
+ * between g[c] and g[c+1]).  Only strided outputs and diagonal channels are computed.
+ * Replaces: gauss_filter = Conv2d(C,C,4*sigma+1,pad 2*sigma) + AvgPool2d(1, stride s)
+ * (models/networks.py:807-813). */
+int sgan_gauss_down_fwd(const float* in, int32_t in_ld, int32_t H, int32_t W, int32_t C, int32_t Creal,
+                        const float* g, int32_t g_chan_stride, int32_t k, int32_t pad, int32_t s,
+                        float* out, int32_t out_ld, int32_t Ho, int32_t Wo, void* stream);
+int sgan_gauss_down_bwd(const float* dout, int32_t dout_ld, int32_t Ho, int32_t Wo, int32_t C, int32_t Creal,
+                        const float* g, int32_t g_chan_stride, int32_t k, int32_t pad, int32_t s,
+                        float* din, int32_t din_ld, int32_t H, int32_t W, void* stream);
+
+/* ---- GAN loss on a logits map (channel 0 of an NHWC-4 tensor) --------------------------------
+ * mode 0: BCE(sigmoid(x), t) with torch's log clamp at -100 (GANLoss, --no_lsgan);
+ * mode 1: MSE(x, t) (lsgan, no sigmoid).  loss_out[0] = mean loss; p_out (optional) = sigmoid(x).
+ * The backward writes dlogits[p][0] = gout[0] * dloss/dx, other stored channels 0.
+ * Replaces: nn.Sigmoid (models/networks.py:836-837) + nn.BCELoss / nn.MSELoss inside GANLoss
+ * (models/networks.py:160-163,183-185). */
+int sgan_gan_loss_fwd(const float* logits, int32_t ld, int32_t npix, float target, int32_t mode,
+                      float* loss_out, float* p_out, void* stream);
+int sgan_gan_loss_bwd(const float* logits, int32_t ld, int32_t npix, float target, int32_t mode,
+                      const float* gout, float* dlogits, int32_t dld, void* stream);
+
+/* ---- standalone nn.Sigmoid on channel 0 of a logits map (models/networks.py:836-837) --------
+ * Only needed when a caller wants the probability map itself; the GAN loss above consumes logits. */
+int sgan_sigmoid_fwd(const float* x, int32_t ld, int32_t npix, float* p, int32_t pld, void* stream);
+int sgan_sigmoid_bwd(const float* dp, int32_t dpld, const float* p, int32_t pld, int32_t npix, float* dx,
+                     int32_t dxld, void* stream);
+
+/* ---- elementwise helpers ---------------------------------------------------------------------
+ * tanh backward: dx = dy * (1 - y*y)                                   (nn.Tanh, networks.py:540)
+ * strided gather into NHWC with zero channel padding (layout boundary of the module API). */
+int sgan_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+int sgan_to_nhwc(const float* src, int64_t sc, int64_t sh, int64_t sw, int32_t H, int32_t W, int32_t Creal,
+                 float* dst, int32_t dst_ld, int32_t Cstore, void* stream);
+
+/* ---- Adam over up to 64 contiguous fp32 segments in one launch --------------------------------
+ * torch.optim.Adam default form (models/fcgan_model.py:98-109):
+ *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * `state_dev` points at 16 bytes of device memory owned by the optimizer: int32 step counter t
+ * (starts at 0) followed by two kernel-private floats.  A 1-thread prep launch does t += 1 and
+ * derives the bias corrections in fp64, the streaming launch applies them -- so a captured
+ * hipGraph replays with the right t.  `lr_dev` points at a device float (the LR schedule writes it). */
+typedef struct sgan_adam_seg {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+} sgan_adam_seg;
+int sgan_adam_multi(const sgan_adam_seg* segs, int32_t nseg, const float* lr_dev, float beta1, float beta2,
+                    float eps, int32_t* state_dev, void* stream);
+
+/* ---- N(0,1) fill (Philox4x32-10 + Box-Muller), counter-based -----------------------------------
+ * Replaces: noise_.normal_(0, 1) (models/fcgan_model.py:126-127).  `offset_dev` is a device uint64
+ * the kernel reads and block 0 advances by n (graph-replay safe). */
+int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGAN_HIP_H */

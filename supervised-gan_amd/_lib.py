@@ -1,0 +1,81 @@
+"""ctypes binding of libsgan_hip.so (include/sgan_hip.h).  There is NO fallback: if the library is
+missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsgan_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+CONV, CONVT = 0, 1
+
+
+class NormDesc(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("count", C.c_int32), ("eps", C.c_float), ("act", C.c_int32), ("slope", C.c_float)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32),
+                ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cout", C.c_int32)]
+
+
+class BnRunningDesc(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p), ("C", C.c_int32), ("count", C.c_int32)]
+
+
+class AdamSeg(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
+
+
+# name -> argtypes; every entry returns int except the two string getters
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SIGNATURES = {
+    "sgan_conv_fwd": [C.POINTER(ConvDesc), _P, _I, C.POINTER(NormDesc), _P, _P, _P, _I, _I, _P, _P],
+    "sgan_conv_dgrad": [C.POINTER(ConvDesc), _P, _I, _P, _P, _I, _P, _I, C.POINTER(NormDesc), _P, _P],
+    "sgan_conv_wgrad": [C.POINTER(ConvDesc), _P, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
+    "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _P, _P, _P],
+    "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],
+    "sgan_gauss_down_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    "sgan_gauss_down_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    "sgan_gan_loss_fwd": [_P, _I, _I, _F, _I, _P, _P, _P],
+    "sgan_gan_loss_bwd": [_P, _I, _I, _F, _I, _P, _P, _I, _P],
+    "sgan_sigmoid_fwd": [_P, _I, _I, _P, _I, _P],
+    "sgan_sigmoid_bwd": [_P, _I, _P, _I, _I, _P, _I, _P],
+    "sgan_tanh_bwd": [_P, _P, _P, _L, _P],
+    "sgan_to_nhwc": [_P, _L, _L, _L, _I, _I, _I, _P, _I, _I, _P],
+    "sgan_adam_multi": [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _P, _P],
+    "sgan_normal_fill": [_P, _L, C.c_uint64, _P, _P],
+}
+
+_lib = None
+
+
+class SganError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes library; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SganError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C supervised-gan_amd/csrc`.  There is no CPU/PyTorch fallback for this path.")
+        l = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        l.sgan_version.restype = C.c_char_p
+        l.sgan_last_error.restype = C.c_char_p
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SganError(f"{what} failed ({rc}): {lib().sgan_last_error().decode()}")

@@ -1,0 +1,85 @@
+"""BaseModel (models/base_model.py:5-64): trainer protocol + checkpoint I/O.
+
+Checkpoint layout is the reference's: one file per network, `<epoch>_net_<label>.pth`, holding the
+bare CPU state_dict with the reference's key names and logical shapes.  Loading tolerates old-torch
+checkpoints (InstanceNorm running stats present, BatchNorm num_batches_tracked absent)."""
+import os
+from collections import OrderedDict
+
+import torch
+
+
+class BaseModel:
+    def name(self):
+        return 'BaseModel'
+
+    def initialize(self, opt):
+        self.opt = opt
+        self.gpu_ids = opt.gpu_ids
+        self.isTrain = opt.isTrain
+        self.device = torch.device('cuda', self.gpu_ids[0]) if self.gpu_ids else torch.device('cpu')
+        self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
+        self.model_dir = getattr(opt, 'pretrained_model_dir', '')
+
+    def Tensor(self, *size):
+        return torch.empty(*size, dtype=torch.float32, device=self.device)
+
+    def set_input(self, input):
+        self.input = input
+
+    def forward(self):
+        pass
+
+    def test(self):
+        pass
+
+    def get_image_paths(self):
+        pass
+
+    def optimize_parameters(self):
+        pass
+
+    def get_current_visuals(self):
+        return self.input
+
+    def get_current_errors(self):
+        return {}
+
+    def save(self, label):
+        pass
+
+    def save_network(self, network, network_label, epoch_label, gpu_ids=[], model_dir=''):
+        save_filename = '%s_net_%s.pth' % (epoch_label, network_label)
+        save_path = os.path.join(model_dir or self.save_dir, save_filename)
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        # same content as `torch.save(network.cpu().state_dict(), path)` without moving the live module
+        sd = OrderedDict((k, v.detach().to('cpu').contiguous()) for k, v in network.state_dict().items())
+        torch.save(sd, save_path)
+
+    def load_network(self, network, network_label, epoch_label, model_dir=''):
+        save_filename = '%s_net_%s.pth' % (epoch_label, network_label)
+        save_path = os.path.join(model_dir or self.save_dir, save_filename)
+        sd = torch.load(save_path, map_location='cpu')
+        load_state_dict_compat(network, sd)
+
+    def update_learning_rate(self):
+        pass
+
+
+def load_state_dict_compat(network, sd):
+    """load_state_dict that accepts checkpoints written by torch <= 0.3 (the reference's authoring
+    era): those carry `running_mean/var` for InstanceNorm2d(affine=False) layers (dropped here: the
+    layers never used them) and lack BatchNorm `num_batches_tracked`."""
+    own = network.state_dict()
+    clean = OrderedDict()
+    for k, v in sd.items():
+        if k in own:
+            clean[k] = v
+        elif k.endswith('running_mean') or k.endswith('running_var'):
+            continue   # stale InstanceNorm buffers
+        else:
+            raise KeyError('unexpected key %s in checkpoint' % k)
+    missing = [k for k in own if k not in clean and not k.endswith('num_batches_tracked')]
+    if missing:
+        raise KeyError('missing keys in checkpoint: %s' % missing)
+    network.load_state_dict(clean, strict=False)

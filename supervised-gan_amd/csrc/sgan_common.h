@@ -1,0 +1,101 @@
+// Internal definitions shared by the gfx950 kernels of libsgan_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/sgan_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// thread-local last-error string (sgan_last_error()).
+extern thread_local char g_sgan_err[512];
+int sgan_fail(int code, const char* fmt, ...);
+
+#define SGAN_CHECK(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return sgan_fail(SGAN_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define SGAN_LAUNCH_CHECK()                                                                   \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) return sgan_fail(SGAN_ERR_HIP, "%s:%d: %s", __FILE__, __LINE__, \
+                                               hipGetErrorString(e_));                        \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// Tap / phase description shared by the implicit-GEMM forward, backward-data and backward-weight
+// kernels.  A conv-like op is a set of <= 4 output "phases"; phase (oa, ob) covers output pixels
+// (py*os + oa, px*os + ob), py < Hp, px < Wp, and each of its taps reads the gathered tensor at
+// (py*is + dy, px*is + dx) and the weight slab at w_off.
+//   Conv2d fwd / ConvT dgrad : 1 phase, k*k taps, is = stride, os = 1, dy = ky - pad
+//   ConvT fwd / Conv dgrad   : stride^2 phases, (k/stride)^2 taps each, is = 1, os = stride
+// ------------------------------------------------------------------------------------------
+#define SGAN_MAX_TAPS 16
+#define SGAN_MAX_PHASES 4
+
+struct SgTap {
+    int16_t dy, dx;
+    int32_t w_off;  // element offset of this tap's [Cout][Cin] slab in the master weight
+};
+
+struct SgPhase {
+    int32_t oa, ob;  // output phase offset
+    int32_t Hp, Wp;  // phase grid
+    int32_t ntaps;
+    int32_t ktot;    // ntaps * (gathered channels)
+    SgTap taps[SGAN_MAX_TAPS];
+};
+
+struct SgNorm {  // device-side copy of sgan_norm_desc
+    const double* stats;
+    const float* gamma;
+    const float* beta;
+    int32_t count;
+    float eps;
+    int32_t act;
+    float slope;
+};
+
+static inline SgNorm sg_norm_from(const sgan_norm_desc* d) {
+    SgNorm n;
+    if (d) {
+        n.stats = d->stats; n.gamma = d->gamma; n.beta = d->beta;
+        n.count = d->count; n.eps = d->eps; n.act = d->act; n.slope = d->slope;
+    } else {
+        n.stats = nullptr; n.gamma = nullptr; n.beta = nullptr;
+        n.count = 1; n.eps = 0.f; n.act = SGAN_ACT_NONE; n.slope = 0.f;
+    }
+    return n;
+}
+
+// Build the phase tables.  `gather_*` is the tensor the taps read (forward input for fwd/wgrad,
+// dout for dgrad); `grid_*` is the tensor the phases tile (forward output for fwd/wgrad, din for
+// dgrad).  `transposed_access` selects the scatter form (ConvT fwd, Conv dgrad).
+int sg_build_phases(const sgan_conv_desc* d, bool dgrad, SgPhase* ph, int* nphase, int* is, int* os);
+
+// mean / rstd of channel c from accumulated (sum, sumsq) statistics (biased variance)
+__device__ __forceinline__ void sg_mean_rstd(const SgNorm& n, int C, int c, float& mean, float& rstd) {
+    double s = n.stats[c], q = n.stats[C + c];
+    double inv = 1.0 / (double)n.count;
+    double m = s * inv;
+    double var = q * inv - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)n.eps));
+}
+
+__device__ __forceinline__ float sg_act(float y, int act, float slope) {
+    if (act == SGAN_ACT_RELU) return y > 0.f ? y : 0.f;
+    if (act == SGAN_ACT_LRELU) return y > 0.f ? y : y * slope;
+    return y;
+}
+
+__device__ __forceinline__ float sg_act_grad(float y, int act, float slope) {
+    if (act == SGAN_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == SGAN_ACT_LRELU) return y > 0.f ? 1.f : slope;
+    return 1.f;
+}

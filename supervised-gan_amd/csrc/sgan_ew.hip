@@ -1,0 +1,482 @@
+// HBM-bound kernels of the hot path for gfx950: norm backward, BatchNorm running statistics,
+// Gaussian pre-filter (strided, diagonal only), GAN loss on the logits map, tanh backward, layout
+// boundary copy, multi-segment Adam, Philox normal fill.  All are 16-byte-per-lane streaming
+// kernels (or tiny single-workgroup reductions); none allocates or synchronises.
+#include "sgan_common.h"
+
+thread_local char g_sgan_err[512] = {0};
+
+int sgan_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_sgan_err, sizeof(g_sgan_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* sgan_version(void) { return "sgan_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+extern "C" const char* sgan_last_error(void) { return g_sgan_err; }
+
+static inline int ew_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------
+// InstanceNorm / BatchNorm(batch 1) backward, in place on dy
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(float* dy, int dy_ld, const float* x, int x_ld,
+                                                                int npix, int C, SgNorm xn, const double* sums,
+                                                                float* dgamma, float* dbeta) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cA = reinterpret_cast<float*>(smem);  // gamma * rstd
+    float* cMean = cA + C;
+    float* cRstd = cMean + C;
+    float* cS1 = cRstd + C;  // s1 / M
+    float* cS2 = cS1 + C;    // s2 / M
+    const double invM = 1.0 / (double)npix;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mean, rstd;
+        sg_mean_rstd(xn, C, c, mean, rstd);
+        const float g = xn.gamma ? xn.gamma[c] : 1.f;
+        cA[c] = g * rstd;
+        cMean[c] = mean;
+        cRstd[c] = rstd;
+        cS1[c] = (float)(sums[c] * invM);
+        cS2[c] = (float)(sums[C + c] * invM);
+        if (blockIdx.x == 0) {
+            if (dgamma) dgamma[c] += (float)sums[C + c];
+            if (dbeta) dbeta[c] += (float)sums[c];
+        }
+    }
+    __syncthreads();
+    const int CQ = C >> 2;
+    const int64_t total = (int64_t)npix * CQ;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int p = (int)(e / CQ), c = (int)(e - (int64_t)p * CQ) * 4;
+        f32x4 d = *reinterpret_cast<const f32x4*>(dy + (int64_t)p * dy_ld + c);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)p * x_ld + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xhat = (xv[j] - cMean[c + j]) * cRstd[c + j];
+            d[j] = cA[c + j] * (d[j] - cS1[c + j] - xhat * cS2[c + j]);
+        }
+        *reinterpret_cast<f32x4*>(dy + (int64_t)p * dy_ld + c) = d;
+    }
+}
+
+extern "C" int sgan_norm_bwd_apply(float* dy, int32_t dy_ld, const float* x, int32_t x_ld, int32_t npix, int32_t C,
+                                   const sgan_norm_desc* x_norm, const double* bwd_sums, float* dgamma, float* dbeta,
+                                   void* stream) {
+    SGAN_CHECK(dy && x && x_norm && x_norm->stats && bwd_sums, "null argument");
+    SGAN_CHECK((C & 3) == 0 && C > 0 && C <= 4096 && dy_ld >= C && x_ld >= C && (dy_ld & 3) == 0 && (x_ld & 3) == 0, "bad dims");
+    const int64_t total = (int64_t)npix * (C >> 2);
+    int blocks = ew_cdiv(total, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sg_norm_bwd_apply_kernel, dim3(blocks), dim3(256), (size_t)5 * C * 4, (hipStream_t)stream, dy, dy_ld,
+                       x, x_ld, npix, C, sg_norm_from(x_norm), bwd_sums, dgamma, dbeta);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm running statistics for up to 16 layers in one launch
+// ------------------------------------------------------------------------------------------
+struct SgBnRunTable {
+    sgan_bn_running_desc l[16];
+    int n;
+    float momentum;
+};
+
+__global__ __launch_bounds__(256) void sg_bn_running_kernel(SgBnRunTable T) {
+    const sgan_bn_running_desc& L = T.l[blockIdx.x];
+    const double inv = 1.0 / (double)L.count;
+    const double unb = L.count > 1 ? (double)L.count / (double)(L.count - 1) : 1.0;
+    if (threadIdx.x == 0 && L.num_batches_tracked) L.num_batches_tracked[0] += 1;
+    for (int c = threadIdx.x; c < L.C; c += 256) {
+        const double m = L.stats[c] * inv;
+        double var = L.stats[L.C + c] * inv - m * m;
+        if (var < 0.0) var = 0.0;
+        L.running_mean[c] = (1.f - T.momentum) * L.running_mean[c] + T.momentum * (float)m;
+        L.running_var[c] = (1.f - T.momentum) * L.running_var[c] + T.momentum * (float)(var * unb);
+    }
+}
+
+extern "C" int sgan_bn_running_update(const sgan_bn_running_desc* layers, int32_t n, float momentum, void* stream) {
+    SGAN_CHECK(layers && n > 0 && n <= 16, "1..16 layers per launch");
+    SgBnRunTable T;
+    for (int i = 0; i < n; ++i) T.l[i] = layers[i];
+    T.n = n;
+    T.momentum = momentum;
+    hipLaunchKernelGGL(sg_bn_running_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, T);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Gaussian pre-filter: depthwise (diagonal of the dense reference weight), strided outputs only
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_gauss_fwd_kernel(const float* in, int in_ld, int H, int W, int C, int Creal,
+                                                           const float* g, int gcs, int k, int pad, int s, float* out,
+                                                           int out_ld, int Ho, int Wo) {
+    const int64_t total = (int64_t)Ho * Wo * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int64_t pix = e / C;
+        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+        float acc = 0.f;
+        if (c < Creal) {
+            const float* gc = g + (int64_t)c * gcs;
+            for (int ky = 0; ky < k; ++ky) {
+                const int iy = oy * s + ky - pad;
+                if ((unsigned)iy >= (unsigned)H) continue;
+                for (int kx = 0; kx < k; ++kx) {
+                    const int ix = ox * s + kx - pad;
+                    if ((unsigned)ix >= (unsigned)W) continue;
+                    acc += gc[ky * k + kx] * in[((int64_t)iy * W + ix) * in_ld + c];
+                }
+            }
+        }
+        out[pix * out_ld + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_gauss_bwd_kernel(const float* dout, int dout_ld, int Ho, int Wo, int C, int Creal,
+                                                           const float* g, int gcs, int k, int pad, int s, float* din,
+                                                           int din_ld, int H, int W) {
+    const int64_t total = (int64_t)H * W * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int64_t pix = e / C;
+        const int ix = (int)(pix % W), iy = (int)(pix / W);
+        float acc = 0.f;
+        if (c < Creal) {
+            const float* gc = g + (int64_t)c * gcs;
+            for (int ky = 0; ky < k; ++ky) {
+                const int ry = iy + pad - ky;
+                if (ry < 0 || ry % s != 0) continue;
+                const int oy = ry / s;
+                if (oy >= Ho) continue;
+                for (int kx = 0; kx < k; ++kx) {
+                    const int rx = ix + pad - kx;
+                    if (rx < 0 || rx % s != 0) continue;
+                    const int ox = rx / s;
+                    if (ox >= Wo) continue;
+                    acc += gc[ky * k + kx] * dout[((int64_t)oy * Wo + ox) * dout_ld + c];
+                }
+            }
+        }
+        din[pix * din_ld + c] = acc;
+    }
+}
+
+extern "C" int sgan_gauss_down_fwd(const float* in, int32_t in_ld, int32_t H, int32_t W, int32_t C, int32_t Creal,
+                                   const float* g, int32_t g_chan_stride, int32_t k, int32_t pad, int32_t s, float* out,
+                                   int32_t out_ld, int32_t Ho, int32_t Wo, void* stream) {
+    SGAN_CHECK(in && g && out && k > 0 && s > 0 && Creal <= C, "bad argument");
+    SGAN_CHECK(Ho == (H + 2 * pad - k) / s + 1 && Wo == (W + 2 * pad - k) / s + 1, "gauss geometry mismatch");
+    const int64_t total = (int64_t)Ho * Wo * C;
+    int blocks = ew_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sg_gauss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, in_ld, H, W, C, Creal, g,
+                       g_chan_stride, k, pad, s, out, out_ld, Ho, Wo);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_gauss_down_bwd(const float* dout, int32_t dout_ld, int32_t Ho, int32_t Wo, int32_t C, int32_t Creal,
+                                   const float* g, int32_t g_chan_stride, int32_t k, int32_t pad, int32_t s, float* din,
+                                   int32_t din_ld, int32_t H, int32_t W, void* stream) {
+    SGAN_CHECK(dout && g && din && k > 0 && s > 0 && Creal <= C, "bad argument");
+    SGAN_CHECK(Ho == (H + 2 * pad - k) / s + 1 && Wo == (W + 2 * pad - k) / s + 1, "gauss geometry mismatch");
+    const int64_t total = (int64_t)H * W * C;
+    int blocks = ew_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sg_gauss_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, dout_ld, Ho, Wo, C, Creal,
+                       g, g_chan_stride, k, pad, s, din, din_ld, H, W);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// GAN loss on the logits map (one workgroup; the maps are <= 67x67)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(1024) void sg_gan_loss_fwd_kernel(const float* logits, int ld, int npix, float target, int mode,
+                                                               float* loss_out, float* p_out) {
+    __shared__ double wsum[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < npix; i += 1024) {
+        const float x = logits[(int64_t)i * ld];
+        float l;
+        if (mode == 0) {
+            const float p = sg_sigmoid(x);
+            if (p_out) p_out[(int64_t)i * ld] = p;
+            const float lp = fmaxf(logf(p), -100.f);
+            const float lq = fmaxf(log1pf(-p), -100.f);
+            l = -(target * lp + (1.f - target) * lq);
+        } else {
+            const float d = x - target;
+            l = d * d;
+        }
+        acc += (double)l;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += wsum[i];
+        loss_out[0] = (float)(t / (double)npix);
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_gan_loss_bwd_kernel(const float* logits, int ld, int npix, float target, int mode,
+                                                              const float* gout, float* dlogits, int dld) {
+    const float go = gout[0] / (float)npix;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        const float x = logits[(int64_t)i * ld];
+        float d;
+        if (mode == 0) d = (sg_sigmoid(x) - target) * go;
+        else d = 2.f * (x - target) * go;
+        float* o = dlogits + (int64_t)i * dld;
+        o[0] = d;
+        for (int c = 1; c < dld; ++c) o[c] = 0.f;
+    }
+}
+
+extern "C" int sgan_gan_loss_fwd(const float* logits, int32_t ld, int32_t npix, float target, int32_t mode, float* loss_out,
+                                 float* p_out, void* stream) {
+    SGAN_CHECK(logits && loss_out && npix > 0 && ld >= 1 && (mode == 0 || mode == 1), "bad argument");
+    hipLaunchKernelGGL(sg_gan_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ld, npix, target, mode,
+                       loss_out, p_out);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_gan_loss_bwd(const float* logits, int32_t ld, int32_t npix, float target, int32_t mode, const float* gout,
+                                 float* dlogits, int32_t dld, void* stream) {
+    SGAN_CHECK(logits && gout && dlogits && npix > 0 && dld >= 1 && (mode == 0 || mode == 1), "bad argument");
+    int blocks = ew_cdiv(npix, 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(sg_gan_loss_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, ld, npix, target,
+                       mode, gout, dlogits, dld);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// standalone sigmoid on channel 0 of a logits map (only used when the caller wants probabilities;
+// the training path feeds the logits straight to sgan_gan_loss_*)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_sigmoid_fwd_kernel(const float* x, int ld, int npix, float* p, int pld) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        float* o = p + (int64_t)i * pld;
+        o[0] = sg_sigmoid(x[(int64_t)i * ld]);
+        for (int c = 1; c < pld; ++c) o[c] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_sigmoid_bwd_kernel(const float* dp, int dpld, const float* p, int pld, int npix,
+                                                             float* dx, int dxld) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        const float pv = p[(int64_t)i * pld];
+        float* o = dx + (int64_t)i * dxld;
+        o[0] = dp[(int64_t)i * dpld] * pv * (1.f - pv);
+        for (int c = 1; c < dxld; ++c) o[c] = 0.f;
+    }
+}
+
+extern "C" int sgan_sigmoid_fwd(const float* x, int32_t ld, int32_t npix, float* p, int32_t pld, void* stream) {
+    SGAN_CHECK(x && p && npix > 0, "bad argument");
+    int blocks = ew_cdiv(npix, 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(sg_sigmoid_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, npix, p, pld);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_sigmoid_bwd(const float* dp, int32_t dpld, const float* p, int32_t pld, int32_t npix, float* dx,
+                                int32_t dxld, void* stream) {
+    SGAN_CHECK(dp && p && dx && npix > 0, "bad argument");
+    int blocks = ew_cdiv(npix, 256);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(sg_sigmoid_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dp, dpld, p, pld, npix, dx, dxld);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// tanh backward, layout boundary copy
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_tanh_bwd_kernel(const float* dy, const float* y, float* dx, int64_t n4) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        const f32x4 d = reinterpret_cast<const f32x4*>(dy)[e];
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[e];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = d[j] * (1.f - v[j] * v[j]);
+        reinterpret_cast<f32x4*>(dx)[e] = o;
+    }
+}
+
+extern "C" int sgan_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    SGAN_CHECK(dy && y && dx && n > 0 && (n & 3) == 0, "bad argument");
+    int blocks = ew_cdiv(n / 4, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sg_tanh_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n / 4);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+__global__ __launch_bounds__(256) void sg_to_nhwc_kernel(const float* src, int64_t sc, int64_t sh, int64_t sw, int H, int W,
+                                                         int Creal, float* dst, int dst_ld, int Cstore) {
+    const int64_t total = (int64_t)H * W * Cstore;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % Cstore);
+        const int64_t pix = e / Cstore;
+        const int x = (int)(pix % W), y = (int)(pix / W);
+        dst[pix * dst_ld + c] = c < Creal ? src[c * sc + y * sh + x * sw] : 0.f;
+    }
+}
+
+extern "C" int sgan_to_nhwc(const float* src, int64_t sc, int64_t sh, int64_t sw, int32_t H, int32_t W, int32_t Creal,
+                            float* dst, int32_t dst_ld, int32_t Cstore, void* stream) {
+    SGAN_CHECK(src && dst && H > 0 && W > 0 && Creal <= Cstore && dst_ld >= Cstore, "bad argument");
+    const int64_t total = (int64_t)H * W * Cstore;
+    int blocks = ew_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sg_to_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, sc, sh, sw, H, W, Creal, dst,
+                       dst_ld, Cstore);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam: one prep launch (step counter + bias corrections, fp64) and one streaming launch
+// ------------------------------------------------------------------------------------------
+struct SgAdamTable {
+    sgan_adam_seg s[64];
+    int nseg;
+};
+
+__global__ void sg_adam_prep_kernel(int32_t* state, const float* lr, float b1, float b2) {
+    const int t = state[0] + 1;
+    state[0] = t;
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    reinterpret_cast<float*>(state)[1] = (float)((double)lr[0] / bc1);
+    reinterpret_cast<float*>(state)[2] = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ __launch_bounds__(256) void sg_adam_kernel(SgAdamTable T, const int32_t* state, float b1, float b2, float eps) {
+    const sgan_adam_seg& S = T.s[blockIdx.y];
+    const float step_size = reinterpret_cast<const float*>(state)[1];
+    const float inv_sqrt_bc2 = reinterpret_cast<const float*>(state)[2];
+    const int64_t n4 = S.n >> 2;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        f32x4 p = reinterpret_cast<f32x4*>(S.p)[e];
+        const f32x4 g = reinterpret_cast<const f32x4*>(S.g)[e];
+        f32x4 m = reinterpret_cast<f32x4*>(S.m)[e];
+        f32x4 v = reinterpret_cast<f32x4*>(S.v)[e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m[j] = b1 * m[j] + (1.f - b1) * g[j];
+            v[j] = b2 * v[j] + (1.f - b2) * g[j] * g[j];
+            const float denom = sqrtf(v[j]) * inv_sqrt_bc2 + eps;
+            p[j] -= step_size * (m[j] / denom);
+        }
+        reinterpret_cast<f32x4*>(S.p)[e] = p;
+        reinterpret_cast<f32x4*>(S.m)[e] = m;
+        reinterpret_cast<f32x4*>(S.v)[e] = v;
+    }
+    // tail (n not a multiple of 4)
+    if (blockIdx.x == 0 && threadIdx.x < (S.n & 3)) {
+        const int64_t e = (n4 << 2) + threadIdx.x;
+        const float g = S.g[e];
+        const float m = b1 * S.m[e] + (1.f - b1) * g;
+        const float v = b2 * S.v[e] + (1.f - b2) * g * g;
+        S.m[e] = m;
+        S.v[e] = v;
+        S.p[e] -= step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+    }
+}
+
+extern "C" int sgan_adam_multi(const sgan_adam_seg* segs, int32_t nseg, const float* lr_dev, float beta1, float beta2,
+                               float eps, int32_t* state_dev, void* stream) {
+    SGAN_CHECK(segs && nseg > 0 && nseg <= 64 && lr_dev && state_dev, "bad argument");
+    SgAdamTable T;
+    int64_t maxn = 0;
+    for (int i = 0; i < nseg; ++i) {
+        T.s[i] = segs[i];
+        SGAN_CHECK(segs[i].p && segs[i].g && segs[i].m && segs[i].v && segs[i].n > 0, "bad segment %d", i);
+        SGAN_CHECK(((uintptr_t)segs[i].p & 15) == 0 && ((uintptr_t)segs[i].g & 15) == 0 && ((uintptr_t)segs[i].m & 15) == 0 &&
+                       ((uintptr_t)segs[i].v & 15) == 0, "segment %d not 16-byte aligned", i);
+        if (segs[i].n > maxn) maxn = segs[i].n;
+    }
+    T.nseg = nseg;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sg_adam_prep_kernel, dim3(1), dim3(1), 0, st, state_dev, lr_dev, beta1, beta2);
+    SGAN_LAUNCH_CHECK();
+    int bx = ew_cdiv(maxn / 4 + 1, 256 * 2);
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(sg_adam_kernel, dim3(bx, nseg), dim3(256), 0, st, T, state_dev, beta1, beta2, eps);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// N(0,1) fill: Philox4x32-10, Box-Muller
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sg_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                          uint32_t* out) {
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void sg_normal_fill_kernel(float* dst, int64_t n, uint64_t seed, const uint64_t* offset) {
+    const uint64_t off = offset ? offset[0] : 0;
+    const int64_t nq = (n + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+        const uint64_t ctr = off + (uint64_t)q;
+        uint32_t r[4];
+        sg_philox((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+            const float u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);       // [0,1)
+            const float rad = sqrtf(-2.0f * logf(u1));
+            float sn, cs;
+            sincosf(6.28318530717958647692f * u2, &sn, &cs);
+            z[2 * h] = rad * cs;
+            z[2 * h + 1] = rad * sn;
+        }
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) dst[q * 4 + j] = z[j];
+    }
+}
+
+__global__ void sg_rng_advance_kernel(uint64_t* offset, uint64_t by) { offset[0] += by; }
+
+extern "C" int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, void* stream) {
+    SGAN_CHECK(dst && n > 0, "bad argument");
+    const int64_t nq = (n + 3) >> 2;
+    int blocks = ew_cdiv(nq, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sg_normal_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, n, seed, offset_dev);
+    SGAN_LAUNCH_CHECK();
+    if (offset_dev) {
+        hipLaunchKernelGGL(sg_rng_advance_kernel, dim3(1), dim3(1), 0, st, offset_dev, (uint64_t)nq);
+        SGAN_LAUNCH_CHECK();
+    }
+    return SGAN_OK;
+}

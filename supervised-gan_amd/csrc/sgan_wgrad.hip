@@ -1,0 +1,257 @@
+// Conv2d / ConvTranspose2d backward-weight (+ bias) for gfx950 (CDNA4), fp32.
+//
+//   dW[co][kcol] += sum_pixels dOut[pixel][co] * Acol[pixel][kcol],  kcol = (tap, ci)
+//
+// Acol is the same on-the-fly im2col gather (with the producer's norm + activation applied while
+// staging) that the forward kernel uses, so (tap, ci) is one flat GEMM-N dimension and even the
+// 2-channel image layers fill a 64-wide tile.  The reduction runs over pixels:
+//  * both operands arrive in their natural NHWC form [pixel][channel] and are written to LDS
+//    untransposed ([32 pixels][C + pad] rows, pad chosen so the two 16-lane halves of a
+//    ds_read_b32 fragment read hit disjoint banks);
+//  * v_mfma_f32_16x16x4_f32 with A = dOut^T (rows = co), B = Acol (cols = kcol), k = pixel;
+//  * split-K over pixel ranges; partial tiles are combined with fp32 atomics straight into the
+//    gradient buffer (which the optimizer's zero_grad memsets), the bias gradient is the column
+//    sum of the dOut tile taken by the kcol-tile-0 workgroups.
+//
+// Reference ops replaced: convolution_backward (weight, bias) of every nn.Conv2d /
+// nn.ConvTranspose2d on the path (models/networks.py:502-529, :815-835).
+#include "sgan_common.h"
+
+struct SgWgradParams {
+    const float* in;
+    const float* dout;
+    float* dw;
+    float* dbias;
+    int32_t Hin, Win, Cin, in_ld;
+    int32_t Hout, Wout, Cout, dout_ld;
+    int32_t is, os;
+    int32_t w_ns;
+    int32_t nphase, nsplit;
+    SgNorm pro;
+    SgPhase phase[SGAN_MAX_PHASES];
+};
+
+template <int BCO, int BKC, int WGC, int WGK>
+__global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams P) {
+    constexpr int BP = 32;
+    constexpr int WTC = BCO / WGC, WTK = BKC / WGK, MB = WTC / 16, NB = WTK / 16;
+    constexpr int LDD = (BCO % 32 == 0) ? BCO + 16 : BCO;
+    constexpr int LDA = (BKC % 32 == 0) ? BKC + 16 : BKC;
+    constexpr int DQ = BCO / 4, AQ = BKC / 4;  // float4 per pixel row
+    constexpr int D_IT = (BP * DQ + 255) / 256, A_IT = (BP * AQ + 255) / 256;
+    static_assert(WGC * WGK == 4, "4 waves");
+    static_assert(256 % AQ == 0 && 256 % DQ == 0, "row mapping");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ds = reinterpret_cast<float*>(smem);  // [2][BP*LDD]
+    float* As = Ds + 2 * BP * LDD;               // [2][BP*LDA]
+    float* pscale = As + 2 * BP * LDA;           // [Cin]
+    float* pshift = pscale + P.Cin;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wc = wid / WGK, wk = wid % WGK;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int phz = blockIdx.z / P.nsplit, split = blockIdx.z % P.nsplit;
+    const SgPhase& ph = P.phase[phz];
+    const int Hp = ph.Hp, Wp = ph.Wp, M = Hp * Wp, ktot = ph.ktot;
+    const int kc0 = blockIdx.x * BKC, co0 = blockIdx.y * BCO;
+    if (kc0 >= ktot || M == 0) return;
+    const int nchunk_total = (M + BP - 1) / BP;
+    const int per = (nchunk_total + P.nsplit - 1) / P.nsplit;
+    const int ch_begin = split * per, ch_end = min(nchunk_total, ch_begin + per);
+    if (ch_begin >= ch_end) return;
+    const int Cin = P.Cin, Cout = P.Cout;
+    const bool has_pro = (P.pro.stats != nullptr) || (P.pro.act != SGAN_ACT_NONE);
+
+    if (has_pro) {
+        for (int c = tid; c < Cin; c += 256) {
+            float sc = 1.f, sh = 0.f;
+            if (P.pro.stats) {
+                float mean, rstd;
+                sg_mean_rstd(P.pro, Cin, c, mean, rstd);
+                const float g = P.pro.gamma ? P.pro.gamma[c] : 1.f;
+                const float b = P.pro.beta ? P.pro.beta[c] : 0.f;
+                sc = g * rstd;
+                sh = b - mean * sc;
+            }
+            pscale[c] = sc;
+            pshift[c] = sh;
+        }
+    }
+
+    // A (im2col) staging: this thread's column group is fixed for the whole kernel
+    const int a_c4 = tid % AQ, a_row0 = tid / AQ;
+    constexpr int A_ROWS_PER_IT = 256 / AQ;
+    const int a_kcol = kc0 + a_c4 * 4;
+    const bool a_kok = a_kcol < ktot;
+    const int a_tap = a_kok ? a_kcol / Cin : 0;
+    const int a_c = a_kcol - a_tap * Cin;
+    const int a_dy = ph.taps[a_tap].dy, a_dx = ph.taps[a_tap].dx;
+    // D staging
+    const int d_c4 = tid % DQ, d_row0 = tid / DQ;
+    constexpr int D_ROWS_PER_IT = 256 / DQ;
+    const bool d_cok = co0 + d_c4 * 4 < Cout;
+
+    f32x4 a_reg[A_IT], d_reg[D_IT];
+    bool a_val[A_IT];
+
+    auto load_chunk = [&](int ch) {
+        const int mb = ch * BP;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int prow = a_row0 + it * A_ROWS_PER_IT;
+            const int m = mb + prow;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            bool ok = false;
+            if (prow < BP && m < M && a_kok) {
+                const int py = m / Wp, px = m - py * Wp;
+                const int iy = py * P.is + a_dy, ix = px * P.is + a_dx;
+                if ((unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win) {
+                    v = *reinterpret_cast<const f32x4*>(P.in + ((int64_t)iy * P.Win + ix) * P.in_ld + a_c);
+                    ok = true;
+                }
+            }
+            a_reg[it] = v;
+            a_val[it] = ok;
+        }
+#pragma unroll
+        for (int it = 0; it < D_IT; ++it) {
+            const int prow = d_row0 + it * D_ROWS_PER_IT;
+            const int m = mb + prow;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (prow < BP && m < M && d_cok) {
+                const int py = m / Wp, px = m - py * Wp;
+                const int64_t pix = (int64_t)(py * P.os + ph.oa) * P.Wout + (px * P.os + ph.ob);
+                v = *reinterpret_cast<const f32x4*>(P.dout + pix * P.dout_ld + co0 + d_c4 * 4);
+            }
+            d_reg[it] = v;
+        }
+    };
+
+    auto store_chunk = [&](int buf) {
+        float* Ab = As + buf * BP * LDA;
+        float* Db = Ds + buf * BP * LDD;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int prow = a_row0 + it * A_ROWS_PER_IT;
+            f32x4 v = a_reg[it];
+            if (has_pro && a_val[it]) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + a_c);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + a_c);
+                v.x = sg_act(v.x * sc.x + sh.x, P.pro.act, P.pro.slope);
+                v.y = sg_act(v.y * sc.y + sh.y, P.pro.act, P.pro.slope);
+                v.z = sg_act(v.z * sc.z + sh.z, P.pro.act, P.pro.slope);
+                v.w = sg_act(v.w * sc.w + sh.w, P.pro.act, P.pro.slope);
+            }
+            if (prow < BP) *reinterpret_cast<f32x4*>(Ab + prow * LDA + a_c4 * 4) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < D_IT; ++it) {
+            const int prow = d_row0 + it * D_ROWS_PER_IT;
+            if (prow < BP) *reinterpret_cast<f32x4*>(Db + prow * LDD + d_c4 * 4) = d_reg[it];
+        }
+    };
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const bool do_bias = (P.dbias != nullptr) && (blockIdx.x == 0);
+
+    __syncthreads();  // pscale/pshift visible
+    load_chunk(ch_begin);
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const int buf = (ch - ch_begin) & 1;
+        store_chunk(buf);
+        __syncthreads();
+        if (ch + 1 < ch_end) load_chunk(ch + 1);
+        const float* Ab = As + buf * BP * LDA;
+        const float* Db = Ds + buf * BP * LDD;
+#pragma unroll
+        for (int k4 = 0; k4 < BP / 4; ++k4) {
+            float af[MB], bf[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) af[i] = Db[(k4 * 4 + fq) * LDD + wc * WTC + i * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bf[j] = Ab[(k4 * 4 + fq) * LDA + wk * WTK + j * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_bias && tid < BCO) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int p = 0; p < BP; ++p) s += Db[p * LDD + tid];
+            bsum += s;
+        }
+    }
+
+    // ---- combine: fp32 atomics into the gradient buffer ----
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int kcol = kc0 + wk * WTK + j * 16 + fr;
+        if (kcol >= ktot) continue;
+        const int tap = kcol / Cin, ci = kcol - tap * Cin;
+        float* base = P.dw + ph.taps[tap].w_off + ci;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wc * WTC + i * 16 + fq * 4 + r;
+                if (co < Cout) atomicAdd(base + (int64_t)co * P.w_ns, acc[i][j][r]);
+            }
+        }
+    }
+    if (do_bias && tid < BCO && co0 + tid < Cout) atomicAdd(P.dbias + co0 + tid, bsum);
+}
+
+static inline int sgw_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <int BCO, int BKC, int WGC, int WGK>
+static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
+    constexpr int LDD = (BCO % 32 == 0) ? BCO + 16 : BCO;
+    constexpr int LDA = (BKC % 32 == 0) ? BKC + 16 : BKC;
+    int maxM = 0, maxK = 0;
+    for (int i = 0; i < P.nphase; ++i) {
+        maxM = max(maxM, P.phase[i].Hp * P.phase[i].Wp);
+        maxK = max(maxK, P.phase[i].ktot);
+    }
+    if (maxM == 0) return SGAN_OK;
+    const int tiles = sgw_cdiv(maxK, BKC) * sgw_cdiv(P.Cout, BCO) * P.nphase;
+    const int nchunk = sgw_cdiv(maxM, 32);
+    int nsplit = 1024 / tiles;
+    if (nsplit > nchunk / 4) nsplit = nchunk / 4;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 512) nsplit = 512;
+    P.nsplit = nsplit;
+    dim3 grid(sgw_cdiv(maxK, BKC), sgw_cdiv(P.Cout, BCO), P.nphase * nsplit);
+    const size_t lds = (size_t)(2 * 32 * LDD + 2 * 32 * LDA + 2 * P.Cin) * 4;
+    hipLaunchKernelGGL((sg_wgrad_kernel<BCO, BKC, WGC, WGK>), grid, dim3(256), lds, st, P);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_conv_wgrad(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
+                               const float* dout, int32_t dout_ld, float* dw, float* dbias, void* stream) {
+    if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
+    SGAN_CHECK((d->Cin & 3) == 0 && (d->Cout & 3) == 0, "stored channels must be multiples of 4");
+    SGAN_CHECK(in && dout && dw, "null tensor");
+    SGAN_CHECK(in_ld >= d->Cin && dout_ld >= d->Cout && (in_ld & 3) == 0 && (dout_ld & 3) == 0, "bad leading dims");
+    SgWgradParams P;
+    memset(&P, 0, sizeof(P));
+    int rc = sg_build_phases(d, false, P.phase, &P.nphase, &P.is, &P.os);
+    if (rc) return rc;
+    P.in = in; P.dout = dout; P.dw = dw; P.dbias = dbias;
+    P.Hin = d->Hin; P.Win = d->Win; P.Cin = d->Cin; P.in_ld = in_ld;
+    P.Hout = d->Hout; P.Wout = d->Wout; P.Cout = d->Cout; P.dout_ld = dout_ld;
+    P.w_ns = d->Cin;
+    P.pro = sg_norm_from(in_norm);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->Cout <= 16) return sg_launch_wgrad<16, 128, 1, 4>(P, st);
+    if (d->Cout <= 32) return sg_launch_wgrad<32, 64, 1, 4>(P, st);
+    return sg_launch_wgrad<64, 64, 2, 2>(P, st);
+}

@@ -1,0 +1,184 @@
+"""FCGANModel (models/fcgan_model.py:26-236): the unconditional GAN trainer -- noise -> G -> fake,
+multi-scale discriminator list, D step / G step, Adam, checkpoint save/load, linear LR decay --
+driving the MI355X kernels.  Method names, loss definitions and update order follow the reference
+line by line in *behaviour*; data stays device resident and every network call is one autograd node.
+
+Deviations, all observable-behaviour preserving:
+  * sigmoid+BCE is evaluated by one kernel on the discriminator logits (GANLoss);
+  * `--skip_wasted_D_wgrad`: the reference computes discriminator weight gradients during the G step
+    and zeroes them before they are ever used (fcgan_model.py:176,182); with the flag they are not
+    computed;
+  * latent noise comes from a counter-based Philox kernel (`normal_fill`), not torch's RNG stream."""
+from collections import OrderedDict
+
+import torch
+
+from . import networks, ops
+from .base_model import BaseModel
+from .image_pool import ImagePool
+from .optim import FusedAdam
+
+
+class FCGANModel(BaseModel):
+    def name(self):
+        return 'FCGANModel'
+
+    def initialize(self, opt):
+        BaseModel.initialize(self, opt)
+        self.isTrain = opt.isTrain
+        # parse which_channel (fcgan_model.py:47-58)
+        idx_dict = {'r': 0, 'g': 1, 'b': 2}
+        self.chnl_idx_input, self.chnl_idx_visual = [], []
+        for s in opt.which_channel.split('_'):
+            self.chnl_idx_visual.append([idx_dict[c] for c in s])
+            self.chnl_idx_input += [idx_dict[c] for c in s]
+        opt.input_nc = len(self.chnl_idx_input)
+        self._chnl_dev = torch.tensor(self.chnl_idx_input, dtype=torch.long, device=self.device)
+
+        zshape = (opt.batchSize, opt.noise_nc, opt.noiseSize, opt.noiseSize)
+        self.input = self.Tensor(opt.batchSize, opt.input_nc, opt.fineSize, opt.fineSize)
+        self.noise = None
+        self.noise_ = self.Tensor(*zshape)
+        self._rng_seed = 0 if opt.manualSeed is None else int(opt.manualSeed)
+        self._rng_offset = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.noise_source = None    # optional callable() -> z tensor (tests inject latents)
+        self.fixed_noiseA = self._draw_noise().clone()
+        self.fixed_noiseB = self._draw_noise().clone()
+
+        self.netG = networks.define_G(opt.input_nc, 0, opt.ngf, opt.which_model_netG, opt.norm, not opt.no_dropout,
+                                      n_layers_G=opt.n_layers_G, use_residual=opt.use_residual,
+                                      use_fcn=opt.noiseSize != 1, noise_nc=opt.noise_nc,
+                                      add_gaussian_noise=opt.add_gaussian_noise, gaussian_sigma=opt.gaussian_sigma,
+                                      upsample_mode=opt.upsample_mode, n_layers_CRN_block=opt.n_layers_CRN_block,
+                                      share_label_weights=not opt.no_share_label_block_weights, gpu_ids=self.gpu_ids)
+        if self.isTrain:
+            use_sigmoid = opt.no_lsgan
+            assert (len(opt.scale_factor) == len(opt.lambda_D) == len(opt.n_layers_D))
+            self.n_netD = len(opt.scale_factor)
+            self.netD = []
+            for scale, n_layers in zip(opt.scale_factor, opt.n_layers_D):
+                d = networks.define_D(opt.input_nc, opt.ndf, opt.which_model_netD, n_layers_D=n_layers, norm=opt.norm,
+                                      use_sigmoid=use_sigmoid, scale_factor=scale, gpu_ids=self.gpu_ids)
+                d.fuse_sigmoid_into_loss = True
+                self.netD.append(d)
+        if not self.isTrain or opt.continue_train:
+            self.load_network(self.netG, 'G', opt.which_epoch)
+            if self.isTrain:
+                for netD, n in zip(self.netD, range(self.n_netD)):
+                    self.load_network(netD, 'D_%d' % n, opt.which_epoch)
+
+        if self.isTrain:
+            self.fake_pool = ImagePool(opt.pool_size)
+            self.old_lr = opt.lr
+            self.criterionGAN = networks.GANLoss(use_lsgan=not opt.no_lsgan)
+            self.optimizer_G = FusedAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+            params = []
+            for netD in self.netD:
+                params += list(netD.model.parameters())   # "all learnable parameters should be in netD.model"
+            self.optimizer_D = FusedAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.grad_sync = None   # data-parallel hook: callable(optimizer) run between backward and step
+
+    # ---- data ---------------------------------------------------------------------------------
+    def _draw_noise(self):
+        if self.noise_source is not None:
+            z = self.noise_source()
+            self.noise_.copy_(z)
+        else:
+            ops.normal_fill(self.noise_, self._rng_seed, self._rng_offset)
+        return self.noise_
+
+    def set_input(self, input):
+        AorB = self.opt.which_direction == 'A'
+        data = input['A' if AorB else 'B']
+        data = data.to(self.device, non_blocking=True).index_select(1, self._chnl_dev)
+        self.input.resize_(data.size()).copy_(data)
+        self.image_paths = input.get('A_paths' if AorB else 'B_paths')
+
+    def forward(self):
+        self.real = self.input
+        self.noise = self._draw_noise()
+        self.fake = self.netG.forward(self.noise)
+
+    sample_noise = forward
+
+    def test(self):
+        with torch.no_grad():
+            self.noise = self._draw_noise()
+            self.fake = self.netG.forward(self.noise)
+
+    def get_image_paths(self):
+        return self.image_paths
+
+    # ---- losses ---------------------------------------------------------------------------------
+    def backward_D(self):
+        fake = self.fake_pool.query(self.fake)
+        self.loss_D_fake = 0
+        for netD in self.netD:
+            pred_fake = netD.forward(fake.detach())
+            self.loss_D_fake = self.loss_D_fake + self.criterionGAN(pred_fake, False)
+        real = self.real
+        self.loss_D_real = 0
+        for netD in self.netD:
+            pred_real = netD.forward(real)
+            self.loss_D_real = self.loss_D_real + self.criterionGAN(pred_real, True)
+        self.loss_D = (self.loss_D_fake + self.loss_D_real) * 0.5
+        self.loss_D.backward()
+
+    def backward_G(self):
+        fake = self.fake
+        self.loss_G = 0
+        skip = getattr(self.opt, 'skip_wasted_D_wgrad', False)
+        for netD, lambda_D in zip(self.netD, self.opt.lambda_D):
+            netD.compute_param_grads = not skip
+            pred_fake = netD.forward(fake)
+            netD.compute_param_grads = True
+            if not self.opt.no_logD_trick:
+                self.loss_G = self.loss_G + self.criterionGAN(pred_fake, True) * lambda_D
+            else:
+                self.loss_G = self.loss_G + -self.criterionGAN(pred_fake, False) * lambda_D
+        self.loss_G.backward()
+
+    def optimize_parameters(self):
+        self.forward()
+        for _ in range(self.opt.n_update_D):
+            self.optimizer_D.zero_grad()
+            self.backward_D()
+            if self.grad_sync is not None:
+                self.grad_sync(self.optimizer_D)
+            self.optimizer_D.step()
+            if self.opt.n_update_D > 1:
+                self.sample_noise()
+        for _ in range(self.opt.n_update_G):
+            self.optimizer_G.zero_grad()
+            self.backward_G()
+            if self.grad_sync is not None:
+                self.grad_sync(self.optimizer_G)
+            self.optimizer_G.step()
+            if self.opt.n_update_G > 1:
+                self.sample_noise()
+
+    def get_current_errors(self):
+        return OrderedDict([('G_GAN', float(self.loss_G)), ('D_real', float(self.loss_D_real)),
+                            ('D_fake', float(self.loss_D_fake))])
+
+    def get_current_visuals(self, save_real=False, save_as_single_image=True):
+        out = OrderedDict()
+        if self.isTrain or save_real:
+            out['real'] = self.real.detach()
+        out['fake'] = self.fake.detach()
+        return out
+
+    def save(self, label):
+        self.save_network(self.netG, 'G', label, gpu_ids=self.gpu_ids)
+        for netD, n in zip(self.netD, range(self.n_netD)):
+            self.save_network(netD, 'D_%d' % n, label, self.gpu_ids)
+
+    def update_learning_rate(self):
+        lrd = self.opt.lr / self.opt.niter_decay
+        lr = self.old_lr - lrd
+        for opt_ in (self.optimizer_D, self.optimizer_G):
+            for param_group in opt_.param_groups:
+                param_group['lr'] = lr
+            opt_.sync_lr()
+        print('update learning rate: %f -> %f' % (self.old_lr, lr))
+        self.old_lr = lr

@@ -1,0 +1,619 @@
+"""Drop-in counterpart of the reference's network factory (models/networks.py) on MI355X.
+
+Same entry points -- `define_G`, `define_D`, `GANLoss`, `WeightedL1Loss`, `print_network`,
+`weights_init` -- same argument names, same returned-object protocol (`.forward`, `.parameters()`,
+`netD.model.parameters()`, `.state_dict()` with the reference's key names and logical shapes,
+`netD.gauss_filter`), but a network is a *layer program* over NHWC buffers executed by
+hand-written gfx950 kernels (include/sgan_hip.h); normalisation and activations never exist as
+separate passes (they are applied while the consumer conv stages its input) and the whole net is
+one autograd node.
+
+Implemented: which_model_netG in {fcgan, deconv (README alias)}, which_model_netD in
+{n_layers, basic}.  Other names raise NotImplementedError like the reference does for unknown
+names (models/networks.py:95,123)."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, CONV, CONVT, SganError
+from .ops import pad4
+
+BN_EPS = 1e-5       # nn.BatchNorm2d default
+IN_EPS = 1e-5       # nn.InstanceNorm2d default
+BN_MOMENTUM = 0.1
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers restated from the reference
+# ------------------------------------------------------------------------------------------------
+def matlab_style_gauss2D(shape=(3, 3), sigma=0.5):
+    """fspecial('gaussian') (models/networks.py:22-33)."""
+    m, n = [(ss - 1.) / 2. for ss in shape]
+    y, x = np.ogrid[-m:m + 1, -n:n + 1]
+    h = np.exp(-(x * x + y * y) / (2. * sigma * sigma))
+    h[h < np.finfo(h.dtype).eps * h.max()] = 0
+    sumh = h.sum()
+    if sumh != 0:
+        h /= sumh
+    return h
+
+
+def init_gauss_filters(nf, kw, sigma):
+    """models/networks.py:36-40."""
+    filters = np.zeros((nf, nf, kw, kw))
+    for i in range(nf):
+        filters[i, i, :, :] = matlab_style_gauss2D((kw, kw), sigma)
+    return filters
+
+
+def weights_init(m):
+    """models/networks.py:13-19, applied to our parameter containers (class-name free)."""
+    kind = getattr(m, "_sgan_kind", None)
+    if kind == "conv":
+        m.weight.data.normal_(0.0, 0.02)
+    elif kind == "bn":
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+
+
+def print_network(net):
+    """models/networks.py:135-140."""
+    num_params = sum(p.numel() for p in net.parameters())
+    print(net)
+    print('Total number of parameters: %d' % num_params)
+
+
+# ------------------------------------------------------------------------------------------------
+# layer program
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class LayerSpec:
+    key: str                 # index of the conv inside the reference's nn.Sequential ("0", "3", ...)
+    kind: int                # CONV / CONVT
+    k: int
+    stride: int
+    pad: int
+    cin: int                 # logical channels
+    cout: int
+    bias: bool
+    norm: Optional[str]      # None | "in" | "bn" : normalisation of THIS layer's output
+    act: int                 # activation after the norm (applied by the consumer on load)
+    slope: float = 0.0
+    # filled by the net
+    w_off: int = 0
+    b_off: int = -1
+    g_off: int = -1          # BN gamma / beta offsets
+    be_off: int = -1
+
+    @property
+    def cin_s(self):
+        return pad4(self.cin)
+
+    @property
+    def cout_s(self):
+        return pad4(self.cout)
+
+    def out_hw(self, h, w):
+        if self.kind == CONV:
+            return (h + 2 * self.pad - self.k) // self.stride + 1, (w + 2 * self.pad - self.k) // self.stride + 1
+        return (h - 1) * self.stride - 2 * self.pad + self.k, (w - 1) * self.stride - 2 * self.pad + self.k
+
+
+class _ParamBox(nn.Module):
+    """Stand-in for one numbered child of the reference's nn.Sequential: owns `weight` / `bias`
+    Parameters that are strided views into the net's flat storage."""
+
+    def __init__(self, kind):
+        super().__init__()
+        self._sgan_kind = kind
+
+    def extra_repr(self):
+        return ", ".join(f"{n}={tuple(p.shape)}" for n, p in self._parameters.items() if p is not None)
+
+
+class ChainNet(nn.Module):
+    """A sequential conv net as a layer program over flat fp32 storage.
+
+    Master layouts (include/sgan_hip.h): conv weight [kh*kw][Cout_s][Cin_s]; exposed to
+    state_dict()/optimizers as strided views with the reference's logical shapes, so checkpoints
+    interchange with the reference without any conversion pass."""
+
+    final_act = ACT_NONE
+
+    def __init__(self, layers: List[LayerSpec]):
+        super().__init__()
+        self.layers = layers
+        off = 0
+        for L in layers:
+            L.w_off = off
+            off += L.k * L.k * L.cout_s * L.cin_s
+            if L.bias:
+                L.b_off = off
+                off += L.cout_s
+            if L.norm == "bn":
+                L.g_off = off
+                off += L.cout_s
+                L.be_off = off
+                off += L.cout_s
+        self._nflat = off
+        self._flat = torch.zeros(off, dtype=torch.float32)
+        self._gflat = torch.zeros(off, dtype=torch.float32)
+        self.model = nn.Module()
+        self._bn_boxes = {}
+        for L in layers:
+            box = _ParamBox("conv")
+            box.weight = nn.Parameter(torch.empty(0))
+            box.bias = nn.Parameter(torch.empty(0)) if L.bias else None
+            self.model.add_module(L.key, box)
+            if L.norm == "bn":
+                nb = _ParamBox("bn")
+                nb.weight = nn.Parameter(torch.empty(0))
+                nb.bias = nn.Parameter(torch.empty(0))
+                nb.register_buffer("running_mean", torch.zeros(L.cout))
+                nb.register_buffer("running_var", torch.ones(L.cout))
+                nb.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+                self.model.add_module(str(int(L.key) + 1), nb)
+                self._bn_boxes[L.key] = nb
+        self._rebind()
+        self._default_bias_init()
+        self.compute_param_grads = True   # trainers may clear this while only dX is wanted (G step)
+        self._geom_cache = {}
+
+    # ---- storage <-> Parameter views -------------------------------------------------------
+    def _views(self, flat, L: LayerSpec):
+        m = flat[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s].view(L.k, L.k, L.cout_s, L.cin_s)
+        if L.kind == CONVT:
+            w = m.permute(3, 2, 0, 1)[:L.cin, :L.cout]       # logical [Cin, Cout, kh, kw]
+        else:
+            w = m.permute(2, 3, 0, 1)[:L.cout, :L.cin]       # logical [Cout, Cin, kh, kw]
+        b = flat[L.b_off: L.b_off + L.cout] if L.bias else None
+        g = flat[L.g_off: L.g_off + L.cout] if L.norm == "bn" else None
+        be = flat[L.be_off: L.be_off + L.cout] if L.norm == "bn" else None
+        return w, b, g, be
+
+    def _rebind(self):
+        for L in self.layers:
+            box = getattr(self.model, L.key)
+            w, b, g, be = self._views(self._flat, L)
+            gw, gb, gg, gbe = self._views(self._gflat, L)
+            box.weight.data = w
+            box.weight.grad = gw
+            box.weight._sgan_seg = (self, L.w_off, L.k * L.k * L.cout_s * L.cin_s)
+            if L.bias:
+                box.bias.data = b
+                box.bias.grad = gb
+                box.bias._sgan_seg = (self, L.b_off, L.cout_s)
+            if L.norm == "bn":
+                nb = self._bn_boxes[L.key]
+                nb.weight.data, nb.weight.grad = g, gg
+                nb.bias.data, nb.bias.grad = be, gbe
+                nb.weight._sgan_seg = (self, L.g_off, L.cout_s)
+                nb.bias._sgan_seg = (self, L.be_off, L.cout_s)
+
+    def _default_bias_init(self):
+        """torch's default conv bias init U(+-1/sqrt(fan_in)); weights_init leaves it in place in the
+        reference (models/networks.py:13-19 touches only .weight of convs)."""
+        for L in self.layers:
+            if L.bias:
+                fan_in = (L.cin if L.kind == CONV else L.cout) * L.k * L.k
+                bound = 1.0 / math.sqrt(fan_in)
+                getattr(self.model, L.key).bias.data.uniform_(-bound, bound)
+
+    def _ensure_grads(self):
+        """Re-attach .grad views if someone set them to None (torch's zero_grad(set_to_none=True))."""
+        for L in self.layers:
+            box = getattr(self.model, L.key)
+            gw, gb, gg, gbe = self._views(self._gflat, L)
+            pairs = [(box.weight, gw)]
+            if L.bias:
+                pairs.append((box.bias, gb))
+            if L.norm == "bn":
+                nb = self._bn_boxes[L.key]
+                pairs += [(nb.weight, gg), (nb.bias, gbe)]
+            for p, gv in pairs:
+                if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+                    gv.zero_()
+                    p.grad = gv
+
+    def _apply(self, fn, recurse=True):
+        self._flat = fn(self._flat)
+        self._gflat = fn(self._gflat)
+        for mod in self.modules():
+            for k, buf in mod._buffers.items():
+                if buf is not None:
+                    mod._buffers[k] = fn(buf)
+        for p in self._extra_parameters():
+            p.data = fn(p.data)
+            if p.grad is not None:
+                p.grad = fn(p.grad)
+        self._rebind()
+        self._geom_cache = {}
+        return self
+
+    def _extra_parameters(self):
+        return []
+
+    def flat_segment(self):
+        """(params, grads, numel) of the contiguous storage behind `self.model.parameters()`."""
+        return self._flat, self._gflat, self._nflat
+
+    def zero_grad_flat(self):
+        self._gflat.zero_()
+
+    # ---- geometry ---------------------------------------------------------------------------
+    def _geometry(self, H, W):
+        key = (H, W)
+        if key not in self._geom_cache:
+            geo = []
+            h, w = H, W
+            for L in self.layers:
+                ho, wo = L.out_hw(h, w)
+                if ho <= 0 or wo <= 0:
+                    raise SganError(f"input {H}x{W} too small for layer {L.key}")
+                geo.append((ops.conv_desc(L.kind, L.k, L.stride, L.pad, h, w, L.cin_s, ho, wo, L.cout_s), h, w, ho, wo))
+                h, w = ho, wo
+            self._geom_cache[key] = geo
+        return self._geom_cache[key]
+
+    def _wb(self, L: LayerSpec):
+        w = self._flat[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s]
+        b = self._flat[L.b_off: L.b_off + L.cout_s] if L.bias else None
+        return w, b
+
+    def _gwb(self, L: LayerSpec):
+        w = self._gflat[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s]
+        b = self._gflat[L.b_off: L.b_off + L.cout_s] if L.bias else None
+        return w, b
+
+    def _norm_of(self, li, stats, count):
+        """How a consumer reads layer li's raw output: its norm (from `stats`) + activation."""
+        L = self.layers[li]
+        if L.norm is None:
+            return ops.norm_desc(None, None, None, count, 0.0, L.act, L.slope)
+        st = stats[li]
+        if L.norm == "bn":
+            g = self._flat[L.g_off: L.g_off + L.cout_s]
+            be = self._flat[L.be_off: L.be_off + L.cout_s]
+            return ops.norm_desc(st, g, be, count, BN_EPS, L.act, L.slope)
+        return ops.norm_desc(st, None, None, count, IN_EPS, L.act, L.slope)
+
+    # ---- forward / backward programs ----------------------------------------------------------
+    def run_forward(self, x: torch.Tensor, update_running=True):
+        """x: [H, W, Cs] NHWC buffer.  Returns (outs, stats): raw conv outputs and per-layer stats."""
+        ops.require_gpu(x, type(self).__name__)
+        if self._flat.device != x.device:
+            raise SganError(f"module parameters are on {self._flat.device}, input on {x.device}")
+        H, W, Cs = x.shape
+        assert Cs == self.layers[0].cin_s, (Cs, self.layers[0].cin_s)
+        geo = self._geometry(H, W)
+        n_stats = sum(2 * L.cout_s for L in self.layers if L.norm)
+        arena = torch.zeros(max(n_stats, 1), dtype=torch.float64, device=x.device)
+        stats, o = [], 0
+        for L in self.layers:
+            if L.norm:
+                stats.append(arena[o: o + 2 * L.cout_s])
+                o += 2 * L.cout_s
+            else:
+                stats.append(None)
+        outs = []
+        cur = x
+        for li, L in enumerate(self.layers):
+            desc, h, w, ho, wo = geo[li]
+            out = torch.empty((ho, wo, L.cout_s), dtype=torch.float32, device=x.device)
+            in_norm = self._norm_of(li - 1, stats, h * w) if li > 0 else None
+            wt, b = self._wb(L)
+            last = li == len(self.layers) - 1
+            ops.conv_fwd(desc, cur, in_norm, wt, b, out, self.final_act if last else ACT_NONE, stats[li])
+            outs.append(out)
+            cur = out
+        if update_running and self._bn_boxes:
+            rl = []
+            for li, L in enumerate(self.layers):
+                if L.norm == "bn":
+                    nb = self._bn_boxes[L.key]
+                    _, _, _, ho, wo = geo[li]
+                    rl.append((stats[li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo))
+            ops.bn_running_update(rl, BN_MOMENTUM)
+        return outs, stats
+
+    def run_backward(self, x, outs, stats, dout, need_dx: bool, want_wgrad: bool):
+        """dout: gradient w.r.t. the net output (after final_act), [Ho, Wo, Cs].  Returns dx or None."""
+        geo = self._geometry(x.shape[0], x.shape[1])
+        nL = len(self.layers)
+        dev = x.device
+        if want_wgrad:
+            self._ensure_grads()
+        dcur = dout
+        if self.final_act == ACT_TANH:
+            d2 = torch.empty_like(outs[-1])
+            ops.tanh_bwd(dcur.contiguous(), outs[-1], d2)
+            dcur = d2
+        n_sums = sum(2 * L.cout_s for L in self.layers if L.norm)
+        arena = torch.zeros(max(n_sums, 1), dtype=torch.float64, device=dev)
+        sums, o = [], 0
+        for L in self.layers:
+            if L.norm:
+                sums.append(arena[o: o + 2 * L.cout_s])
+                o += 2 * L.cout_s
+            else:
+                sums.append(None)
+        dx = None
+        for li in range(nL - 1, -1, -1):
+            L = self.layers[li]
+            desc, h, w, ho, wo = geo[li]
+            src = outs[li - 1] if li > 0 else x
+            in_norm = self._norm_of(li - 1, stats, h * w) if li > 0 else None
+            wt, _ = self._wb(L)
+            if want_wgrad:
+                gw, gb = self._gwb(L)
+                ops.conv_wgrad(desc, src, in_norm, dcur, gw, gb)
+            if li > 0:
+                P = self.layers[li - 1]
+                din = torch.empty((h, w, P.cout_s), dtype=torch.float32, device=dev)
+                ops.conv_dgrad(desc, dcur, wt, din, src, in_norm, sums[li - 1])
+                if P.norm:
+                    dg = self._gflat[P.g_off: P.g_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
+                    db = self._gflat[P.be_off: P.be_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
+                    ops.norm_bwd_apply(din, src, in_norm, sums[li - 1], dg, db)
+                dcur = din
+            elif need_dx:
+                dx = torch.empty((h, w, L.cin_s), dtype=torch.float32, device=dev)
+                ops.conv_dgrad(desc, dcur, wt, dx, None, None, None)
+        return dx
+
+
+class _ChainFn(torch.autograd.Function):
+    """One autograd node per network call."""
+
+    @staticmethod
+    def forward(ctx, net: "ChainNet", x_logical, *params):
+        xb = net._prepare_input(x_logical)
+        outs, stats = net.run_forward(xb["chain_in"])
+        ctx.net, ctx.xb, ctx.outs, ctx.stats = net, xb, outs, stats
+        ctx.want_wgrad = net.compute_param_grads and any(ctx.needs_input_grad[2:])
+        ctx.need_dx = ctx.needs_input_grad[1]
+        return ops.logical_view(outs[-1], net.layers[-1].cout)
+
+    @staticmethod
+    def backward(ctx, gout):
+        net = ctx.net
+        g = ops.as_nhwc(gout)
+        dchain = net.run_backward(ctx.xb["chain_in"], ctx.outs, ctx.stats, g, ctx.need_dx, ctx.want_wgrad)
+        dx = net._finish_input_grad(ctx.xb, dchain) if ctx.need_dx else None
+        return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class FCGANGenerator(ChainNet):
+    """FCGANGenerator (models/networks.py:493-540): ConvT(k4,s2,p1) -> BatchNorm -> ReLU x n_layers,
+    ConvT -> Tanh.  `norm_layer` is hard-wired to BatchNorm by define_G (models/networks.py:87) and
+    the net never leaves train mode."""
+    final_act = ACT_TANH
+
+    def __init__(self, noise_nc, input_nc, ngf=64, n_layers=3, use_dropout=False, use_fcn=False, gpu_ids=[]):
+        if not use_fcn:
+            raise NotImplementedError("FCGANGenerator with noiseSize==1 (k4 s1 p0 first layer) is not on the MI355X path")
+        if use_dropout:
+            raise NotImplementedError("FCGANGenerator dropout is not on the MI355X path (README uses --no_dropout)")
+        layers = []
+        nf = min(2 ** (n_layers - 1), 8)
+        layers.append(LayerSpec("0", CONVT, 4, 2, 1, noise_nc, ngf * nf, False, "bn", ACT_RELU))
+        idx = 3
+        for n in range(1, n_layers):
+            nf_prev, nf = nf, min(2 ** (n_layers - n - 1), 8)
+            layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, ngf * nf_prev, ngf * nf, True, "bn", ACT_RELU))
+            idx += 3
+        layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, ngf, input_nc, False, None, ACT_NONE))
+        super().__init__(layers)
+        self.gpu_ids = gpu_ids
+
+    def _prepare_input(self, x):
+        return {"chain_in": ops.as_nhwc(x)}
+
+    def _finish_input_grad(self, xb, dchain):
+        return ops.logical_view(dchain, self.layers[0].cin)
+
+    def forward(self, x, activation=None):
+        if activation is not None and not isinstance(activation, nn.Tanh):
+            raise NotImplementedError("only the default Tanh output activation is implemented")
+        params = list(self.model.parameters())
+        return _ChainFn.apply(self, x, *params)
+
+
+class NLayerDiscriminator(ChainNet):
+    """NLayerDiscriminator (models/networks.py:798-847): [gauss prefilter + stride pick] ->
+    Conv(k4,s2,p2)+LReLU -> (Conv s2 + norm + LReLU) x (n-1) -> Conv s1 + norm + LReLU -> Conv s1 [-> Sigmoid]."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm="instance", use_sigmoid=False, scale_factor=1,
+                 num_classes=2, gpu_ids=[]):
+        if num_classes != 2:
+            raise NotImplementedError("multi-class logits are not on the MI355X path")
+        nrm = {"instance": "in", "batch": "bn"}[norm]
+        kw, padw = 4, int(np.ceil((4 - 1) / 2))
+        layers = [LayerSpec("0", CONV, kw, 2, padw, input_nc, ndf, True, None, ACT_LRELU, 0.2)]
+        nf, idx = 1, 2
+        for n in range(1, n_layers):
+            nf_prev, nf = nf, min(2 ** n, 8)
+            layers.append(LayerSpec(str(idx), CONV, kw, 2, padw, ndf * nf_prev, ndf * nf, True, nrm, ACT_LRELU, 0.2))
+            idx += 3
+        nf_prev, nf = nf, min(2 ** n_layers, 8)
+        layers.append(LayerSpec(str(idx), CONV, kw, 1, padw, ndf * nf_prev, ndf * nf, True, nrm, ACT_LRELU, 0.2))
+        idx += 3
+        layers.append(LayerSpec(str(idx), CONV, kw, 1, padw, ndf * nf, 1, True, None, ACT_NONE))
+        super().__init__(layers)
+        self.gpu_ids = gpu_ids
+        self.use_sigmoid = use_sigmoid
+        self.scale_factor = int(scale_factor)
+        self.input_nc = input_nc
+        self.gauss_filter = None
+        # trainers that feed the output straight into GANLoss set this: forward then returns the logits
+        # tagged for the fused sigmoid+BCE kernel instead of launching a separate sigmoid
+        self.fuse_sigmoid_into_loss = False
+        if self.scale_factor > 1:
+            sigma = self.scale_factor // 2        # Python-2 integer division in the reference (:808)
+            kg = 4 * sigma + 1
+            box = _ParamBox("conv")
+            box.weight = nn.Parameter(torch.zeros(input_nc, input_nc, kg, kg))
+            self.gauss_filter = nn.Module()
+            self.gauss_filter.add_module("0", box)
+            self._gauss = (kg, 2 * sigma)
+
+    def _extra_parameters(self):
+        return [self.gauss_filter._modules["0"].weight] if self.gauss_filter is not None else []
+
+    def _gauss_args(self):
+        wg = self.gauss_filter._modules["0"].weight
+        kg, padg = self._gauss
+        return wg, (self.input_nc + 1) * kg * kg, kg, padg
+
+    def _prepare_input(self, x):
+        xb = {"img": ops.as_nhwc(x)}
+        if self.scale_factor > 1:
+            wg, gcs, kg, padg = self._gauss_args()
+            H, W, Cs = xb["img"].shape
+            s = self.scale_factor
+            Ho, Wo = (H + 2 * padg - kg) // 1 + 1, (W + 2 * padg - kg) // 1 + 1       # conv output
+            Ho, Wo = (Ho - 1) // s + 1, (Wo - 1) // s + 1                              # AvgPool2d(1, stride s)
+            out = torch.empty((Ho, Wo, Cs), dtype=torch.float32, device=x.device)
+            # conv(pad) then pick every s-th pixel == strided conv with the same pad
+            ops.gauss_down_fwd(xb["img"], self.input_nc, wg, gcs, kg, padg, s, out)
+            xb["chain_in"] = out
+        else:
+            xb["chain_in"] = xb["img"]
+        return xb
+
+    def _finish_input_grad(self, xb, dchain):
+        if self.scale_factor > 1:
+            wg, gcs, kg, padg = self._gauss_args()
+            dimg = torch.empty_like(xb["img"])
+            ops.gauss_down_bwd(dchain, self.input_nc, wg, gcs, kg, padg, self.scale_factor, dimg)
+            dchain = dimg
+        return ops.logical_view(dchain, self.input_nc)
+
+    def forward(self, x):
+        params = list(self.model.parameters())
+        logits = _ChainFn.apply(self, x, *params)
+        if not self.use_sigmoid:
+            return logits
+        if self.fuse_sigmoid_into_loss:
+            logits._sgan_pending_sigmoid = True
+            return logits
+        p = _SigmoidFn.apply(logits)
+        p._sgan_logits = logits
+        return p
+
+
+class _SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits):
+        lb = ops.as_nhwc(logits)
+        pb = torch.empty_like(lb)
+        ops.sigmoid_fwd(lb, pb)
+        ctx.pb = pb
+        return ops.logical_view(pb, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        gb = ops.as_nhwc(g)
+        dx = torch.empty_like(ctx.pb)
+        ops.sigmoid_bwd(gb, ctx.pb, dx)
+        return ops.logical_view(dx, 1)
+
+
+class _GanLossFn(torch.autograd.Function):
+    """Sigmoid + BCELoss(mean) (or MSELoss) against a constant target, on the logits map."""
+
+    @staticmethod
+    def forward(ctx, logits, target, mode):
+        lb = ops.as_nhwc(logits)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        ops.gan_loss_fwd(lb, target, mode, loss)
+        ctx.lb, ctx.target, ctx.mode = lb, target, mode
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        d = torch.empty_like(ctx.lb)
+        ops.gan_loss_bwd(ctx.lb, ctx.target, ctx.mode, gout.contiguous(), d)
+        return ops.logical_view(d, 1), None, None
+
+
+class GANLoss(nn.Module):
+    """GANLoss (models/networks.py:152-185).  With `use_lsgan=False` the reference applies BCELoss to
+    the discriminator's Sigmoid output; here the loss kernel consumes the logits behind that output
+    (numerically the same function, torch's -100 log clamp included)."""
+
+    def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, tensor=torch.FloatTensor):
+        super().__init__()
+        self.real_label = target_real_label
+        self.fake_label = target_fake_label
+        self.use_lsgan = use_lsgan
+        self.Tensor = tensor
+
+    def __call__(self, input, target_is_real):
+        t = self.real_label if target_is_real else self.fake_label
+        if self.use_lsgan:
+            return _GanLossFn.apply(input, t, 1)
+        logits = getattr(input, "_sgan_logits", None)
+        if logits is None and getattr(input, "_sgan_pending_sigmoid", False):
+            logits = input
+        if logits is None:
+            raise SganError("GANLoss(use_lsgan=False) needs the output of a supervised_gan_amd discriminator built with "
+                            "use_sigmoid=True (it carries its logits); got a plain tensor")
+        return _GanLossFn.apply(logits, t, 0)
+
+
+class WeightedL1Loss(nn.Module):
+    """WeightedL1Loss (models/networks.py:205-214) -- cgan path, not on the fcgan hot path yet."""
+
+    def __call__(self, x, y, w=None):
+        raise NotImplementedError("WeightedL1Loss: cgan path is scheduled after the fcgan path (SURVEY 8f)")
+
+
+# ------------------------------------------------------------------------------------------------
+# factories (models/networks.py:53-132)
+# ------------------------------------------------------------------------------------------------
+def define_G(input_nc, output_nc, ngf, which_model_netG, norm='batch', use_dropout=False, n_layers_G=5,
+             use_residual=False, use_fcn=False, noise_nc=0, add_gaussian_noise=False, gaussian_sigma=0.1,
+             n_layers_G_skip=-1, upsample_mode='convt', share_label_weights=True, n_layers_CRN_block=1, gpu_ids=[]):
+    if which_model_netG in ('fcgan', 'deconv'):   # README spells it `deconv` (README.md:33)
+        netG = FCGANGenerator(noise_nc, input_nc, ngf, n_layers=n_layers_G, use_dropout=use_dropout, use_fcn=use_fcn,
+                              gpu_ids=gpu_ids)
+    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks', 'unet_128', 'unet_256', 'autoencoder', 'crn',
+                              'fcgan_star', 'dcgan'):
+        raise NotImplementedError('Generator model name [%s] is not on the MI355X path yet' % which_model_netG)
+    else:
+        raise NotImplementedError('Generator model name [%s] is not recognized' % which_model_netG)
+    netG.apply(weights_init)
+    if len(gpu_ids) > 0:
+        netG.cuda(gpu_ids[0])
+    return netG
+
+
+def define_D(input_nc, ndf, which_model_netD, n_layers_D=3, norm='batch', use_sigmoid=False, scale_factor=1,
+             num_classes=2, gpu_ids=[]):
+    if which_model_netD == 'basic':
+        netD = NLayerDiscriminator(input_nc, ndf, n_layers=3, norm=norm, use_sigmoid=use_sigmoid,
+                                   scale_factor=scale_factor, num_classes=num_classes, gpu_ids=gpu_ids)
+    elif which_model_netD == 'n_layers':
+        netD = NLayerDiscriminator(input_nc, ndf, n_layers=n_layers_D, norm=norm, use_sigmoid=use_sigmoid,
+                                   scale_factor=scale_factor, num_classes=num_classes, gpu_ids=gpu_ids)
+    elif which_model_netD in ('n_layers_sep', 'dcgan'):
+        raise NotImplementedError('Discriminator model name [%s] is not on the MI355X path yet' % which_model_netD)
+    else:
+        raise NotImplementedError('Discriminator model name [%s] is not recognized' % which_model_netD)
+    netD.apply(weights_init)
+    if scale_factor > 1:
+        for param in netD.gauss_filter.parameters():
+            sigma = int(scale_factor) // 2
+            kw = 4 * sigma + 1
+            param.data = torch.FloatTensor(init_gauss_filters(input_nc, kw, sigma))
+    if len(gpu_ids) > 0:
+        netD.cuda(gpu_ids[0])
+    return netD

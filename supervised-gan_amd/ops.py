@@ -1,0 +1,176 @@
+"""Thin torch-tensor -> pointer wrappers over the C ABI (include/sgan_hip.h).
+
+Activation tensors are `[H, W, Cs]` fp32 CUDA tensors (NHWC, batch 1, Cs = stored channels, a
+multiple of 4; `tensor.stride(1)` is the pixel stride so channel slices of wider buffers work).
+Everything here launches on torch's current stream and never synchronises."""
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _lib as L
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, CONV, CONVT  # noqa: F401
+
+
+def pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise L.SganError(f"{what}: supervised_gan_amd kernels run on an MI355X (gfx950) only; got a {t.device} tensor. "
+                          "There is no CPU fallback -- move the module and its inputs to cuda.")
+
+
+def _act(t):
+    assert t.dim() == 3 and t.stride(2) == 1 and t.dtype == torch.float32, (t.shape, t.stride(), t.dtype)
+    return t
+
+
+def conv_desc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s):
+    return L.ConvDesc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s)
+
+
+def norm_desc(stats=None, gamma=None, beta=None, count=1, eps=1e-5, act=ACT_NONE, slope=0.0):
+    """None when the read is a plain one (no norm, no activation)."""
+    if stats is None and act == ACT_NONE:
+        return None
+    d = L.NormDesc(_ptr(stats).value, _ptr(gamma).value, _ptr(beta).value, int(count), float(eps), int(act), float(slope))
+    d._keep = (stats, gamma, beta)
+    return d
+
+
+def _nd(d):
+    return C.byref(d) if d is not None else None
+
+
+def conv_fwd(desc, x, in_norm, w, bias, out, out_act=ACT_NONE, out_stats=None):
+    L.check(L.lib().sgan_conv_fwd(C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(w), _ptr(bias),
+                                  _ptr(_act(out)), out.stride(1), out_act, _ptr(out_stats), _stream()), "sgan_conv_fwd")
+
+
+def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None):
+    L.check(L.lib().sgan_conv_dgrad(C.byref(desc), _ptr(_act(dout)), dout.stride(1), _ptr(w), _ptr(_act(din)), din.stride(1),
+                                    _ptr(x), x.stride(1) if x is not None else 0, _nd(x_norm), _ptr(bwd_sums), _stream()),
+            "sgan_conv_dgrad")
+
+
+def conv_wgrad(desc, x, in_norm, dout, dw, dbias):
+    L.check(L.lib().sgan_conv_wgrad(C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(_act(dout)), dout.stride(1),
+                                    _ptr(dw), _ptr(dbias), _stream()), "sgan_conv_wgrad")
+
+
+def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None):
+    H, W, Cs = dy.shape
+    L.check(L.lib().sgan_norm_bwd_apply(_ptr(_act(dy)), dy.stride(1), _ptr(_act(x)), x.stride(1), H * W, Cs, _nd(x_norm),
+                                        _ptr(bwd_sums), _ptr(dgamma), _ptr(dbeta), _stream()), "sgan_norm_bwd_apply")
+
+
+def bn_running_update(layers, momentum=0.1):
+    """layers: list of (stats, running_mean, running_var, num_batches_tracked, C, count)."""
+    arr = (L.BnRunningDesc * len(layers))()
+    for i, (st, rm, rv, nbt, c, cnt) in enumerate(layers):
+        arr[i] = L.BnRunningDesc(st.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr() if nbt is not None else 0, c, cnt)
+    L.check(L.lib().sgan_bn_running_update(arr, len(layers), momentum, _stream()), "sgan_bn_running_update")
+
+
+def gauss_down_fwd(x, Creal, g, g_chan_stride, k, pad, s, out):
+    H, W, Cs = x.shape
+    Ho, Wo, _ = out.shape
+    L.check(L.lib().sgan_gauss_down_fwd(_ptr(_act(x)), x.stride(1), H, W, Cs, Creal, _ptr(g), g_chan_stride, k, pad, s,
+                                        _ptr(_act(out)), out.stride(1), Ho, Wo, _stream()), "sgan_gauss_down_fwd")
+
+
+def gauss_down_bwd(dout, Creal, g, g_chan_stride, k, pad, s, din):
+    Ho, Wo, Cs = dout.shape
+    H, W, _ = din.shape
+    L.check(L.lib().sgan_gauss_down_bwd(_ptr(_act(dout)), dout.stride(1), Ho, Wo, Cs, Creal, _ptr(g), g_chan_stride, k, pad, s,
+                                        _ptr(_act(din)), din.stride(1), H, W, _stream()), "sgan_gauss_down_bwd")
+
+
+def gan_loss_fwd(logits, target, mode, loss_out, p_out=None):
+    H, W, _ = logits.shape
+    L.check(L.lib().sgan_gan_loss_fwd(_ptr(_act(logits)), logits.stride(1), H * W, float(target), mode, _ptr(loss_out),
+                                      _ptr(p_out), _stream()), "sgan_gan_loss_fwd")
+
+
+def gan_loss_bwd(logits, target, mode, gout, dlogits):
+    H, W, _ = logits.shape
+    L.check(L.lib().sgan_gan_loss_bwd(_ptr(_act(logits)), logits.stride(1), H * W, float(target), mode, _ptr(gout),
+                                      _ptr(_act(dlogits)), dlogits.stride(1), _stream()), "sgan_gan_loss_bwd")
+
+
+def sigmoid_fwd(x, p):
+    H, W, _ = x.shape
+    L.check(L.lib().sgan_sigmoid_fwd(_ptr(_act(x)), x.stride(1), H * W, _ptr(_act(p)), p.stride(1), _stream()), "sgan_sigmoid_fwd")
+
+
+def sigmoid_bwd(dp, p, dx):
+    H, W, _ = p.shape
+    L.check(L.lib().sgan_sigmoid_bwd(_ptr(_act(dp)), dp.stride(1), _ptr(_act(p)), p.stride(1), H * W, _ptr(_act(dx)),
+                                     dx.stride(1), _stream()), "sgan_sigmoid_bwd")
+
+
+def tanh_bwd(dy, y, dx):
+    assert dy.is_contiguous() and y.is_contiguous() and dx.is_contiguous()
+    L.check(L.lib().sgan_tanh_bwd(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream()), "sgan_tanh_bwd")
+
+
+def adam_multi(segs, lr_dev, beta1, beta2, eps, state_dev):
+    """segs: list of (p, g, m, v, n) flat fp32 tensors (16-byte aligned)."""
+    arr = (L.AdamSeg * len(segs))()
+    for i, (p, g, m, v, n) in enumerate(segs):
+        arr[i] = L.AdamSeg(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n)
+    L.check(L.lib().sgan_adam_multi(arr, len(segs), _ptr(lr_dev), beta1, beta2, eps, _ptr(state_dev), _stream()), "sgan_adam_multi")
+
+
+def normal_fill(dst, seed, offset_dev=None):
+    assert dst.is_contiguous() and dst.dtype == torch.float32
+    L.check(L.lib().sgan_normal_fill(_ptr(dst), dst.numel(), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(offset_dev), _stream()),
+            "sgan_normal_fill")
+
+
+# ------------------------------------------------------------------------------------------------
+# NCHW <-> NHWC boundary.  Tensors handed to user code are logical [1, C, H, W] *views* of our
+# padded NHWC buffers (zero copy); a weak registry lets us recognise such a view (or its .detach())
+# when it comes back, otherwise one strided-gather kernel converts the layout.
+# ------------------------------------------------------------------------------------------------
+_VIEW_REGISTRY = {}
+
+
+def logical_view(buf: torch.Tensor, C_real: int) -> torch.Tensor:
+    """[H, W, Cs] buffer -> logical [1, C_real, H, W] view; registered for zero-copy round trips."""
+    v = buf.permute(2, 0, 1)[:C_real].unsqueeze(0)
+    _VIEW_REGISTRY[buf.data_ptr()] = (weakref.ref(buf), C_real)
+    if len(_VIEW_REGISTRY) > 4096:
+        for k in [k for k, (r, _) in _VIEW_REGISTRY.items() if r() is None]:
+            del _VIEW_REGISTRY[k]
+    return v
+
+
+def as_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Logical [1, C, H, W] tensor (any strides) -> padded NHWC buffer [H, W, pad4(C)]."""
+    require_gpu(t, "as_nhwc")
+    assert t.dim() == 4 and t.shape[0] == 1, f"batch 1 NCHW expected, got {tuple(t.shape)}"
+    if t.dtype != torch.float32:
+        raise L.SganError(f"fp32 expected, got {t.dtype}")
+    _, Cr, H, W = t.shape
+    Cs = pad4(Cr)
+    ent = _VIEW_REGISTRY.get(t.data_ptr())
+    if ent is not None:
+        buf = ent[0]()
+        if (buf is not None and ent[1] == Cr and buf.shape == (H, W, Cs) and buf.data_ptr() == t.data_ptr()
+                and t.stride(1) == 1 and t.stride(2) == buf.stride(0) and t.stride(3) == buf.stride(1)):
+            return buf
+    out = torch.empty((H, W, Cs), device=t.device, dtype=torch.float32)
+    L.check(L.lib().sgan_to_nhwc(_ptr(t), t.stride(1), t.stride(2), t.stride(3), H, W, Cr, _ptr(out), Cs, Cs, _stream()),
+            "sgan_to_nhwc")
+    return out

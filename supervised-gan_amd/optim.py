@@ -1,0 +1,80 @@
+"""Fused Adam over the flat parameter storage of supervised_gan_amd networks.
+
+Mirrors `torch.optim.Adam(params, lr=, betas=)` as the reference trainers use it
+(models/fcgan_model.py:98-109: beta1 = opt.beta1 = 0.5, beta2 = 0.999, eps 1e-8, no weight decay):
+same constructor call, `param_groups[i]['lr']` writable by the LR schedule, `zero_grad()`, `step()`.
+One sgan_adam_multi launch updates every parameter of the optimizer; the step counter and the LR
+live in device memory so that a captured hipGraph of the training step replays correctly."""
+import torch
+
+from . import ops
+from ._lib import SganError
+
+
+class FusedAdam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = list(params)
+        if not params:
+            raise ValueError("optimizer got an empty parameter list")
+        self.param_groups = [{"params": params, "lr": float(lr), "betas": tuple(betas), "eps": float(eps)}]
+        # map every parameter to its range in a network's flat storage and merge adjacent ranges
+        ranges = {}
+        for p in params:
+            seg = getattr(p, "_sgan_seg", None)
+            if seg is None:
+                raise SganError("FusedAdam only handles parameters of supervised_gan_amd networks "
+                                "(use torch.optim.Adam for foreign parameters)")
+            net, off, n = seg
+            ranges.setdefault(id(net), (net, []))[1].append((off, n))
+        self._segs = []   # (net, off, n)
+        for net, rs in ranges.values():
+            rs.sort()
+            cur_off, cur_n = rs[0]
+            for off, n in rs[1:]:
+                if off == cur_off + cur_n:
+                    cur_n += n
+                else:
+                    self._segs.append((net, cur_off, cur_n))
+                    cur_off, cur_n = off, n
+            self._segs.append((net, cur_off, cur_n))
+        self._state = None
+        self._lr_host = None
+
+    def _lazy_state(self):
+        if self._state is not None:
+            return
+        dev = self._segs[0][0]._flat.device
+        self._m = [torch.zeros(n, dtype=torch.float32, device=dev) for _, _, n in self._segs]
+        self._v = [torch.zeros(n, dtype=torch.float32, device=dev) for _, _, n in self._segs]
+        self._state = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def sync_lr(self):
+        """Push param_groups[0]['lr'] to the device scalar (call outside graph capture)."""
+        self._lazy_state()
+        lr = self.param_groups[0]["lr"]
+        if lr != self._lr_host:
+            self._lr_dev.fill_(lr)
+            self._lr_host = lr
+
+    def zero_grad(self, set_to_none=False):
+        for net, off, n in self._segs:
+            net._gflat[off: off + n].zero_()
+
+    def segments(self):
+        """[(params, grads)] flat views -- what the data-parallel all-reduce works on."""
+        return [(net._flat[off: off + n], net._gflat[off: off + n]) for net, off, n in self._segs]
+
+    @torch.no_grad()
+    def step(self):
+        self._lazy_state()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        g = self.param_groups[0]
+        segs = [(net._flat[off: off + n], net._gflat[off: off + n], m, v, n)
+                for (net, off, n), m, v in zip(self._segs, self._m, self._v)]
+        ops.adam_multi(segs, self._lr_dev, g["betas"][0], g["betas"][1], g["eps"], self._state)
+
+    @property
+    def step_count(self):
+        return int(self._state[0].item()) if self._state is not None else 0

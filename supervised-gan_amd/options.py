@@ -1,0 +1,140 @@
+"""Option surface of the reference (options/base_options.py:11-144, options/train_options.py:4-66,
+options/test_options.py) for the trainers on the MI355X path: same flag names, types, defaults and
+`nargs='+'` list flags, same `parse()` protocol (gpu_ids string -> list, opt.txt dump).  Flags that only
+steer out-of-scope subsystems (visdom, dataset folders) are accepted and ignored."""
+import argparse
+import os
+
+import torch
+
+
+class BaseOptions:
+    def __init__(self):
+        self.parser = argparse.ArgumentParser()
+        self.initialized = False
+        self.isTrain = False
+
+    def initialize(self):
+        a = self.parser.add_argument
+        a('--dataroot', default='synthetic', help='path to images, or "synthetic" (MI355X bench feeder)')
+        a('--batchSize', type=int, default=1)
+        a('--loadSize', type=int, default=286)
+        a('--fineSize', type=int, default=256)
+        a('--patchSize', type=int, default=70)
+        a('--input_nc', type=int, default=3)
+        a('--noise_nc', type=int, default=8)
+        a('--noiseSize', type=int, default=1)
+        a('--noiseSizeVal', type=int, default=1)
+        a('--output_nc', type=int, default=3)
+        a('--ngf', type=int, default=64)
+        a('--ndf', type=int, default=64)
+        a('--which_model_netD', type=str, default='basic')
+        a('--which_model_netG', type=str, default='resnet_9blocks')
+        a('--n_layers_D', type=int, default=[3], nargs='+')
+        a('--n_layers_G', type=int, default=5)
+        a('--scale_factor', type=int, default=[1], nargs='+')
+        a('--gpu_ids', type=str, default='0')
+        a('--name', type=str, default='experiment_name')
+        a('--dataset_mode', type=str, default='unaligned')
+        a('--model', type=str, default='cycle_gan')
+        a('--which_direction', type=str, default='AtoB')
+        a('--nThreads', default=2, type=int)
+        a('--checkpoints_dir', type=str, default='./checkpoints')
+        a('--norm', type=str, default='instance')
+        a('--serial_batches', action='store_true')
+        a('--display_winsize', type=int, default=256)
+        a('--display_id', type=int, default=1)
+        a('--display_port', type=int, default=8097)
+        a('--display_single_pane_ncols', type=int, default=0)
+        a('--identity', type=float, default=0.0)
+        a('--no_dropout', action='store_true')
+        a('--max_dataset_size', type=int, default=float("inf"))
+        a('--resize_or_crop', type=str, default='resize_and_crop')
+        a('--no_flip', action='store_true')
+        a('--no_rotate', action='store_true')
+        a('--use_residual', action='store_true')
+        a('--add_gaussian_noise', action='store_true')
+        a('--gaussian_sigma', type=float, default=0.1)
+        a('--which_channel', type=str, default='rg')
+        a('--manualSeed', type=int, default=None)
+        a('--display_title', type=str, default='loss over time')
+        a('--n_layers_G_skip', type=int, default=-1)
+        a('--weights', type=float, default=None, nargs='+')
+        a('--upsample_mode', type=str, default='convt')
+        a('--no_share_label_block_weights', action='store_true')
+        a('--n_layers_CRN_block', type=int, default=1)
+        a('--pretrained_model_dir', type=str, default='')
+        # MI355X path extras (not in the reference)
+        a('--skip_wasted_D_wgrad', action='store_true',
+          help='do not compute discriminator weight gradients during the G step (the reference computes and discards them)')
+        a('--hip_graph', action='store_true', help='capture the training step into hipGraphs')
+        self.initialized = True
+
+    def parse(self, args=None, save=True, verbose=True):
+        if not self.initialized:
+            self.initialize()
+        self.opt = self.parser.parse_args(args)
+        self.opt.isTrain = self.isTrain
+        str_ids = self.opt.gpu_ids.split(',')
+        self.opt.gpu_ids = [int(s) for s in str_ids if int(s) >= 0]
+        if len(self.opt.gpu_ids) > 0 and torch.cuda.is_available():
+            torch.cuda.set_device(self.opt.gpu_ids[0])
+        args_ = vars(self.opt)
+        if verbose:
+            print('------------ Options -------------')
+            for k, v in sorted(args_.items()):
+                print('%s: %s' % (str(k), str(v)))
+            print('-------------- End ----------------')
+        if save:
+            expr_dir = os.path.join(self.opt.checkpoints_dir, self.opt.name)
+            os.makedirs(expr_dir, exist_ok=True)
+            with open(os.path.join(expr_dir, 'opt.txt'), 'wt') as f:
+                f.write('------------ Options -------------\n')
+                for k, v in sorted(args_.items()):
+                    f.write('%s: %s\n' % (str(k), str(v)))
+                f.write('-------------- End ----------------\n')
+        return self.opt
+
+
+class TrainOptions(BaseOptions):
+    def initialize(self):
+        BaseOptions.initialize(self)
+        a = self.parser.add_argument
+        a('--display_freq', type=int, default=100)
+        a('--print_freq', type=int, default=100)
+        a('--save_latest_freq', type=int, default=5000)
+        a('--save_epoch_freq', type=int, default=5)
+        a('--continue_train', action='store_true')
+        a('--phase', type=str, default='train')
+        a('--which_epoch', type=str, default='latest')
+        a('--niter', type=int, default=100)
+        a('--niter_decay', type=int, default=100)
+        a('--beta1', type=float, default=0.5)
+        a('--lr', type=float, default=0.0002)
+        a('--no_lsgan', action='store_true')
+        a('--lambda_A', type=float, default=10.0)
+        a('--lambda_B', type=float, default=10.0)
+        a('--n_update_G', type=int, default=1)
+        a('--n_update_D', type=int, default=1)
+        a('--lambda_D', type=float, default=[1.0], nargs='+')
+        a('--pool_size', type=int, default=50)
+        a('--no_html', action='store_true')
+        a('--no_cgan', action='store_true')
+        a('--noise_pool_size', type=int, default=100)
+        a('--optimizer', type=str, default='adam')
+        a('--pool_reject_prob', type=float, default=0.5)
+        a('--no_logD_trick', action='store_true')
+        self.isTrain = True
+
+
+class TestOptions(BaseOptions):
+    def initialize(self):
+        BaseOptions.initialize(self)
+        a = self.parser.add_argument
+        a('--ntest', type=int, default=float("inf"))
+        a('--results_dir', type=str, default='./results/')
+        a('--aspect_ratio', type=float, default=1.0)
+        a('--phase', type=str, default='test')
+        a('--which_epoch', type=str, default='latest')
+        a('--how_many', type=int, default=50)
+        self.isTrain = False

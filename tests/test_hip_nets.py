@@ -1,0 +1,130 @@
+"""Network-level parity on the MI355X: the drop-in `define_G` / `define_D` modules against golden
+vectors produced by the real reference (tests/golden, see oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def N():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")
+    from supervised_gan_amd import _lib, networks
+    _lib.lib()
+    return networks
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def rel(a, b):
+    a = a.detach() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))
+    b = b.detach() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b))
+    return O.rel_err(a, b)
+
+
+def test_fcgan_g_small(N, golden_dir):
+    g = load(golden_dir, "fcgan_g_small.npz")
+    G = N.define_G(2, 0, 8, "fcgan", "instance", False, n_layers_G=5, use_fcn=True, noise_nc=8, gpu_ids=[0])
+    sd = O.init_fcgan_g(11, 8, 2, 8, 5)
+    G.load_state_dict(sd)
+    z = O.np_normal(101, (1, 8, 2, 2)).cuda().requires_grad_(True)
+    r = O.np_normal(102, (1, 2, 128, 128)).cuda()
+    y = G.forward(z)
+    assert y.shape == (1, 2, 128, 128)
+    (y * r).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, g["y"]) < TOL
+    assert rel(z.grad, g["dz"]) < TOL
+    params = dict(G.named_parameters())
+    undet = O.norm_cancelled_keys_g(5)
+    for k in g.files:
+        if k.startswith("grad/"):
+            name = k[5:]
+            if name in undet:
+                scale = np.abs(g["grad/" + name.replace(".bias", ".weight")]).max()
+                assert np.abs(params[name].grad.cpu().numpy() - g[k]).max() < TOL * scale, name
+            else:
+                assert rel(params[name].grad, g[k]) < TOL, name
+        if k.startswith("buf/"):
+            assert rel(G.state_dict()[k[4:]].double(), g[k].astype(np.float64)) < TOL, k
+
+
+@pytest.mark.parametrize("s", [1, 2, 4])
+def test_nlayer_d_small(N, golden_dir, s):
+    g = load(golden_dir, f"nlayer_d_small_s{s}.npz")
+    D = N.define_D(2, 8, "n_layers", n_layers_D=3, norm="instance", use_sigmoid=True, scale_factor=s, gpu_ids=[0])
+    D.load_state_dict(O.init_nlayer_d(20 + s, 2, 8, 3, s))
+    x = O.np_uniform(200 + s, (1, 2, 128, 128)).cuda().requires_grad_(True)
+    crit = N.GANLoss(use_lsgan=False)
+    p = D.forward(x)
+    assert p.shape == g["p"].shape
+    l_real = crit(p, True)
+    D.fuse_sigmoid_into_loss = True        # second call exercises the logits-tagged path
+    l_fake = crit(D.forward(x), False)
+    (l_real * 0.7 + l_fake * 0.3).backward()
+    torch.cuda.synchronize()
+    assert rel(p, g["p"]) < TOL
+    assert abs(float(l_real) - float(g["l_real"])) < 1e-4
+    assert abs(float(l_fake) - float(g["l_fake"])) < 1e-4
+    assert rel(x.grad, g["dx"]) < TOL
+    params = dict(D.named_parameters())
+    undet = O.norm_cancelled_keys_d(2, 8, 3)
+    for k in g.files:
+        if k.startswith("grad/"):
+            name = k[5:]
+            if name in undet:
+                scale = np.abs(g["grad/" + name.replace(".bias", ".weight")]).max()
+                assert np.abs(params[name].grad.cpu().numpy() - g[k]).max() < TOL * scale, name
+            else:
+                assert rel(params[name].grad, g[k]) < TOL, name
+
+
+def test_nlayer_d_n4_lsgan(N, golden_dir):
+    g = load(golden_dir, "nlayer_d_small_n4_lsgan.npz")
+    D = N.define_D(3, 8, "n_layers", n_layers_D=4, norm="instance", use_sigmoid=False, scale_factor=1, gpu_ids=[0])
+    D.load_state_dict(O.init_nlayer_d(29, 3, 8, 4, 1))
+    x = O.np_uniform(209, (1, 3, 128, 128)).cuda().requires_grad_(True)
+    p = D.forward(x)
+    loss = N.GANLoss(use_lsgan=True)(p, True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(p, g["p"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    assert rel(x.grad, g["dx"]) < TOL
+    params = dict(D.named_parameters())
+    assert rel(params["model.0.weight"].grad, g["grad/model.0.weight"]) < TOL
+    assert rel(params["model.11.weight"].grad, g["grad/model.11.weight"]) < TOL
+
+
+def test_skip_param_grads_and_grad_reattach(N):
+    """G-step mode (no discriminator weight gradients) and torch-style zero_grad(set_to_none=True)."""
+    D = N.define_D(2, 8, "n_layers", n_layers_D=3, norm="instance", use_sigmoid=True, scale_factor=2, gpu_ids=[0])
+    x = torch.rand(1, 2, 64, 64, device="cuda").requires_grad_(True)
+    crit = N.GANLoss(use_lsgan=False)
+    D.compute_param_grads = False
+    crit(D.forward(x), True).backward()
+    assert float(D._gflat.abs().max()) == 0.0 and x.grad is not None and float(x.grad.abs().max()) > 0
+    D.compute_param_grads = True
+    for p in D.model.parameters():
+        p.grad = None
+    crit(D.forward(x.detach()), True).backward()
+    g1 = D._gflat.clone()
+    assert all(p.grad is not None for p in D.model.parameters()) and float(g1.abs().max()) > 0
+    crit(D.forward(x.detach()), True).backward()       # accumulates like autograd does
+    assert O.rel_err(D._gflat, 2 * g1) < 1e-4
+
+
+def test_cpu_tensors_fail_loudly(N):
+    from supervised_gan_amd._lib import SganError
+    D = N.define_D(2, 8, "n_layers", n_layers_D=3, norm="instance", use_sigmoid=True)
+    with pytest.raises(SganError):
+        D.forward(torch.rand(1, 2, 64, 64))

@@ -1,0 +1,282 @@
+"""Per-kernel parity of libsgan_hip.so (through the C ABI) against plain PyTorch fp32 on CPU.
+Tolerance: max|a-b| / max|b| <= 1e-3 (north-star tolerance; observed values are ~1e-6)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+EXPECT = 2e-5     # what exact-fp32 MFMA accumulation should actually deliver
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")
+    from supervised_gan_amd import ops
+    from supervised_gan_amd import _lib
+    _lib.lib()   # raises if libsgan_hip.so is missing -- no fallback
+    return ops
+
+
+def _norm_act(x, norm, gamma, beta, act, slope):
+    if norm == "in":
+        x = F.instance_norm(x, eps=1e-5)
+    elif norm == "bn":
+        x = F.batch_norm(x, None, None, gamma, beta, training=True, eps=1e-5)
+    if act == 1:
+        x = F.relu(x)
+    elif act == 2:
+        x = F.leaky_relu(x, slope)
+    return x
+
+
+CASES = [
+    # kind, k, s, p, cin, cout, H, W, norm(in-side), act
+    ("conv", 4, 2, 2, 2, 32, 37, 41, None, 0),      # D first layer on an odd-sized 2-channel image
+    ("conv", 4, 2, 2, 32, 64, 33, 33, None, 2),     # D second layer (input = LReLU(conv0), no norm)
+    ("conv", 4, 2, 2, 64, 128, 17, 19, "in", 2),
+    ("conv", 4, 1, 2, 128, 256, 9, 11, "in", 2),    # stride-1 pad-2 (H+1 outputs)
+    ("conv", 4, 1, 2, 256, 1, 10, 12, "in", 2),     # logits head: Cout = 1
+    ("convT", 4, 2, 1, 8, 64, 4, 4, None, 0),       # G first layer (latent input)
+    ("convT", 4, 2, 1, 64, 32, 9, 7, "bn", 1),      # BN(gamma,beta)+ReLU on load
+    ("convT", 4, 2, 1, 32, 2, 16, 16, "bn", 1),     # G last layer: Cout = 2
+    ("conv", 3, 1, 1, 10, 64, 8, 8, None, 0),       # CRN-style k3 with 10 (padded to 12) channels
+    ("conv", 4, 2, 1, 64, 128, 16, 16, "in", 2),    # unet down
+    ("conv", 4, 2, 2, 3, 64, 64, 64, None, 0),      # cgan D first layer (3 channels)
+    ("conv", 4, 2, 2, 64, 128, 129, 129, "in", 2),  # > 1 split, odd
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}_k{c[1]}s{c[2]}p{c[3]}_{c[4]}to{c[5]}_{c[6]}x{c[7]}_{c[8]}" for c in CASES])
+def test_conv_layer_fwd_bwd(hip, case):
+    from hip_utils import from_buf, from_master, master_weight, pad_vec, rel, stats_of, to_buf
+    from supervised_gan_amd.ops import pad4
+    ops = hip
+    kind, k, s, p, cin, cout, H, W, norm, act = case
+    tr = kind == "convT"
+    g = torch.Generator().manual_seed(1000 + CASES.index(case))
+    x = (torch.randn(1, cin, H, W, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = (torch.randn(*wshape, generator=g) * 0.05).requires_grad_(True)
+    b = (torch.randn(cout, generator=g) * 0.1).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(cin, generator=g)).requires_grad_(True) if norm == "bn" else None
+    beta = (0.1 * torch.randn(cin, generator=g)).requires_grad_(True) if norm == "bn" else None
+    slope = 0.2
+
+    a = _norm_act(x, norm, gamma, beta, act, slope)
+    out = F.conv_transpose2d(a, w, b, stride=s, padding=p) if tr else F.conv2d(a, w, b, stride=s, padding=p)
+    R = torch.randn(out.shape, generator=g)
+    (out * R).sum().backward()
+    Ho, Wo = out.shape[2:]
+
+    desc = ops.conv_desc(1 if tr else 0, k, s, p, H, W, pad4(cin), Ho, Wo, pad4(cout))
+    xb = to_buf(x.detach())
+    wm = master_weight(w.detach(), tr)
+    bb = pad_vec(b.detach())
+    st_in = stats_of(x.detach()) if norm else None
+    gam = pad_vec(gamma.detach()) if gamma is not None else None
+    bet = pad_vec(beta.detach()) if beta is not None else None
+    in_norm = ops.norm_desc(st_in, gam, bet, H * W, 1e-5, act, slope)
+
+    # ---- forward (+ output statistics) ----
+    ob = torch.full((Ho, Wo, pad4(cout)), float("nan"), device="cuda")
+    ost = torch.zeros(2 * pad4(cout), dtype=torch.float64, device="cuda")
+    ops.conv_fwd(desc, xb, in_norm, wm, bb, ob, 0, ost)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ob).all()
+    e = rel(from_buf(ob, cout), out)
+    assert e < TOL, e
+    assert e < EXPECT * 10, e
+    ref_st = stats_of(out.detach(), "cpu")
+    assert rel(ost, ref_st) < 1e-4
+    if pad4(cout) != cout:
+        assert float(ob[..., cout:].abs().max()) == 0.0     # padded channels stay exactly zero
+
+    # ---- backward data (+ act', norm sums) then norm backward ----
+    Rb = to_buf(R)
+    din = torch.full((H, W, pad4(cin)), float("nan"), device="cuda")
+    sums = torch.zeros(2 * pad4(cin), dtype=torch.float64, device="cuda") if norm else None
+    ops.conv_dgrad(desc, Rb, wm, din, xb, in_norm, sums)
+    dgam = torch.zeros(pad4(cin), device="cuda") if norm == "bn" else None
+    dbet = torch.zeros(pad4(cin), device="cuda") if norm == "bn" else None
+    if norm:
+        ops.norm_bwd_apply(din, xb, in_norm, sums, dgam, dbet)
+    torch.cuda.synchronize()
+    e = rel(from_buf(din, cin), x.grad)
+    assert e < TOL, e
+    if norm == "bn":
+        assert rel(dgam[:cin], gamma.grad) < TOL
+        assert rel(dbet[:cin], beta.grad) < TOL
+
+    # ---- backward weight / bias (accumulating) ----
+    dw = torch.zeros_like(wm)
+    db = torch.zeros_like(bb)
+    ops.conv_wgrad(desc, xb, in_norm, Rb, dw, db)
+    torch.cuda.synchronize()
+    e = rel(from_master(dw, k, cin, cout, tr), w.grad)
+    assert e < TOL, e
+    assert rel(db[:cout], b.grad) < TOL
+    # accumulate semantics: a second call doubles
+    ops.conv_wgrad(desc, xb, in_norm, Rb, dw, db)
+    torch.cuda.synchronize()
+    assert rel(from_master(dw, k, cin, cout, tr), 2 * w.grad) < TOL
+
+
+def test_conv_plain_dgrad_and_tanh(hip):
+    """dgrad without a forward tensor (image gradient) and the tanh epilogue / tanh backward."""
+    from hip_utils import from_buf, master_weight, rel, to_buf
+    from supervised_gan_amd.ops import pad4
+    ops = hip
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 2, 21, 23, generator=g, requires_grad=True)
+    w = (torch.randn(16, 2, 4, 4, generator=g) * 0.1)
+    out = torch.tanh(F.conv2d(x, w, None, stride=2, padding=2))
+    R = torch.randn(out.shape, generator=g)
+    (out * R).sum().backward()
+    Ho, Wo = out.shape[2:]
+    desc = ops.conv_desc(0, 4, 2, 2, 21, 23, 4, Ho, Wo, 16)
+    xb, wm = to_buf(x.detach()), master_weight(w, False)
+    ob = torch.empty(Ho, Wo, 16, device="cuda")
+    ops.conv_fwd(desc, xb, None, wm, None, ob, 3, None)
+    assert rel(from_buf(ob, 16), out) < 1e-5
+    d = torch.empty_like(ob)
+    ops.tanh_bwd(to_buf(R), ob, d)
+    dx = torch.empty(21, 23, 4, device="cuda")
+    ops.conv_dgrad(desc, d, wm, dx, None, None, None)
+    torch.cuda.synchronize()
+    assert rel(from_buf(dx, 2), x.grad) < 1e-4
+    assert float(dx[..., 2:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("s,nc", [(2, 2), (4, 2), (2, 3)])
+def test_gauss_down(hip, s, nc):
+    import sgan_oracle as O
+    from hip_utils import from_buf, rel, to_buf
+    ops = hip
+    H = W = 64 + s
+    x = torch.randn(1, nc, H, W, requires_grad=True)
+    wg = O.gauss_filter_weight(nc, s)
+    y = O.gauss_down(x, wg, s)
+    R = torch.randn_like(y)
+    (y * R).sum().backward()
+    kg, padg = 4 * (s // 2) + 1, 2 * (s // 2)
+    Ho, Wo = y.shape[2:]
+    xb = to_buf(x.detach())
+    out = torch.empty(Ho, Wo, 4, device="cuda")
+    wgd = wg.cuda()
+    ops.gauss_down_fwd(xb, nc, wgd, (nc + 1) * kg * kg, kg, padg, s, out)
+    din = torch.empty(H, W, 4, device="cuda")
+    ops.gauss_down_bwd(to_buf(R), nc, wgd, (nc + 1) * kg * kg, kg, padg, s, din)
+    torch.cuda.synchronize()
+    assert rel(from_buf(out, nc), y) < 1e-5
+    assert rel(from_buf(din, nc), x.grad) < 1e-5
+    assert float(out[..., nc:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode,target", [(0, 1.0), (0, 0.0), (1, 1.0), (1, 0.0)])
+def test_gan_loss(hip, mode, target):
+    from hip_utils import from_buf, rel, to_buf
+    ops = hip
+    x = (torch.randn(1, 1, 67, 67) * 3).requires_grad_(True)
+    x.data[0, 0, 0, :4] = torch.tensor([-120.0, 120.0, -30.0, 30.0])    # exercise the -100 clamp / saturation
+    t = torch.full_like(x, target)
+    loss = F.binary_cross_entropy(torch.sigmoid(x), t) if mode == 0 else F.mse_loss(x, t)
+    (loss * 0.37).backward()
+    xb = to_buf(x.detach())
+    lo = torch.zeros((), device="cuda")
+    ops.gan_loss_fwd(xb, target, mode, lo)
+    d = torch.empty_like(xb)
+    ops.gan_loss_bwd(xb, target, mode, torch.tensor(0.37, device="cuda"), d)
+    torch.cuda.synchronize()
+    assert abs(float(lo) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    assert rel(from_buf(d, 1), x.grad) < 1e-5
+    assert float(d[..., 1:].abs().max()) == 0.0
+
+
+def test_sigmoid_and_layout(hip):
+    from hip_utils import from_buf, rel, to_buf
+    ops = hip
+    x = torch.randn(1, 1, 19, 19, requires_grad=True)
+    p = torch.sigmoid(x)
+    R = torch.randn_like(p)
+    (p * R).sum().backward()
+    xb = to_buf(x.detach())
+    pb = torch.empty_like(xb)
+    ops.sigmoid_fwd(xb, pb)
+    dx = torch.empty_like(xb)
+    ops.sigmoid_bwd(to_buf(R), pb, dx)
+    assert rel(from_buf(pb, 1), p) < 1e-6 and rel(from_buf(dx, 1), x.grad) < 1e-5
+    # layout boundary: arbitrary strides -> padded NHWC; registered views come back zero-copy
+    t = torch.randn(1, 3, 9, 11, device="cuda")
+    nb = ops.as_nhwc(t)
+    assert nb.shape == (9, 11, 4) and torch.equal(nb[..., :3], t[0].permute(1, 2, 0)) and float(nb[..., 3].abs().max()) == 0
+    v = ops.logical_view(nb, 3)
+    assert torch.equal(v, t)
+    assert ops.as_nhwc(v).data_ptr() == nb.data_ptr()
+    assert ops.as_nhwc(v.detach()).data_ptr() == nb.data_ptr()
+    assert ops.as_nhwc(t.permute(0, 1, 3, 2)).shape == (11, 9, 4)
+
+
+def test_adam_matches_reference_form(hip):
+    import sgan_oracle as O
+    ops = hip
+    n = 10007 * 4
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = O.Adam([ref_p], lr=2e-4, beta1=0.5)
+    p = p0.clone().cuda()
+    gr = torch.zeros(n, device="cuda")
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    state = torch.zeros(4, dtype=torch.int32, device="cuda")
+    lr = torch.full((1,), 2e-4, device="cuda")
+    for step in range(5):
+        grad = torch.randn(n, generator=g) * (10.0 ** (step - 3))
+        ref_p.grad = grad.clone()
+        opt.step()
+        gr.copy_(grad)
+        ops.adam_multi([(p, gr, m, v, n)], lr, 0.5, 0.999, 1e-8, state)
+    torch.cuda.synchronize()
+    assert int(state[0]) == 5
+    assert float((p.cpu() - ref_p.detach()).abs().max()) < 1e-6
+    assert float((m.cpu() - opt.m[0]).abs().max()) < 1e-6 * float(opt.m[0].abs().max()) + 1e-12
+
+
+def test_bn_running_update(hip):
+    from hip_utils import stats_of
+    ops = hip
+    x = torch.randn(1, 8, 16, 16) * 2 + 1
+    rm, rv = torch.zeros(8), torch.ones(8)
+    F.batch_norm(x, rm, rv, None, None, training=True, momentum=0.1)
+    st = stats_of(x)
+    rmd, rvd = torch.zeros(8, device="cuda"), torch.ones(8, device="cuda")
+    nbt = torch.zeros((), dtype=torch.long, device="cuda")
+    ops.bn_running_update([(st, rmd, rvd, nbt, 8, 256)], 0.1)
+    torch.cuda.synchronize()
+    assert float((rmd.cpu() - rm).abs().max()) < 1e-6 and float((rvd.cpu() - rv).abs().max()) < 1e-5
+    assert int(nbt) == 1
+
+
+def test_normal_fill_moments_and_counter(hip):
+    ops = hip
+    n = 1 << 20
+    a = torch.empty(n, device="cuda")
+    b = torch.empty(n, device="cuda")
+    off = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.normal_fill(a, 123, off)
+    ops.normal_fill(b, 123, off)
+    torch.cuda.synchronize()
+    assert int(off) == 2 * (n // 4)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    assert abs(float((a * b).mean())) < 5e-3          # the two draws are independent
+    k = float(((a - a.mean()) ** 4).mean() / a.var() ** 2)
+    assert abs(k - 3.0) < 0.05
+    c = torch.empty(n, device="cuda")
+    ops.normal_fill(c, 123, None)
+    assert torch.equal(a, c)                           # counter-based: same (seed, offset) -> same numbers

@@ -1,0 +1,130 @@
+"""Whole-training-step parity on the MI355X for BASELINE configs[1] (fcgan: deconv G + 3 PatchGAN D,
+512x512, bs 1) against the reference's golden step and against the CPU oracle.
+
+The strict gate is step 1 BEFORE the optimizer acts (fake, the three losses, every gradient) plus the
+Adam kernel on its own (test_hip_ops); the multi-step trajectory is only compared through the losses,
+because the reference's trajectory is chaotic (see tests/test_oracle_golden.py::test_fcgan_step)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sgan_oracle as O
+from test_oracle_golden import check_step1, real_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def build_model(cfg, n_init_draws, extra=()):
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")
+    from supervised_gan_amd.fcgan_model import FCGANModel
+    from supervised_gan_amd.options import TrainOptions
+    argv = ["--name", "t", "--model", "fcgan", "--which_direction", "A", "--fineSize", str(cfg.fineSize),
+            "--input_nc", str(cfg.input_nc), "--which_model_netG", "deconv", "--n_layers_G", str(cfg.n_layers_G),
+            "--ngf", str(cfg.ngf), "--which_model_netD", "n_layers", "--n_layers_D", *map(str, cfg.n_layers_D),
+            "--ndf", str(cfg.ndf), "--scale_factor", *map(str, cfg.scale_factor), "--lambda_D", *map(str, cfg.lambda_D),
+            "--noise_nc", str(cfg.noise_nc), "--noiseSize", str(cfg.noiseSize), "--norm", "instance", "--no_dropout",
+            "--n_update_G", str(cfg.n_update_G), "--no_lsgan", "--which_channel", "rg", "--gpu_ids", "0",
+            "--checkpoints_dir", "/tmp/sgan_ckpt", *extra]
+    opt = TrainOptions().parse(argv, save=False, verbose=False)
+    m = FCGANModel()
+    m.initialize(opt)
+    m.netG.load_state_dict(O.init_fcgan_g(1, cfg.noise_nc, cfg.input_nc, cfg.ngf, cfg.n_layers_G))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D, cfg.scale_factor)):
+        m.netD[i].load_state_dict(O.init_nlayer_d(2 + i, cfg.input_nc, cfg.ndf, nl, sf))
+    zshape = (1, cfg.noise_nc, cfg.noiseSize, cfg.noiseSize)
+    ctr = {"i": n_init_draws}
+
+    def src():
+        z = O.np_normal(5000 + ctr["i"], zshape)
+        ctr["i"] += 1
+        return z
+    m.noise_source = src
+    return m
+
+
+def step1_with_captures(m, real3):
+    c = m.opt
+    cap = {}
+    m.set_input({"A": real3, "A_paths": ["synthetic"]})
+    m.forward()
+    cap["fake"] = m.fake.detach().cpu().clone()
+    m.optimizer_D.zero_grad()
+    m.backward_D()
+    cap["gradD"] = [{k: p.grad.detach().cpu().clone() for k, p in d.named_parameters() if k.startswith("model.")}
+                    for d in m.netD]
+    cap["loss_D"] = [float(m.loss_D_real), float(m.loss_D_fake)]
+    m.optimizer_D.step()
+    for it in range(c.n_update_G):
+        m.optimizer_G.zero_grad()
+        m.backward_G()
+        if it == 0:
+            cap["gradG"] = {k: p.grad.detach().cpu().clone() for k, p in m.netG.named_parameters()}
+            cap["loss_G"] = float(m.loss_G)
+        m.optimizer_G.step()
+        if c.n_update_G > 1:
+            m.sample_noise()
+    return cap
+
+
+def real3(cfg, step):
+    return O.np_uniform(7000 + step, (1, 3, cfg.fineSize, cfg.fineSize))
+
+
+@pytest.mark.parametrize("name,kw,extra", [
+    ("fcgan_step_small.npz", dict(ngf=8, ndf=8, noiseSize=2, n_update_G=2), ()),
+    ("fcgan_step_full.npz", dict(n_update_G=2), ()),                           # BASELINE configs[1] shape, fp32
+    ("fcgan_step_full_nug1.npz", dict(n_update_G=1), ()),
+    ("fcgan_step_full.npz", dict(n_update_G=2), ("--skip_wasted_D_wgrad",)),   # same results without the wasted wgrads
+])
+def test_fcgan_step_vs_reference_golden(golden_dir, name, kw, extra):
+    g = np.load(os.path.join(golden_dir, name))
+    cfg = O.FCGANConfig(**kw)
+    m = build_model(cfg, int(g["n_init_noise_draws"]), extra)
+    cap = step1_with_captures(m, real3(cfg, 0))
+    torch.cuda.synchronize()
+    check_step1(cap, g, cfg, tol=1e-3)
+    losses = [list(m.get_current_errors().values())]
+    for step in range(1, g["losses"].shape[0]):
+        m.set_input({"A": real3(cfg, step), "A_paths": ["synthetic"]})
+        m.optimize_parameters()
+        losses.append(list(m.get_current_errors().values()))
+    # trajectory: losses only, at the spread two CPU runs of the reference itself show (~1e-2 by step 3)
+    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2, (losses, g["losses"])
+    assert m.optimizer_D.step_count == g["losses"].shape[0]
+    assert m.optimizer_G.step_count == g["losses"].shape[0] * cfg.n_update_G
+
+
+def test_checkpoint_roundtrip_with_oracle(tmp_path):
+    """save() writes the reference's file names / keys / shapes; the CPU oracle (a restatement of the
+    reference nets) consumes them directly and reproduces the HIP forward."""
+    cfg = O.FCGANConfig(ngf=8, ndf=8, noiseSize=2)
+    m = build_model(cfg, 0)
+    m.opt.checkpoints_dir = str(tmp_path)
+    m.save_dir = str(tmp_path / "t")
+    m.save("latest")
+    files = sorted(os.listdir(m.save_dir))
+    assert files == ["latest_net_D_0.pth", "latest_net_D_1.pth", "latest_net_D_2.pth", "latest_net_G.pth"]
+    sdG = torch.load(os.path.join(m.save_dir, "latest_net_G.pth"))
+    ref = O.init_fcgan_g(1, 8, 2, 8, 5)
+    assert list(sdG.keys()) == list(ref.keys())
+    for k in ref:
+        assert sdG[k].shape == ref[k].shape and sdG[k].device.type == "cpu" and sdG[k].is_contiguous()
+        assert torch.equal(sdG[k], ref[k].detach()), k
+    z = O.np_normal(77, (1, 8, 2, 2))
+    y_ref = O.fcgan_g_forward({k: v.clone() for k, v in sdG.items()}, z, 5)
+    y = m.netG.forward(z.cuda())
+    assert O.rel_err(y, y_ref) < 1e-3
+    sdD = torch.load(os.path.join(m.save_dir, "latest_net_D_2.pth"))
+    assert set(sdD.keys()) == set(O.init_nlayer_d(4, 2, 8, 3, 4).keys())
+    x = O.np_uniform(78, (1, 2, 128, 128))
+    p_ref = O.nlayer_d_forward(sdD, x, 3, 4, True)
+    m.netD[2].fuse_sigmoid_into_loss = False
+    assert O.rel_err(m.netD[2].forward(x.cuda()), p_ref) < 1e-3
+    # and back: load into a fresh model (old-torch style extras tolerated)
+    from supervised_gan_amd.base_model import load_state_dict_compat
+    sdD["model.3.running_mean"] = torch.zeros(16)
+    sdD["model.3.running_var"] = torch.ones(16)
+    load_state_dict_compat(m.netD[2], sdD)

@@ -255,6 +255,20 @@ def golden_step(name, cfg: O.FCGANConfig, seed: int, nsteps: int, full_params: b
                 losses.append([float(model.loss_G), float(model.loss_D_real), float(model.loss_D_fake)])
             arrs["losses"] = np.asarray(losses, dtype=np.float64)
             arrs["n_noise_draws"] = np.int64(inj.n)
+        # probe: G-step gradients through the INITIAL discriminators (fresh model, same seeds, the
+        # reference's own forward() + backward_G()).  Step 1's real G step runs after D's first Adam
+        # update, which is sign(g)-like and therefore not reproducible to 1e-3 even by the reference.
+        with NoiseInjector(zshape, 5000):
+            probe = build_ref_fcgan(cfg, seed, tmp)
+            probe.set_input({"A": O.np_uniform(7000, (1, 3, cfg.fineSize, cfg.fineSize)), "A_paths": ["synthetic"]})
+            probe.forward()
+            probe.optimizer_G.zero_grad()
+            probe.optimizer_D.zero_grad()
+            probe.backward_G()
+            capture_grads(arrs, "probeG/gradG", probe.netG)
+            for i, d in enumerate(probe.netD):
+                capture_grads(arrs, f"probeG/gradD_{i}", d)      # the "wasted" D gradients of the G step
+            arrs["probeG/loss_G"] = np.float64(float(probe.loss_G))
         nets = {"G": model.netG}
         for i, d in enumerate(model.netD):
             nets[f"D_{i}"] = d

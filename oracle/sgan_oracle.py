@@ -391,6 +391,17 @@ class FCGANOracle:
                 self.forward()
         return cap
 
+    def probe_G(self, real):
+        """forward() + backward_G() on the initial weights (capture point 'probeG' of make_golden.py)."""
+        self.real = real
+        self.forward()
+        self.opt_G.zero_grad()
+        self.opt_D.zero_grad()
+        self.backward_G()
+        return {"gradG": {k: v.grad.detach().clone() for k, v in self.G.items() if v.grad is not None},
+                "gradD": [{k: v.grad.detach().clone() for k, v in d.items() if k.startswith("model.")} for d in self.D],
+                "loss_G": float(self.loss_G.detach())}
+
     def losses(self):
         return {"G_GAN": float(self.loss_G.detach()), "D_real": float(self.loss_D_real.detach()),
                 "D_fake": float(self.loss_D_fake.detach())}

@@ -236,8 +236,15 @@ __global__ __launch_bounds__(256) void sg_gan_loss_bwd_kernel(const float* logit
     for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
         const float x = logits[(int64_t)i * ld];
         float d;
-        if (mode == 0) d = (sg_sigmoid(x) - target) * go;
-        else d = 2.f * (x - target) * go;
+        if (mode == 0) {
+            // torch: dL/dp = (p - t) / max((1 - p) * p, 1e-12), then sigmoid' = p (1 - p).  Identical to
+            // (p - t) except where p(1-p) underflows below the clamp (|x| > ~27), where it decays to 0.
+            const float p = sg_sigmoid(x);
+            const float pq = (1.f - p) * p;
+            d = (p - target) / fmaxf(pq, 1e-12f) * go * pq;
+        } else {
+            d = 2.f * (x - target) * go;
+        }
         float* o = dlogits + (int64_t)i * dld;
         o[0] = d;
         for (int c = 1; c < dld; ++c) o[c] = 0.f;

@@ -280,3 +280,47 @@ def test_normal_fill_moments_and_counter(hip):
     c = torch.empty(n, device="cuda")
     ops.normal_fill(c, 123, None)
     assert torch.equal(a, c)                           # counter-based: same (seed, offset) -> same numbers
+
+
+# BASELINE configs[1] layer shapes (fcgan: deconv G ngf 32 on an 8x8x8 latent, PatchGAN D ndf 32 on 2x512x512)
+FULL_LAYERS = [
+    ("convT", 4, 2, 1, 8, 256, 8), ("convT", 4, 2, 1, 256, 256, 16), ("convT", 4, 2, 1, 256, 128, 32),
+    ("convT", 4, 2, 1, 128, 64, 64), ("convT", 4, 2, 1, 64, 32, 128), ("convT", 4, 2, 1, 32, 2, 256),
+    ("conv", 4, 2, 2, 2, 32, 512), ("conv", 4, 2, 2, 32, 64, 257), ("conv", 4, 2, 2, 64, 128, 129),
+    ("conv", 4, 1, 2, 128, 256, 65), ("conv", 4, 1, 2, 256, 1, 66),
+]
+
+
+@pytest.mark.parametrize("layer", FULL_LAYERS, ids=[f"{l[0]}_{l[4]}to{l[5]}_{l[6]}" for l in FULL_LAYERS])
+def test_full_size_adjoint_identities(hip, layer):
+    """Size-independent property at the full BASELINE shapes: the three kernels are exact transposes of
+    one another,  <conv(x; w), r>  ==  <x, dgrad(r; w)>  ==  <w, wgrad(x, r)>  (bilinear, no activation
+    kinks involved), and the bias gradient is the pixel sum of r."""
+    from supervised_gan_amd.ops import pad4
+    ops = hip
+    kind, k, s, p, cin, cout, H = layer
+    tr = kind == "convT"
+    Ho = (H - 1) * s - 2 * p + k if tr else (H + 2 * p - k) // s + 1
+    cs_i, cs_o = pad4(cin), pad4(cout)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.zeros(H, H, cs_i, device="cuda")
+    x[..., :cin] = torch.randn(H, H, cin, device="cuda", generator=g)
+    w = torch.zeros(k * k, cs_o, cs_i, device="cuda")
+    w[:, :cout, :cin] = torch.randn(k * k, cout, cin, device="cuda", generator=g) * 0.05
+    r = torch.zeros(Ho, Ho, cs_o, device="cuda")
+    r[..., :cout] = torch.randn(Ho, Ho, cout, device="cuda", generator=g)
+    desc = ops.conv_desc(1 if tr else 0, k, s, p, H, H, cs_i, Ho, Ho, cs_o)
+    y = torch.empty(Ho, Ho, cs_o, device="cuda")
+    ops.conv_fwd(desc, x, None, w.view(-1), None, y, 0, None)
+    dx = torch.empty(H, H, cs_i, device="cuda")
+    ops.conv_dgrad(desc, r, w.view(-1), dx, None, None, None)
+    dw = torch.zeros_like(w)
+    db = torch.zeros(cs_o, device="cuda")
+    ops.conv_wgrad(desc, x, None, r, dw.view(-1), db)
+    torch.cuda.synchronize()
+    a = float((y.double() * r.double()).sum())
+    b = float((x.double() * dx.double()).sum())
+    c = float((w.double() * dw.double()).sum())
+    scale = float(y.double().norm() * r.double().norm())
+    assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+    assert float((db.double() - r.double().sum((0, 1))).abs().max()) <= 1e-4 * float(r.double().abs().sum((0, 1)).max())

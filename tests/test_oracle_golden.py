@@ -119,34 +119,64 @@ def real_batch(cfg, step):
     return O.np_uniform(7000 + step, (1, 3, cfg.fineSize, cfg.fineSize))[:, :2].contiguous()
 
 
-def check_grad(name, grad, g, prefix, scale_key=None, tol=TOL):
-    """grad vs golden summary + strided sample; error measured against max|grad| of the tensor
-    (or of `scale_key`'s tensor for analytically-zero gradients)."""
+def grad_errors(grad, g, prefix, name, scale_key=None):
+    """(max-abs error / scale, relative L2 error) of `grad` against the golden strided sample.  scale =
+    max|grad| of the golden tensor, or of `scale_key`'s tensor for analytically-zero gradients."""
     ref_sum = g[f"{prefix}/summary/{name}"]
     ref_smp = g[f"{prefix}/sample/{name}"]
     scale = g[f"{prefix}/summary/{scale_key}"][1] if scale_key else ref_sum[1]
-    flat = grad.detach().reshape(-1)
+    flat = grad.detach().reshape(-1).cpu()
     smp = flat[torch.from_numpy(O.grad_sample_idx(flat.numel()))].double().numpy()
-    assert np.abs(smp - ref_smp).max() <= tol * scale + 1e-12, (prefix, name, np.abs(smp - ref_smp).max(), scale)
-    if not scale_key:
-        s = O.tensor_summary(flat)
-        assert abs(s[1] - ref_sum[1]) <= tol * scale, (prefix, name, s, ref_sum)
-        assert abs(s[2] - ref_sum[2]) <= tol * ref_sum[2] + 1e-12, (prefix, name, s, ref_sum)
+    e_max = np.abs(smp - ref_smp).max() / (scale + 1e-30)
+    e_l2 = np.linalg.norm(smp - ref_smp) / (np.linalg.norm(ref_smp) + 1e-30)
+    return float(e_max), float(e_l2)
 
 
-def check_step1(cap, g, cfg, tol=TOL):
+def check_grads(grads, g, prefix, undet, tol=TOL, robust=False, tally=None):
+    """strict: every tensor within tol (max-abs / max|g|).  robust (full-size GPU runs): a ReLU/LeakyReLU
+    input within ~1e-7 of zero makes the reference's own gradient jump by O(1e-2) in one channel, and two
+    fp32 implementations cannot agree on such a sign (27 M activations per 512x512 step => a couple per
+    step); so every tensor must be within 2e-2 in relative L2 and `tally` records how many also meet the
+    strict bound ('What parity means')."""
+    for k, v in grads.items():
+        if f"{prefix}/summary/{k}" not in g.files:
+            continue
+        if k in undet:   # analytically zero: compare on the scale of the same layer's weight gradient
+            e_max, _ = grad_errors(v, g, prefix, k, k.replace(".bias", ".weight"))
+            assert e_max <= (2e-2 if robust else tol), (prefix, k, e_max)
+            continue
+        e_max, e_l2 = grad_errors(v, g, prefix, k)
+        if tally is not None:
+            tally.append((prefix, k, e_max, e_l2))
+        if robust:
+            assert e_l2 <= 2e-2, (prefix, k, e_max, e_l2)
+        else:
+            assert e_max <= tol, (prefix, k, e_max, e_l2)
+
+
+def check_forward(cap, g, tol=TOL):
     assert rel(cap["fake"][:, :, :64, :64], g["step1/fake_crop"]) < tol
     fs = O.tensor_summary(cap["fake"])
     assert abs(fs[2] - g["step1/fake_summary"][2]) <= tol * g["step1/fake_summary"][2]
     assert np.abs(np.asarray(cap["loss_D"]) - g["step1/loss_D"]).max() < tol
-    assert abs(cap["loss_G"] - float(g["step1/loss_G"])) < tol
+
+
+def check_step1(cap, g, cfg, tol=TOL, robust=False, tally=None, check_gradG=True):
+    check_forward(cap, g, tol)
     for i, gd in enumerate(cap["gradD"]):
-        undet = O.norm_cancelled_keys_d(cfg.input_nc, cfg.ndf, cfg.n_layers_D[i])
-        for k, v in gd.items():
-            check_grad(k, v, g, f"step1/gradD_{i}", k.replace(".bias", ".weight") if k in undet else None, tol)
-    undet = O.norm_cancelled_keys_g(cfg.n_layers_G)
-    for k, v in cap["gradG"].items():
-        check_grad(k, v, g, "step1/gradG", k.replace(".bias", ".weight") if k in undet else None, tol)
+        check_grads(gd, g, f"step1/gradD_{i}", O.norm_cancelled_keys_d(cfg.input_nc, cfg.ndf, cfg.n_layers_D[i]),
+                    tol, robust, tally)
+    if check_gradG:   # taken after D's first Adam update: only reproducible by bit-identical arithmetic
+        assert abs(cap["loss_G"] - float(g["step1/loss_G"])) < tol
+        check_grads(cap["gradG"], g, "step1/gradG", O.norm_cancelled_keys_g(cfg.n_layers_G), tol, robust, tally)
+
+
+def check_probe(pr, g, cfg, tol=TOL, robust=False, tally=None):
+    assert abs(pr["loss_G"] - float(g["probeG/loss_G"])) < tol
+    check_grads(pr["gradG"], g, "probeG/gradG", O.norm_cancelled_keys_g(cfg.n_layers_G), tol, robust, tally)
+    for i, gd in enumerate(pr["gradD"]):
+        check_grads(gd, g, f"probeG/gradD_{i}", O.norm_cancelled_keys_d(cfg.input_nc, cfg.ndf, cfg.n_layers_D[i]),
+                    tol, robust, tally)
 
 
 @pytest.mark.parametrize("name,kw", [
@@ -162,6 +192,8 @@ def test_fcgan_step(golden_dir, name, kw):
     g = load(golden_dir, name)
     cfg = O.FCGANConfig(**kw)
     m = make_oracle(cfg, int(g["n_init_noise_draws"]))
+    pr = make_oracle(cfg, int(g["n_init_noise_draws"])).probe_G(real_batch(cfg, 0))
+    check_probe(pr, g, cfg, tol=1e-4)
     cap = m.step1_with_captures(real_batch(cfg, 0))
     check_step1(cap, g, cfg, tol=1e-4)
     losses = [list(m.losses().values())]

@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fcgan training-step images/sec (deconv G + 3x PatchGAN D, 512x512, bs=1/GPU)
+on N MI355X, with the dominant kernel's roofline fraction and a CPU baseline timed in the same run.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = FCGANModel.optimize_parameters() of the README fcgan recipe (README.md:33: n_update_D=1,
+n_update_G=2, pool_size=50) on one synthetic 2x512x512 batch that is already resident in HBM.
+Rank 0 prints ONE JSON line (contract in the task statement / DESIGN.md section "Measurement")."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# SURVEY 8(d) / BASELINE.md section 3: conv MACs per forward pass of the reference nets
+GMAC_G, GMAC_D = 1.9483, 4.7386
+
+
+def flops_per_image(n_update_G):
+    g_f, g_b, d_f, d_b = (3, 2, 4, 4) if n_update_G == 2 else (1, 1, 3, 3)
+    return 2.0 * 1e9 * (g_f * GMAC_G + 2 * g_b * GMAC_G + d_f * GMAC_D + 2 * d_b * GMAC_D)
+
+
+def build_model(args, rank):
+    from supervised_gan_amd.fcgan_model import FCGANModel
+    from supervised_gan_amd.options import TrainOptions
+    argv = ["--name", "bench", "--model", "fcgan", "--which_direction", "A", "--dataset_mode", "single",
+            "--loadSize", "512", "--fineSize", "512", "--batchSize", "1", "--input_nc", "2",
+            "--which_model_netG", "deconv", "--n_layers_G", "5", "--ngf", "32", "--which_model_netD", "n_layers",
+            "--n_layers_D", "3", "3", "3", "--ndf", "32", "--scale_factor", "1", "2", "4",
+            "--lambda_D", "0.5", "0.4", "0.1", "--noise_nc", "8", "--noiseSize", "8", "--norm", "instance",
+            "--no_dropout", "--n_update_G", str(args.n_update_G), "--no_lsgan", "--which_channel", "rg",
+            "--manualSeed", str(rank), "--gpu_ids", str(torch.cuda.current_device()),
+            "--checkpoints_dir", "/tmp/sgan_bench_ckpt"]
+    if args.skip_wasted_D_wgrad:
+        argv.append("--skip_wasted_D_wgrad")
+    opt = TrainOptions().parse(argv, save=False, verbose=False)
+    torch.manual_seed(0)          # identical initial weights on every rank (also broadcast below)
+    m = FCGANModel()
+    m.initialize(opt)
+    return m
+
+
+def synthetic_ring(n, rank, device):
+    g = torch.Generator().manual_seed(123 + rank)
+    return [{"A": (torch.rand(1, 3, 512, 512, generator=g) * 2 - 1).to(device), "A_paths": ["synthetic"]} for _ in range(n)]
+
+
+def profile_kernels(model, ring, steps=3):
+    """Per-kernel-instantiation time and algorithmic flops of the conv kernels, measured live with
+    events on the launch stream around every sgan_conv_* call of `steps` eager steps."""
+    from supervised_gan_amd import _lib, ops
+    lib = _lib.lib()
+    recs = []
+
+    def wrap(name, flop_fn):
+        orig = getattr(ops, name)
+
+        def f(desc, *a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(desc, *a, **k)
+            e1.record()
+            recs.append((lib.sgan_last_kernel().decode(), flop_fn(desc), e0, e1))
+            return r
+        setattr(ops, name, f)
+        return orig
+
+    def flops(desc):   # algorithmic: logical (unpadded) channel counts are not visible here; padded == logical
+        # except for the 1-3 channel image/logit tensors, where the padded figure would overstate work,
+        # so count the logical ones: stored 4 <- logical {1,2} on this net (2-ch image, 1-ch logits)
+        cin = desc.Cin if desc.Cin > 4 else 2
+        cout = desc.Cout if desc.Cout > 4 else (2 if desc.kind == 1 else 1)
+        pix = desc.Hout * desc.Wout if desc.kind == 0 else desc.Hin * desc.Win
+        return 2.0 * pix * cin * cout * desc.k * desc.k
+
+    origs = {n: wrap(n, flops) for n in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
+    try:
+        for i in range(steps):
+            model.set_input(ring[i % len(ring)])
+            model.optimize_parameters()
+        torch.cuda.synchronize()
+    finally:
+        for n, o in origs.items():
+            setattr(ops, n, o)
+    agg = {}
+    for name, fl, e0, e1 in recs:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+        a[2] += fl
+    return {k: {"launches_per_step": v[0] / steps, "avg_us": 1e3 * v[1] / v[0], "ms_per_step": v[1] / steps,
+                "tflops": v[2] / (v[1] * 1e-3) / 1e12, "gflop_per_launch": v[2] / v[0] / 1e9} for k, v in agg.items()}
+
+
+def cpu_baseline(n_update_G, budget_s=20.0):
+    """The CPU oracle (fp32 restatement of the reference step, pinned against reference goldens)
+    timed on this box's host cores on the same workload; bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sgan_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    # a 1-GPU slice of the box owns 16 cores; 256 OpenMP threads on this bs=1 workload thrash for minutes
+    cores = int(os.environ.get("SGAN_CPU_THREADS", min(avail, 16)))
+    torch.set_num_threads(cores)
+    cfg = O.FCGANConfig(n_update_G=n_update_G)
+    o = O.FCGANOracle(cfg, seed=0)
+    g = torch.Generator().manual_seed(5)
+    o.noise_iter = iter(lambda: torch.randn(1, 8, 8, 8, generator=g), None)
+    real = [torch.rand(1, 2, 512, 512, generator=g) * 2 - 1 for _ in range(4)]
+    o.optimize_parameters(real[0])          # warm-up (allocator, oneDNN primitive caches)
+    o.optimize_parameters(real[1])
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        o.optimize_parameters(real[n % 4])
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 40:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of the same fcgan 512x512 bs=1 n_update_G={n_update_G} workload after 2 warm-up steps, "
+                      f"torch {torch.__version__} fp32 CPU oracle, {cores} threads"}
+
+
+def main():
+    if os.environ.get("SGAN_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SGAN_BENCH_WATCHDOG"]), exit=True)
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n_update_G", type=int, default=2, help="README recipe uses 2 (README.md:33)")
+    ap.add_argument("--eager", action="store_true", help="do not capture the step into hipGraphs")
+    ap.add_argument("--skip_wasted_D_wgrad", action="store_true")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_kernel_profile", action="store_true")
+    args = ap.parse_args()
+
+    from supervised_gan_amd import dist as sdist
+    rank, world, local = sdist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    model = build_model(args, rank)
+    sdist.broadcast_parameters([model.netG] + model.netD)
+    if world > 1:
+        model.grad_sync = sdist.GradAverager()
+    ring = synthetic_ring(64, rank, device)
+
+    kern = None
+    if rank == 0 and not args.no_kernel_profile:
+        kern = profile_kernels(model, ring, steps=3)
+
+    if args.eager:
+        def step(i):
+            model.set_input(ring[i % len(ring)])
+            model.optimize_parameters()
+    else:
+        from supervised_gan_amd.graph_step import GraphedFCGANStep
+        gs = GraphedFCGANStep(model)
+        gs.capture(ring[0])
+
+        def step(i):
+            gs.step(ring[i % len(ring)])
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    errs = model.get_current_errors()
+    assert all(v == v and abs(v) < 1e4 for v in errs.values()), errs     # finite losses after the run
+
+    if rank == 0:
+        ips = world * args.steps / dt
+        fl = flops_per_image(args.n_update_G)
+        out = {
+            "metric": "train-step images/sec, fcgan 512x512 bs=1/GPU",
+            "value": ips, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "fcgan deconv-G(ngf32, z 8x8x8) + 3x PatchGAN-D(ndf32, n_layers 3, scale 1/2/4) 512x512 bs=1, "
+                                   f"n_update_D=1 n_update_G={args.n_update_G}, Adam, pool 50 (BASELINE configs[1] shape, fp32 compute)",
+                       "parallelism": f"dp{world}", "global_batch": world, "hip_graph": not args.eager,
+                       "skip_wasted_D_wgrad": bool(args.skip_wasted_D_wgrad),
+                       "gflop_per_image_reference_executed": fl / 1e9,
+                       "achieved_tflops_per_gpu_reference_executed": fl * ips / world / 1e12},
+            "losses": {k: round(v, 5) for k, v in errs.items()},
+        }
+        if kern:
+            dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
+            peak = 157.3   # fp32 matrix peak, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": peak,
+                               "unit": "TFLOP/s", "frac": kern[dom]["tflops"] / peak, "traffic": None,
+                               "avg_launch_us": kern[dom]["avg_us"], "gflop_per_launch": kern[dom]["gflop_per_launch"],
+                               "launches_per_step": kern[dom]["launches_per_step"]}
+            out["kernels"] = {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kern.items())}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.n_update_G)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

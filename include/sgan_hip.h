@@ -70,6 +70,9 @@ typedef struct sgan_conv_desc {
 
 const char* sgan_version(void);
 const char* sgan_last_error(void);
+/* name of the kernel template instantiation the calling thread's last sgan_conv_* call launched
+ * (matches the name rocprofv3 reports) -- lets a benchmark attribute time and flops per kernel */
+const char* sgan_last_kernel(void);
 
 /* ---- Conv2d / ConvTranspose2d: forward ------------------------------------------------------
  * out = conv(act(norm(in)), w) + bias ; optionally out = tanh(out) ; optionally accumulates the

@@ -72,6 +72,7 @@ def lib():
             fn.restype = C.c_int
         l.sgan_version.restype = C.c_char_p
         l.sgan_last_error.restype = C.c_char_p
+        l.sgan_last_kernel.restype = C.c_char_p
         _lib = l
     return _lib
 

@@ -13,6 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // thread-local last-error string (sgan_last_error()).
 extern thread_local char g_sgan_err[512];
 int sgan_fail(int code, const char* fmt, ...);
+extern thread_local const char* g_sgan_last_kernel;  // name of the kernel the last conv entry point launched
 
 #define SGAN_CHECK(cond, ...)                                   \
     do {                                                        \

@@ -5,6 +5,7 @@
 #include "sgan_common.h"
 
 thread_local char g_sgan_err[512] = {0};
+thread_local const char* g_sgan_last_kernel = "";
 
 int sgan_fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -16,6 +17,7 @@ int sgan_fail(int code, const char* fmt, ...) {
 
 extern "C" const char* sgan_version(void) { return "sgan_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
 extern "C" const char* sgan_last_error(void) { return g_sgan_err; }
+extern "C" const char* sgan_last_kernel(void) { return g_sgan_last_kernel; }
 
 static inline int ew_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

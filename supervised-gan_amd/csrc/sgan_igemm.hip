@@ -44,7 +44,8 @@ struct SgIgemmParams {
 
 __device__ __forceinline__ int sg_swz(int row, int kslot) { return (kslot ^ ((row >> 1) & 7)) << 2; }
 
-template <int BM, int BN, int WGM, int WGN>
+// BKC: B operand is k-contiguous in memory (forward: W[tap][n][k]); otherwise n-contiguous (backward-data)
+template <int BM, int BN, int WGM, int WGN, bool BKC>
 __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MB = WTM / 16, NB = WTN / 16;
     constexpr int A_IT = BM * 8 / 256;
@@ -98,26 +99,44 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
         }
     }
 
-    // ---- per-thread staging coordinates (fixed over the k loop) ----
+    // ---- per-thread staging state ----
+    // A: this thread owns kslot a_ks of rows (tid>>3) + 32*it.  Its (tap, channel) position walks forward
+    // by 32 k per tile: 32 = adv_tap * Ck + adv_c, so one conditional wrap per tile and no division.
+    const int adv_tap = 32 / Ck, adv_c = 32 - adv_tap * Ck;
+    const int ntaps = P.phase[phz].ntaps;
+    const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
     int a_iy[A_IT], a_ix[A_IT], a_dst[A_IT];
-    bool a_ok[A_IT];
+    bool a_rowok[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int e = tid + it * 256;
         const int row = e >> 3, ks = e & 7;
         const int m = m0 + row;
-        a_ok[it] = m < M;
+        a_rowok[it] = m < M;
         const int py = m / Wp, px = m - py * Wp;
         a_iy[it] = py * P.is;
         a_ix[it] = px * P.is;
         a_dst[it] = row * 32 + sg_swz(row, ks);
     }
     const int a_ks = tid & 7;  // same for every it (256 % 8 == 0)
+    int a_tap = (a_ks * 4) / Ck;
+    int a_c = a_ks * 4 - a_tap * Ck;
 
     f32x4 a_reg[A_IT];
-    int a_c[A_IT];
+    bool a_ok[A_IT];
+    int a_cs = 0;  // channel of the staged A registers (for the prologue transform)
     f32x4 b_reg[B_IT];
-    const bool b_kcontig = (P.w_ks == 1);
+    bool b_ok[B_IT];
+    constexpr bool b_kcontig = BKC;
+    // B, n-contiguous form (backward-data): element (k = e / NQ, n4 = e % NQ); its own (tap, channel) walk
+    constexpr int NQ = BN / 4;
+    int b_tap[B_IT], b_c[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int k = (tid + it * 256) / NQ;
+        b_tap[it] = k / Ck;
+        b_c[it] = k - b_tap[it] * Ck;
+    }
 
     f32x4 acc[MB][NB];
 #pragma unroll
@@ -127,49 +146,52 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
 
     __syncthreads();  // tap table visible
 
-    auto load_tile = [&](int kt) {
+    // All loads are unconditional (invalid elements read offset 0 of the tensor and are zeroed when the
+    // registers are written to LDS), so hipcc issues them back to back and waits only at first use.
+    auto load_tile = [&]() {
         {
-            const int k0 = kt * 32 + a_ks * 4;
-            const bool kok = k0 < ktot;
-            const int tap = kok ? k0 / Ck : 0;
-            const int c = k0 - tap * Ck;
+            const bool kok = a_tap < ntaps;
+            const int tap = kok ? a_tap : 0;
             const int dy = tdy[tap], dx = tdx[tap];
+            a_cs = kok ? a_c : 0;
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
                 const int iy = a_iy[it] + dy, ix = a_ix[it] + dx;
-                const bool ok = a_ok[it] && kok && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (ok) v = *reinterpret_cast<const f32x4*>(P.in + ((int64_t)iy * P.Win + ix) * P.in_ld + c);
-                a_reg[it] = v;
-                a_c[it] = ok ? c : -1;
+                const bool ok = a_rowok[it] && kok && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+                const int64_t off = ok ? ((int64_t)iy * P.Win + ix) * P.in_ld + a_c : 0;
+                a_reg[it] = *reinterpret_cast<const f32x4*>(P.in + off);
+                a_ok[it] = ok;
             }
-        }
-        if (b_kcontig) {
+            if constexpr (b_kcontig) {
+                const int wtap = two[tap];
 #pragma unroll
-            for (int it = 0; it < B_IT; ++it) {
-                const int e = tid + it * 256;
-                const int n = e >> 3, ks = e & 7;
-                const int k0 = kt * 32 + ks * 4;
-                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (e < BN * 8 && k0 < ktot && n0 + n < N) {
-                    const int tap = k0 / Ck, c = k0 - tap * Ck;
-                    v = *reinterpret_cast<const f32x4*>(P.w + two[tap] + (int64_t)(n0 + n) * P.w_ns + c);
+                for (int it = 0; it < B_IT; ++it) {
+                    const int e = tid + it * 256;
+                    const int n = e >> 3;
+                    const bool ok = (B_IT * 256 == BN * 8 || e < BN * 8) && kok && n0 + n < N;
+                    const int64_t off = ok ? wtap + (int64_t)(n0 + n) * P.w_ns + a_c : 0;
+                    b_reg[it] = *reinterpret_cast<const f32x4*>(P.w + off);
+                    b_ok[it] = ok;
                 }
-                b_reg[it] = v;
             }
-        } else {
-            constexpr int NQ = BN / 4;  // float4 per k row
+            a_tap += adv_tap;
+            a_c += adv_c;
+            if (a_c >= Ck) { a_c -= Ck; ++a_tap; }
+        }
+        if constexpr (!b_kcontig) {
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) {
                 const int e = tid + it * 256;
                 const int k = e / NQ, n4 = e % NQ;
-                const int kk = kt * 32 + k;
-                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (k < 32 && kk < ktot && n0 + n4 * 4 < N) {
-                    const int tap = kk / Ck, c = kk - tap * Ck;
-                    v = *reinterpret_cast<const f32x4*>(P.w + two[tap] + (int64_t)c * P.w_ks + n0 + n4 * 4);
-                }
-                b_reg[it] = v;
+                const bool tok = b_tap[it] < ntaps;
+                const int wtap = two[tok ? b_tap[it] : 0];
+                const bool ok = (B_IT * 256 <= 32 * NQ || k < 32) && tok && n0 + n4 * 4 < N;
+                const int64_t off = ok ? wtap + (int64_t)b_c[it] * P.w_ks + n0 + n4 * 4 : 0;
+                b_reg[it] = *reinterpret_cast<const f32x4*>(P.w + off);
+                b_ok[it] = ok;
+                b_tap[it] += adv_tap;
+                b_c[it] += adv_c;
+                if (b_c[it] >= Ck) { b_c[it] -= Ck; ++b_tap[it]; }
             }
         }
     };
@@ -177,38 +199,45 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     auto store_tile = [&](int buf) {
         float* Ab = As + buf * BM * 32;
         float* Bb = Bs + buf * BN * 32;
+        f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has_pro) {
+            sc = *reinterpret_cast<const f32x4*>(pscale + a_cs);
+            sh = *reinterpret_cast<const f32x4*>(pshift + a_cs);
+        }
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             f32x4 v = a_reg[it];
-            const int c = a_c[it];
-            if (has_pro && c >= 0) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + c);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + c);
-                v.x = sg_act(v.x * sc.x + sh.x, P.pro.act, P.pro.slope);
-                v.y = sg_act(v.y * sc.y + sh.y, P.pro.act, P.pro.slope);
-                v.z = sg_act(v.z * sc.z + sh.z, P.pro.act, P.pro.slope);
-                v.w = sg_act(v.w * sc.w + sh.w, P.pro.act, P.pro.slope);
+            if (has_pro) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float y = v[j] * sc[j] + sh[j];
+                    v[j] = y > 0.f ? y : y * pro_neg;
+                }
             }
+            if (!a_ok[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(Ab + a_dst[it]) = v;
         }
-        if (b_kcontig) {
+        if constexpr (b_kcontig) {
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) {
                 const int e = tid + it * 256;
                 const int n = e >> 3, ks = e & 7;
-                if (e < BN * 8) *reinterpret_cast<f32x4*>(Bb + n * 32 + sg_swz(n, ks)) = b_reg[it];
+                f32x4 v = b_reg[it];
+                if (!b_ok[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (B_IT * 256 == BN * 8 || e < BN * 8) *reinterpret_cast<f32x4*>(Bb + n * 32 + sg_swz(n, ks)) = v;
             }
         } else {
-            constexpr int NQ = BN / 4;
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) {
                 const int e = tid + it * 256;
                 const int k = e / NQ, n4 = e % NQ;
-                if (k < 32) {
+                f32x4 v = b_reg[it];
+                if (!b_ok[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (B_IT * 256 <= 32 * NQ || k < 32) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int row = n4 * 4 + j;
-                        Bb[row * 32 + sg_swz(row, k >> 2) + (k & 3)] = b_reg[it][j];
+                        Bb[row * 32 + sg_swz(row, k >> 2) + (k & 3)] = v[j];
                     }
                 }
             }
@@ -218,12 +247,12 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     const int nkt = (ktot + 31) >> 5;
     const int fr = lane & 15, fq = lane >> 4;
 
-    load_tile(0);
+    load_tile();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         store_tile(buf);
         __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        if (kt + 1 < nkt) load_tile();
         const float* Ab = As + buf * BM * 32;
         const float* Bb = Bs + buf * BN * 32;
 #pragma unroll
@@ -267,6 +296,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
             x_g = P.xn.gamma ? P.xn.gamma[n] : 1.f;
             x_b = P.xn.beta ? P.xn.beta[n] : 0.f;
         }
+        const float xn_neg = P.xn.act == SGAN_ACT_NONE ? 1.f : (P.xn.act == SGAN_ACT_RELU ? 0.f : P.xn.slope);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
@@ -281,7 +311,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
                         const float x = P.xref[pix * P.xref_ld + n];
                         const float xhat = (x - x_mean) * x_rstd;
                         const float y = xnorm ? (x_g * xhat + x_b) : x;
-                        v *= sg_act_grad(y, P.xn.act, P.xn.slope);
+                        v *= (y > 0.f ? 1.f : xn_neg);
                         s1 += v;
                         s2 += v * xhat;
                     } else {
@@ -388,6 +418,7 @@ int sg_build_phases(const sgan_conv_desc* d, bool dgrad, SgPhase* ph, int* nphas
 
 template <int BM, int BN, int WGM, int WGN>
 static int sg_launch_igemm(const SgIgemmParams& P, hipStream_t st) {
+    const bool bkc = P.w_ks == 1;
     int maxM = 0;
     for (int i = 0; i < P.nphase; ++i) {
         const int M = P.phase[i].Hp * P.phase[i].Wp;
@@ -397,8 +428,15 @@ static int sg_launch_igemm(const SgIgemmParams& P, hipStream_t st) {
     dim3 grid(sg_cdiv(maxM, BM), sg_cdiv(P.N, BN), P.nphase);
     const size_t lds = (size_t)(2 * BM * 32 + 2 * BN * 32 + 2 * BN) * 4 + 3 * SGAN_MAX_TAPS * 4 + (size_t)2 * P.Ck * 4;
     if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
-    hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN>), grid, dim3(256), lds, st, P);
+    if (bkc) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true>), grid, dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, false>), grid, dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();
+    if (bkc)
+        g_sgan_last_kernel = BM == 64 ? "sg_igemm_kernel<64,64,2,2,true>" : BN == 64 ? "sg_igemm_kernel<128,64,2,2,true>"
+                             : BN == 32 ? "sg_igemm_kernel<128,32,4,1,true>" : "sg_igemm_kernel<128,16,4,1,true>";
+    else
+        g_sgan_last_kernel = BM == 64 ? "sg_igemm_kernel<64,64,2,2,false>" : BN == 64 ? "sg_igemm_kernel<128,64,2,2,false>"
+                             : BN == 32 ? "sg_igemm_kernel<128,32,4,1,false>" : "sg_igemm_kernel<128,16,4,1,false>";
     return SGAN_OK;
 }
 

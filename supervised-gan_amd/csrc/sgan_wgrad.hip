@@ -93,62 +93,84 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams P) {
     const bool d_cok = co0 + d_c4 * 4 < Cout;
 
     f32x4 a_reg[A_IT], d_reg[D_IT];
-    bool a_val[A_IT];
+    bool a_val[A_IT], d_val[D_IT];
+    const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
+    const int oa = ph.oa, ob = ph.ob;
 
-    auto load_chunk = [&](int ch) {
-        const int mb = ch * BP;
+    // pixel walk: row r of chunk ch is pixel m = ch*32 + r; (py, px) advance by 32 pixels per chunk with one
+    // conditional wrap (32 = adv_y * Wp + adv_x) -- no division inside the loop
+    const int adv_y = BP / Wp, adv_x = BP - adv_y * Wp;
+    int a_py[A_IT], a_px[A_IT], d_py[D_IT], d_px[D_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int m = ch_begin * BP + a_row0 + it * A_ROWS_PER_IT;
+        a_py[it] = m / Wp;
+        a_px[it] = m - a_py[it] * Wp;
+    }
+#pragma unroll
+    for (int it = 0; it < D_IT; ++it) {
+        const int m = ch_begin * BP + d_row0 + it * D_ROWS_PER_IT;
+        d_py[it] = m / Wp;
+        d_px[it] = m - d_py[it] * Wp;
+    }
+
+    // loads are unconditional (invalid rows read offset 0 and are zeroed at the LDS store)
+    auto load_chunk = [&]() {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int prow = a_row0 + it * A_ROWS_PER_IT;
-            const int m = mb + prow;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            bool ok = false;
-            if (prow < BP && m < M && a_kok) {
-                const int py = m / Wp, px = m - py * Wp;
-                const int iy = py * P.is + a_dy, ix = px * P.is + a_dx;
-                if ((unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win) {
-                    v = *reinterpret_cast<const f32x4*>(P.in + ((int64_t)iy * P.Win + ix) * P.in_ld + a_c);
-                    ok = true;
-                }
-            }
-            a_reg[it] = v;
+            const int iy = a_py[it] * P.is + a_dy, ix = a_px[it] * P.is + a_dx;
+            const bool ok = (A_IT * A_ROWS_PER_IT == BP || prow < BP) && a_py[it] < Hp && a_kok &&
+                            (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+            const int64_t off = ok ? ((int64_t)iy * P.Win + ix) * P.in_ld + a_c : 0;
+            a_reg[it] = *reinterpret_cast<const f32x4*>(P.in + off);
             a_val[it] = ok;
+            a_py[it] += adv_y;
+            a_px[it] += adv_x;
+            if (a_px[it] >= Wp) { a_px[it] -= Wp; ++a_py[it]; }
         }
 #pragma unroll
         for (int it = 0; it < D_IT; ++it) {
             const int prow = d_row0 + it * D_ROWS_PER_IT;
-            const int m = mb + prow;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (prow < BP && m < M && d_cok) {
-                const int py = m / Wp, px = m - py * Wp;
-                const int64_t pix = (int64_t)(py * P.os + ph.oa) * P.Wout + (px * P.os + ph.ob);
-                v = *reinterpret_cast<const f32x4*>(P.dout + pix * P.dout_ld + co0 + d_c4 * 4);
-            }
-            d_reg[it] = v;
+            const bool ok = (D_IT * D_ROWS_PER_IT == BP || prow < BP) && d_py[it] < Hp && d_cok;
+            const int64_t pix = (int64_t)(d_py[it] * P.os + oa) * P.Wout + (d_px[it] * P.os + ob);
+            const int64_t off = ok ? pix * P.dout_ld + co0 + d_c4 * 4 : 0;
+            d_reg[it] = *reinterpret_cast<const f32x4*>(P.dout + off);
+            d_val[it] = ok;
+            d_py[it] += adv_y;
+            d_px[it] += adv_x;
+            if (d_px[it] >= Wp) { d_px[it] -= Wp; ++d_py[it]; }
         }
     };
 
     auto store_chunk = [&](int buf) {
         float* Ab = As + buf * BP * LDA;
         float* Db = Ds + buf * BP * LDD;
+        f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has_pro) {
+            sc = *reinterpret_cast<const f32x4*>(pscale + a_c);
+            sh = *reinterpret_cast<const f32x4*>(pshift + a_c);
+        }
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int prow = a_row0 + it * A_ROWS_PER_IT;
             f32x4 v = a_reg[it];
-            if (has_pro && a_val[it]) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + a_c);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + a_c);
-                v.x = sg_act(v.x * sc.x + sh.x, P.pro.act, P.pro.slope);
-                v.y = sg_act(v.y * sc.y + sh.y, P.pro.act, P.pro.slope);
-                v.z = sg_act(v.z * sc.z + sh.z, P.pro.act, P.pro.slope);
-                v.w = sg_act(v.w * sc.w + sh.w, P.pro.act, P.pro.slope);
+            if (has_pro) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float y = v[j] * sc[j] + sh[j];
+                    v[j] = y > 0.f ? y : y * pro_neg;
+                }
             }
-            if (prow < BP) *reinterpret_cast<f32x4*>(Ab + prow * LDA + a_c4 * 4) = v;
+            if (!a_val[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (A_IT * A_ROWS_PER_IT == BP || prow < BP) *reinterpret_cast<f32x4*>(Ab + prow * LDA + a_c4 * 4) = v;
         }
 #pragma unroll
         for (int it = 0; it < D_IT; ++it) {
             const int prow = d_row0 + it * D_ROWS_PER_IT;
-            if (prow < BP) *reinterpret_cast<f32x4*>(Db + prow * LDD + d_c4 * 4) = d_reg[it];
+            f32x4 v = d_reg[it];
+            if (!d_val[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (D_IT * D_ROWS_PER_IT == BP || prow < BP) *reinterpret_cast<f32x4*>(Db + prow * LDD + d_c4 * 4) = v;
         }
     };
 
@@ -161,12 +183,12 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams P) {
     const bool do_bias = (P.dbias != nullptr) && (blockIdx.x == 0);
 
     __syncthreads();  // pscale/pshift visible
-    load_chunk(ch_begin);
+    load_chunk();
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int buf = (ch - ch_begin) & 1;
         store_chunk(buf);
         __syncthreads();
-        if (ch + 1 < ch_end) load_chunk(ch + 1);
+        if (ch + 1 < ch_end) load_chunk();
         const float* Ab = As + buf * BP * LDA;
         const float* Db = Ds + buf * BP * LDD;
 #pragma unroll
@@ -232,6 +254,8 @@ static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
     const size_t lds = (size_t)(2 * 32 * LDD + 2 * 32 * LDA + 2 * P.Cin) * 4;
     hipLaunchKernelGGL((sg_wgrad_kernel<BCO, BKC, WGC, WGK>), grid, dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = BCO == 64 ? "sg_wgrad_kernel<64,64,2,2>" : BCO == 32 ? "sg_wgrad_kernel<32,64,1,4>"
+                                                                            : "sg_wgrad_kernel<16,128,1,4>";
     return SGAN_OK;
 }
 

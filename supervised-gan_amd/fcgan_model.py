@@ -61,6 +61,8 @@ class FCGANModel(BaseModel):
                                       use_sigmoid=use_sigmoid, scale_factor=scale, gpu_ids=self.gpu_ids)
                 d.fuse_sigmoid_into_loss = True
                 self.netD.append(d)
+            if self.gpu_ids:
+                networks.pack_flat(self.netD)   # one arena: single Adam segment, single gradient all-reduce
         if not self.isTrain or opt.continue_train:
             self.load_network(self.netG, 'G', opt.which_epoch)
             if self.isTrain:
@@ -77,6 +79,7 @@ class FCGANModel(BaseModel):
                 params += list(netD.model.parameters())   # "all learnable parameters should be in netD.model"
             self.optimizer_D = FusedAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
             self.grad_sync = None   # data-parallel hook: callable(optimizer) run between backward and step
+            self._pool_override = None   # graphed step: static buffer the host-side ImagePool fills
 
     # ---- data ---------------------------------------------------------------------------------
     def _draw_noise(self):
@@ -111,7 +114,7 @@ class FCGANModel(BaseModel):
 
     # ---- losses ---------------------------------------------------------------------------------
     def backward_D(self):
-        fake = self.fake_pool.query(self.fake)
+        fake = self._pool_override if self._pool_override is not None else self.fake_pool.query(self.fake)
         self.loss_D_fake = 0
         for netD in self.netD:
             pred_fake = netD.forward(fake.detach())

@@ -1,0 +1,91 @@
+"""hipGraph capture of FCGANModel.optimize_parameters (models/fcgan_model.py:178-193).
+
+A bs=1 fcgan step is ~300 short kernels; launched eagerly from Python the host is the bottleneck.
+The step is therefore captured once into hipGraphs and replayed:
+
+    graph A : forward()                      latent fill + G forward -> static `fake`
+    host    : ImagePool.query(fake)          the reference's python-random history policy, one D2D copy
+    graph B : D step, then the G step(s)     zero_grad / backward / Adam, loss scalars left on device
+
+Everything that changes from step to step lives in device memory the kernels read and advance
+themselves (Adam step counter and LR, Philox offset, BatchNorm num_batches_tracked), so replays are
+faithful.  With data parallelism the gradient all-reduce is not captured: graph B is cut at the
+two/three synchronisation points and RCCL runs between the pieces on the same stream."""
+import torch
+
+from . import ops
+
+
+class GraphedFCGANStep:
+    def __init__(self, model, warmup_steps=2):
+        self.m = model
+        opt = model.opt
+        assert opt.n_update_D == 1, "graphed step supports n_update_D == 1 (every README recipe)"
+        assert opt.batchSize == 1
+        self._captured = False
+        self._warmup_steps = warmup_steps
+
+    # the step cut into capturable segments; "sync_D"/"sync_G" are the data-parallel hand-off points
+    def _program(self):
+        m, o = self.m, self.m.opt
+        prog = [[m.optimizer_D.zero_grad, m.backward_D], "sync_D", [m.optimizer_D.step]]
+        for _ in range(o.n_update_G):
+            prog[-1] += [m.optimizer_G.zero_grad, m.backward_G]
+            prog += ["sync_G", [m.optimizer_G.step]]
+            if o.n_update_G > 1:
+                prog[-1].append(m.sample_noise)
+        return prog
+
+    def capture(self, example_input):
+        m = self.m
+        assert m.noise_source is None, "graphed step draws its latents on the device"
+        for _ in range(self._warmup_steps):   # lazy state (optimizer moments, caches) must exist before capture
+            m.set_input(example_input)
+            m.optimize_parameters()
+        m.optimizer_D.sync_lr()
+        m.optimizer_G.sync_lr()
+        torch.cuda.synchronize()
+        H = W = m.opt.fineSize
+        self.fake_for_D = torch.zeros((H, W, ops.pad4(m.opt.input_nc)), dtype=torch.float32, device=m.device)
+        m._pool_override = ops.logical_view(self.fake_for_D, m.opt.input_nc)
+        self.gA = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gA):
+            m.forward()
+        self._fakeA = m.fake
+        pool = self.gA.pool()
+        self.segs = []
+        merged = []
+        for item in self._program():
+            if isinstance(item, str):
+                if m.grad_sync is not None:
+                    self.segs.append(("graph", self._capture(merged, pool)))
+                    self.segs.append(("sync", m.optimizer_D if item == "sync_D" else m.optimizer_G))
+                    merged = []
+            else:
+                merged += item
+        if merged:
+            self.segs.append(("graph", self._capture(merged, pool)))
+        self._captured = True
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def _capture(fns, pool):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool):
+            for f in fns:
+                f()
+        return g
+
+    def step(self, data=None):
+        """One training step == FCGANModel.optimize_parameters() (set_input first when data is given)."""
+        m = self.m
+        if data is not None:
+            m.set_input(data)
+        self.gA.replay()
+        q = m.fake_pool.query(self._fakeA)
+        self.fake_for_D.copy_(ops.as_nhwc(q))
+        for kind, obj in self.segs:
+            if kind == "graph":
+                obj.replay()
+            else:
+                m.grad_sync(obj)

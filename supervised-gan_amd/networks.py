@@ -145,6 +145,7 @@ class ChainNet(nn.Module):
         self._nflat = off
         self._flat = torch.zeros(off, dtype=torch.float32)
         self._gflat = torch.zeros(off, dtype=torch.float32)
+        self._arena = (self._flat, self._gflat, 0)   # (param arena, grad arena, this net's offset); see pack_flat()
         self.model = nn.Module()
         self._bn_boxes = {}
         for L in layers:
@@ -223,8 +224,9 @@ class ChainNet(nn.Module):
                     p.grad = gv
 
     def _apply(self, fn, recurse=True):
-        self._flat = fn(self._flat)
-        self._gflat = fn(self._gflat)
+        self._flat = fn(self._flat).clone() if self._arena[0] is not self._flat else fn(self._flat)
+        self._gflat = fn(self._gflat).clone() if self._arena[1] is not self._gflat else fn(self._gflat)
+        self._arena = (self._flat, self._gflat, 0)
         for mod in self.modules():
             for k, buf in mod._buffers.items():
                 if buf is not None:
@@ -367,6 +369,26 @@ class ChainNet(nn.Module):
                 dx = torch.empty((h, w, L.cin_s), dtype=torch.float32, device=dev)
                 ops.conv_dgrad(desc, dcur, wt, dx, None, None, None)
         return dx
+
+
+def pack_flat(nets):
+    """Re-home the flat parameter / gradient storage of several networks in ONE contiguous arena, so an
+    optimizer over all of them is a single Adam segment and a single gradient all-reduce (the three
+    fcgan discriminators: 3 x 693,729 parameters -> one 8.3 MB buffer)."""
+    nets = list(nets)
+    dev = nets[0]._flat.device
+    total = sum(n._nflat for n in nets)
+    arena_p = torch.empty(total, dtype=torch.float32, device=dev)
+    arena_g = torch.zeros(total, dtype=torch.float32, device=dev)
+    off = 0
+    for n in nets:
+        arena_p[off: off + n._nflat].copy_(n._flat)
+        n._flat = arena_p[off: off + n._nflat]
+        n._gflat = arena_g[off: off + n._nflat]
+        n._arena = (arena_p, arena_g, off)
+        n._rebind()
+        off += n._nflat
+    return arena_p, arena_g
 
 
 class _ChainFn(torch.autograd.Function):

@@ -17,7 +17,8 @@ class FusedAdam:
         if not params:
             raise ValueError("optimizer got an empty parameter list")
         self.param_groups = [{"params": params, "lr": float(lr), "betas": tuple(betas), "eps": float(eps)}]
-        # map every parameter to its range in a network's flat storage and merge adjacent ranges
+        # map every parameter to its range in an arena (a network's flat storage, or the shared arena
+        # several networks were packed into) and merge adjacent ranges
         ranges = {}
         for p in params:
             seg = getattr(p, "_sgan_seg", None)
@@ -25,27 +26,28 @@ class FusedAdam:
                 raise SganError("FusedAdam only handles parameters of supervised_gan_amd networks "
                                 "(use torch.optim.Adam for foreign parameters)")
             net, off, n = seg
-            ranges.setdefault(id(net), (net, []))[1].append((off, n))
-        self._segs = []   # (net, off, n)
-        for net, rs in ranges.values():
+            arena_p, arena_g, base = net._arena
+            ranges.setdefault(arena_p.data_ptr(), (arena_p, arena_g, []))[2].append((base + off, n))
+        self._segs = []   # (param arena, grad arena, off, n)
+        for arena_p, arena_g, rs in ranges.values():
             rs.sort()
             cur_off, cur_n = rs[0]
             for off, n in rs[1:]:
                 if off == cur_off + cur_n:
                     cur_n += n
                 else:
-                    self._segs.append((net, cur_off, cur_n))
+                    self._segs.append((arena_p, arena_g, cur_off, cur_n))
                     cur_off, cur_n = off, n
-            self._segs.append((net, cur_off, cur_n))
+            self._segs.append((arena_p, arena_g, cur_off, cur_n))
         self._state = None
         self._lr_host = None
 
     def _lazy_state(self):
         if self._state is not None:
             return
-        dev = self._segs[0][0]._flat.device
-        self._m = [torch.zeros(n, dtype=torch.float32, device=dev) for _, _, n in self._segs]
-        self._v = [torch.zeros(n, dtype=torch.float32, device=dev) for _, _, n in self._segs]
+        dev = self._segs[0][0].device
+        self._m = [torch.zeros(n, dtype=torch.float32, device=dev) for _, _, _, n in self._segs]
+        self._v = [torch.zeros(n, dtype=torch.float32, device=dev) for _, _, _, n in self._segs]
         self._state = torch.zeros(4, dtype=torch.int32, device=dev)
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
 
@@ -58,12 +60,12 @@ class FusedAdam:
             self._lr_host = lr
 
     def zero_grad(self, set_to_none=False):
-        for net, off, n in self._segs:
-            net._gflat[off: off + n].zero_()
+        for _, ag, off, n in self._segs:
+            ag[off: off + n].zero_()
 
     def segments(self):
         """[(params, grads)] flat views -- what the data-parallel all-reduce works on."""
-        return [(net._flat[off: off + n], net._gflat[off: off + n]) for net, off, n in self._segs]
+        return [(ap[off: off + n], ag[off: off + n]) for ap, ag, off, n in self._segs]
 
     @torch.no_grad()
     def step(self):
@@ -71,8 +73,8 @@ class FusedAdam:
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         g = self.param_groups[0]
-        segs = [(net._flat[off: off + n], net._gflat[off: off + n], m, v, n)
-                for (net, off, n), m, v in zip(self._segs, self._m, self._v)]
+        segs = [(ap[off: off + n], ag[off: off + n], m, v, n)
+                for (ap, ag, off, n), m, v in zip(self._segs, self._m, self._v)]
         ops.adam_multi(segs, self._lr_dev, g["betas"][0], g["betas"][1], g["eps"], self._state)
 
     @property

@@ -41,6 +41,8 @@ def build_model(args, rank):
             "--checkpoints_dir", "/tmp/sgan_bench_ckpt"]
     if args.skip_wasted_D_wgrad:
         argv.append("--skip_wasted_D_wgrad")
+    if args.no_d_streams:
+        argv.append("--no_d_streams")
     opt = TrainOptions().parse(argv, save=False, verbose=False)
     torch.manual_seed(0)          # identical initial weights on every rank (also broadcast below)
     m = FCGANModel()
@@ -82,12 +84,14 @@ def profile_kernels(model, ring, steps=3):
         return 2.0 * pix * cin * cout * desc.k * desc.k
 
     origs = {n: wrap(n, flops) for n in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
+    saved_streams, model._streams = model._streams, []     # one stream: kernels are timed one at a time
     try:
         for i in range(steps):
             model.set_input(ring[i % len(ring)])
             model.optimize_parameters()
         torch.cuda.synchronize()
     finally:
+        model._streams = saved_streams
         for n, o in origs.items():
             setattr(ops, n, o)
     agg = {}
@@ -143,6 +147,7 @@ def main():
     ap.add_argument("--n_update_G", type=int, default=2, help="README recipe uses 2 (README.md:33)")
     ap.add_argument("--eager", action="store_true", help="do not capture the step into hipGraphs")
     ap.add_argument("--skip_wasted_D_wgrad", action="store_true")
+    ap.add_argument("--no_d_streams", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_profile", action="store_true")
     args = ap.parse_args()

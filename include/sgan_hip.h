@@ -80,10 +80,15 @@ const char* sgan_last_kernel(void);
  * Replaces: nn.ConvTranspose2d k4 s2 p1 (models/networks.py:502,516,523,529),
  *           nn.Conv2d k4 s2 p2 / k4 s1 p2 (models/networks.py:815,824,831,835),
  *           nn.Conv2d k4 s2 p1 (models/networks.py:356,385), nn.Conv2d k3 s1 p1 (:686,752,774),
- *           nn.Tanh (models/networks.py:540). */
+ *           nn.Tanh (models/networks.py:540).
+ *
+ * Workspace (forward and backward-data): deep reductions on small grids are split over K; the fp32
+ * partial tiles live in a caller-owned scratch buffer.  Call with workspace_bytes == -1 (nothing is
+ * launched) to get the recommended size in KiB as the return value (0 = none); passing NULL / a smaller
+ * buffer is allowed and simply disables the split. */
 int sgan_conv_fwd(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
                   const float* w, const float* bias, float* out, int32_t out_ld, int32_t out_act,
-                  double* out_stats, void* stream);
+                  double* out_stats, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- backward-data ---------------------------------------------------------------------------
  * din = conv_bwd_data(dout, w), then multiplied by act'(norm(x)) of the forward tensor `x` at the
@@ -95,7 +100,7 @@ int sgan_conv_fwd(const sgan_conv_desc* d, const float* in, int32_t in_ld, const
  * built by FCGANModel.backward_D / backward_G (models/fcgan_model.py:146-176). */
 int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32_t dout_ld, const float* w,
                     float* din, int32_t din_ld, const float* x, int32_t x_ld, const sgan_norm_desc* x_norm,
-                    double* bwd_sums, void* stream);
+                    double* bwd_sums, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- backward-weight ---------------------------------------------------------------------------
  * dw += act(norm(in))^T (x) dout over all pixels (master layout), dbias += sum_pixels dout.

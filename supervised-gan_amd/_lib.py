@@ -33,8 +33,8 @@ class AdamSeg(C.Structure):
 # name -> argtypes; every entry returns int except the two string getters
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
-    "sgan_conv_fwd": [C.POINTER(ConvDesc), _P, _I, C.POINTER(NormDesc), _P, _P, _P, _I, _I, _P, _P],
-    "sgan_conv_dgrad": [C.POINTER(ConvDesc), _P, _I, _P, _P, _I, _P, _I, C.POINTER(NormDesc), _P, _P],
+    "sgan_conv_fwd": [C.POINTER(ConvDesc), _P, _I, C.POINTER(NormDesc), _P, _P, _P, _I, _I, _P, _P, _L, _P],
+    "sgan_conv_dgrad": [C.POINTER(ConvDesc), _P, _I, _P, _P, _I, _P, _I, C.POINTER(NormDesc), _P, _P, _L, _P],
     "sgan_conv_wgrad": [C.POINTER(ConvDesc), _P, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
     "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _P, _P, _P],
     "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],

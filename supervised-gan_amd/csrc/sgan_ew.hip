@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(float* dy, int d
         cS1[c] = (float)(sums[c] * invM);
         cS2[c] = (float)(sums[C + c] * invM);
         if (blockIdx.x == 0) {
-            if (dgamma) dgamma[c] += (float)sums[C + c];
-            if (dbeta) dbeta[c] += (float)sums[c];
+            if (dgamma) atomicAdd(&dgamma[c], (float)sums[C + c]);   // concurrent chains may share the buffer
+            if (dbeta) atomicAdd(&dbeta[c], (float)sums[c]);
         }
     }
     __syncthreads();

@@ -37,6 +37,10 @@ struct SgIgemmParams {
     int32_t w_ns, w_ks;  // element strides of B[k-channel][n] inside a tap slab
     int32_t out_act;
     int32_t nphase;
+    int32_t ablate;  // diagnostics only (SGAN_DEBUG_ABLATE): 1 = skip MFMAs, 2 = skip global loads, 4 = skip LDS stores
+    int32_t ksplit;       // > 1: split-K, raw partial tiles go to `slab`, sg_splitk_epilogue_kernel finishes
+    float* slab;          // [ksplit][Hout*Wout][N] fp32 partials (caller workspace)
+    int64_t slab_stride;  // Hout*Wout*N
     SgNorm pro;  // prologue on the gathered tensor
     SgNorm xn;   // how the forward consumer read xref (dact)
     SgPhase phase[SGAN_MAX_PHASES];
@@ -57,15 +61,13 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     float* As = reinterpret_cast<float*>(smem);  // [2][BM*32]
     float* Bs = As + 2 * BM * 32;                // [2][BN*32]
     float* red = Bs + 2 * BN * 32;               // [2*BN]
-    int* tdy = reinterpret_cast<int*>(red + 2 * BN);  // [16]
-    int* tdx = tdy + SGAN_MAX_TAPS;
-    int* two = tdx + SGAN_MAX_TAPS;
-    float* pscale = reinterpret_cast<float*>(two + SGAN_MAX_TAPS);  // [Ck]
+    int4* ttab = reinterpret_cast<int4*>(red + 2 * BN);  // [16] {dy, dx, gather offset, weight slab offset}
+    float* pscale = reinterpret_cast<float*>(ttab + SGAN_MAX_TAPS);  // [Ck]
     float* pshift = pscale + P.Ck;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
-    const int phz = blockIdx.z;
+    const int phz = blockIdx.z / P.ksplit, split = blockIdx.z - phz * P.ksplit;
     const int Hp = P.phase[phz].Hp, Wp = P.phase[phz].Wp;
     const int M = Hp * Wp;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -73,17 +75,20 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     const int oa = P.phase[phz].oa, ob = P.phase[phz].ob;
     const int ktot = P.phase[phz].ktot;
     const int Ck = P.Ck, N = P.N;
-    const bool has_pro = (P.pro.stats != nullptr) || (P.pro.act != SGAN_ACT_NONE);
+    // this workgroup's k-tile range (split-K)
+    const int nkt_total = (ktot + 31) >> 5;
+    const int kt_per = (nkt_total + P.ksplit - 1) / P.ksplit;
+    const int kt0 = split * kt_per;
+    const int nkt = min(nkt_total, kt0 + kt_per) - kt0;   // may be <= 0 for a trailing split: writes zeros
 
     // ---- one-time setup: tap table, prologue scale/shift, reduction scratch ----
     if (tid < SGAN_MAX_TAPS) {
         const bool v = tid < P.phase[phz].ntaps;
-        tdy[tid] = v ? (int)P.phase[phz].taps[tid].dy : 0;
-        tdx[tid] = v ? (int)P.phase[phz].taps[tid].dx : 0;
-        two[tid] = v ? P.phase[phz].taps[tid].w_off : 0;
+        const int dy = v ? (int)P.phase[phz].taps[tid].dy : 0, dx = v ? (int)P.phase[phz].taps[tid].dx : 0;
+        ttab[tid] = make_int4(dy, dx, (dy * P.Win + dx) * P.in_ld, v ? P.phase[phz].taps[tid].w_off : 0);
     }
     for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
-    if (has_pro) {
+    {   // always present (identity when there is no prologue) so the main loop is branch-free
         for (int c = tid; c < Ck; c += 256) {
             float sc = 1.f, sh = 0.f;
             if (P.pro.stats) {
@@ -102,10 +107,11 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     // ---- per-thread staging state ----
     // A: this thread owns kslot a_ks of rows (tid>>3) + 32*it.  Its (tap, channel) position walks forward
     // by 32 k per tile: 32 = adv_tap * Ck + adv_c, so one conditional wrap per tile and no division.
+    // Element offset of a gathered chunk = a_base[row] + ttab[tap].z + channel: two adds per tile.
     const int adv_tap = 32 / Ck, adv_c = 32 - adv_tap * Ck;
     const int ntaps = P.phase[phz].ntaps;
     const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
-    int a_iy[A_IT], a_ix[A_IT], a_dst[A_IT];
+    int a_iy[A_IT], a_ix[A_IT], a_base[A_IT], a_dst[A_IT];
     bool a_rowok[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -116,11 +122,12 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
         const int py = m / Wp, px = m - py * Wp;
         a_iy[it] = py * P.is;
         a_ix[it] = px * P.is;
+        a_base[it] = (a_iy[it] * P.Win + a_ix[it]) * P.in_ld;
         a_dst[it] = row * 32 + sg_swz(row, ks);
     }
     const int a_ks = tid & 7;  // same for every it (256 % 8 == 0)
-    int a_tap = (a_ks * 4) / Ck;
-    int a_c = a_ks * 4 - a_tap * Ck;
+    int a_tap = (kt0 * 32 + a_ks * 4) / Ck;
+    int a_c = kt0 * 32 + a_ks * 4 - a_tap * Ck;
 
     f32x4 a_reg[A_IT];
     bool a_ok[A_IT];
@@ -133,10 +140,22 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     int b_tap[B_IT], b_c[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int k = (tid + it * 256) / NQ;
+        const int k = kt0 * 32 + (tid + it * 256) / NQ;
         b_tap[it] = k / Ck;
         b_c[it] = k - b_tap[it] * Ck;
     }
+    int b_base[B_IT];     // k-contiguous form: row n of the weight slab
+    bool b_rowok[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int e = tid + it * 256;
+        const int n = e >> 3;
+        b_rowok[it] = (B_IT * 256 == BN * 8 || e < BN * 8) && n0 + n < N;
+        b_base[it] = (n0 + n) * P.w_ns;
+    }
+    // element offsets / validity of the NEXT tile to load (filled by next_addrs one iteration ahead)
+    int a_off_n[A_IT], b_off_n[B_IT], a_cs_n = 0;
+    bool a_ok_n[A_IT], b_ok_n[B_IT];
 
     f32x4 acc[MB][NB];
 #pragma unroll
@@ -146,32 +165,29 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
 
     __syncthreads();  // tap table visible
 
-    // All loads are unconditional (invalid elements read offset 0 of the tensor and are zeroed when the
-    // registers are written to LDS), so hipcc issues them back to back and waits only at first use.
-    auto load_tile = [&]() {
+    // Pure address arithmetic for the next tile (no memory traffic except the LDS tap table): scheduled
+    // inside the MFMA block of the previous tile.  Invalid elements get offset 0 and are zeroed when the
+    // registers are written to LDS, so the loads themselves are unconditional.
+    auto next_addrs = [&]() {
         {
             const bool kok = a_tap < ntaps;
-            const int tap = kok ? a_tap : 0;
-            const int dy = tdy[tap], dx = tdx[tap];
-            a_cs = kok ? a_c : 0;
+            const int4 t = ttab[kok ? a_tap : 0];
+            a_cs_n = kok ? a_c : 0;
+            const int toff = t.z + a_c;
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
-                const int iy = a_iy[it] + dy, ix = a_ix[it] + dx;
+                const int iy = a_iy[it] + t.x, ix = a_ix[it] + t.y;
                 const bool ok = a_rowok[it] && kok && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-                const int64_t off = ok ? ((int64_t)iy * P.Win + ix) * P.in_ld + a_c : 0;
-                a_reg[it] = *reinterpret_cast<const f32x4*>(P.in + off);
-                a_ok[it] = ok;
+                a_off_n[it] = ok ? a_base[it] + toff : 0;   // 32-bit: host checks < 2^30 elements
+                a_ok_n[it] = ok;
             }
             if constexpr (b_kcontig) {
-                const int wtap = two[tap];
+                const int woff = t.w + a_c;
 #pragma unroll
                 for (int it = 0; it < B_IT; ++it) {
-                    const int e = tid + it * 256;
-                    const int n = e >> 3;
-                    const bool ok = (B_IT * 256 == BN * 8 || e < BN * 8) && kok && n0 + n < N;
-                    const int64_t off = ok ? wtap + (int64_t)(n0 + n) * P.w_ns + a_c : 0;
-                    b_reg[it] = *reinterpret_cast<const f32x4*>(P.w + off);
-                    b_ok[it] = ok;
+                    const bool ok = b_rowok[it] && kok;
+                    b_off_n[it] = ok ? b_base[it] + woff : 0;
+                    b_ok_n[it] = ok;
                 }
             }
             a_tap += adv_tap;
@@ -184,11 +200,10 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
                 const int e = tid + it * 256;
                 const int k = e / NQ, n4 = e % NQ;
                 const bool tok = b_tap[it] < ntaps;
-                const int wtap = two[tok ? b_tap[it] : 0];
+                const int wtap = ttab[tok ? b_tap[it] : 0].w;
                 const bool ok = (B_IT * 256 <= 32 * NQ || k < 32) && tok && n0 + n4 * 4 < N;
-                const int64_t off = ok ? wtap + (int64_t)b_c[it] * P.w_ks + n0 + n4 * 4 : 0;
-                b_reg[it] = *reinterpret_cast<const f32x4*>(P.w + off);
-                b_ok[it] = ok;
+                b_off_n[it] = ok ? wtap + b_c[it] * P.w_ks + n0 + n4 * 4 : 0;
+                b_ok_n[it] = ok;
                 b_tap[it] += adv_tap;
                 b_c[it] += adv_c;
                 if (b_c[it] >= Ck) { b_c[it] -= Ck; ++b_tap[it]; }
@@ -196,23 +211,34 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
         }
     };
 
+    // Issue the global loads of the tile whose offsets next_addrs prepared.
+    auto issue_loads = [&]() {
+        if (P.ablate & 2) return;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            a_reg[it] = *reinterpret_cast<const f32x4*>(P.in + a_off_n[it]);
+            a_ok[it] = a_ok_n[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            b_reg[it] = *reinterpret_cast<const f32x4*>(P.w + b_off_n[it]);
+            b_ok[it] = b_ok_n[it];
+        }
+        a_cs = a_cs_n;
+    };
+
     auto store_tile = [&](int buf) {
         float* Ab = As + buf * BM * 32;
         float* Bb = Bs + buf * BN * 32;
-        f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (has_pro) {
-            sc = *reinterpret_cast<const f32x4*>(pscale + a_cs);
-            sh = *reinterpret_cast<const f32x4*>(pshift + a_cs);
-        }
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + a_cs);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + a_cs);
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             f32x4 v = a_reg[it];
-            if (has_pro) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y = v[j] * sc[j] + sh[j];
-                    v[j] = y > 0.f ? y : y * pro_neg;
-                }
+            for (int j = 0; j < 4; ++j) {
+                const float y = v[j] * sc[j] + sh[j];
+                v[j] = y > 0.f ? y : y * pro_neg;
             }
             if (!a_ok[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(Ab + a_dst[it]) = v;
@@ -244,15 +270,22 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
         }
     };
 
-    const int nkt = (ktot + 31) >> 5;
     const int fr = lane & 15, fq = lane >> 4;
 
-    load_tile();
+    // Software pipeline, one barrier per k-tile, loop body = one basic block in three fenced phases:
+    //   (1) issue the global loads of tile kt+1 from offsets prepared during the previous iteration;
+    //   (2) MFMA block on tile kt (LDS buffer kt&1), with the address arithmetic of tile kt+2 interleaved;
+    //   (3) transform + write tile kt+1 into the other LDS buffer (first use of the loads), barrier.
+    // Loads past the end of K read offset 0 and land as zeros in a buffer that is never consumed.
+    next_addrs();
+    issue_loads();
+    next_addrs();
+    store_tile(0);
+    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        store_tile(buf);
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile();
+        issue_loads();
+        __builtin_amdgcn_sched_barrier(0);
         const float* Ab = As + buf * BM * 32;
         const float* Bb = Bs + buf * BN * 32;
 #pragma unroll
@@ -268,6 +301,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
                 const int row = wn * WTN + j * 16 + fr;
                 bf[j] = *reinterpret_cast<const f32x4*>(Bb + row * 32 + sg_swz(row, kh * 4 + fq));
             }
+            if (!(P.ablate & 1)) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -275,12 +309,42 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
 #pragma unroll
                     for (int j = 0; j < NB; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+                for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(bf[j]));
+            }
         }
-        // no second barrier: the next iteration writes the OTHER buffer, and the barrier at its top
-        // orders those writes against this iteration's reads of `buf` two iterations later.
+        next_addrs();
+        // keep the consumers of the in-flight loads (masking, transform, LDS store) behind the MFMA block:
+        // without this hipcc hoists the first use -- and its s_waitcnt vmcnt(0) -- to the top of the loop
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(P.ablate & 4)) store_tile(buf ^ 1);
+        __syncthreads();
     }
 
     // ---- epilogue ----
+    if (P.ksplit > 1) {   // split-K: raw partial tile to this split's slab; sg_splitk_epilogue_kernel finishes
+        float* sl = P.slab + (int64_t)split * P.slab_stride;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + fr;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * WTM + i * 16 + fq * 4 + r;
+                    if (m < M && n < N) {
+                        const int py = m / Wp, px = m - py * Wp;
+                        const int64_t pix = (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);
+                        sl[pix * N + n] = acc[i][j][r];
+                    }
+                }
+            }
+        }
+        return;
+    }
     const bool dact = P.xref != nullptr;
     const bool want_stats = P.stats != nullptr;
 #pragma unroll
@@ -339,6 +403,215 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
         if (tid < BN && n0 + tid < N) {
             atomicAdd(&P.stats[n0 + tid], (double)red[tid]);
             atomicAdd(&P.stats[N + n0 + tid], (double)red[BN + tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Direct kernel for results with <= 4 stored channels (PatchGAN logits head Cout = 1, generator output
+// Cout = 2, image gradient of the first discriminator conv Cin = 2).  Such a GEMM has N = 4: an MFMA
+// tile would be >= 75 % padding and, worse, one workgroup would walk the whole K = 4096 reduction
+// serially.  Here LPP lanes share one output pixel: each lane takes every LPP-th 16-byte chunk of the
+// (tap, channel) reduction (coalesced 16 B/lane loads of the gathered NHWC tensor and of the weights,
+// which stay L1/L2 resident), keeps 4 accumulators, and a shuffle tree combines the lanes.
+// Same prologue (norm + activation on load) and bias / tanh epilogue as the MFMA kernel.
+// ------------------------------------------------------------------------------------------
+template <int LPP, bool BKC>
+__global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* tdy = reinterpret_cast<int*>(smem);
+    int* tdx = tdy + SGAN_MAX_TAPS;
+    int* two = tdx + SGAN_MAX_TAPS;
+    float* pscale = reinterpret_cast<float*>(two + SGAN_MAX_TAPS);
+    float* pshift = pscale + P.Ck;
+    const int tid = threadIdx.x;
+    const int phz = blockIdx.z;
+    const int Wp = P.phase[phz].Wp, M = P.phase[phz].Hp * Wp;
+    const int ntaps = P.phase[phz].ntaps, Ck = P.Ck;
+    const bool has_pro = (P.pro.stats != nullptr) || (P.pro.act != SGAN_ACT_NONE);
+    const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
+    if (tid < SGAN_MAX_TAPS) {
+        const bool v = tid < ntaps;
+        tdy[tid] = v ? (int)P.phase[phz].taps[tid].dy : 0;
+        tdx[tid] = v ? (int)P.phase[phz].taps[tid].dx : 0;
+        two[tid] = v ? P.phase[phz].taps[tid].w_off : 0;
+    }
+    if (has_pro) {
+        for (int c = tid; c < Ck; c += 256) {
+            float sc = 1.f, sh = 0.f;
+            if (P.pro.stats) {
+                float mean, rstd;
+                sg_mean_rstd(P.pro, Ck, c, mean, rstd);
+                const float g = P.pro.gamma ? P.pro.gamma[c] : 1.f;
+                const float b = P.pro.beta ? P.pro.beta[c] : 0.f;
+                sc = g * rstd;
+                sh = b - mean * sc;
+            }
+            pscale[c] = sc;
+            pshift[c] = sh;
+        }
+    }
+    __syncthreads();
+    constexpr int PPB = 256 / LPP;  // pixels per workgroup
+    const int sub = tid % LPP;
+    const int m = blockIdx.x * PPB + tid / LPP;
+    const bool mok = m < M;
+    const int py = mok ? m / Wp : 0, px = mok ? m - py * Wp : 0;
+    const int iy0 = py * P.is, ix0 = px * P.is;
+    // (tap, channel) walk of this lane: chunk q = sub, sub + LPP, ...  (4 k per chunk)
+    const int adv_tap = (4 * LPP) / Ck, adv_c = 4 * LPP - adv_tap * Ck;
+    int tap = (4 * sub) / Ck;
+    int c = 4 * sub - tap * Ck;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nq = (P.phase[phz].ktot + 4 * LPP - 1) / (4 * LPP);
+    for (int q = 0; q < nq; ++q) {
+        const bool kok = tap < ntaps;
+        const int t = kok ? tap : 0;
+        const int iy = iy0 + tdy[t], ix = ix0 + tdx[t];
+        const bool ok = mok && kok && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+        const int cc = kok ? c : 0;
+        const int off = ok ? (iy * P.Win + ix) * P.in_ld + cc : 0;
+        f32x4 a = *reinterpret_cast<const f32x4*>(P.in + off);
+        const float* wb = P.w + two[t];
+        f32x4 w0, w1, w2, w3;
+        if constexpr (BKC) {  // forward: W[tap][n][k] -> one 16-byte chunk of k per output channel n
+            w0 = *reinterpret_cast<const f32x4*>(wb + 0 * P.w_ns + cc);
+            w1 = *reinterpret_cast<const f32x4*>(wb + 1 * P.w_ns + cc);
+            w2 = *reinterpret_cast<const f32x4*>(wb + 2 * P.w_ns + cc);
+            w3 = *reinterpret_cast<const f32x4*>(wb + 3 * P.w_ns + cc);
+        } else {              // backward-data: W[tap][k][n], n = 0..3 contiguous -> one chunk per k
+            w0 = *reinterpret_cast<const f32x4*>(wb + (int64_t)(cc + 0) * P.w_ks);
+            w1 = *reinterpret_cast<const f32x4*>(wb + (int64_t)(cc + 1) * P.w_ks);
+            w2 = *reinterpret_cast<const f32x4*>(wb + (int64_t)(cc + 2) * P.w_ks);
+            w3 = *reinterpret_cast<const f32x4*>(wb + (int64_t)(cc + 3) * P.w_ks);
+        }
+        if (has_pro) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + cc);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + cc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = a[j] * sc[j] + sh[j];
+                a[j] = y > 0.f ? y : y * pro_neg;
+            }
+        }
+        if (!ok) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (BKC) {
+            acc[0] += a[0] * w0[0] + a[1] * w0[1] + a[2] * w0[2] + a[3] * w0[3];
+            acc[1] += a[0] * w1[0] + a[1] * w1[1] + a[2] * w1[2] + a[3] * w1[3];
+            acc[2] += a[0] * w2[0] + a[1] * w2[1] + a[2] * w2[2] + a[3] * w2[3];
+            acc[3] += a[0] * w3[0] + a[1] * w3[1] + a[2] * w3[2] + a[3] * w3[3];
+        } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[n] += a[0] * w0[n] + a[1] * w1[n] + a[2] * w2[n] + a[3] * w3[n];
+        }
+        tap += adv_tap;
+        c += adv_c;
+        if (c >= Ck) { c -= Ck; ++tap; }
+    }
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[n] += __shfl_xor(acc[n], o);
+    }
+    if (sub == 0 && mok) {
+        const int64_t pix = (int64_t)(py * P.os + P.phase[phz].oa) * P.Wout + (px * P.os + P.phase[phz].ob);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float v = acc[n] + (P.bias ? P.bias[n] : 0.f);
+            if (P.out_act == SGAN_ACT_TANH) v = tanhf(v);
+            acc[n] = v;
+        }
+        *reinterpret_cast<f32x4*>(P.out + pix * P.out_ld) = acc;
+    }
+}
+
+template <int LPP>
+static int sg_launch_small_n(const SgIgemmParams& P, hipStream_t st) {
+    int maxM = 0;
+    for (int i = 0; i < P.nphase; ++i) maxM = max(maxM, P.phase[i].Hp * P.phase[i].Wp);
+    if (maxM == 0) return SGAN_OK;
+    constexpr int PPB = 256 / LPP;
+    dim3 grid((maxM + PPB - 1) / PPB, 1, P.nphase);
+    const size_t lds = 3 * SGAN_MAX_TAPS * 4 + (size_t)2 * P.Ck * 4;
+    if (P.w_ks == 1) hipLaunchKernelGGL((sg_conv_small_n_kernel<LPP, true>), grid, dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((sg_conv_small_n_kernel<LPP, false>), grid, dim3(256), lds, st, P);
+    SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = LPP == 64 ? "sg_conv_small_n_kernel<64>" : LPP == 16 ? "sg_conv_small_n_kernel<16>" : "sg_conv_small_n_kernel<8>";
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-K finish: out = epilogue( sum_s slab[s] ) -- the same epilogue as the unsplit kernel (bias,
+// per-channel statistics, tanh; or act'(norm(x)) and the two norm-backward sums), as one 16-byte-
+// per-lane streaming pass.  Thread t always works on channel group t % (N/4), so the statistics are
+// accumulated in registers and reach memory as one LDS atomic + one fp64 atomic per channel per block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = P.N, NQ = N >> 2;
+    float* red = reinterpret_cast<float*>(smem);  // [2N]
+    float* cMean = red + 2 * N;                  // [N] (dact with norm)
+    float* cRstd = cMean + N;
+    float* cG = cRstd + N;
+    float* cB = cG + N;
+    const bool dact = P.xref != nullptr;
+    const bool xnorm = dact && P.xn.stats != nullptr;
+    const bool want_stats = P.stats != nullptr;
+    for (int i = threadIdx.x; i < 2 * N; i += 256) red[i] = 0.f;
+    for (int c = threadIdx.x; c < N; c += 256) {
+        float mean = 0.f, rstd = 1.f;
+        if (xnorm) sg_mean_rstd(P.xn, N, c, mean, rstd);
+        cMean[c] = mean;
+        cRstd[c] = rstd;
+        cG[c] = (xnorm && P.xn.gamma) ? P.xn.gamma[c] : 1.f;
+        cB[c] = (xnorm && P.xn.beta) ? P.xn.beta[c] : 0.f;
+    }
+    __syncthreads();
+    const float xn_neg = P.xn.act == SGAN_ACT_NONE ? 1.f : (P.xn.act == SGAN_ACT_RELU ? 0.f : P.xn.slope);
+    const int64_t total = (int64_t)P.Hout * P.Wout * NQ;
+    const int64_t stride = (int64_t)gridDim.x * 256;   // host makes this a multiple of NQ
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = (int)(e0 % NQ) * 4;
+    f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (P.bias) bias = *reinterpret_cast<const f32x4*>(P.bias + n);
+    f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    for (int64_t e = e0; e < total; e += stride) {
+        const int64_t pix = e / NQ;
+        f32x4 v = bias;
+        for (int sp = 0; sp < P.ksplit; ++sp) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(P.slab + sp * P.slab_stride + pix * N + n);
+            v += t;
+        }
+        if (dact) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(P.xref + pix * P.xref_ld + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xhat = (x[j] - cMean[n + j]) * cRstd[n + j];
+                const float y = xnorm ? (cG[n + j] * xhat + cB[n + j]) : x[j];
+                v[j] *= (y > 0.f ? 1.f : xn_neg);
+                s1[j] += v[j];
+                s2[j] += v[j] * xhat;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s1[j] += v[j];
+                s2[j] += v[j] * v[j];
+                if (P.out_act == SGAN_ACT_TANH) v[j] = tanhf(v[j]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(P.out + pix * P.out_ld + n) = v;
+    }
+    if (want_stats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&red[n + j], s1[j]);
+            atomicAdd(&red[N + n + j], s2[j]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < N; c += 256) {
+            atomicAdd(&P.stats[c], (double)red[c]);
+            atomicAdd(&P.stats[N + c], (double)red[N + c]);
         }
     }
 }
@@ -416,17 +689,53 @@ int sg_build_phases(const sgan_conv_desc* d, bool dgrad, SgPhase* ph, int* nphas
     return SGAN_OK;
 }
 
-template <int BM, int BN, int WGM, int WGN>
-static int sg_launch_igemm(const SgIgemmParams& P, hipStream_t st) {
-    const bool bkc = P.w_ks == 1;
+static int sg_max_m(const SgIgemmParams& P) {
     int maxM = 0;
-    for (int i = 0; i < P.nphase; ++i) {
-        const int M = P.phase[i].Hp * P.phase[i].Wp;
-        if (M > maxM) maxM = M;
-    }
+    for (int i = 0; i < P.nphase; ++i) maxM = max(maxM, P.phase[i].Hp * P.phase[i].Wp);
+    return maxM;
+}
+
+static int sg_max_k(const SgIgemmParams& P) {
+    int k = 0;
+    for (int i = 0; i < P.nphase; ++i) k = max(k, P.phase[i].ktot);
+    return k;
+}
+
+// Split-K plan: deep reductions on small grids (a 17x17 layer is 24 workgroups walking 64-128 k-tiles one
+// after the other) are cut so that ~2-3 workgroups land on every CU; co-resident workgroups then overlap
+// each other's staging and MFMA phases.  Needs N % 4 == 0 channels with 256 % (N/4) == 0 for the epilogue.
+static int sg_plan_ksplit(const SgIgemmParams& P, int BM, int BN) {
+    const int maxM = sg_max_m(P);
+    if (maxM == 0) return 1;
+    const int NQ = P.N >> 2;
+    if (NQ <= 0 || 256 % NQ != 0 || (P.out_ld & 3) || (P.xref && (P.xref_ld & 3))) return 1;
+    const long blocks = (long)sg_cdiv(maxM, BM) * sg_cdiv(P.N, BN) * P.nphase;
+    const int nkt = sg_cdiv(sg_max_k(P), 32);
+    // measured on MI355X (tools/bench_layers.py): the slab round trip only pays when the grid is well under
+    // one workgroup per CU, and the deeper the reduction the larger the grid it still pays for
+    const int min_nkt = blocks <= 32 ? 16 : blocks <= 96 ? 32 : blocks <= 192 ? 64 : 1 << 30;
+    if (nkt < min_nkt) return 1;
+    int ks = (int)sg_cdiv(512, (int)blocks);
+    ks = min(ks, nkt / 4);
+    ks = min(ks, 32);
+    if (ks < 2) return 1;
+    const int per = sg_cdiv(nkt, ks);
+    return sg_cdiv(nkt, per);   // every split non-empty
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes) {
+    const bool bkc = P.w_ks == 1;
+    const int maxM = sg_max_m(P);
     if (maxM == 0) return SGAN_OK;
-    dim3 grid(sg_cdiv(maxM, BM), sg_cdiv(P.N, BN), P.nphase);
-    const size_t lds = (size_t)(2 * BM * 32 + 2 * BN * 32 + 2 * BN) * 4 + 3 * SGAN_MAX_TAPS * 4 + (size_t)2 * P.Ck * 4;
+    int ks = sg_plan_ksplit(P, BM, BN);
+    const int64_t slab = (int64_t)P.Hout * P.Wout * P.N;
+    if (ks > 1 && (!ws || ws_bytes < (int64_t)ks * slab * 4)) ks = 1;   // no workspace: unsplit (still correct)
+    P.ksplit = ks;
+    P.slab = ks > 1 ? ws : nullptr;
+    P.slab_stride = slab;
+    dim3 grid(sg_cdiv(maxM, BM), sg_cdiv(P.N, BN), P.nphase * ks);
+    const size_t lds = (size_t)(2 * BM * 32 + 2 * BN * 32 + 2 * BN) * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
     if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
     if (bkc) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true>), grid, dim3(256), lds, st, P);
     else hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, false>), grid, dim3(256), lds, st, P);
@@ -437,25 +746,62 @@ static int sg_launch_igemm(const SgIgemmParams& P, hipStream_t st) {
     else
         g_sgan_last_kernel = BM == 64 ? "sg_igemm_kernel<64,64,2,2,false>" : BN == 64 ? "sg_igemm_kernel<128,64,2,2,false>"
                              : BN == 32 ? "sg_igemm_kernel<128,32,4,1,false>" : "sg_igemm_kernel<128,16,4,1,false>";
+    if (ks > 1) {
+        const int NQ = P.N >> 2;
+        const int64_t total = (int64_t)P.Hout * P.Wout * NQ;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 1024) blocks = 1024;   // 256 % NQ == 0, so blocks * 256 is a multiple of NQ
+        const size_t elds = (size_t)6 * P.N * 4;
+        hipLaunchKernelGGL(sg_splitk_epilogue_kernel, dim3(blocks), dim3(256), elds, st, P);
+        SGAN_LAUNCH_CHECK();
+    }
     return SGAN_OK;
 }
 
-static int sg_dispatch_igemm(const SgIgemmParams& P, hipStream_t st) {
-    int maxM = 0;
-    for (int i = 0; i < P.nphase; ++i) {
-        const int M = P.phase[i].Hp * P.phase[i].Wp;
-        if (M > maxM) maxM = M;
-    }
-    if (P.N <= 16) return sg_launch_igemm<128, 16, 4, 1>(P, st);
-    if (P.N <= 32) return sg_launch_igemm<128, 32, 4, 1>(P, st);
+static void sg_pick_tile(const SgIgemmParams& P, int* BM, int* BN) {
+    if (P.N <= 16) { *BM = 128; *BN = 16; return; }
+    if (P.N <= 32) { *BM = 128; *BN = 32; return; }
     // 128x64 tiles only when they still fill the chip (256 CUs, 2 workgroups each)
-    const long blocks128 = (long)sg_cdiv(maxM, 128) * sg_cdiv(P.N, 64) * P.nphase;
-    if (blocks128 >= 512) return sg_launch_igemm<128, 64, 2, 2>(P, st);
-    return sg_launch_igemm<64, 64, 2, 2>(P, st);
+    const long blocks128 = (long)sg_cdiv(sg_max_m(P), 128) * sg_cdiv(P.N, 64) * P.nphase;
+    *BM = blocks128 >= 512 ? 128 : 64;
+    *BN = 64;
+}
+
+static bool sg_use_small_n(const SgIgemmParams& P) { return P.N == 4 && !P.xref && !P.stats && (P.out_ld & 3) == 0; }
+
+static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes) {
+    static const int ablate = getenv("SGAN_DEBUG_ABLATE") ? atoi(getenv("SGAN_DEBUG_ABLATE")) : 0;
+    P.ablate = ablate;
+    P.ksplit = 1;
+    P.slab = nullptr;
+    P.slab_stride = 0;
+    if (sg_use_small_n(P)) {   // skinny result: direct kernel
+        const int ktot = sg_max_k(P);
+        if (ktot >= 2048) return sg_launch_small_n<64>(P, st);
+        if (ktot >= 256) return sg_launch_small_n<16>(P, st);
+        return sg_launch_small_n<8>(P, st);
+    }
+    int BM, BN;
+    sg_pick_tile(P, &BM, &BN);
+    if (BN == 16) return sg_launch_igemm<128, 16, 4, 1>(P, st, ws, ws_bytes);
+    if (BN == 32) return sg_launch_igemm<128, 32, 4, 1>(P, st, ws, ws_bytes);
+    if (BM == 128) return sg_launch_igemm<128, 64, 2, 2>(P, st, ws, ws_bytes);
+    return sg_launch_igemm<64, 64, 2, 2>(P, st, ws, ws_bytes);
+}
+
+static int64_t sg_workspace_need(const SgIgemmParams& P) {
+    if (sg_use_small_n(P)) return 0;
+    int BM, BN;
+    sg_pick_tile(P, &BM, &BN);
+    const int ks = sg_plan_ksplit(P, BM, BN);
+    return ks > 1 ? (int64_t)ks * P.Hout * P.Wout * P.N * 4 : 0;
 }
 
 static int sg_check_common(const sgan_conv_desc* d) {
     if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
+    if ((int64_t)d->Hin * d->Win * d->Cin >= (1ll << 30) || (int64_t)d->Hout * d->Wout * d->Cout >= (1ll << 30) ||
+        (int64_t)d->k * d->k * d->Cin * d->Cout >= (1ll << 30))
+        return sgan_fail(SGAN_ERR_UNSUPPORTED, "tensor too large for 32-bit element offsets");
     if ((d->Cin & 3) || (d->Cout & 3)) return sgan_fail(SGAN_ERR_INVALID, "stored channels must be multiples of 4 (Cin %d Cout %d)", d->Cin, d->Cout);
     if (d->Hin <= 0 || d->Win <= 0 || d->Hout <= 0 || d->Wout <= 0) return sgan_fail(SGAN_ERR_INVALID, "empty tensor");
     return SGAN_OK;
@@ -463,7 +809,7 @@ static int sg_check_common(const sgan_conv_desc* d) {
 
 extern "C" int sgan_conv_fwd(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
                              const float* w, const float* bias, float* out, int32_t out_ld, int32_t out_act,
-                             double* out_stats, void* stream) {
+                             double* out_stats, void* workspace, int64_t workspace_bytes, void* stream) {
     int rc = sg_check_common(d);
     if (rc) return rc;
     SGAN_CHECK(in && w && out, "null tensor");
@@ -480,12 +826,13 @@ extern "C" int sgan_conv_fwd(const sgan_conv_desc* d, const float* in, int32_t i
     P.out_act = out_act;
     P.pro = sg_norm_from(in_norm);
     P.xn = sg_norm_from(nullptr);
-    return sg_dispatch_igemm(P, (hipStream_t)stream);
+    if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)
+    return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
 }
 
 extern "C" int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32_t dout_ld, const float* w,
                                float* din, int32_t din_ld, const float* x, int32_t x_ld, const sgan_norm_desc* x_norm,
-                               double* bwd_sums, void* stream) {
+                               double* bwd_sums, void* workspace, int64_t workspace_bytes, void* stream) {
     int rc = sg_check_common(d);
     if (rc) return rc;
     SGAN_CHECK(dout && w && din, "null tensor");
@@ -503,5 +850,6 @@ extern "C" int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32
     P.out_act = SGAN_ACT_NONE;
     P.pro = sg_norm_from(nullptr);
     P.xn = sg_norm_from(x ? x_norm : nullptr);
-    return sg_dispatch_igemm(P, (hipStream_t)stream);
+    if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)
+    return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
 }

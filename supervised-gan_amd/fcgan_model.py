@@ -80,6 +80,8 @@ class FCGANModel(BaseModel):
             self.optimizer_D = FusedAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
             self.grad_sync = None   # data-parallel hook: callable(optimizer) run between backward and step
             self._pool_override = None   # graphed step: static buffer the host-side ImagePool fills
+            n_streams = 2 * self.n_netD if (self.gpu_ids and not getattr(opt, 'no_d_streams', False)) else 0
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
 
     # ---- data ---------------------------------------------------------------------------------
     def _draw_noise(self):
@@ -113,33 +115,61 @@ class FCGANModel(BaseModel):
         return self.image_paths
 
     # ---- losses ---------------------------------------------------------------------------------
+    def _d_losses(self, jobs):
+        """[(netD, input, target_is_real)] -> list of loss tensors.  The discriminator chains are
+        independent and individually too small to fill 256 CUs (a 17x17 layer is 24 workgroups), so each
+        runs on its own HIP stream, forked from and joined back into the current one; autograd replays
+        every chain's backward on the stream its forward used."""
+        streams = self._streams[:len(jobs)] if self._streams else None
+        losses = []
+        if not streams:
+            for netD, x, is_real in jobs:
+                losses.append(self.criterionGAN(netD.forward(x), is_real))
+            return losses
+        cur = torch.cuda.current_stream()
+        for st, (netD, x, is_real) in zip(streams, jobs):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                l = self.criterionGAN(netD.forward(x), is_real)
+            l.record_stream(cur)
+            losses.append(l)
+        for st in streams:
+            cur.wait_stream(st)
+        return losses
+
+    def _join_streams(self):
+        """The chains' backward kernels (weight-gradient atomics included) ran on the side streams: the
+        optimizer step that follows on the current stream must wait for them."""
+        cur = torch.cuda.current_stream()
+        for st in self._streams:
+            cur.wait_stream(st)
+
     def backward_D(self):
         fake = self._pool_override if self._pool_override is not None else self.fake_pool.query(self.fake)
-        self.loss_D_fake = 0
-        for netD in self.netD:
-            pred_fake = netD.forward(fake.detach())
-            self.loss_D_fake = self.loss_D_fake + self.criterionGAN(pred_fake, False)
-        real = self.real
-        self.loss_D_real = 0
-        for netD in self.netD:
-            pred_real = netD.forward(real)
-            self.loss_D_real = self.loss_D_real + self.criterionGAN(pred_real, True)
+        fake = fake.detach()
+        losses = self._d_losses([(d, fake, False) for d in self.netD] + [(d, self.real, True) for d in self.netD])
+        n = self.n_netD
+        self.loss_D_fake = sum(losses[1:n], losses[0])
+        self.loss_D_real = sum(losses[n + 1:], losses[n])
         self.loss_D = (self.loss_D_fake + self.loss_D_real) * 0.5
         self.loss_D.backward()
+        self._join_streams()
 
     def backward_G(self):
-        fake = self.fake
-        self.loss_G = 0
         skip = getattr(self.opt, 'skip_wasted_D_wgrad', False)
-        for netD, lambda_D in zip(self.netD, self.opt.lambda_D):
+        for netD in self.netD:
             netD.compute_param_grads = not skip
-            pred_fake = netD.forward(fake)
+        losses = self._d_losses([(d, self.fake, not self.opt.no_logD_trick) for d in self.netD])
+        for netD in self.netD:
             netD.compute_param_grads = True
+        self.loss_G = 0
+        for l, lambda_D in zip(losses, self.opt.lambda_D):
             if not self.opt.no_logD_trick:
-                self.loss_G = self.loss_G + self.criterionGAN(pred_fake, True) * lambda_D
+                self.loss_G = self.loss_G + l * lambda_D
             else:
-                self.loss_G = self.loss_G + -self.criterionGAN(pred_fake, False) * lambda_D
+                self.loss_G = self.loss_G + -l * lambda_D
         self.loss_G.backward()
+        self._join_streams()
 
     def optimize_parameters(self):
         self.forward()

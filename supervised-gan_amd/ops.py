@@ -52,15 +52,25 @@ def _nd(d):
     return C.byref(d) if d is not None else None
 
 
+def _workspace(kib, device):
+    """Split-K scratch for one call (torch's caching allocator; static inside a captured graph)."""
+    if kib < 0:
+        raise L.SganError(f"workspace query failed ({kib}): {L.lib().sgan_last_error().decode()}")
+    return torch.empty(kib * 256, dtype=torch.float32, device=device) if kib > 0 else None
+
+
 def conv_fwd(desc, x, in_norm, w, bias, out, out_act=ACT_NONE, out_stats=None):
-    L.check(L.lib().sgan_conv_fwd(C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(w), _ptr(bias),
-                                  _ptr(_act(out)), out.stride(1), out_act, _ptr(out_stats), _stream()), "sgan_conv_fwd")
+    args = (C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(w), _ptr(bias), _ptr(_act(out)), out.stride(1),
+            out_act, _ptr(out_stats))
+    ws = _workspace(L.lib().sgan_conv_fwd(*args, None, -1, None), x.device)
+    L.check(L.lib().sgan_conv_fwd(*args, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "sgan_conv_fwd")
 
 
 def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None):
-    L.check(L.lib().sgan_conv_dgrad(C.byref(desc), _ptr(_act(dout)), dout.stride(1), _ptr(w), _ptr(_act(din)), din.stride(1),
-                                    _ptr(x), x.stride(1) if x is not None else 0, _nd(x_norm), _ptr(bwd_sums), _stream()),
-            "sgan_conv_dgrad")
+    args = (C.byref(desc), _ptr(_act(dout)), dout.stride(1), _ptr(w), _ptr(_act(din)), din.stride(1),
+            _ptr(x), x.stride(1) if x is not None else 0, _nd(x_norm), _ptr(bwd_sums))
+    ws = _workspace(L.lib().sgan_conv_dgrad(*args, None, -1, None), dout.device)
+    L.check(L.lib().sgan_conv_dgrad(*args, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "sgan_conv_dgrad")
 
 
 def conv_wgrad(desc, x, in_norm, dout, dw, dbias):

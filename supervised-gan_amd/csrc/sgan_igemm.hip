@@ -21,7 +21,13 @@
 //
 // Reference ops replaced: nn.Conv2d / nn.ConvTranspose2d forward + convolution_backward(input)
 // as instantiated at models/networks.py:502-529 (FCGANGenerator) and :815-835 (NLayerDiscriminator).
+#include <type_traits>
+
 #include "sgan_common.h"
+
+#ifndef SG_ABLATE
+#define SG_ABLATE 0   // diagnostics build only: 1 = skip MFMAs, 2 = skip global loads, 4 = skip LDS stores
+#endif
 
 struct SgIgemmParams {
     const float* in;    // gathered tensor
@@ -129,11 +135,12 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     int a_tap = (kt0 * 32 + a_ks * 4) / Ck;
     int a_c = kt0 * 32 + a_ks * 4 - a_tap * Ck;
 
-    f32x4 a_reg[A_IT];
-    bool a_ok[A_IT];
-    int a_cs = 0;  // channel of the staged A registers (for the prologue transform)
-    f32x4 b_reg[B_IT];
-    bool b_ok[B_IT];
+    // two register sets: tile kt+1 (landed, being written to LDS) and tile kt+2 (in flight)
+    f32x4 a_reg[2][A_IT];
+    bool a_ok[2][A_IT];
+    int a_cs[2] = {0, 0};  // channel of the staged A registers (for the prologue transform)
+    f32x4 b_reg[2][B_IT];
+    bool b_ok[2][B_IT];
     constexpr bool b_kcontig = BKC;
     // B, n-contiguous form (backward-data): element (k = e / NQ, n4 = e % NQ); its own (tap, channel) walk
     constexpr int NQ = BN / 4;
@@ -212,35 +219,39 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     };
 
     // Issue the global loads of the tile whose offsets next_addrs prepared.
-    auto issue_loads = [&]() {
-        if (P.ablate & 2) return;
+    // Issue the global loads of the tile whose offsets next_addrs prepared, into register set S.
+    auto issue_loads = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        if constexpr (SG_ABLATE & 2) return;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            a_reg[it] = *reinterpret_cast<const f32x4*>(P.in + a_off_n[it]);
-            a_ok[it] = a_ok_n[it];
+            a_reg[S][it] = *reinterpret_cast<const f32x4*>(P.in + a_off_n[it]);
+            a_ok[S][it] = a_ok_n[it];
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            b_reg[it] = *reinterpret_cast<const f32x4*>(P.w + b_off_n[it]);
-            b_ok[it] = b_ok_n[it];
+            b_reg[S][it] = *reinterpret_cast<const f32x4*>(P.w + b_off_n[it]);
+            b_ok[S][it] = b_ok_n[it];
         }
-        a_cs = a_cs_n;
+        a_cs[S] = a_cs_n;
     };
 
-    auto store_tile = [&](int buf) {
-        float* Ab = As + buf * BM * 32;
-        float* Bb = Bs + buf * BN * 32;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + a_cs);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + a_cs);
+    // Transform (norm + activation of the producer layer), mask and write register set S to LDS buffer S.
+    auto store_tile = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        float* Ab = As + S * BM * 32;
+        float* Bb = Bs + S * BN * 32;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + a_cs[S]);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + a_cs[S]);
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            f32x4 v = a_reg[it];
+            f32x4 v = a_reg[S][it];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float y = v[j] * sc[j] + sh[j];
                 v[j] = y > 0.f ? y : y * pro_neg;
             }
-            if (!a_ok[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!a_ok[S][it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(Ab + a_dst[it]) = v;
         }
         if constexpr (b_kcontig) {
@@ -248,8 +259,8 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
             for (int it = 0; it < B_IT; ++it) {
                 const int e = tid + it * 256;
                 const int n = e >> 3, ks = e & 7;
-                f32x4 v = b_reg[it];
-                if (!b_ok[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 v = b_reg[S][it];
+                if (!b_ok[S][it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (B_IT * 256 == BN * 8 || e < BN * 8) *reinterpret_cast<f32x4*>(Bb + n * 32 + sg_swz(n, ks)) = v;
             }
         } else {
@@ -257,8 +268,8 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
             for (int it = 0; it < B_IT; ++it) {
                 const int e = tid + it * 256;
                 const int k = e / NQ, n4 = e % NQ;
-                f32x4 v = b_reg[it];
-                if (!b_ok[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 v = b_reg[S][it];
+                if (!b_ok[S][it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (B_IT * 256 <= 32 * NQ || k < 32) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -272,20 +283,16 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
 
     const int fr = lane & 15, fq = lane >> 4;
 
-    // Software pipeline, one barrier per k-tile, loop body = one basic block in three fenced phases:
-    //   (1) issue the global loads of tile kt+1 from offsets prepared during the previous iteration;
-    //   (2) MFMA block on tile kt (LDS buffer kt&1), with the address arithmetic of tile kt+2 interleaved;
-    //   (3) transform + write tile kt+1 into the other LDS buffer (first use of the loads), barrier.
-    // Loads past the end of K read offset 0 and land as zeros in a buffer that is never consumed.
-    next_addrs();
-    issue_loads();
-    next_addrs();
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        issue_loads();
-        __builtin_amdgcn_sched_barrier(0);
+    // Software pipeline, one barrier per k-tile, global loads two tiles ahead.  Iteration kt (S = kt & 1):
+    //   (1) issue the loads of tile kt+2 into register set S (offsets prepared one iteration earlier);
+    //   (2) one scheduling region: MFMA block on tile kt (LDS buffer S)  ||  transform + LDS store of tile
+    //       kt+1 (register set S^1, loaded a whole iteration ago, so its wait is free) into buffer S^1  ||
+    //       address arithmetic of tile kt+3;
+    //   (3) barrier.
+    // Tiles past the end of K read offset 0 and land as zeros in a buffer that is never consumed.
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto mfma_tile = [&](int buf) {
         const float* Ab = As + buf * BM * 32;
         const float* Bb = Bs + buf * BN * 32;
 #pragma unroll
@@ -301,14 +308,14 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
                 const int row = wn * WTN + j * 16 + fr;
                 bf[j] = *reinterpret_cast<const f32x4*>(Bb + row * 32 + sg_swz(row, kh * 4 + fq));
             }
-            if (!(P.ablate & 1)) {
+            if constexpr (!(SG_ABLATE & 1)) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < MB; ++i)
+                    for (int i = 0; i < MB; ++i)
 #pragma unroll
-                    for (int j = 0; j < NB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int i = 0; i < MB; ++i) asm volatile("" ::"v"(af[i]));
@@ -316,12 +323,30 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
                 for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(bf[j]));
             }
         }
-        next_addrs();
-        // keep the consumers of the in-flight loads (masking, transform, LDS store) behind the MFMA block:
-        // without this hipcc hoists the first use -- and its s_waitcnt vmcnt(0) -- to the top of the loop
+    };
+    auto iteration = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        issue_loads(std::integral_constant<int, S>{});          // tile kt+2
         __builtin_amdgcn_sched_barrier(0);
-        if (!(P.ablate & 4)) store_tile(buf ^ 1);
+        mfma_tile(S);                                            // tile kt
+        if constexpr (!(SG_ABLATE & 4)) store_tile(std::integral_constant<int, S ^ 1>{});   // tile kt+1
+        next_addrs();                                            // tile kt+3
         __syncthreads();
+    };
+    next_addrs();
+    issue_loads(I0{});   // tile 0
+    next_addrs();
+    issue_loads(I1{});   // tile 1
+    next_addrs();        // offsets of tile 2
+    store_tile(I0{});
+    __syncthreads();
+    {
+        int kt = 0;
+        for (; kt + 1 < nkt; kt += 2) {
+            iteration(I0{});
+            iteration(I1{});
+        }
+        if (kt < nkt) iteration(I0{});
     }
 
     // ---- epilogue ----
@@ -578,10 +603,16 @@ __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmPa
     for (int64_t e = e0; e < total; e += stride) {
         const int64_t pix = e / NQ;
         f32x4 v = bias;
-        for (int sp = 0; sp < P.ksplit; ++sp) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(P.slab + sp * P.slab_stride + pix * N + n);
-            v += t;
+        const float* sp0 = P.slab + pix * N + n;
+        int sp = 0;
+        for (; sp + 4 <= P.ksplit; sp += 4) {   // four independent 16-byte loads in flight
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(sp0 + (sp + 0) * P.slab_stride);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(sp0 + (sp + 1) * P.slab_stride);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(sp0 + (sp + 2) * P.slab_stride);
+            const f32x4 t3 = *reinterpret_cast<const f32x4*>(sp0 + (sp + 3) * P.slab_stride);
+            v += (t0 + t1) + (t2 + t3);
         }
+        for (; sp < P.ksplit; ++sp) v += *reinterpret_cast<const f32x4*>(sp0 + sp * P.slab_stride);
         if (dact) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(P.xref + pix * P.xref_ld + n);
 #pragma unroll

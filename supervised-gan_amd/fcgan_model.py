@@ -42,8 +42,12 @@ class FCGANModel(BaseModel):
         self._rng_seed = 0 if opt.manualSeed is None else int(opt.manualSeed)
         self._rng_offset = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.noise_source = None    # optional callable() -> z tensor (tests inject latents)
-        self.fixed_noiseA = self._draw_noise().clone()
-        self.fixed_noiseB = self._draw_noise().clone()
+        if self.device.type == 'cuda':
+            self.fixed_noiseA = self._draw_noise().clone()
+            self.fixed_noiseB = self._draw_noise().clone()
+        else:   # a CPU-resident model can be built (checkpoint surgery, tests) but never runs a network
+            self.fixed_noiseA = torch.randn(zshape)
+            self.fixed_noiseB = torch.randn(zshape)
 
         self.netG = networks.define_G(opt.input_nc, 0, opt.ngf, opt.which_model_netG, opt.norm, not opt.no_dropout,
                                       n_layers_G=opt.n_layers_G, use_residual=opt.use_residual,

@@ -1,0 +1,74 @@
+"""Data-parallel path on CPU: world_size 2, gloo.  The kernels need a GPU, the N>1 host logic does not:
+identical initial weights after broadcast, one contiguous gradient segment per optimizer (pack_flat),
+and all-reduced gradients == mean of the per-rank gradients."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from supervised_gan_amd import dist as sdist
+    from supervised_gan_amd import networks as N
+    from supervised_gan_amd.optim import FusedAdam
+    r, w, _ = sdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                     # different init per rank on purpose
+    nets = [N.define_D(2, 8, "n_layers", n_layers_D=3, norm="instance", use_sigmoid=True, scale_factor=s) for s in (1, 2, 4)]
+    G = N.define_G(2, 0, 8, "fcgan", "instance", False, n_layers_G=5, use_fcn=True, noise_nc=8)
+    N.pack_flat(nets)
+    sdist.broadcast_parameters([G] + nets)
+    opt_D = FusedAdam([p for d in nets for p in d.model.parameters()], lr=2e-4, betas=(0.5, 0.999))
+    opt_G = FusedAdam(G.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    assert len(opt_D.segments()) == 1 and len(opt_G.segments()) == 1       # one all-reduce per optimizer
+    assert opt_D.segments()[0][1].numel() == sum(d._nflat for d in nets)
+    # rank-dependent "gradients" written through the parameter .grad views
+    for i, p in enumerate(p for d in nets for p in d.model.parameters()):
+        p.grad.fill_(float(rank + 1) * (i + 1))
+    avg = sdist.GradAverager()
+    avg(opt_D)
+    avg(opt_G)
+    out = {
+        "w": torch.cat([d._flat.clone() for d in nets] + [G._flat.clone()]),
+        "g": [float(p.grad.flatten()[0]) for d in nets for p in d.model.parameters()],
+        "bytes": avg.bytes, "calls": avg.calls,
+        "gauss": nets[1].state_dict()["gauss_filter.0.weight"].clone(),
+    }
+    q.put((rank, out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_broadcast_and_grad_average():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert torch.equal(res[0]["w"], res[1]["w"])                     # broadcast: identical weights
+    assert torch.equal(res[0]["gauss"], res[1]["gauss"])
+    n = len(res[0]["g"])
+    expect = [1.5 * (i + 1) for i in range(n)]                        # mean of (1, 2) * (i + 1)
+    assert res[0]["g"] == expect and res[1]["g"] == expect
+    assert res[0]["calls"] == 2 and res[0]["bytes"] == res[0]["w"].numel() * 4

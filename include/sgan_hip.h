@@ -74,6 +74,16 @@ const char* sgan_last_error(void);
  * (matches the name rocprofv3 reports) -- lets a benchmark attribute time and flops per kernel */
 const char* sgan_last_kernel(void);
 
+/* ---- optional per-launch timing (diagnostics; single-threaded; do not enable during graph capture) ----
+ * While enabled, every main conv kernel launch (implicit-GEMM / small-N / backward-weight; not the split-K
+ * epilogue) is bracketed by two HIP events recorded on the launch stream from inside the library.  After a
+ * device synchronise, record i (0 <= i < sgan_profile_count(), launch order) yields the kernel's name as
+ * rocprofv3 reports it and its duration.  sgan_profile_enable() also clears the records. */
+int sgan_profile_enable(int on);
+int sgan_profile_count(void);
+int sgan_profile_mark(void* stream); /* records an empty bracket named "null": the events' own cost, to subtract */
+int sgan_profile_read(int i, const char** name, float* ms);
+
 /* ---- Conv2d / ConvTranspose2d: forward ------------------------------------------------------
  * out = conv(act(norm(in)), w) + bias ; optionally out = tanh(out) ; optionally accumulates the
  * per-channel sum / sumsq of the (pre-tanh) result into out_stats.

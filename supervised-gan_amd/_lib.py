@@ -48,6 +48,10 @@ SIGNATURES = {
     "sgan_to_nhwc": [_P, _L, _L, _L, _I, _I, _I, _P, _I, _I, _P],
     "sgan_adam_multi": [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _P, _P],
     "sgan_normal_fill": [_P, _L, C.c_uint64, _P, _P],
+    "sgan_profile_enable": [_I],
+    "sgan_profile_count": [],
+    "sgan_profile_mark": [_P],
+    "sgan_profile_read": [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_float)],
 }
 
 _lib = None

@@ -16,6 +16,12 @@ extern thread_local char g_sgan_err[512];
 int sgan_fail(int code, const char* fmt, ...);
 extern thread_local const char* g_sgan_last_kernel;  // name of the kernel the last conv entry point launched
 
+// Optional per-launch timing (sgan_profile_*): when enabled, every main conv kernel launch is bracketed by two
+// HIP events recorded on the launch stream from inside the library (back to back with the launch, so a busy
+// queue yields kernel-only durations comparable with rocprofv3 --kernel-trace).
+void sg_prof_begin(hipStream_t st);
+void sg_prof_end(hipStream_t st, const char* name);
+
 #define SGAN_CHECK(cond, ...)                                   \
     do {                                                        \
         if (!(cond)) return sgan_fail(SGAN_ERR_INVALID, __VA_ARGS__); \

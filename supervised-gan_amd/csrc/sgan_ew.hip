@@ -19,6 +19,55 @@ extern "C" const char* sgan_version(void) { return "sgan_hip 0.1 (gfx950, fp32 M
 extern "C" const char* sgan_last_error(void) { return g_sgan_err; }
 extern "C" const char* sgan_last_kernel(void) { return g_sgan_last_kernel; }
 
+// ---- optional per-launch timing -------------------------------------------------------------
+#define SG_PROF_MAX 8192
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t g_prof_e0[SG_PROF_MAX], g_prof_e1[SG_PROF_MAX];
+static const char* g_prof_name[SG_PROF_MAX];
+static bool g_prof_open = false;
+
+void sg_prof_begin(hipStream_t st) {
+    if (!g_prof_on || g_prof_n >= SG_PROF_MAX) return;
+    if (hipEventCreate(&g_prof_e0[g_prof_n]) != hipSuccess || hipEventCreate(&g_prof_e1[g_prof_n]) != hipSuccess) return;
+    (void)hipEventRecord(g_prof_e0[g_prof_n], st);
+    g_prof_open = true;
+}
+
+void sg_prof_end(hipStream_t st, const char* name) {
+    if (!g_prof_open) return;
+    (void)hipEventRecord(g_prof_e1[g_prof_n], st);
+    g_prof_name[g_prof_n] = name;
+    ++g_prof_n;
+    g_prof_open = false;
+}
+
+extern "C" int sgan_profile_enable(int on) {   // single-threaded diagnostic facility; resets the record list
+    for (int i = 0; i < g_prof_n; ++i) {
+        (void)hipEventDestroy(g_prof_e0[i]);
+        (void)hipEventDestroy(g_prof_e1[i]);
+    }
+    g_prof_n = 0;
+    g_prof_on = on != 0;
+    return SGAN_OK;
+}
+
+extern "C" int sgan_profile_count(void) { return g_prof_n; }
+
+// an empty bracket ("null"): the fixed cost of the two event records themselves, for calibration
+extern "C" int sgan_profile_mark(void* stream) {
+    sg_prof_begin((hipStream_t)stream);
+    sg_prof_end((hipStream_t)stream, "null");
+    return SGAN_OK;
+}
+
+extern "C" int sgan_profile_read(int i, const char** name, float* ms) {   // caller synchronised the device first
+    if (i < 0 || i >= g_prof_n || !name || !ms) return sgan_fail(SGAN_ERR_INVALID, "bad profile record index");
+    *name = g_prof_name[i];
+    if (hipEventElapsedTime(ms, g_prof_e0[i], g_prof_e1[i]) != hipSuccess) return sgan_fail(SGAN_ERR_HIP, "hipEventElapsedTime failed");
+    return SGAN_OK;
+}
+
 static inline int ew_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------------------------------

@@ -558,10 +558,12 @@ static int sg_launch_small_n(const SgIgemmParams& P, hipStream_t st) {
     constexpr int PPB = 256 / LPP;
     dim3 grid((maxM + PPB - 1) / PPB, 1, P.nphase);
     const size_t lds = 3 * SGAN_MAX_TAPS * 4 + (size_t)2 * P.Ck * 4;
+    sg_prof_begin(st);
     if (P.w_ks == 1) hipLaunchKernelGGL((sg_conv_small_n_kernel<LPP, true>), grid, dim3(256), lds, st, P);
     else hipLaunchKernelGGL((sg_conv_small_n_kernel<LPP, false>), grid, dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = LPP == 64 ? "sg_conv_small_n_kernel<64>" : LPP == 16 ? "sg_conv_small_n_kernel<16>" : "sg_conv_small_n_kernel<8>";
+    sg_prof_end(st, g_sgan_last_kernel);
     return SGAN_OK;
 }
 
@@ -768,6 +770,7 @@ static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t 
     dim3 grid(sg_cdiv(maxM, BM), sg_cdiv(P.N, BN), P.nphase * ks);
     const size_t lds = (size_t)(2 * BM * 32 + 2 * BN * 32 + 2 * BN) * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
     if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
+    sg_prof_begin(st);
     if (bkc) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true>), grid, dim3(256), lds, st, P);
     else hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, false>), grid, dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();
@@ -777,6 +780,7 @@ static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t 
     else
         g_sgan_last_kernel = BM == 64 ? "sg_igemm_kernel<64,64,2,2,false>" : BN == 64 ? "sg_igemm_kernel<128,64,2,2,false>"
                              : BN == 32 ? "sg_igemm_kernel<128,32,4,1,false>" : "sg_igemm_kernel<128,16,4,1,false>";
+    sg_prof_end(st, g_sgan_last_kernel);
     if (ks > 1) {
         const int NQ = P.N >> 2;
         const int64_t total = (int64_t)P.Hout * P.Wout * NQ;

@@ -252,10 +252,12 @@ static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
     P.nsplit = nsplit;
     dim3 grid(sgw_cdiv(maxK, BKC), sgw_cdiv(P.Cout, BCO), P.nphase * nsplit);
     const size_t lds = (size_t)(2 * 32 * LDD + 2 * 32 * LDA + 2 * P.Cin) * 4;
+    sg_prof_begin(st);
     hipLaunchKernelGGL((sg_wgrad_kernel<BCO, BKC, WGC, WGK>), grid, dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = BCO == 64 ? "sg_wgrad_kernel<64,64,2,2>" : BCO == 32 ? "sg_wgrad_kernel<32,64,1,4>"
                                                                             : "sg_wgrad_kernel<16,128,1,4>";
+    sg_prof_end(st, g_sgan_last_kernel);
     return SGAN_OK;
 }
 

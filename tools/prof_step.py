@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import argparse, torch
 import bench
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--n_update_G", type=int, default=2)
-ap.add_argument("--skip_wasted_D_wgrad", action="store_true")
+ap.add_argument("--skip_wasted_D_wgrad", action="store_true"); ap.add_argument("--no_d_streams", action="store_true")
 a = ap.parse_args()
 m = bench.build_model(a, 0)
 ring = bench.synthetic_ring(4, 0, torch.device("cuda", 0))

@@ -43,6 +43,8 @@ def build_model(args, rank):
         argv.append("--skip_wasted_D_wgrad")
     if args.no_d_streams:
         argv.append("--no_d_streams")
+    if getattr(args, "no_group", False):
+        argv.append("--no_group")
     opt = TrainOptions().parse(argv, save=False, verbose=False)
     torch.manual_seed(0)          # identical initial weights on every rank (also broadcast below)
     m = FCGANModel()
@@ -74,21 +76,24 @@ def profile_kernels(model, ring, reps=3):
         pix = desc.Hout * desc.Wout if desc.kind == 0 else desc.Hin * desc.Win
         return 2.0 * pix * cin * cout * desc.k * desc.k
 
-    def wrap(name):
+    def wrap(name, grouped):
         orig = getattr(ops, name)
 
-        def f(desc, *a, **k):
-            calls.append((orig, desc, a, k))
-            return orig(desc, *a, **k)
+        def f(first, *a, **k):
+            fl = sum(flops(j[0]) for j in first) if grouped else flops(first)
+            calls.append((orig, (first,) + a, k, fl))
+            return orig(first, *a, **k)
         setattr(ops, name, f)
         return orig
 
+    names = {"conv_fwd": False, "conv_dgrad": False, "conv_wgrad": False,
+             "conv_fwd_grouped": True, "conv_dgrad_grouped": True, "conv_wgrad_grouped": True}
     saved_streams, model._streams = model._streams, []     # one stream: kernels are timed one at a time
     try:
         for i in range(2):      # untimed: code-object loads and allocator growth are not kernel time
             model.set_input(ring[i % len(ring)])
             model.optimize_parameters()
-        origs = {n: wrap(n) for n in ("conv_fwd", "conv_dgrad", "conv_wgrad")}
+        origs = {n: wrap(n, gr) for n, gr in names.items()}
         try:
             model.set_input(ring[2 % len(ring)])
             model.optimize_parameters()
@@ -96,13 +101,13 @@ def profile_kernels(model, ring, reps=3):
             for n_, o in origs.items():
                 setattr(ops, n_, o)
         torch.cuda.synchronize()
-        for fn, desc, a, k in calls[:64]:     # fill the queue before the timed records start
-            fn(desc, *a, **k)
+        for fn, a, k, _ in calls[:64]:     # fill the queue before the timed records start
+            fn(*a, **k)
         lib.sgan_profile_enable(1)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for _ in range(reps):
-            for fn, desc, a, k in calls:
-                fn(desc, *a, **k)
+            for fn, a, k, _ in calls:
+                fn(*a, **k)
                 lib.sgan_profile_mark(st)      # empty bracket behind every launch: the event pair's own cost
         torch.cuda.synchronize()
         n = lib.sgan_profile_count()
@@ -119,7 +124,7 @@ def profile_kernels(model, ring, reps=3):
             a_ = agg.setdefault(nm, [0, 0.0, 0.0])
             a_[0] += 1
             a_[1] += max(m - overhead, 1e-4)
-            a_[2] += flops(calls[i % len(calls)][1])
+            a_[2] += calls[i % len(calls)][3]
         agg["_event_pair_overhead_us"] = [1, overhead, 0.0]
     finally:
         lib.sgan_profile_enable(0)
@@ -173,6 +178,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not capture the step into hipGraphs")
     ap.add_argument("--skip_wasted_D_wgrad", action="store_true")
     ap.add_argument("--no_d_streams", action="store_true")
+    ap.add_argument("--no_group", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_profile", action="store_true")
     args = ap.parse_args()

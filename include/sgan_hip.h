@@ -112,6 +112,39 @@ int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32_t dout_ld,
                     float* din, int32_t din_ld, const float* x, int32_t x_ld, const sgan_norm_desc* x_norm,
                     double* bwd_sums, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- grouped launches -----------------------------------------------------------------------------
+ * Up to 8 independent problems of the SAME layer type (kind, k, stride, pad, stored channels) in ONE kernel
+ * launch, each with its own tensors, weights and spatial size -- the matching layer of the three
+ * multi-scale discriminators on the fake and on the real batch (models/fcgan_model.py:150-159) is one
+ * launch instead of six.  Semantics per job are exactly those of the single-problem entry points (which
+ * are the n == 1 case).  All jobs must agree on the activation codes of their norm descriptors. */
+typedef struct sgan_conv_fwd_job {
+    const sgan_conv_desc* d;
+    const float* in; int32_t in_ld; const sgan_norm_desc* in_norm;
+    const float* w; const float* bias;
+    float* out; int32_t out_ld;
+    double* out_stats;
+} sgan_conv_fwd_job;
+typedef struct sgan_conv_dgrad_job {
+    const sgan_conv_desc* d;
+    const float* dout; int32_t dout_ld;
+    const float* w;
+    float* din; int32_t din_ld;
+    const float* x; int32_t x_ld; const sgan_norm_desc* x_norm;
+    double* bwd_sums;
+} sgan_conv_dgrad_job;
+typedef struct sgan_conv_wgrad_job {
+    const sgan_conv_desc* d;
+    const float* in; int32_t in_ld; const sgan_norm_desc* in_norm;
+    const float* dout; int32_t dout_ld;
+    float* dw; float* dbias;
+} sgan_conv_wgrad_job;
+int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, int32_t out_act, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t n, void* workspace, int64_t workspace_bytes,
+                            void* stream);
+int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* stream);
+
 /* ---- backward-weight ---------------------------------------------------------------------------
  * dw += act(norm(in))^T (x) dout over all pixels (master layout), dbias += sum_pixels dout.
  * Accumulates (atomics) into caller-owned gradient buffers.

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsgan_hip.so")
+# SGAN_HIP_LIB: diagnostics only (e.g. an -DSG_ABLATE build of the same sources)
+LIB_PATH = os.environ.get("SGAN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsgan_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 CONV, CONVT = 0, 1
@@ -19,6 +20,22 @@ class ConvDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32),
                 ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cout", C.c_int32)]
+
+
+class ConvFwdJob(C.Structure):
+    _fields_ = [("d", C.POINTER(ConvDesc)), ("inp", C.c_void_p), ("in_ld", C.c_int32), ("in_norm", C.POINTER(NormDesc)),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_stats", C.c_void_p)]
+
+
+class ConvDgradJob(C.Structure):
+    _fields_ = [("d", C.POINTER(ConvDesc)), ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("w", C.c_void_p),
+                ("din", C.c_void_p), ("din_ld", C.c_int32), ("x", C.c_void_p), ("x_ld", C.c_int32),
+                ("x_norm", C.POINTER(NormDesc)), ("bwd_sums", C.c_void_p)]
+
+
+class ConvWgradJob(C.Structure):
+    _fields_ = [("d", C.POINTER(ConvDesc)), ("inp", C.c_void_p), ("in_ld", C.c_int32), ("in_norm", C.POINTER(NormDesc)),
+                ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("dw", C.c_void_p), ("dbias", C.c_void_p)]
 
 
 class BnRunningDesc(C.Structure):
@@ -36,6 +53,9 @@ SIGNATURES = {
     "sgan_conv_fwd": [C.POINTER(ConvDesc), _P, _I, C.POINTER(NormDesc), _P, _P, _P, _I, _I, _P, _P, _L, _P],
     "sgan_conv_dgrad": [C.POINTER(ConvDesc), _P, _I, _P, _P, _I, _P, _I, C.POINTER(NormDesc), _P, _P, _L, _P],
     "sgan_conv_wgrad": [C.POINTER(ConvDesc), _P, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
+    "sgan_conv_fwd_grouped": [C.POINTER(ConvFwdJob), _I, _I, _P, _L, _P],
+    "sgan_conv_dgrad_grouped": [C.POINTER(ConvDgradJob), _I, _P, _L, _P],
+    "sgan_conv_wgrad_grouped": [C.POINTER(ConvWgradJob), _I, _P],
     "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _P, _P, _P],
     "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],
     "sgan_gauss_down_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],

@@ -29,34 +29,85 @@
 #define SG_ABLATE 0   // diagnostics build only: 1 = skip MFMAs, 2 = skip global loads, 4 = skip LDS stores
 #endif
 
-struct SgIgemmParams {
+#define SG_MAX_PROB 8
+
+// One launch serves up to SG_MAX_PROB independent problems of the SAME layer type (same kind / k / stride /
+// pad / channels, hence the same taps) but their own tensors and spatial sizes -- e.g. the matching layer of
+// the three discriminators on the fake and on the real batch.  blockIdx.x walks the concatenated M tiles of
+// every (problem, phase); `tile0` is the prefix table.
+struct SgProb {
     const float* in;    // gathered tensor
     float* out;         // result tensor
     const float* w;     // master weight
     const float* bias;  // [N] or null
     const float* xref;  // dact epilogue: forward tensor at the output positions, or null
     double* stats;      // [2N]: fwd (sum, sumsq) of the result, or bwd sums (s1, s2); or null
-    int32_t Hin, Win, Ck, in_ld;    // gathered tensor geometry, Ck = its channels (GEMM-K channels)
-    int32_t Hout, Wout, N, out_ld;  // result tensor geometry, N = its channels
-    int32_t xref_ld;
+    const double* pro_stats;  // prologue norm of the gathered tensor (or null)
+    const float* pro_gamma;
+    const float* pro_beta;
+    const double* xn_stats;   // norm the forward consumer applied to xref (or null)
+    const float* xn_gamma;
+    const float* xn_beta;
+    int32_t Hin, Win, in_ld;     // gathered tensor geometry
+    int32_t Hout, Wout, out_ld;  // result tensor geometry
+    int32_t xref_ld, pro_count, xn_count;
+    int32_t Hp[SGAN_MAX_PHASES], Wp[SGAN_MAX_PHASES];
+    int32_t tile0[SGAN_MAX_PHASES];  // first blockIdx.x of (this problem, phase)
+};
+
+struct SgIgemmParams {   // the kernel argument (~2.3 KB)
+    int32_t Ck, N;        // GEMM-K channels (gathered tensor), GEMM-N channels (result tensor)
     int32_t is, os;
-    int32_t w_ns, w_ks;  // element strides of B[k-channel][n] inside a tap slab
+    int32_t w_ns, w_ks;   // element strides of B[k-channel][n] inside a tap slab
     int32_t out_act;
-    int32_t nphase;
-    int32_t ablate;  // diagnostics only (SGAN_DEBUG_ABLATE): 1 = skip MFMAs, 2 = skip global loads, 4 = skip LDS stores
-    int32_t ksplit;       // > 1: split-K, raw partial tiles go to `slab`, sg_splitk_epilogue_kernel finishes
+    int32_t nphase, nprob;
+    int32_t ksplit;       // > 1 (single problem only): split-K, raw partial tiles go to `slab`
+    int32_t pro_act, xn_act;
+    float pro_slope, xn_slope, pro_eps, xn_eps;
+    int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
+    SgTap taps[SGAN_MAX_PHASES][SGAN_MAX_TAPS];
     float* slab;          // [ksplit][Hout*Wout][N] fp32 partials (caller workspace)
     int64_t slab_stride;  // Hout*Wout*N
-    SgNorm pro;  // prologue on the gathered tensor
-    SgNorm xn;   // how the forward consumer read xref (dact)
-    SgPhase phase[SGAN_MAX_PHASES];
+    SgProb q[SG_MAX_PROB];
 };
+
+// The view of ONE problem the kernel bodies work with (scalarised by the compiler).
+struct SgLocal {
+    const float* in; float* out; const float* w; const float* bias; const float* xref; double* stats;
+    int32_t Hin, Win, Ck, in_ld, Hout, Wout, N, out_ld, xref_ld, is, os, w_ns, w_ks, out_act, ksplit;
+    float* slab; int64_t slab_stride;
+    SgNorm pro, xn;
+};
+
+__device__ __forceinline__ SgLocal sg_local(const SgIgemmParams& G, int g) {
+    const SgProb& Q = G.q[g];
+    SgLocal P;
+    P.in = Q.in; P.out = Q.out; P.w = Q.w; P.bias = Q.bias; P.xref = Q.xref; P.stats = Q.stats;
+    P.Hin = Q.Hin; P.Win = Q.Win; P.Ck = G.Ck; P.in_ld = Q.in_ld; P.Hout = Q.Hout; P.Wout = Q.Wout; P.N = G.N;
+    P.out_ld = Q.out_ld; P.xref_ld = Q.xref_ld; P.is = G.is; P.os = G.os; P.w_ns = G.w_ns; P.w_ks = G.w_ks;
+    P.out_act = G.out_act; P.ksplit = G.ksplit; P.slab = G.slab; P.slab_stride = G.slab_stride;
+    P.pro.stats = Q.pro_stats; P.pro.gamma = Q.pro_gamma; P.pro.beta = Q.pro_beta; P.pro.count = Q.pro_count;
+    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope;
+    P.xn.stats = Q.xn_stats; P.xn.gamma = Q.xn_gamma; P.xn.beta = Q.xn_beta; P.xn.count = Q.xn_count;
+    P.xn.eps = G.xn_eps; P.xn.act = G.xn_act; P.xn.slope = G.xn_slope;
+    return P;
+}
+
+// blockIdx.x -> (problem, phase, M tile) through the prefix table
+__device__ __forceinline__ void sg_decode_tile(const SgIgemmParams& G, int bx, int& g, int& phz, int& mtile) {
+    g = 0;
+    phz = 0;
+    for (int gi = 0; gi < G.nprob; ++gi)
+        for (int ph = 0; ph < G.nphase; ++ph)
+            if (bx >= G.q[gi].tile0[ph]) { g = gi; phz = ph; }
+    mtile = bx - G.q[g].tile0[phz];
+}
 
 __device__ __forceinline__ int sg_swz(int row, int kslot) { return (kslot ^ ((row >> 1) & 7)) << 2; }
 
 // BKC: B operand is k-contiguous in memory (forward: W[tap][n][k]); otherwise n-contiguous (backward-data)
 template <int BM, int BN, int WGM, int WGN, bool BKC>
-__global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
+__global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MB = WTM / 16, NB = WTN / 16;
     constexpr int A_IT = BM * 8 / 256;
     constexpr int B_IT = (BN * 8 + 255) / 256;
@@ -69,17 +120,19 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     float* red = Bs + 2 * BN * 32;               // [2*BN]
     int4* ttab = reinterpret_cast<int4*>(red + 2 * BN);  // [16] {dy, dx, gather offset, weight slab offset}
     float* pscale = reinterpret_cast<float*>(ttab + SGAN_MAX_TAPS);  // [Ck]
-    float* pshift = pscale + P.Ck;
+    float* pshift = pscale + G.Ck;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
-    const int phz = blockIdx.z / P.ksplit, split = blockIdx.z - phz * P.ksplit;
-    const int Hp = P.phase[phz].Hp, Wp = P.phase[phz].Wp;
+    int g, phz, mtile;
+    sg_decode_tile(G, blockIdx.x, g, phz, mtile);
+    const SgLocal P = sg_local(G, g);
+    const int split = blockIdx.z;
+    const int Hp = G.q[g].Hp[phz], Wp = G.q[g].Wp[phz];
     const int M = Hp * Wp;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    if (m0 >= M) return;  // phases of an odd-sized grid differ in size (block-uniform exit)
-    const int oa = P.phase[phz].oa, ob = P.phase[phz].ob;
-    const int ktot = P.phase[phz].ktot;
+    const int m0 = mtile * BM, n0 = blockIdx.y * BN;
+    const int oa = G.oa[phz], ob = G.ob[phz];
+    const int ktot = G.ktot[phz];
     const int Ck = P.Ck, N = P.N;
     // this workgroup's k-tile range (split-K)
     const int nkt_total = (ktot + 31) >> 5;
@@ -89,9 +142,9 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
 
     // ---- one-time setup: tap table, prologue scale/shift, reduction scratch ----
     if (tid < SGAN_MAX_TAPS) {
-        const bool v = tid < P.phase[phz].ntaps;
-        const int dy = v ? (int)P.phase[phz].taps[tid].dy : 0, dx = v ? (int)P.phase[phz].taps[tid].dx : 0;
-        ttab[tid] = make_int4(dy, dx, (dy * P.Win + dx) * P.in_ld, v ? P.phase[phz].taps[tid].w_off : 0);
+        const bool v = tid < G.ntaps[phz];
+        const int dy = v ? (int)G.taps[phz][tid].dy : 0, dx = v ? (int)G.taps[phz][tid].dx : 0;
+        ttab[tid] = make_int4(dy, dx, (dy * P.Win + dx) * P.in_ld, v ? G.taps[phz][tid].w_off : 0);
     }
     for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
     {   // always present (identity when there is no prologue) so the main loop is branch-free
@@ -115,7 +168,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
     // by 32 k per tile: 32 = adv_tap * Ck + adv_c, so one conditional wrap per tile and no division.
     // Element offset of a gathered chunk = a_base[row] + ttab[tap].z + channel: two adds per tile.
     const int adv_tap = 32 / Ck, adv_c = 32 - adv_tap * Ck;
-    const int ntaps = P.phase[phz].ntaps;
+    const int ntaps = G.ntaps[phz];
     const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
     int a_iy[A_IT], a_ix[A_IT], a_base[A_IT], a_dst[A_IT];
     bool a_rowok[A_IT];
@@ -442,24 +495,26 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams P) {
 // Same prologue (norm + activation on load) and bias / tanh epilogue as the MFMA kernel.
 // ------------------------------------------------------------------------------------------
 template <int LPP, bool BKC>
-__global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParams P) {
+__global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParams G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* tdy = reinterpret_cast<int*>(smem);
     int* tdx = tdy + SGAN_MAX_TAPS;
     int* two = tdx + SGAN_MAX_TAPS;
     float* pscale = reinterpret_cast<float*>(two + SGAN_MAX_TAPS);
-    float* pshift = pscale + P.Ck;
+    float* pshift = pscale + G.Ck;
     const int tid = threadIdx.x;
-    const int phz = blockIdx.z;
-    const int Wp = P.phase[phz].Wp, M = P.phase[phz].Hp * Wp;
-    const int ntaps = P.phase[phz].ntaps, Ck = P.Ck;
+    int g, phz, mtile;
+    sg_decode_tile(G, blockIdx.x, g, phz, mtile);
+    const SgLocal P = sg_local(G, g);
+    const int Wp = G.q[g].Wp[phz], M = G.q[g].Hp[phz] * Wp;
+    const int ntaps = G.ntaps[phz], Ck = P.Ck;
     const bool has_pro = (P.pro.stats != nullptr) || (P.pro.act != SGAN_ACT_NONE);
     const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
     if (tid < SGAN_MAX_TAPS) {
         const bool v = tid < ntaps;
-        tdy[tid] = v ? (int)P.phase[phz].taps[tid].dy : 0;
-        tdx[tid] = v ? (int)P.phase[phz].taps[tid].dx : 0;
-        two[tid] = v ? P.phase[phz].taps[tid].w_off : 0;
+        tdy[tid] = v ? (int)G.taps[phz][tid].dy : 0;
+        tdx[tid] = v ? (int)G.taps[phz][tid].dx : 0;
+        two[tid] = v ? G.taps[phz][tid].w_off : 0;
     }
     if (has_pro) {
         for (int c = tid; c < Ck; c += 256) {
@@ -479,7 +534,7 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
     __syncthreads();
     constexpr int PPB = 256 / LPP;  // pixels per workgroup
     const int sub = tid % LPP;
-    const int m = blockIdx.x * PPB + tid / LPP;
+    const int m = mtile * PPB + tid / LPP;
     const bool mok = m < M;
     const int py = mok ? m / Wp : 0, px = mok ? m - py * Wp : 0;
     const int iy0 = py * P.is, ix0 = px * P.is;
@@ -488,7 +543,7 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
     int tap = (4 * sub) / Ck;
     int c = 4 * sub - tap * Ck;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nq = (P.phase[phz].ktot + 4 * LPP - 1) / (4 * LPP);
+    const int nq = (G.ktot[phz] + 4 * LPP - 1) / (4 * LPP);
     for (int q = 0; q < nq; ++q) {
         const bool kok = tap < ntaps;
         const int t = kok ? tap : 0;
@@ -539,7 +594,7 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
         for (int n = 0; n < 4; ++n) acc[n] += __shfl_xor(acc[n], o);
     }
     if (sub == 0 && mok) {
-        const int64_t pix = (int64_t)(py * P.os + P.phase[phz].oa) * P.Wout + (px * P.os + P.phase[phz].ob);
+        const int64_t pix = (int64_t)(py * P.os + G.oa[phz]) * P.Wout + (px * P.os + G.ob[phz]);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             float v = acc[n] + (P.bias ? P.bias[n] : 0.f);
@@ -550,13 +605,14 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
     }
 }
 
+static int sg_fill_tiles(SgIgemmParams& P, int rows_per_tile);   // prefix table; returns total tiles
+
 template <int LPP>
-static int sg_launch_small_n(const SgIgemmParams& P, hipStream_t st) {
-    int maxM = 0;
-    for (int i = 0; i < P.nphase; ++i) maxM = max(maxM, P.phase[i].Hp * P.phase[i].Wp);
-    if (maxM == 0) return SGAN_OK;
+static int sg_launch_small_n(SgIgemmParams& P, hipStream_t st) {
     constexpr int PPB = 256 / LPP;
-    dim3 grid((maxM + PPB - 1) / PPB, 1, P.nphase);
+    const int tiles = sg_fill_tiles(P, PPB);
+    if (tiles == 0) return SGAN_OK;
+    dim3 grid(tiles, 1, 1);
     const size_t lds = 3 * SGAN_MAX_TAPS * 4 + (size_t)2 * P.Ck * 4;
     sg_prof_begin(st);
     if (P.w_ks == 1) hipLaunchKernelGGL((sg_conv_small_n_kernel<LPP, true>), grid, dim3(256), lds, st, P);
@@ -573,8 +629,9 @@ static int sg_launch_small_n(const SgIgemmParams& P, hipStream_t st) {
 // per-lane streaming pass.  Thread t always works on channel group t % (N/4), so the statistics are
 // accumulated in registers and reach memory as one LDS atomic + one fp64 atomic per channel per block.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmParams P) {
+__global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmParams G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SgLocal P = sg_local(G, 0);   // split-K is single-problem
     const int N = P.N, NQ = N >> 2;
     float* red = reinterpret_cast<float*>(smem);  // [2N]
     float* cMean = red + 2 * N;                  // [N] (dact with norm)
@@ -722,27 +779,41 @@ int sg_build_phases(const sgan_conv_desc* d, bool dgrad, SgPhase* ph, int* nphas
     return SGAN_OK;
 }
 
-static int sg_max_m(const SgIgemmParams& P) {
-    int maxM = 0;
-    for (int i = 0; i < P.nphase; ++i) maxM = max(maxM, P.phase[i].Hp * P.phase[i].Wp);
-    return maxM;
+static int sg_fill_tiles(SgIgemmParams& P, int rows_per_tile) {
+    int t = 0;
+    for (int g = 0; g < P.nprob; ++g)
+        for (int ph = 0; ph < P.nphase; ++ph) {
+            P.q[g].tile0[ph] = t;
+            t += sg_cdiv(P.q[g].Hp[ph] * P.q[g].Wp[ph], rows_per_tile);
+        }
+    for (int g = 0; g < P.nprob; ++g)
+        for (int ph = P.nphase; ph < SGAN_MAX_PHASES; ++ph) P.q[g].tile0[ph] = 1 << 30;
+    return t;
 }
 
 static int sg_max_k(const SgIgemmParams& P) {
     int k = 0;
-    for (int i = 0; i < P.nphase; ++i) k = max(k, P.phase[i].ktot);
+    for (int i = 0; i < P.nphase; ++i) k = max(k, P.ktot[i]);
     return k;
 }
 
-// Split-K plan: deep reductions on small grids (a 17x17 layer is 24 workgroups walking 64-128 k-tiles one
-// after the other) are cut so that ~2-3 workgroups land on every CU; co-resident workgroups then overlap
-// each other's staging and MFMA phases.  Needs N % 4 == 0 channels with 256 % (N/4) == 0 for the epilogue.
+static long sg_total_tiles(const SgIgemmParams& P, int BM) {
+    long t = 0;
+    for (int g = 0; g < P.nprob; ++g)
+        for (int ph = 0; ph < P.nphase; ++ph) t += sg_cdiv(P.q[g].Hp[ph] * P.q[g].Wp[ph], BM);
+    return t;
+}
+
+// Split-K plan (single problem only): deep reductions on small grids (a 17x17 layer is 24 workgroups walking
+// 64-128 k-tiles one after the other) are cut so that ~2 workgroups land on every CU.  Needs N % 4 == 0 channels
+// with 256 % (N/4) == 0 for the epilogue.
 static int sg_plan_ksplit(const SgIgemmParams& P, int BM, int BN) {
-    const int maxM = sg_max_m(P);
-    if (maxM == 0) return 1;
+    if (P.nprob != 1) return 1;
+    const SgProb& Q = P.q[0];
     const int NQ = P.N >> 2;
-    if (NQ <= 0 || 256 % NQ != 0 || (P.out_ld & 3) || (P.xref && (P.xref_ld & 3))) return 1;
-    const long blocks = (long)sg_cdiv(maxM, BM) * sg_cdiv(P.N, BN) * P.nphase;
+    if (NQ <= 0 || 256 % NQ != 0 || (Q.out_ld & 3) || (Q.xref && (Q.xref_ld & 3))) return 1;
+    const long blocks = sg_total_tiles(P, BM) * sg_cdiv(P.N, BN);
+    if (blocks == 0) return 1;
     const int nkt = sg_cdiv(sg_max_k(P), 32);
     // measured on MI355X (tools/bench_layers.py): the slab round trip only pays when the grid is well under
     // one workgroup per CU, and the deeper the reduction the larger the grid it still pays for
@@ -759,15 +830,15 @@ static int sg_plan_ksplit(const SgIgemmParams& P, int BM, int BN) {
 template <int BM, int BN, int WGM, int WGN>
 static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes) {
     const bool bkc = P.w_ks == 1;
-    const int maxM = sg_max_m(P);
-    if (maxM == 0) return SGAN_OK;
+    const int tiles = sg_fill_tiles(P, BM);
+    if (tiles == 0) return SGAN_OK;
     int ks = sg_plan_ksplit(P, BM, BN);
-    const int64_t slab = (int64_t)P.Hout * P.Wout * P.N;
+    const int64_t slab = (int64_t)P.q[0].Hout * P.q[0].Wout * P.N;
     if (ks > 1 && (!ws || ws_bytes < (int64_t)ks * slab * 4)) ks = 1;   // no workspace: unsplit (still correct)
     P.ksplit = ks;
     P.slab = ks > 1 ? ws : nullptr;
     P.slab_stride = slab;
-    dim3 grid(sg_cdiv(maxM, BM), sg_cdiv(P.N, BN), P.nphase * ks);
+    dim3 grid(tiles, sg_cdiv(P.N, BN), ks);
     const size_t lds = (size_t)(2 * BM * 32 + 2 * BN * 32 + 2 * BN) * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
     if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
     sg_prof_begin(st);
@@ -783,7 +854,7 @@ static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t 
     sg_prof_end(st, g_sgan_last_kernel);
     if (ks > 1) {
         const int NQ = P.N >> 2;
-        const int64_t total = (int64_t)P.Hout * P.Wout * NQ;
+        const int64_t total = (int64_t)P.q[0].Hout * P.q[0].Wout * NQ;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 1024) blocks = 1024;   // 256 % NQ == 0, so blocks * 256 is a multiple of NQ
         const size_t elds = (size_t)6 * P.N * 4;
@@ -797,16 +868,19 @@ static void sg_pick_tile(const SgIgemmParams& P, int* BM, int* BN) {
     if (P.N <= 16) { *BM = 128; *BN = 16; return; }
     if (P.N <= 32) { *BM = 128; *BN = 32; return; }
     // 128x64 tiles only when they still fill the chip (256 CUs, 2 workgroups each)
-    const long blocks128 = (long)sg_cdiv(sg_max_m(P), 128) * sg_cdiv(P.N, 64) * P.nphase;
+    const long blocks128 = sg_total_tiles(P, 128) * sg_cdiv(P.N, 64);
     *BM = blocks128 >= 512 ? 128 : 64;
     *BN = 64;
 }
 
-static bool sg_use_small_n(const SgIgemmParams& P) { return P.N == 4 && !P.xref && !P.stats && (P.out_ld & 3) == 0; }
+static bool sg_use_small_n(const SgIgemmParams& P) {
+    if (P.N != 4) return false;
+    for (int g = 0; g < P.nprob; ++g)
+        if (P.q[g].xref || P.q[g].stats || (P.q[g].out_ld & 3)) return false;
+    return true;
+}
 
 static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes) {
-    static const int ablate = getenv("SGAN_DEBUG_ABLATE") ? atoi(getenv("SGAN_DEBUG_ABLATE")) : 0;
-    P.ablate = ablate;
     P.ksplit = 1;
     P.slab = nullptr;
     P.slab_stride = 0;
@@ -829,7 +903,7 @@ static int64_t sg_workspace_need(const SgIgemmParams& P) {
     int BM, BN;
     sg_pick_tile(P, &BM, &BN);
     const int ks = sg_plan_ksplit(P, BM, BN);
-    return ks > 1 ? (int64_t)ks * P.Hout * P.Wout * P.N * 4 : 0;
+    return ks > 1 ? (int64_t)ks * P.q[0].Hout * P.q[0].Wout * P.N * 4 : 0;
 }
 
 static int sg_check_common(const sgan_conv_desc* d) {
@@ -842,49 +916,120 @@ static int sg_check_common(const sgan_conv_desc* d) {
     return SGAN_OK;
 }
 
+static bool sg_same_layer(const sgan_conv_desc* a, const sgan_conv_desc* b) {
+    return a->kind == b->kind && a->k == b->k && a->stride == b->stride && a->pad == b->pad && a->Cin == b->Cin && a->Cout == b->Cout;
+}
+
+// common part of a group from its first descriptor; per-problem phase sizes from each descriptor
+static int sg_group_geometry(SgIgemmParams& P, const sgan_conv_desc* const* descs, int n, bool dgrad) {
+    if (n < 1 || n > SG_MAX_PROB) return sgan_fail(SGAN_ERR_INVALID, "1..%d problems per grouped launch", SG_MAX_PROB);
+    memset(&P, 0, sizeof(P));
+    P.nprob = n;
+    for (int g = 0; g < n; ++g) {
+        int rc = sg_check_common(descs[g]);
+        if (rc) return rc;
+        if (!sg_same_layer(descs[0], descs[g])) return sgan_fail(SGAN_ERR_INVALID, "grouped problems must be the same layer type");
+        SgPhase ph[SGAN_MAX_PHASES];
+        int nphase, is, os;
+        rc = sg_build_phases(descs[g], dgrad, ph, &nphase, &is, &os);
+        if (rc) return rc;
+        if (g == 0) {
+            P.nphase = nphase; P.is = is; P.os = os;
+            for (int i = 0; i < nphase; ++i) {
+                P.oa[i] = ph[i].oa; P.ob[i] = ph[i].ob; P.ntaps[i] = ph[i].ntaps; P.ktot[i] = ph[i].ktot;
+                for (int t = 0; t < ph[i].ntaps; ++t) P.taps[i][t] = ph[i].taps[t];
+            }
+        }
+        for (int i = 0; i < nphase; ++i) { P.q[g].Hp[i] = ph[i].Hp; P.q[g].Wp[i] = ph[i].Wp; }
+    }
+    return SGAN_OK;
+}
+
+static void sg_set_norm(const sgan_norm_desc* d, const double** stats, const float** gamma, const float** beta, int32_t* count) {
+    *stats = d ? d->stats : nullptr;
+    *gamma = d ? d->gamma : nullptr;
+    *beta = d ? d->beta : nullptr;
+    *count = d ? d->count : 1;
+}
+
+extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, int32_t out_act, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    SGAN_CHECK(jobs && n >= 1 && n <= SG_MAX_PROB, "1..%d jobs", SG_MAX_PROB);
+    SGAN_CHECK(out_act == SGAN_ACT_NONE || out_act == SGAN_ACT_TANH, "out_act must be none or tanh");
+    const sgan_conv_desc* descs[SG_MAX_PROB];
+    for (int g = 0; g < n; ++g) descs[g] = jobs[g].d;
+    SgIgemmParams P;
+    int rc = sg_group_geometry(P, descs, n, false);
+    if (rc) return rc;
+    const sgan_conv_desc* d0 = jobs[0].d;
+    P.Ck = d0->Cin; P.N = d0->Cout;
+    P.w_ns = d0->Cin; P.w_ks = 1;  // B[k=ci][n=co] = W[tap][co][ci]
+    P.out_act = out_act;
+    const sgan_norm_desc* n0 = jobs[0].in_norm;
+    P.pro_act = n0 ? n0->act : SGAN_ACT_NONE; P.pro_slope = n0 ? n0->slope : 0.f; P.pro_eps = n0 ? n0->eps : 0.f;
+    P.xn_act = SGAN_ACT_NONE;
+    for (int g = 0; g < n; ++g) {
+        const sgan_conv_fwd_job& J = jobs[g];
+        SGAN_CHECK(J.in && J.w && J.out, "null tensor in job %d", g);
+        SGAN_CHECK(J.in_ld >= J.d->Cin && J.out_ld >= J.d->Cout && (J.in_ld & 3) == 0, "bad leading dims in job %d", g);
+        SGAN_CHECK((J.in_norm ? J.in_norm->act : SGAN_ACT_NONE) == P.pro_act, "grouped jobs must share the prologue activation");
+        SgProb& Q = P.q[g];
+        Q.in = J.in; Q.out = J.out; Q.w = J.w; Q.bias = J.bias; Q.xref = nullptr; Q.stats = J.out_stats;
+        Q.Hin = J.d->Hin; Q.Win = J.d->Win; Q.in_ld = J.in_ld; Q.Hout = J.d->Hout; Q.Wout = J.d->Wout; Q.out_ld = J.out_ld;
+        sg_set_norm(J.in_norm, &Q.pro_stats, &Q.pro_gamma, &Q.pro_beta, &Q.pro_count);
+        Q.xn_count = 1;
+    }
+    if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)
+    return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
+}
+
+extern "C" int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t n, void* workspace, int64_t workspace_bytes,
+                                       void* stream) {
+    SGAN_CHECK(jobs && n >= 1 && n <= SG_MAX_PROB, "1..%d jobs", SG_MAX_PROB);
+    const sgan_conv_desc* descs[SG_MAX_PROB];
+    for (int g = 0; g < n; ++g) descs[g] = jobs[g].d;
+    SgIgemmParams P;
+    int rc = sg_group_geometry(P, descs, n, true);
+    if (rc) return rc;
+    const sgan_conv_desc* d0 = jobs[0].d;
+    P.Ck = d0->Cout; P.N = d0->Cin;
+    P.w_ns = 1; P.w_ks = d0->Cin;  // B[k=co][n=ci] = W[tap][co][ci]
+    P.out_act = SGAN_ACT_NONE;
+    P.pro_act = SGAN_ACT_NONE;
+    const sgan_norm_desc* x0 = jobs[0].x ? jobs[0].x_norm : nullptr;
+    P.xn_act = x0 ? x0->act : SGAN_ACT_NONE; P.xn_slope = x0 ? x0->slope : 0.f; P.xn_eps = x0 ? x0->eps : 0.f;
+    for (int g = 0; g < n; ++g) {
+        const sgan_conv_dgrad_job& J = jobs[g];
+        SGAN_CHECK(J.dout && J.w && J.din, "null tensor in job %d", g);
+        SGAN_CHECK(J.dout_ld >= J.d->Cout && J.din_ld >= J.d->Cin && (J.dout_ld & 3) == 0, "bad leading dims in job %d", g);
+        SGAN_CHECK(!J.x || J.x_ld >= J.d->Cin, "bad x_ld in job %d", g);
+        SGAN_CHECK(!(J.bwd_sums && !J.x), "bwd_sums needs x (job %d)", g);
+        SGAN_CHECK((J.x != nullptr) == (jobs[0].x != nullptr), "grouped jobs must all have / all lack the forward tensor");
+        const sgan_norm_desc* xn = J.x ? J.x_norm : nullptr;
+        SGAN_CHECK((xn ? xn->act : SGAN_ACT_NONE) == P.xn_act, "grouped jobs must share the activation");
+        SgProb& Q = P.q[g];
+        Q.in = J.dout; Q.out = J.din; Q.w = J.w; Q.bias = nullptr; Q.xref = J.x; Q.stats = J.bwd_sums;
+        Q.Hin = J.d->Hout; Q.Win = J.d->Wout; Q.in_ld = J.dout_ld; Q.Hout = J.d->Hin; Q.Wout = J.d->Win; Q.out_ld = J.din_ld;
+        Q.xref_ld = J.x_ld;
+        Q.pro_count = 1;
+        sg_set_norm(xn, &Q.xn_stats, &Q.xn_gamma, &Q.xn_beta, &Q.xn_count);
+    }
+    if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)
+    return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
+}
+
 extern "C" int sgan_conv_fwd(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
                              const float* w, const float* bias, float* out, int32_t out_ld, int32_t out_act,
                              double* out_stats, void* workspace, int64_t workspace_bytes, void* stream) {
-    int rc = sg_check_common(d);
-    if (rc) return rc;
-    SGAN_CHECK(in && w && out, "null tensor");
-    SGAN_CHECK(in_ld >= d->Cin && out_ld >= d->Cout && (in_ld & 3) == 0, "bad leading dims");
-    SGAN_CHECK(out_act == SGAN_ACT_NONE || out_act == SGAN_ACT_TANH, "out_act must be none or tanh");
-    SgIgemmParams P;
-    memset(&P, 0, sizeof(P));
-    rc = sg_build_phases(d, false, P.phase, &P.nphase, &P.is, &P.os);
-    if (rc) return rc;
-    P.in = in; P.out = out; P.w = w; P.bias = bias; P.xref = nullptr; P.stats = out_stats;
-    P.Hin = d->Hin; P.Win = d->Win; P.Ck = d->Cin; P.in_ld = in_ld;
-    P.Hout = d->Hout; P.Wout = d->Wout; P.N = d->Cout; P.out_ld = out_ld; P.xref_ld = 0;
-    P.w_ns = d->Cin; P.w_ks = 1;  // B[k=ci][n=co] = W[tap][co][ci]
-    P.out_act = out_act;
-    P.pro = sg_norm_from(in_norm);
-    P.xn = sg_norm_from(nullptr);
-    if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)
-    return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
+    if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
+    sgan_conv_fwd_job j = {d, in, in_ld, in_norm, w, bias, out, out_ld, out_stats};
+    return sgan_conv_fwd_grouped(&j, 1, out_act, workspace, workspace_bytes, stream);
 }
 
 extern "C" int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32_t dout_ld, const float* w,
                                float* din, int32_t din_ld, const float* x, int32_t x_ld, const sgan_norm_desc* x_norm,
                                double* bwd_sums, void* workspace, int64_t workspace_bytes, void* stream) {
-    int rc = sg_check_common(d);
-    if (rc) return rc;
-    SGAN_CHECK(dout && w && din, "null tensor");
-    SGAN_CHECK(dout_ld >= d->Cout && din_ld >= d->Cin && (dout_ld & 3) == 0, "bad leading dims");
-    SGAN_CHECK(!x || x_ld >= d->Cin, "bad x_ld");
-    SGAN_CHECK(!(bwd_sums && !x), "bwd_sums needs x");
-    SgIgemmParams P;
-    memset(&P, 0, sizeof(P));
-    rc = sg_build_phases(d, true, P.phase, &P.nphase, &P.is, &P.os);
-    if (rc) return rc;
-    P.in = dout; P.out = din; P.w = w; P.bias = nullptr; P.xref = x; P.stats = bwd_sums;
-    P.Hin = d->Hout; P.Win = d->Wout; P.Ck = d->Cout; P.in_ld = dout_ld;
-    P.Hout = d->Hin; P.Wout = d->Win; P.N = d->Cin; P.out_ld = din_ld; P.xref_ld = x_ld;
-    P.w_ns = 1; P.w_ks = d->Cin;  // B[k=co][n=ci] = W[tap][co][ci]
-    P.out_act = SGAN_ACT_NONE;
-    P.pro = sg_norm_from(nullptr);
-    P.xn = sg_norm_from(x ? x_norm : nullptr);
-    if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)
-    return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
+    if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
+    sgan_conv_dgrad_job j = {d, dout, dout_ld, w, din, din_ld, x, x_ld, x_norm, bwd_sums};
+    return sgan_conv_dgrad_grouped(&j, 1, workspace, workspace_bytes, stream);
 }

@@ -17,22 +17,44 @@
 // nn.ConvTranspose2d on the path (models/networks.py:502-529, :815-835).
 #include "sgan_common.h"
 
-struct SgWgradParams {
+#define SGW_MAX_PROB 8
+
+struct SgWgradProb {
     const float* in;
     const float* dout;
     float* dw;
     float* dbias;
-    int32_t Hin, Win, Cin, in_ld;
-    int32_t Hout, Wout, Cout, dout_ld;
+    const double* pro_stats;
+    const float* pro_gamma;
+    const float* pro_beta;
+    int32_t Hin, Win, in_ld;
+    int32_t Hout, Wout, dout_ld;
+    int32_t pro_count;
+    int32_t nsplit;  // pixel-range splits of this problem
+    int32_t z0;      // first blockIdx.z of this problem (z = z0 + phase * nsplit + split)
+    int32_t Hp[SGAN_MAX_PHASES], Wp[SGAN_MAX_PHASES];
+};
+
+struct SgWgradParams {   // kernel argument: common layer description + up to 8 problems (see sgan_igemm.hip)
+    int32_t Cin, Cout;
     int32_t is, os;
     int32_t w_ns;
-    int32_t nphase, nsplit;
+    int32_t nphase, nprob;
+    int32_t pro_act;
+    float pro_slope, pro_eps;
+    int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
+    SgTap taps[SGAN_MAX_PHASES][SGAN_MAX_TAPS];
+    SgWgradProb q[SGW_MAX_PROB];
+};
+
+struct SgWgradLocal {
+    const float* in; const float* dout; float* dw; float* dbias;
+    int32_t Hin, Win, Cin, in_ld, Hout, Wout, Cout, dout_ld, is, os, w_ns, nsplit;
     SgNorm pro;
-    SgPhase phase[SGAN_MAX_PHASES];
 };
 
 template <int BCO, int BKC, int WGC, int WGK>
-__global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams P) {
+__global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     constexpr int BP = 32;
     constexpr int WTC = BCO / WGC, WTK = BKC / WGK, MB = WTC / 16, NB = WTK / 16;
     constexpr int LDD = (BCO % 32 == 0) ? BCO + 16 : BCO;
@@ -46,14 +68,25 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams P) {
     float* Ds = reinterpret_cast<float*>(smem);  // [2][BP*LDD]
     float* As = Ds + 2 * BP * LDD;               // [2][BP*LDA]
     float* pscale = As + 2 * BP * LDA;           // [Cin]
-    float* pshift = pscale + P.Cin;
+    float* pshift = pscale + G.Cin;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wc = wid / WGK, wk = wid % WGK;
     const int fr = lane & 15, fq = lane >> 4;
-    const int phz = blockIdx.z / P.nsplit, split = blockIdx.z % P.nsplit;
-    const SgPhase& ph = P.phase[phz];
-    const int Hp = ph.Hp, Wp = ph.Wp, M = Hp * Wp, ktot = ph.ktot;
+    int g = 0;
+    for (int gi = 1; gi < G.nprob; ++gi)
+        if ((int)blockIdx.z >= G.q[gi].z0) g = gi;
+    const SgWgradProb& Q = G.q[g];
+    SgWgradLocal P;
+    P.in = Q.in; P.dout = Q.dout; P.dw = Q.dw; P.dbias = Q.dbias;
+    P.Hin = Q.Hin; P.Win = Q.Win; P.Cin = G.Cin; P.in_ld = Q.in_ld; P.Hout = Q.Hout; P.Wout = Q.Wout; P.Cout = G.Cout;
+    P.dout_ld = Q.dout_ld; P.is = G.is; P.os = G.os; P.w_ns = G.w_ns; P.nsplit = Q.nsplit;
+    P.pro.stats = Q.pro_stats; P.pro.gamma = Q.pro_gamma; P.pro.beta = Q.pro_beta; P.pro.count = Q.pro_count;
+    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope;
+    const int zl = blockIdx.z - Q.z0;
+    const int phz = zl / P.nsplit, split = zl % P.nsplit;
+    const int Hp = Q.Hp[phz], Wp = Q.Wp[phz], M = Hp * Wp, ktot = G.ktot[phz];
+    const int ph_oa = G.oa[phz], ph_ob = G.ob[phz];
     const int kc0 = blockIdx.x * BKC, co0 = blockIdx.y * BCO;
     if (kc0 >= ktot || M == 0) return;
     const int nchunk_total = (M + BP - 1) / BP;
@@ -86,7 +119,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams P) {
     const bool a_kok = a_kcol < ktot;
     const int a_tap = a_kok ? a_kcol / Cin : 0;
     const int a_c = a_kcol - a_tap * Cin;
-    const int a_dy = ph.taps[a_tap].dy, a_dx = ph.taps[a_tap].dx;
+    const int a_dy = G.taps[phz][a_tap].dy, a_dx = G.taps[phz][a_tap].dx;
     // D staging
     const int d_c4 = tid % DQ, d_row0 = tid / DQ;
     constexpr int D_ROWS_PER_IT = 256 / DQ;
@@ -95,7 +128,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams P) {
     f32x4 a_reg[A_IT], d_reg[D_IT];
     bool a_val[A_IT], d_val[D_IT];
     const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
-    const int oa = ph.oa, ob = ph.ob;
+    const int oa = ph_oa, ob = ph_ob;
 
     // pixel walk: row r of chunk ch is pixel m = ch*32 + r; (py, px) advance by 32 pixels per chunk with one
     // conditional wrap (32 = adv_y * Wp + adv_x) -- no division inside the loop
@@ -218,7 +251,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams P) {
         const int kcol = kc0 + wk * WTK + j * 16 + fr;
         if (kcol >= ktot) continue;
         const int tap = kcol / Cin, ci = kcol - tap * Cin;
-        float* base = P.dw + ph.taps[tap].w_off + ci;
+        float* base = P.dw + G.taps[phz][tap].w_off + ci;
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
 #pragma unroll
@@ -237,20 +270,32 @@ template <int BCO, int BKC, int WGC, int WGK>
 static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
     constexpr int LDD = (BCO % 32 == 0) ? BCO + 16 : BCO;
     constexpr int LDA = (BKC % 32 == 0) ? BKC + 16 : BKC;
-    int maxM = 0, maxK = 0;
-    for (int i = 0; i < P.nphase; ++i) {
-        maxM = max(maxM, P.phase[i].Hp * P.phase[i].Wp);
-        maxK = max(maxK, P.phase[i].ktot);
+    int maxK = 0;
+    for (int i = 0; i < P.nphase; ++i) maxK = max(maxK, P.ktot[i]);
+    const int tiles = sgw_cdiv(maxK, BKC) * sgw_cdiv(P.Cout, BCO);
+    // pixel-range split per problem: aim at ~1024 workgroups over the whole launch, >= 4 chunks of 32 pixels each
+    long chunks_total = 0;
+    for (int g = 0; g < P.nprob; ++g) {
+        int maxM = 0;
+        for (int i = 0; i < P.nphase; ++i) maxM = max(maxM, P.q[g].Hp[i] * P.q[g].Wp[i]);
+        chunks_total += (long)sgw_cdiv(maxM, 32) * P.nphase;
     }
-    if (maxM == 0) return SGAN_OK;
-    const int tiles = sgw_cdiv(maxK, BKC) * sgw_cdiv(P.Cout, BCO) * P.nphase;
-    const int nchunk = sgw_cdiv(maxM, 32);
-    int nsplit = 1024 / tiles;
-    if (nsplit > nchunk / 4) nsplit = nchunk / 4;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > 512) nsplit = 512;
-    P.nsplit = nsplit;
-    dim3 grid(sgw_cdiv(maxK, BKC), sgw_cdiv(P.Cout, BCO), P.nphase * nsplit);
+    if (chunks_total == 0) return SGAN_OK;
+    const double want_z = 1024.0 / tiles;   // total z extent we would like
+    int z = 0;
+    for (int g = 0; g < P.nprob; ++g) {
+        int maxM = 0;
+        for (int i = 0; i < P.nphase; ++i) maxM = max(maxM, P.q[g].Hp[i] * P.q[g].Wp[i]);
+        const int nchunk = sgw_cdiv(maxM, 32);
+        int nsplit = (int)(want_z * ((double)nchunk * P.nphase / (double)chunks_total) / P.nphase + 0.5);
+        if (nsplit > nchunk / 4) nsplit = nchunk / 4;
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > 512) nsplit = 512;
+        P.q[g].nsplit = nsplit;
+        P.q[g].z0 = z;
+        z += P.nphase * nsplit;
+    }
+    dim3 grid(sgw_cdiv(maxK, BKC), sgw_cdiv(P.Cout, BCO), z);
     const size_t lds = (size_t)(2 * 32 * LDD + 2 * 32 * LDA + 2 * P.Cin) * 4;
     sg_prof_begin(st);
     hipLaunchKernelGGL((sg_wgrad_kernel<BCO, BKC, WGC, WGK>), grid, dim3(256), lds, st, P);
@@ -261,23 +306,54 @@ static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
     return SGAN_OK;
 }
 
-extern "C" int sgan_conv_wgrad(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
-                               const float* dout, int32_t dout_ld, float* dw, float* dbias, void* stream) {
-    if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
-    SGAN_CHECK((d->Cin & 3) == 0 && (d->Cout & 3) == 0, "stored channels must be multiples of 4");
-    SGAN_CHECK(in && dout && dw, "null tensor");
-    SGAN_CHECK(in_ld >= d->Cin && dout_ld >= d->Cout && (in_ld & 3) == 0 && (dout_ld & 3) == 0, "bad leading dims");
+extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* stream) {
+    SGAN_CHECK(jobs && n >= 1 && n <= SGW_MAX_PROB, "1..%d jobs", SGW_MAX_PROB);
     SgWgradParams P;
     memset(&P, 0, sizeof(P));
-    int rc = sg_build_phases(d, false, P.phase, &P.nphase, &P.is, &P.os);
-    if (rc) return rc;
-    P.in = in; P.dout = dout; P.dw = dw; P.dbias = dbias;
-    P.Hin = d->Hin; P.Win = d->Win; P.Cin = d->Cin; P.in_ld = in_ld;
-    P.Hout = d->Hout; P.Wout = d->Wout; P.Cout = d->Cout; P.dout_ld = dout_ld;
-    P.w_ns = d->Cin;
-    P.pro = sg_norm_from(in_norm);
+    P.nprob = n;
+    const sgan_conv_desc* d0 = jobs[0].d;
+    if (!d0) return sgan_fail(SGAN_ERR_INVALID, "null desc");
+    const sgan_norm_desc* n0 = jobs[0].in_norm;
+    P.pro_act = n0 ? n0->act : SGAN_ACT_NONE; P.pro_slope = n0 ? n0->slope : 0.f; P.pro_eps = n0 ? n0->eps : 0.f;
+    for (int g = 0; g < n; ++g) {
+        const sgan_conv_wgrad_job& J = jobs[g];
+        const sgan_conv_desc* d = J.d;
+        if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
+        SGAN_CHECK((d->Cin & 3) == 0 && (d->Cout & 3) == 0, "stored channels must be multiples of 4");
+        SGAN_CHECK(J.in && J.dout && J.dw, "null tensor in job %d", g);
+        SGAN_CHECK(J.in_ld >= d->Cin && J.dout_ld >= d->Cout && (J.in_ld & 3) == 0 && (J.dout_ld & 3) == 0, "bad leading dims in job %d", g);
+        SGAN_CHECK(d->kind == d0->kind && d->k == d0->k && d->stride == d0->stride && d->pad == d0->pad && d->Cin == d0->Cin &&
+                       d->Cout == d0->Cout, "grouped problems must be the same layer type");
+        SGAN_CHECK((J.in_norm ? J.in_norm->act : SGAN_ACT_NONE) == P.pro_act, "grouped jobs must share the prologue activation");
+        SgPhase ph[SGAN_MAX_PHASES];
+        int nphase, is, os;
+        int rc = sg_build_phases(d, false, ph, &nphase, &is, &os);
+        if (rc) return rc;
+        if (g == 0) {
+            P.nphase = nphase; P.is = is; P.os = os;
+            for (int i = 0; i < nphase; ++i) {
+                P.oa[i] = ph[i].oa; P.ob[i] = ph[i].ob; P.ntaps[i] = ph[i].ntaps; P.ktot[i] = ph[i].ktot;
+                for (int t = 0; t < ph[i].ntaps; ++t) P.taps[i][t] = ph[i].taps[t];
+            }
+        }
+        SgWgradProb& Q = P.q[g];
+        for (int i = 0; i < nphase; ++i) { Q.Hp[i] = ph[i].Hp; Q.Wp[i] = ph[i].Wp; }
+        Q.in = J.in; Q.dout = J.dout; Q.dw = J.dw; Q.dbias = J.dbias;
+        Q.Hin = d->Hin; Q.Win = d->Win; Q.in_ld = J.in_ld; Q.Hout = d->Hout; Q.Wout = d->Wout; Q.dout_ld = J.dout_ld;
+        Q.pro_stats = J.in_norm ? J.in_norm->stats : nullptr;
+        Q.pro_gamma = J.in_norm ? J.in_norm->gamma : nullptr;
+        Q.pro_beta = J.in_norm ? J.in_norm->beta : nullptr;
+        Q.pro_count = J.in_norm ? J.in_norm->count : 1;
+    }
+    P.Cin = d0->Cin; P.Cout = d0->Cout; P.w_ns = d0->Cin;
     hipStream_t st = (hipStream_t)stream;
-    if (d->Cout <= 16) return sg_launch_wgrad<16, 128, 1, 4>(P, st);
-    if (d->Cout <= 32) return sg_launch_wgrad<32, 64, 1, 4>(P, st);
+    if (d0->Cout <= 16) return sg_launch_wgrad<16, 128, 1, 4>(P, st);
+    if (d0->Cout <= 32) return sg_launch_wgrad<32, 64, 1, 4>(P, st);
     return sg_launch_wgrad<64, 64, 2, 2>(P, st);
+}
+
+extern "C" int sgan_conv_wgrad(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
+                               const float* dout, int32_t dout_ld, float* dw, float* dbias, void* stream) {
+    sgan_conv_wgrad_job j = {d, in, in_ld, in_norm, dout, dout_ld, dw, dbias};
+    return sgan_conv_wgrad_grouped(&j, 1, stream);
 }

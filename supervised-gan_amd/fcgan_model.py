@@ -84,6 +84,7 @@ class FCGANModel(BaseModel):
             self.optimizer_D = FusedAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
             self.grad_sync = None   # data-parallel hook: callable(optimizer) run between backward and step
             self._pool_override = None   # graphed step: static buffer the host-side ImagePool fills
+            self._group = bool(self.gpu_ids) and not getattr(opt, 'no_group', False)
             n_streams = 2 * self.n_netD if (self.gpu_ids and not getattr(opt, 'no_d_streams', False)) else 0
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
 
@@ -124,6 +125,9 @@ class FCGANModel(BaseModel):
         independent and individually too small to fill 256 CUs (a 17x17 layer is 24 workgroups), so each
         runs on its own HIP stream, forked from and joined back into the current one; autograd replays
         every chain's backward on the stream its forward used."""
+        if self._group and networks.can_group([d for d, _, _ in jobs]):
+            preds = networks.multi_forward([(d, x) for d, x, _ in jobs])      # one launch per layer for all chains
+            return [self.criterionGAN(p, is_real) for p, (_, _, is_real) in zip(preds, jobs)]
         streams = self._streams[:len(jobs)] if self._streams else None
         losses = []
         if not streams:

@@ -412,6 +412,175 @@ class _ChainFn(torch.autograd.Function):
         return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
+# ------------------------------------------------------------------------------------------------
+# grouped execution: several chains of the same architecture, one kernel launch per layer
+# ------------------------------------------------------------------------------------------------
+def _same_architecture(a: "ChainNet", b: "ChainNet") -> bool:
+    if len(a.layers) != len(b.layers) or a.final_act != b.final_act:
+        return False
+    key = lambda L: (L.kind, L.k, L.stride, L.pad, L.cin, L.cout, L.bias, L.norm, L.act, L.slope)
+    return all(key(x) == key(y) for x, y in zip(a.layers, b.layers))
+
+
+def can_group(nets) -> bool:
+    nets = list(nets)
+    return 1 < len(nets) <= 8 and all(_same_architecture(nets[0], n) for n in nets[1:])
+
+
+def _grouped_forward(nets, xs):
+    """nets[j] applied to xs[j] ([H,W,Cs] buffers); per layer ONE grouped launch.  Returns per-job (outs, stats)."""
+    dev = xs[0].device
+    J = len(nets)
+    geos = [n._geometry(x.shape[0], x.shape[1]) for n, x in zip(nets, xs)]
+    per_job = sum(2 * L.cout_s for L in nets[0].layers if L.norm)
+    arena = torch.zeros(max(per_job * J, 1), dtype=torch.float64, device=dev)
+    stats = []
+    for j in range(J):
+        st, o = [], j * per_job
+        for L in nets[j].layers:
+            if L.norm:
+                st.append(arena[o: o + 2 * L.cout_s])
+                o += 2 * L.cout_s
+            else:
+                st.append(None)
+        stats.append(st)
+    outs = [[] for _ in range(J)]
+    cur = list(xs)
+    nL = len(nets[0].layers)
+    for li in range(nL):
+        jobs = []
+        for j, net in enumerate(nets):
+            L = net.layers[li]
+            desc, h, w, ho, wo = geos[j][li]
+            out = torch.empty((ho, wo, L.cout_s), dtype=torch.float32, device=dev)
+            in_norm = net._norm_of(li - 1, stats[j], h * w) if li > 0 else None
+            wt, b = net._wb(L)
+            jobs.append((desc, cur[j], in_norm, wt, b, out, stats[j][li]))
+            outs[j].append(out)
+            cur[j] = out
+        ops.conv_fwd_grouped(jobs, nets[0].final_act if li == nL - 1 else ACT_NONE)
+    for j, net in enumerate(nets):
+        if net._bn_boxes:
+            rl = []
+            for li, L in enumerate(net.layers):
+                if L.norm == "bn":
+                    nb = net._bn_boxes[L.key]
+                    _, _, _, ho, wo = geos[j][li]
+                    rl.append((stats[j][li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo))
+            ops.bn_running_update(rl, BN_MOMENTUM)
+    return outs, stats
+
+
+def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
+    dev = xs[0].device
+    J = len(nets)
+    geos = [n._geometry(x.shape[0], x.shape[1]) for n, x in zip(nets, xs)]
+    nL = len(nets[0].layers)
+    for j, net in enumerate(nets):
+        if want_wgrad[j]:
+            net._ensure_grads()
+    dcur = list(douts)
+    if nets[0].final_act == ACT_TANH:
+        for j in range(J):
+            d2 = torch.empty_like(outs[j][-1])
+            ops.tanh_bwd(dcur[j].contiguous(), outs[j][-1], d2)
+            dcur[j] = d2
+    per_job = sum(2 * L.cout_s for L in nets[0].layers if L.norm)
+    arena = torch.zeros(max(per_job * J, 1), dtype=torch.float64, device=dev)
+    sums = []
+    for j in range(J):
+        sm, o = [], j * per_job
+        for L in nets[j].layers:
+            if L.norm:
+                sm.append(arena[o: o + 2 * L.cout_s])
+                o += 2 * L.cout_s
+            else:
+                sm.append(None)
+        sums.append(sm)
+    dxs = [None] * J
+    for li in range(nL - 1, -1, -1):
+        srcs = [outs[j][li - 1] if li > 0 else xs[j] for j in range(J)]
+        norms = [nets[j]._norm_of(li - 1, stats[j], geos[j][li][1] * geos[j][li][2]) if li > 0 else None for j in range(J)]
+        wj = [j for j in range(J) if want_wgrad[j]]
+        if wj:
+            ops.conv_wgrad_grouped([(geos[j][li][0], srcs[j], norms[j], dcur[j]) + nets[j]._gwb(nets[j].layers[li]) for j in wj])
+        if li > 0:
+            jobs, dins = [], []
+            for j, net in enumerate(nets):
+                Pv = net.layers[li - 1]
+                desc, h, w, ho, wo = geos[j][li]
+                din = torch.empty((h, w, Pv.cout_s), dtype=torch.float32, device=dev)
+                dins.append(din)
+                jobs.append((desc, dcur[j], net._wb(net.layers[li])[0], din, srcs[j], norms[j], sums[j][li - 1]))
+            ops.conv_dgrad_grouped(jobs)
+            for j, net in enumerate(nets):
+                Pv = net.layers[li - 1]
+                if Pv.norm:
+                    bn = Pv.norm == "bn" and want_wgrad[j]
+                    dg = net._gflat[Pv.g_off: Pv.g_off + Pv.cout_s] if bn else None
+                    db = net._gflat[Pv.be_off: Pv.be_off + Pv.cout_s] if bn else None
+                    ops.norm_bwd_apply(dins[j], srcs[j], norms[j], sums[j][li - 1], dg, db)
+                dcur[j] = dins[j]
+        else:
+            dj = [j for j in range(J) if need_dx[j]]
+            if dj:
+                jobs = []
+                for j in dj:
+                    L = nets[j].layers[0]
+                    desc, h, w, ho, wo = geos[j][0]
+                    dxs[j] = torch.empty((h, w, L.cin_s), dtype=torch.float32, device=dev)
+                    jobs.append((desc, dcur[j], nets[j]._wb(L)[0], dxs[j], None, None, None))
+                ops.conv_dgrad_grouped(jobs)
+    return dxs
+
+
+class _MultiChainFn(torch.autograd.Function):
+    """One autograd node for several network calls that share an architecture (the three discriminators on
+    the fake and the real batch): each layer of all of them is ONE kernel launch."""
+
+    @staticmethod
+    def forward(ctx, nets, *tensors):
+        J = len(nets)
+        xlog = tensors[:J]
+        xbs = [net._prepare_input(x) for net, x in zip(nets, xlog)]
+        outs, stats = _grouped_forward(nets, [xb["chain_in"] for xb in xbs])
+        ctx.nets, ctx.xbs, ctx.outs, ctx.stats = nets, xbs, outs, stats
+        ctx.need_dx = [bool(ctx.needs_input_grad[1 + j]) for j in range(J)]
+        any_param = any(ctx.needs_input_grad[1 + J:])
+        ctx.want_wgrad = [net.compute_param_grads and any_param for net in nets]
+        return tuple(ops.logical_view(outs[j][-1], nets[j].layers[-1].cout) for j in range(J))
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        nets = ctx.nets
+        J = len(nets)
+        douts = []
+        for j in range(J):
+            g = gouts[j]
+            if g is None:
+                g = torch.zeros_like(ops.logical_view(ctx.outs[j][-1], nets[j].layers[-1].cout))
+            douts.append(ops.as_nhwc(g))
+        dch = _grouped_backward(nets, [xb["chain_in"] for xb in ctx.xbs], ctx.outs, ctx.stats, douts, ctx.need_dx, ctx.want_wgrad)
+        dxs = tuple(nets[j]._finish_input_grad(ctx.xbs[j], dch[j]) if ctx.need_dx[j] else None for j in range(J))
+        return (None,) + dxs + (None,) * (len(ctx.needs_input_grad) - 1 - J)
+
+
+def multi_forward(jobs):
+    """[(net, x)] -> [net.forward(x)] with one kernel launch per layer for all jobs (same-architecture nets,
+    <= 8 jobs); anything else falls back to one call per job."""
+    jobs = list(jobs)
+    nets = [n for n, _ in jobs]
+    if not can_group(nets):
+        return [n.forward(x) for n, x in jobs]
+    params, seen = [], set()
+    for n in nets:
+        if id(n) not in seen:
+            seen.add(id(n))
+            params += list(n.model.parameters())
+    outs = _MultiChainFn.apply(nets, *[x for _, x in jobs], *params)
+    return [n._wrap_output(o) for n, o in zip(nets, outs)]
+
+
 class FCGANGenerator(ChainNet):
     """FCGANGenerator (models/networks.py:493-540): ConvT(k4,s2,p1) -> BatchNorm -> ReLU x n_layers,
     ConvT -> Tanh.  `norm_layer` is hard-wired to BatchNorm by define_G (models/networks.py:87) and
@@ -446,6 +615,9 @@ class FCGANGenerator(ChainNet):
             raise NotImplementedError("only the default Tanh output activation is implemented")
         params = list(self.model.parameters())
         return _ChainFn.apply(self, x, *params)
+
+    def _wrap_output(self, y):
+        return y
 
 
 class NLayerDiscriminator(ChainNet):
@@ -520,7 +692,9 @@ class NLayerDiscriminator(ChainNet):
 
     def forward(self, x):
         params = list(self.model.parameters())
-        logits = _ChainFn.apply(self, x, *params)
+        return self._wrap_output(_ChainFn.apply(self, x, *params))
+
+    def _wrap_output(self, logits):
         if not self.use_sigmoid:
             return logits
         if self.fuse_sigmoid_into_loss:

@@ -78,6 +78,41 @@ def conv_wgrad(desc, x, in_norm, dout, dw, dbias):
                                     _ptr(dw), _ptr(dbias), _stream()), "sgan_conv_wgrad")
 
 
+def _pn(d):
+    return C.pointer(d) if d is not None else None
+
+
+def conv_fwd_grouped(jobs, out_act=ACT_NONE):
+    """jobs: list of (desc, x, in_norm, w, bias, out, out_stats) of the same layer type -> one launch."""
+    arr = (L.ConvFwdJob * len(jobs))()
+    for i, (desc, x, in_norm, w, bias, out, st) in enumerate(jobs):
+        arr[i] = L.ConvFwdJob(C.pointer(desc), _ptr(_act(x)).value, x.stride(1), _pn(in_norm), _ptr(w).value, _ptr(bias).value,
+                              _ptr(_act(out)).value, out.stride(1), _ptr(st).value)
+    ws = _workspace(L.lib().sgan_conv_fwd_grouped(arr, len(jobs), out_act, None, -1, None), jobs[0][1].device)
+    L.check(L.lib().sgan_conv_fwd_grouped(arr, len(jobs), out_act, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
+            "sgan_conv_fwd_grouped")
+
+
+def conv_dgrad_grouped(jobs):
+    """jobs: list of (desc, dout, w, din, x, x_norm, bwd_sums)."""
+    arr = (L.ConvDgradJob * len(jobs))()
+    for i, (desc, dout, w, din, x, x_norm, sums) in enumerate(jobs):
+        arr[i] = L.ConvDgradJob(C.pointer(desc), _ptr(_act(dout)).value, dout.stride(1), _ptr(w).value, _ptr(_act(din)).value,
+                                din.stride(1), _ptr(x).value, x.stride(1) if x is not None else 0, _pn(x_norm), _ptr(sums).value)
+    ws = _workspace(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device)
+    L.check(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
+            "sgan_conv_dgrad_grouped")
+
+
+def conv_wgrad_grouped(jobs):
+    """jobs: list of (desc, x, in_norm, dout, dw, dbias)."""
+    arr = (L.ConvWgradJob * len(jobs))()
+    for i, (desc, x, in_norm, dout, dw, dbias) in enumerate(jobs):
+        arr[i] = L.ConvWgradJob(C.pointer(desc), _ptr(_act(x)).value, x.stride(1), _pn(in_norm), _ptr(_act(dout)).value,
+                                dout.stride(1), _ptr(dw).value, _ptr(dbias).value)
+    L.check(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), _stream()), "sgan_conv_wgrad_grouped")
+
+
 def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None):
     H, W, Cs = dy.shape
     L.check(L.lib().sgan_norm_bwd_apply(_ptr(_act(dy)), dy.stride(1), _ptr(_act(x)), x.stride(1), H * W, Cs, _nd(x_norm),

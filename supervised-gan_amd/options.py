@@ -68,6 +68,7 @@ class BaseOptions:
         a('--skip_wasted_D_wgrad', action='store_true',
           help='do not compute discriminator weight gradients during the G step (the reference computes and discards them)')
         a('--hip_graph', action='store_true', help='capture the training step into hipGraphs')
+        a('--no_group', action='store_true', help='launch every discriminator chain on its own instead of grouped kernels')
         a('--no_d_streams', action='store_true', help='run the discriminator chains on one stream instead of one each')
         self.initialized = True
 

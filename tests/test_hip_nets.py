@@ -128,3 +128,47 @@ def test_cpu_tensors_fail_loudly(N):
     D = N.define_D(2, 8, "n_layers", n_layers_D=3, norm="instance", use_sigmoid=True)
     with pytest.raises(SganError):
         D.forward(torch.rand(1, 2, 64, 64))
+
+
+def test_grouped_chains_equal_individual_chains(N):
+    """The three multi-scale discriminators on two inputs as ONE launch per layer (multi_forward) must give what
+    six separate network calls give: outputs, input gradients, accumulated weight gradients."""
+    Ds = [N.define_D(2, 8, "n_layers", n_layers_D=3, norm="instance", use_sigmoid=True, scale_factor=s, gpu_ids=[0]) for s in (1, 2, 4)]
+    for i, d in enumerate(Ds):
+        d.load_state_dict(O.init_nlayer_d(40 + i, 2, 8, 3, (1, 2, 4)[i]))
+        d.fuse_sigmoid_into_loss = True
+    assert N.can_group(Ds + Ds)
+    xa = O.np_uniform(300, (1, 2, 160, 160)).cuda().requires_grad_(True)
+    xb = O.np_uniform(301, (1, 2, 160, 160)).cuda().requires_grad_(True)
+    crit = N.GANLoss(use_lsgan=False)
+    lam = [0.5, 0.4, 0.1, 0.2, 0.3, 0.6]
+
+    def run(grouped):
+        for d in Ds:
+            d.zero_grad_flat()
+        xa.grad = xb.grad = None
+        jobs = [(d, xa) for d in Ds] + [(d, xb) for d in Ds]
+        preds = N.multi_forward(jobs) if grouped else [d.forward(x) for d, x in jobs]
+        loss = sum(crit(p, i % 2 == 0) * l for i, (p, l) in enumerate(zip(preds, lam)))
+        loss.backward()
+        torch.cuda.synchronize()
+        return ([p.detach().clone() for p in preds], xa.grad.clone(), xb.grad.clone(), [d._gflat.clone() for d in Ds], float(loss))
+
+    pa, ga, gb, wa, la = run(False)
+    pg, gga, ggb, wg, lg = run(True)
+    assert abs(la - lg) < 1e-6
+    # not bit-identical: the single-problem path splits deep reductions over K, the grouped one does not
+    for a, b in zip(pa, pg):
+        assert O.rel_err(b, a) < 1e-4
+    assert O.rel_err(gga, ga) < 1e-3 and O.rel_err(ggb, gb) < 1e-3
+    for a, b in zip(wa, wg):
+        assert O.rel_err(b, a) < 1e-3
+    # G-step mode: no weight gradients
+    for d in Ds:
+        d.zero_grad_flat()
+        d.compute_param_grads = False
+    preds = N.multi_forward([(d, xa) for d in Ds])
+    sum(crit(p, True) for p in preds).backward()
+    assert all(float(d._gflat.abs().max()) == 0.0 for d in Ds)
+    for d in Ds:
+        d.compute_param_grads = True

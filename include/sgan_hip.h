@@ -196,6 +196,20 @@ int sgan_gan_loss_fwd(const float* logits, int32_t ld, int32_t npix, float targe
 int sgan_gan_loss_bwd(const float* logits, int32_t ld, int32_t npix, float target, int32_t mode,
                       const float* gout, float* dlogits, int32_t dld, void* stream);
 
+/* ---- every GAN-loss term of one backward pass at once ----------------------------------------------
+ * total = sum_i weight_i * loss_i over up to 8 logits maps, loss_i as sgan_gan_loss_fwd computes it;
+ * each_out[i] = loss_i (for logging).  The backward writes dlogits_i = gout * weight_i * dloss_i/dx.
+ * Replaces the per-discriminator GANLoss calls plus the scalar arithmetic the trainers wrap around them:
+ * (loss_D_fake + loss_D_real) * 0.5 and sum_i lambda_i * loss_i (models/fcgan_model.py:150-176). */
+typedef struct sgan_gan_loss_job {
+    const float* logits; int32_t ld; int32_t npix;
+    float target; float weight;
+    float* dlogits; int32_t dld;   /* backward only */
+} sgan_gan_loss_job;
+int sgan_gan_loss_multi_fwd(const sgan_gan_loss_job* jobs, int32_t n, int32_t mode, float* each_out, float* total_out,
+                            void* stream);
+int sgan_gan_loss_multi_bwd(const sgan_gan_loss_job* jobs, int32_t n, int32_t mode, const float* gout, void* stream);
+
 /* ---- standalone nn.Sigmoid on channel 0 of a logits map (models/networks.py:836-837) --------
  * Only needed when a caller wants the probability map itself; the GAN loss above consumes logits. */
 int sgan_sigmoid_fwd(const float* x, int32_t ld, int32_t npix, float* p, int32_t pld, void* stream);

@@ -38,6 +38,11 @@ class ConvWgradJob(C.Structure):
                 ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("dw", C.c_void_p), ("dbias", C.c_void_p)]
 
 
+class GanLossJob(C.Structure):
+    _fields_ = [("logits", C.c_void_p), ("ld", C.c_int32), ("npix", C.c_int32), ("target", C.c_float), ("weight", C.c_float),
+                ("dlogits", C.c_void_p), ("dld", C.c_int32)]
+
+
 class BnRunningDesc(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
                 ("num_batches_tracked", C.c_void_p), ("C", C.c_int32), ("count", C.c_int32)]
@@ -62,6 +67,8 @@ SIGNATURES = {
     "sgan_gauss_down_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "sgan_gan_loss_fwd": [_P, _I, _I, _F, _I, _P, _P, _P],
     "sgan_gan_loss_bwd": [_P, _I, _I, _F, _I, _P, _P, _I, _P],
+    "sgan_gan_loss_multi_fwd": [C.POINTER(GanLossJob), _I, _I, _P, _P, _P],
+    "sgan_gan_loss_multi_bwd": [C.POINTER(GanLossJob), _I, _I, _P, _P],
     "sgan_sigmoid_fwd": [_P, _I, _I, _P, _I, _P],
     "sgan_sigmoid_bwd": [_P, _I, _P, _I, _I, _P, _I, _P],
     "sgan_tanh_bwd": [_P, _P, _P, _L, _P],

@@ -323,6 +323,113 @@ extern "C" int sgan_gan_loss_bwd(const float* logits, int32_t ld, int32_t npix, 
 }
 
 // ------------------------------------------------------------------------------------------
+// All GAN-loss terms of one backward pass in two launches: total = sum_i weight_i * loss_i over up to 8
+// logits maps (the three discriminators on the fake and the real batch), each term as in sg_gan_loss_*.
+// Replaces the per-term Sigmoid+BCELoss modules AND the scalar adds/muls the trainers build around them
+// ((fake + real) * 0.5, * lambda_D: models/fcgan_model.py:150-176).
+// ------------------------------------------------------------------------------------------
+struct SgLossMulti {
+    const float* logits[8];
+    float* dlogits[8];
+    int32_t ld[8], dld[8], npix[8];
+    float target[8], weight[8];
+    int32_t n, mode;
+};
+
+__global__ __launch_bounds__(1024) void sg_gan_loss_multi_fwd_kernel(SgLossMulti J, float* each, float* total) {
+    __shared__ double wsum[16];
+    __shared__ double tot;
+    if (threadIdx.x == 0) tot = 0.0;
+    for (int j = 0; j < J.n; ++j) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < J.npix[j]; i += 1024) {
+            const float x = J.logits[j][(int64_t)i * J.ld[j]];
+            float l;
+            if (J.mode == 0) {
+                const float p = sg_sigmoid(x);
+                const float lp = fmaxf(logf(p), -100.f);
+                const float lq = fmaxf(log1pf(-p), -100.f);
+                l = -(J.target[j] * lp + (1.f - J.target[j]) * lq);
+            } else {
+                const float d = x - J.target[j];
+                l = d * d;
+            }
+            acc += (double)l;
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < 16; ++i) t += wsum[i];
+            const float m = (float)(t / (double)J.npix[j]);
+            each[j] = m;
+            tot += (double)J.weight[j] * (double)m;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) total[0] = (float)tot;
+}
+
+__global__ __launch_bounds__(256) void sg_gan_loss_multi_bwd_kernel(SgLossMulti J, const float* gout) {
+    const int j = blockIdx.y;
+    const float go = gout[0] * J.weight[j] / (float)J.npix[j];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < J.npix[j]; i += gridDim.x * 256) {
+        const float x = J.logits[j][(int64_t)i * J.ld[j]];
+        float d;
+        if (J.mode == 0) {
+            const float p = sg_sigmoid(x);
+            const float pq = (1.f - p) * p;
+            d = (p - J.target[j]) / fmaxf(pq, 1e-12f) * go * pq;
+        } else {
+            d = 2.f * (x - J.target[j]) * go;
+        }
+        float* o = J.dlogits[j] + (int64_t)i * J.dld[j];
+        o[0] = d;
+        for (int c = 1; c < J.dld[j]; ++c) o[c] = 0.f;
+    }
+}
+
+static int sg_fill_loss(SgLossMulti& J, const sgan_gan_loss_job* jobs, int n, int mode, bool bwd) {
+    if (!jobs || n < 1 || n > 8 || (mode != 0 && mode != 1)) return sgan_fail(SGAN_ERR_INVALID, "1..8 loss jobs, mode 0/1");
+    memset(&J, 0, sizeof(J));
+    J.n = n;
+    J.mode = mode;
+    for (int i = 0; i < n; ++i) {
+        if (!jobs[i].logits || jobs[i].npix <= 0 || jobs[i].ld < 1 || (bwd && (!jobs[i].dlogits || jobs[i].dld < 1)))
+            return sgan_fail(SGAN_ERR_INVALID, "bad loss job %d", i);
+        J.logits[i] = jobs[i].logits; J.dlogits[i] = jobs[i].dlogits; J.ld[i] = jobs[i].ld; J.dld[i] = jobs[i].dld;
+        J.npix[i] = jobs[i].npix; J.target[i] = jobs[i].target; J.weight[i] = jobs[i].weight;
+    }
+    return SGAN_OK;
+}
+
+extern "C" int sgan_gan_loss_multi_fwd(const sgan_gan_loss_job* jobs, int32_t n, int32_t mode, float* each_out,
+                                       float* total_out, void* stream) {
+    SgLossMulti J;
+    int rc = sg_fill_loss(J, jobs, n, mode, false);
+    if (rc) return rc;
+    SGAN_CHECK(each_out && total_out, "null output");
+    hipLaunchKernelGGL(sg_gan_loss_multi_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, J, each_out, total_out);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_gan_loss_multi_bwd(const sgan_gan_loss_job* jobs, int32_t n, int32_t mode, const float* gout,
+                                       void* stream) {
+    SgLossMulti J;
+    int rc = sg_fill_loss(J, jobs, n, mode, true);
+    if (rc) return rc;
+    SGAN_CHECK(gout, "null gout");
+    int maxp = 0;
+    for (int i = 0; i < n; ++i) maxp = max(maxp, J.npix[i]);
+    hipLaunchKernelGGL(sg_gan_loss_multi_bwd_kernel, dim3((maxp + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, J, gout);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // standalone sigmoid on channel 0 of a logits map (only used when the caller wants probabilities;
 // the training path feeds the logits straight to sgan_gan_loss_*)
 // ------------------------------------------------------------------------------------------

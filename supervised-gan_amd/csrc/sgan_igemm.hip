@@ -93,6 +93,17 @@ __device__ __forceinline__ SgLocal sg_local(const SgIgemmParams& G, int g) {
     return P;
 }
 
+// XCD-aware work-item order (MI355X: 8 XCDs, each with a private 4 MB L2; workgroups are dealt round-robin
+// over the XCDs in launch order, so launch id b lands on the XCD "b % 8").  Give every XCD one CONTIGUOUS
+// range of work items: tiles that share operand rows (same M tile, neighbouring M tiles, all N tiles) then
+// hit the same L2 instead of every L2 having to hold the whole activation tensor plus the weights.
+// Bijective for any count (placement is a speed matter only, never correctness).
+__device__ __forceinline__ int sg_xcd_remap(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // blockIdx.x -> (problem, phase, M tile) through the prefix table
 __device__ __forceinline__ void sg_decode_tile(const SgIgemmParams& G, int bx, int& g, int& phz, int& mtile) {
     g = 0;
@@ -106,7 +117,8 @@ __device__ __forceinline__ void sg_decode_tile(const SgIgemmParams& G, int bx, i
 __device__ __forceinline__ int sg_swz(int row, int kslot) { return (kslot ^ ((row >> 1) & 7)) << 2; }
 
 // BKC: B operand is k-contiguous in memory (forward: W[tap][n][k]); otherwise n-contiguous (backward-data)
-template <int BM, int BN, int WGM, int WGN, bool BKC>
+// PRO: the gathered tensor gets the producer's norm + activation applied while it is staged
+template <int BM, int BN, int WGM, int WGN, bool BKC, bool PRO>
 __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MB = WTM / 16, NB = WTN / 16;
     constexpr int A_IT = BM * 8 / 256;
@@ -124,13 +136,22 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
+    // grid.x enumerates (M tile, N tile) pairs, N fastest, in XCD-contiguous order; grid.z = K split
+    const int ntn = (G.N + BN - 1) / BN;
+    const int item = sg_xcd_remap(blockIdx.x, gridDim.x);
     int g, phz, mtile;
-    sg_decode_tile(G, blockIdx.x, g, phz, mtile);
+    sg_decode_tile(G, item / ntn, g, phz, mtile);
     const SgLocal P = sg_local(G, g);
     const int split = blockIdx.z;
     const int Hp = G.q[g].Hp[phz], Wp = G.q[g].Wp[phz];
     const int M = Hp * Wp;
-    const int m0 = mtile * BM, n0 = blockIdx.y * BN;
+    const int m0 = mtile * BM, n0 = (item % ntn) * BN;
+    // Buffer loads: 32-bit byte offsets against a wave-uniform descriptor, and an out-of-range offset returns
+    // zeros in hardware -- padding taps, rows past M, channels past N and k past the end need no select, no
+    // validity flag and no 64-bit address arithmetic (the loop is VALU-issue bound, not latency bound).
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.w), 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int OOB = (int)0x80000000u;
     const int oa = G.oa[phz], ob = G.ob[phz];
     const int ktot = G.ktot[phz];
     const int Ck = P.Ck, N = P.N;
@@ -188,12 +209,13 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
     int a_tap = (kt0 * 32 + a_ks * 4) / Ck;
     int a_c = kt0 * 32 + a_ks * 4 - a_tap * Ck;
 
-    // two register sets: tile kt+1 (landed, being written to LDS) and tile kt+2 (in flight)
-    f32x4 a_reg[2][A_IT];
-    bool a_ok[2][A_IT];
-    int a_cs[2] = {0, 0};  // channel of the staged A registers (for the prologue transform)
-    f32x4 b_reg[2][B_IT];
-    bool b_ok[2][B_IT];
+    // ring of NSET register sets: tile kt+1 (landed, being written to LDS) and tiles kt+2 .. kt+NSET in flight.
+    // Measured load-to-use latency under load is ~1 us (~2.4 k-tile iterations): three tiles must be in flight.
+    constexpr int NSET = 4;
+    f32x4 a_reg[NSET][A_IT];
+    bool a_ok[NSET][A_IT];
+    int a_cs[NSET] = {0, 0, 0, 0};  // channel of the staged A registers (for the prologue transform)
+    f32x4 b_reg[NSET][B_IT];
     constexpr bool b_kcontig = BKC;
     // B, n-contiguous form (backward-data): element (k = e / NQ, n4 = e % NQ); its own (tap, channel) walk
     constexpr int NQ = BN / 4;
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
     }
     // element offsets / validity of the NEXT tile to load (filled by next_addrs one iteration ahead)
     int a_off_n[A_IT], b_off_n[B_IT], a_cs_n = 0;
-    bool a_ok_n[A_IT], b_ok_n[B_IT];
+    bool a_ok_n[A_IT];
 
     f32x4 acc[MB][NB];
 #pragma unroll
@@ -238,17 +260,13 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
             for (int it = 0; it < A_IT; ++it) {
                 const int iy = a_iy[it] + t.x, ix = a_ix[it] + t.y;
                 const bool ok = a_rowok[it] && kok && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-                a_off_n[it] = ok ? a_base[it] + toff : 0;   // 32-bit: host checks < 2^30 elements
-                a_ok_n[it] = ok;
+                a_off_n[it] = ok ? (a_base[it] + toff) << 2 : OOB;
+                if constexpr (PRO) a_ok_n[it] = ok;
             }
             if constexpr (b_kcontig) {
                 const int woff = t.w + a_c;
 #pragma unroll
-                for (int it = 0; it < B_IT; ++it) {
-                    const bool ok = b_rowok[it] && kok;
-                    b_off_n[it] = ok ? b_base[it] + woff : 0;
-                    b_ok_n[it] = ok;
-                }
+                for (int it = 0; it < B_IT; ++it) b_off_n[it] = (b_rowok[it] && kok) ? (b_base[it] + woff) << 2 : OOB;
             }
             a_tap += adv_tap;
             a_c += adv_c;
@@ -262,8 +280,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
                 const bool tok = b_tap[it] < ntaps;
                 const int wtap = ttab[tok ? b_tap[it] : 0].w;
                 const bool ok = (B_IT * 256 <= 32 * NQ || k < 32) && tok && n0 + n4 * 4 < N;
-                b_off_n[it] = ok ? wtap + b_c[it] * P.w_ks + n0 + n4 * 4 : 0;
-                b_ok_n[it] = ok;
+                b_off_n[it] = ok ? (wtap + b_c[it] * P.w_ks + n0 + n4 * 4) << 2 : OOB;
                 b_tap[it] += adv_tap;
                 b_c[it] += adv_c;
                 if (b_c[it] >= Ck) { b_c[it] -= Ck; ++b_tap[it]; }
@@ -271,63 +288,61 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
         }
     };
 
-    // Issue the global loads of the tile whose offsets next_addrs prepared.
     // Issue the global loads of the tile whose offsets next_addrs prepared, into register set S.
     auto issue_loads = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
         if constexpr (SG_ABLATE & 2) return;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            a_reg[S][it] = *reinterpret_cast<const f32x4*>(P.in + a_off_n[it]);
-            a_ok[S][it] = a_ok_n[it];
+            a_reg[S][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off_n[it], 0, 0));
+            if constexpr (PRO) a_ok[S][it] = a_ok_n[it];
         }
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            b_reg[S][it] = *reinterpret_cast<const f32x4*>(P.w + b_off_n[it]);
-            b_ok[S][it] = b_ok_n[it];
-        }
-        a_cs[S] = a_cs_n;
+        for (int it = 0; it < B_IT; ++it)
+            b_reg[S][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off_n[it], 0, 0));
+        if constexpr (PRO) a_cs[S] = a_cs_n;
     };
 
-    // Transform (norm + activation of the producer layer), mask and write register set S to LDS buffer S.
+    // Transform (norm + activation of the producer layer), mask and write register set S to LDS buffer S & 1.
     auto store_tile = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
-        float* Ab = As + S * BM * 32;
-        float* Bb = Bs + S * BN * 32;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + a_cs[S]);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + a_cs[S]);
+        float* Ab = As + (S & 1) * BM * 32;
+        float* Bb = Bs + (S & 1) * BN * 32;
+        if constexpr (PRO) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + a_cs[S]);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + a_cs[S]);
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            f32x4 v = a_reg[S][it];
+            for (int it = 0; it < A_IT; ++it) {
+                f32x4 v = a_reg[S][it];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float y = v[j] * sc[j] + sh[j];
-                v[j] = y > 0.f ? y : y * pro_neg;
+                for (int j = 0; j < 4; ++j) {
+                    const float y = v[j] * sc[j] + sh[j];
+                    v[j] = y > 0.f ? y : y * pro_neg;
+                }
+                if (!a_ok[S][it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // conv zero padding applies AFTER norm + activation
+                *reinterpret_cast<f32x4*>(Ab + a_dst[it]) = v;
             }
-            if (!a_ok[S][it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(Ab + a_dst[it]) = v;
+        } else {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) *reinterpret_cast<f32x4*>(Ab + a_dst[it]) = a_reg[S][it];
         }
         if constexpr (b_kcontig) {
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) {
                 const int e = tid + it * 256;
                 const int n = e >> 3, ks = e & 7;
-                f32x4 v = b_reg[S][it];
-                if (!b_ok[S][it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (B_IT * 256 == BN * 8 || e < BN * 8) *reinterpret_cast<f32x4*>(Bb + n * 32 + sg_swz(n, ks)) = v;
+                if (B_IT * 256 == BN * 8 || e < BN * 8) *reinterpret_cast<f32x4*>(Bb + n * 32 + sg_swz(n, ks)) = b_reg[S][it];
             }
         } else {
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) {
                 const int e = tid + it * 256;
                 const int k = e / NQ, n4 = e % NQ;
-                f32x4 v = b_reg[S][it];
-                if (!b_ok[S][it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (B_IT * 256 <= 32 * NQ || k < 32) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int row = n4 * 4 + j;
-                        Bb[row * 32 + sg_swz(row, k >> 2) + (k & 3)] = v[j];
+                        Bb[row * 32 + sg_swz(row, k >> 2) + (k & 3)] = b_reg[S][it][j];
                     }
                 }
             }
@@ -336,15 +351,13 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
 
     const int fr = lane & 15, fq = lane >> 4;
 
-    // Software pipeline, one barrier per k-tile, global loads two tiles ahead.  Iteration kt (S = kt & 1):
-    //   (1) issue the loads of tile kt+2 into register set S (offsets prepared one iteration earlier);
-    //   (2) one scheduling region: MFMA block on tile kt (LDS buffer S)  ||  transform + LDS store of tile
-    //       kt+1 (register set S^1, loaded a whole iteration ago, so its wait is free) into buffer S^1  ||
-    //       address arithmetic of tile kt+3;
+    // Software pipeline, one barrier per k-tile, global loads NSET tiles ahead.  Iteration kt (S = kt % NSET):
+    //   (1) issue the loads of tile kt+NSET into register set S (tile kt left it for LDS one iteration ago);
+    //   (2) one scheduling region: MFMA block on tile kt (LDS buffer kt & 1)  ||  transform + LDS store of
+    //       tile kt+1 (register set S+1, issued NSET-1 iterations ago: its counted vmcnt wait is free) into the
+    //       other LDS buffer  ||  address arithmetic of tile kt+NSET+1;
     //   (3) barrier.
     // Tiles past the end of K read offset 0 and land as zeros in a buffer that is never consumed.
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
     auto mfma_tile = [&](int buf) {
         const float* Ab = As + buf * BM * 32;
         const float* Bb = Bs + buf * BN * 32;
@@ -379,27 +392,39 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
     };
     auto iteration = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
-        issue_loads(std::integral_constant<int, S>{});          // tile kt+2
+        issue_loads(std::integral_constant<int, S>{});           // tile kt+NSET
         __builtin_amdgcn_sched_barrier(0);
-        mfma_tile(S);                                            // tile kt
-        if constexpr (!(SG_ABLATE & 4)) store_tile(std::integral_constant<int, S ^ 1>{});   // tile kt+1
-        next_addrs();                                            // tile kt+3
+        mfma_tile(S & 1);                                         // tile kt
+        if constexpr (!(SG_ABLATE & 4)) store_tile(std::integral_constant<int, (S + 1) % NSET>{});   // tile kt+1
+        next_addrs();                                             // tile kt+NSET+1
         __syncthreads();
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
     next_addrs();
     issue_loads(I0{});   // tile 0
     next_addrs();
     issue_loads(I1{});   // tile 1
-    next_addrs();        // offsets of tile 2
+    next_addrs();
+    issue_loads(I2{});   // tile 2
+    next_addrs();
+    issue_loads(I3{});   // tile 3
+    next_addrs();        // offsets of tile 4
     store_tile(I0{});
     __syncthreads();
     {
         int kt = 0;
-        for (; kt + 1 < nkt; kt += 2) {
+        for (; kt + 3 < nkt; kt += 4) {
             iteration(I0{});
             iteration(I1{});
+            iteration(I2{});
+            iteration(I3{});
         }
         if (kt < nkt) iteration(I0{});
+        if (kt + 1 < nkt) iteration(I1{});
+        if (kt + 2 < nkt) iteration(I2{});
     }
 
     // ---- epilogue ----
@@ -838,12 +863,16 @@ static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t 
     P.ksplit = ks;
     P.slab = ks > 1 ? ws : nullptr;
     P.slab_stride = slab;
-    dim3 grid(tiles, sg_cdiv(P.N, BN), ks);
+    dim3 grid(tiles * sg_cdiv(P.N, BN), 1, ks);
     const size_t lds = (size_t)(2 * BM * 32 + 2 * BN * 32 + 2 * BN) * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
     if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
     sg_prof_begin(st);
-    if (bkc) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true>), grid, dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, false>), grid, dim3(256), lds, st, P);
+    bool pro = P.pro_act != SGAN_ACT_NONE;
+    for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
+    if (!bkc && pro) return sgan_fail(SGAN_ERR_UNSUPPORTED, "backward-data has no prologue");
+    if (!bkc) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(256), lds, st, P);
+    else if (pro) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true, true>), grid, dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true, false>), grid, dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();
     if (bkc)
         g_sgan_last_kernel = BM == 64 ? "sg_igemm_kernel<64,64,2,2,true>" : BN == 64 ? "sg_igemm_kernel<128,64,2,2,true>"
@@ -908,9 +937,9 @@ static int64_t sg_workspace_need(const SgIgemmParams& P) {
 
 static int sg_check_common(const sgan_conv_desc* d) {
     if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
-    if ((int64_t)d->Hin * d->Win * d->Cin >= (1ll << 30) || (int64_t)d->Hout * d->Wout * d->Cout >= (1ll << 30) ||
-        (int64_t)d->k * d->k * d->Cin * d->Cout >= (1ll << 30))
-        return sgan_fail(SGAN_ERR_UNSUPPORTED, "tensor too large for 32-bit element offsets");
+    if ((int64_t)d->Hin * d->Win * d->Cin >= (1ll << 28) || (int64_t)d->Hout * d->Wout * d->Cout >= (1ll << 28) ||
+        (int64_t)d->k * d->k * d->Cin * d->Cout >= (1ll << 28))
+        return sgan_fail(SGAN_ERR_UNSUPPORTED, "tensor too large for 31-bit byte offsets");
     if ((d->Cin & 3) || (d->Cout & 3)) return sgan_fail(SGAN_ERR_INVALID, "stored channels must be multiples of 4 (Cin %d Cout %d)", d->Cin, d->Cout);
     if (d->Hin <= 0 || d->Win <= 0 || d->Hout <= 0 || d->Wout <= 0) return sgan_fail(SGAN_ERR_INVALID, "empty tensor");
     return SGAN_OK;

@@ -120,30 +120,36 @@ class FCGANModel(BaseModel):
         return self.image_paths
 
     # ---- losses ---------------------------------------------------------------------------------
-    def _d_losses(self, jobs):
-        """[(netD, input, target_is_real)] -> list of loss tensors.  The discriminator chains are
-        independent and individually too small to fill 256 CUs (a 17x17 layer is 24 workgroups), so each
-        runs on its own HIP stream, forked from and joined back into the current one; autograd replays
-        every chain's backward on the stream its forward used."""
-        if self._group and networks.can_group([d for d, _, _ in jobs]):
+    def _d_losses(self, jobs, weights):
+        """[(netD, input, target_is_real)], weights -> (total, each): total = sum_i w_i * GANLoss(D_i(x_i), t_i).
+
+        The discriminator chains are independent and individually too small for 256 CUs (a 17x17 layer is 24
+        workgroups).  Same-architecture chains run as GROUPED kernels -- one launch per layer for all of them --
+        and every loss term plus the scalar arithmetic around it is one forward and one backward kernel.
+        Fallback (--no_group or heterogeneous discriminators): one HIP stream per chain, forked from and
+        joined back into the current stream."""
+        if self._group and networks.can_group([d for d, _, _ in jobs]) and len(jobs) <= 8:
             preds = networks.multi_forward([(d, x) for d, x, _ in jobs])      # one launch per layer for all chains
-            return [self.criterionGAN(p, is_real) for p, (_, _, is_real) in zip(preds, jobs)]
+            return self.criterionGAN.weighted_sum(preds, [r for _, _, r in jobs], weights)
         streams = self._streams[:len(jobs)] if self._streams else None
         losses = []
         if not streams:
             for netD, x, is_real in jobs:
                 losses.append(self.criterionGAN(netD.forward(x), is_real))
-            return losses
-        cur = torch.cuda.current_stream()
-        for st, (netD, x, is_real) in zip(streams, jobs):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                l = self.criterionGAN(netD.forward(x), is_real)
-            l.record_stream(cur)
-            losses.append(l)
-        for st in streams:
-            cur.wait_stream(st)
-        return losses
+        else:
+            cur = torch.cuda.current_stream()
+            for st, (netD, x, is_real) in zip(streams, jobs):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    l = self.criterionGAN(netD.forward(x), is_real)
+                l.record_stream(cur)
+                losses.append(l)
+            for st in streams:
+                cur.wait_stream(st)
+        total = 0
+        for l, w in zip(losses, weights):
+            total = total + l * w
+        return total, torch.stack([l.detach() for l in losses])
 
     def _join_streams(self):
         """The chains' backward kernels (weight-gradient atomics included) ran on the side streams: the
@@ -153,31 +159,36 @@ class FCGANModel(BaseModel):
             cur.wait_stream(st)
 
     def backward_D(self):
+        """loss_D = 0.5 * (sum_i BCE(D_i(fake), 0) + sum_i BCE(D_i(real), 1))   (fcgan_model.py:146-163)"""
         fake = self._pool_override if self._pool_override is not None else self.fake_pool.query(self.fake)
         fake = fake.detach()
-        losses = self._d_losses([(d, fake, False) for d in self.netD] + [(d, self.real, True) for d in self.netD])
         n = self.n_netD
-        self.loss_D_fake = sum(losses[1:n], losses[0])
-        self.loss_D_real = sum(losses[n + 1:], losses[n])
-        self.loss_D = (self.loss_D_fake + self.loss_D_real) * 0.5
+        self.loss_D, self._each_D = self._d_losses([(d, fake, False) for d in self.netD] + [(d, self.real, True) for d in self.netD],
+                                                   [0.5] * (2 * n))
         self.loss_D.backward()
         self._join_streams()
 
     def backward_G(self):
+        """loss_G = sum_i lambda_i * BCE(D_i(fake), 1)  (log-D trick) or -sum_i lambda_i * BCE(D_i(fake), 0)
+        (fcgan_model.py:165-176)"""
         skip = getattr(self.opt, 'skip_wasted_D_wgrad', False)
         for netD in self.netD:
             netD.compute_param_grads = not skip
-        losses = self._d_losses([(d, self.fake, not self.opt.no_logD_trick) for d in self.netD])
+        trick = not self.opt.no_logD_trick
+        self.loss_G, self._each_G = self._d_losses([(d, self.fake, trick) for d in self.netD],
+                                                   [l if trick else -l for l in self.opt.lambda_D])
         for netD in self.netD:
             netD.compute_param_grads = True
-        self.loss_G = 0
-        for l, lambda_D in zip(losses, self.opt.lambda_D):
-            if not self.opt.no_logD_trick:
-                self.loss_G = self.loss_G + l * lambda_D
-            else:
-                self.loss_G = self.loss_G + -l * lambda_D
         self.loss_G.backward()
         self._join_streams()
+
+    @property
+    def loss_D_fake(self):
+        return self._each_D[:self.n_netD].sum()
+
+    @property
+    def loss_D_real(self):
+        return self._each_D[self.n_netD:].sum()
 
     def optimize_parameters(self):
         self.forward()
@@ -199,7 +210,7 @@ class FCGANModel(BaseModel):
                 self.sample_noise()
 
     def get_current_errors(self):
-        return OrderedDict([('G_GAN', float(self.loss_G)), ('D_real', float(self.loss_D_real)),
+        return OrderedDict([('G_GAN', float(self.loss_G.detach())), ('D_real', float(self.loss_D_real)),
                             ('D_fake', float(self.loss_D_fake))])
 
     def get_current_visuals(self, save_real=False, save_as_single_image=True):

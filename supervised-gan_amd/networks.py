@@ -740,6 +740,27 @@ class _GanLossFn(torch.autograd.Function):
         return ops.logical_view(d, 1), None, None
 
 
+class _GanLossMultiFn(torch.autograd.Function):
+    """total = sum_i w_i * GANLoss(pred_i, target_i) -- one forward and one backward kernel for all terms."""
+
+    @staticmethod
+    def forward(ctx, targets, weights, mode, *logits):
+        lbs = [ops.as_nhwc(l) for l in logits]
+        dev = logits[0].device
+        each = torch.empty(len(lbs), dtype=torch.float32, device=dev)
+        total = torch.empty((), dtype=torch.float32, device=dev)
+        ops.gan_loss_multi_fwd(lbs, targets, weights, mode, each, total)
+        ctx.lbs, ctx.targets, ctx.weights, ctx.mode = lbs, targets, weights, mode
+        ctx.mark_non_differentiable(each)
+        return total, each
+
+    @staticmethod
+    def backward(ctx, gtotal, _geach):
+        ds = [torch.empty_like(lb) for lb in ctx.lbs]
+        ops.gan_loss_multi_bwd(ctx.lbs, ctx.targets, ctx.weights, ctx.mode, gtotal.contiguous(), ds)
+        return (None, None, None) + tuple(ops.logical_view(d, 1) for d in ds)
+
+
 class GANLoss(nn.Module):
     """GANLoss (models/networks.py:152-185).  With `use_lsgan=False` the reference applies BCELoss to
     the discriminator's Sigmoid output; here the loss kernel consumes the logits behind that output
@@ -752,17 +773,27 @@ class GANLoss(nn.Module):
         self.use_lsgan = use_lsgan
         self.Tensor = tensor
 
-    def __call__(self, input, target_is_real):
-        t = self.real_label if target_is_real else self.fake_label
+    def _logits_of(self, input):
         if self.use_lsgan:
-            return _GanLossFn.apply(input, t, 1)
+            return input
         logits = getattr(input, "_sgan_logits", None)
         if logits is None and getattr(input, "_sgan_pending_sigmoid", False):
             logits = input
         if logits is None:
             raise SganError("GANLoss(use_lsgan=False) needs the output of a supervised_gan_amd discriminator built with "
                             "use_sigmoid=True (it carries its logits); got a plain tensor")
-        return _GanLossFn.apply(logits, t, 0)
+        return logits
+
+    def __call__(self, input, target_is_real):
+        t = self.real_label if target_is_real else self.fake_label
+        return _GanLossFn.apply(self._logits_of(input), t, 1 if self.use_lsgan else 0)
+
+    def weighted_sum(self, inputs, targets_are_real, weights):
+        """sum_i weights[i] * self(inputs[i], targets_are_real[i]) as ONE autograd node (<= 8 terms): returns
+        (total, each) where `each` holds the unweighted terms for logging."""
+        ts = [self.real_label if r else self.fake_label for r in targets_are_real]
+        return _GanLossMultiFn.apply(ts, [float(w) for w in weights], 1 if self.use_lsgan else 0,
+                                     *[self._logits_of(i) for i in inputs])
 
 
 class WeightedL1Loss(nn.Module):

@@ -153,6 +153,21 @@ def gan_loss_bwd(logits, target, mode, gout, dlogits):
                                       _ptr(_act(dlogits)), dlogits.stride(1), _stream()), "sgan_gan_loss_bwd")
 
 
+def gan_loss_multi_fwd(logits, targets, weights, mode, each_out, total_out):
+    arr = (L.GanLossJob * len(logits))()
+    for i, (lb, t, w) in enumerate(zip(logits, targets, weights)):
+        arr[i] = L.GanLossJob(_ptr(_act(lb)).value, lb.stride(1), lb.shape[0] * lb.shape[1], float(t), float(w), None, 0)
+    L.check(L.lib().sgan_gan_loss_multi_fwd(arr, len(logits), mode, _ptr(each_out), _ptr(total_out), _stream()), "sgan_gan_loss_multi_fwd")
+
+
+def gan_loss_multi_bwd(logits, targets, weights, mode, gout, dlogits):
+    arr = (L.GanLossJob * len(logits))()
+    for i, (lb, t, w, d) in enumerate(zip(logits, targets, weights, dlogits)):
+        arr[i] = L.GanLossJob(_ptr(_act(lb)).value, lb.stride(1), lb.shape[0] * lb.shape[1], float(t), float(w),
+                              _ptr(_act(d)).value, d.stride(1))
+    L.check(L.lib().sgan_gan_loss_multi_bwd(arr, len(logits), mode, _ptr(gout), _stream()), "sgan_gan_loss_multi_bwd")
+
+
 def sigmoid_fwd(x, p):
     H, W, _ = x.shape
     L.check(L.lib().sgan_sigmoid_fwd(_ptr(_act(x)), x.stride(1), H * W, _ptr(_act(p)), p.stride(1), _stream()), "sgan_sigmoid_fwd")

@@ -15,6 +15,8 @@
 //
 // Reference ops replaced: convolution_backward (weight, bias) of every nn.Conv2d /
 // nn.ConvTranspose2d on the path (models/networks.py:502-529, :815-835).
+#include <type_traits>
+
 #include "sgan_common.h"
 
 #define SGW_MAX_PROB 8
@@ -53,7 +55,8 @@ struct SgWgradLocal {
     SgNorm pro;
 };
 
-template <int BCO, int BKC, int WGC, int WGK>
+// PRO: the forward input gets the producer's norm + activation applied while it is staged
+template <int BCO, int BKC, int WGC, int WGK, bool PRO>
 __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     constexpr int BP = 32;
     constexpr int WTC = BCO / WGC, WTK = BKC / WGK, MB = WTC / 16, NB = WTK / 16;
@@ -94,9 +97,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     const int ch_begin = split * per, ch_end = min(nchunk_total, ch_begin + per);
     if (ch_begin >= ch_end) return;
     const int Cin = P.Cin, Cout = P.Cout;
-    const bool has_pro = (P.pro.stats != nullptr) || (P.pro.act != SGAN_ACT_NONE);
-
-    if (has_pro) {
+    if constexpr (PRO) {
         for (int c = tid; c < Cin; c += 256) {
             float sc = 1.f, sh = 0.f;
             if (P.pro.stats) {
@@ -125,10 +126,20 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     constexpr int D_ROWS_PER_IT = 256 / DQ;
     const bool d_cok = co0 + d_c4 * 4 < Cout;
 
-    f32x4 a_reg[A_IT], d_reg[D_IT];
-    bool a_val[A_IT], d_val[D_IT];
+    // Register ring of NS chunk sets (see sgan_igemm.hip: same pipeline).  Buffer loads: 32-bit byte offsets,
+    // an out-of-range offset returns zeros in hardware, so rows past the image / past this split's pixel range
+    // and padding taps need no select and no flag (except under PRO, where zero padding applies AFTER the
+    // producer's norm + activation).
+    constexpr int NS = 3;
+    f32x4 a_reg[NS][A_IT], d_reg[NS][D_IT];
+    bool a_val[NS][A_IT];
+    int a_off_n[A_IT], d_off_n[D_IT];
+    bool a_ok_n[A_IT];
     const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
     const int oa = ph_oa, ob = ph_ob;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.dout), 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int OOB = (int)0x80000000u;
 
     // pixel walk: row r of chunk ch is pixel m = ch*32 + r; (py, px) advance by 32 pixels per chunk with one
     // conditional wrap (32 = adv_y * Wp + adv_x) -- no division inside the loop
@@ -146,18 +157,18 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
         d_py[it] = m / Wp;
         d_px[it] = m - d_py[it] * Wp;
     }
+    int ch_next = ch_begin;   // chunk whose offsets next_addrs computes next
 
-    // loads are unconditional (invalid rows read offset 0 and are zeroed at the LDS store)
-    auto load_chunk = [&]() {
+    auto next_addrs = [&]() {
+        const bool chok = ch_next < ch_end;   // chunks past this split's range belong to another workgroup
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int prow = a_row0 + it * A_ROWS_PER_IT;
             const int iy = a_py[it] * P.is + a_dy, ix = a_px[it] * P.is + a_dx;
-            const bool ok = (A_IT * A_ROWS_PER_IT == BP || prow < BP) && a_py[it] < Hp && a_kok &&
+            const bool ok = chok && (A_IT * A_ROWS_PER_IT == BP || prow < BP) && a_py[it] < Hp && a_kok &&
                             (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-            const int64_t off = ok ? ((int64_t)iy * P.Win + ix) * P.in_ld + a_c : 0;
-            a_reg[it] = *reinterpret_cast<const f32x4*>(P.in + off);
-            a_val[it] = ok;
+            a_off_n[it] = ok ? ((iy * P.Win + ix) * P.in_ld + a_c) << 2 : OOB;
+            if constexpr (PRO) a_ok_n[it] = ok;
             a_py[it] += adv_y;
             a_px[it] += adv_x;
             if (a_px[it] >= Wp) { a_px[it] -= Wp; ++a_py[it]; }
@@ -165,45 +176,58 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
 #pragma unroll
         for (int it = 0; it < D_IT; ++it) {
             const int prow = d_row0 + it * D_ROWS_PER_IT;
-            const bool ok = (D_IT * D_ROWS_PER_IT == BP || prow < BP) && d_py[it] < Hp && d_cok;
-            const int64_t pix = (int64_t)(d_py[it] * P.os + oa) * P.Wout + (d_px[it] * P.os + ob);
-            const int64_t off = ok ? pix * P.dout_ld + co0 + d_c4 * 4 : 0;
-            d_reg[it] = *reinterpret_cast<const f32x4*>(P.dout + off);
-            d_val[it] = ok;
+            const bool ok = chok && (D_IT * D_ROWS_PER_IT == BP || prow < BP) && d_py[it] < Hp && d_cok;
+            const int pix = (d_py[it] * P.os + oa) * P.Wout + (d_px[it] * P.os + ob);
+            d_off_n[it] = ok ? (pix * P.dout_ld + co0 + d_c4 * 4) << 2 : OOB;
             d_py[it] += adv_y;
             d_px[it] += adv_x;
             if (d_px[it] >= Wp) { d_px[it] -= Wp; ++d_py[it]; }
         }
+        ++ch_next;
     };
 
-    auto store_chunk = [&](int buf) {
-        float* Ab = As + buf * BP * LDA;
-        float* Db = Ds + buf * BP * LDD;
-        f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (has_pro) {
-            sc = *reinterpret_cast<const f32x4*>(pscale + a_c);
-            sh = *reinterpret_cast<const f32x4*>(pshift + a_c);
-        }
+    auto issue_loads = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int prow = a_row0 + it * A_ROWS_PER_IT;
-            f32x4 v = a_reg[it];
-            if (has_pro) {
+            a_reg[S][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off_n[it], 0, 0));
+            if constexpr (PRO) a_val[S][it] = a_ok_n[it];
+        }
+#pragma unroll
+        for (int it = 0; it < D_IT; ++it)
+            d_reg[S][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, d_off_n[it], 0, 0));
+    };
+
+    auto store_chunk = [&](auto S_, int buf) {
+        constexpr int S = decltype(S_)::value;
+        float* Ab = As + buf * BP * LDA;
+        float* Db = Ds + buf * BP * LDD;
+        if constexpr (PRO) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + a_c);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + a_c);
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int prow = a_row0 + it * A_ROWS_PER_IT;
+                f32x4 v = a_reg[S][it];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float y = v[j] * sc[j] + sh[j];
                     v[j] = y > 0.f ? y : y * pro_neg;
                 }
+                if (!a_val[S][it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (A_IT * A_ROWS_PER_IT == BP || prow < BP) *reinterpret_cast<f32x4*>(Ab + prow * LDA + a_c4 * 4) = v;
             }
-            if (!a_val[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (A_IT * A_ROWS_PER_IT == BP || prow < BP) *reinterpret_cast<f32x4*>(Ab + prow * LDA + a_c4 * 4) = v;
+        } else {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int prow = a_row0 + it * A_ROWS_PER_IT;
+                if (A_IT * A_ROWS_PER_IT == BP || prow < BP) *reinterpret_cast<f32x4*>(Ab + prow * LDA + a_c4 * 4) = a_reg[S][it];
+            }
         }
 #pragma unroll
         for (int it = 0; it < D_IT; ++it) {
             const int prow = d_row0 + it * D_ROWS_PER_IT;
-            f32x4 v = d_reg[it];
-            if (!d_val[it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (D_IT * D_ROWS_PER_IT == BP || prow < BP) *reinterpret_cast<f32x4*>(Db + prow * LDD + d_c4 * 4) = v;
+            if (D_IT * D_ROWS_PER_IT == BP || prow < BP) *reinterpret_cast<f32x4*>(Db + prow * LDD + d_c4 * 4) = d_reg[S][it];
         }
     };
 
@@ -216,12 +240,15 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     const bool do_bias = (P.dbias != nullptr) && (blockIdx.x == 0);
 
     __syncthreads();  // pscale/pshift visible
-    load_chunk();
-    for (int ch = ch_begin; ch < ch_end; ++ch) {
-        const int buf = (ch - ch_begin) & 1;
-        store_chunk(buf);
-        __syncthreads();
-        if (ch + 1 < ch_end) load_chunk();
+    using J0 = std::integral_constant<int, 0>;
+    using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>;
+    int it_no = 0;   // chunk index relative to ch_begin (LDS buffer = it_no & 1)
+    auto iteration = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        issue_loads(std::integral_constant<int, S>{});   // chunk it_no + NS
+        __builtin_amdgcn_sched_barrier(0);
+        const int buf = it_no & 1;
         const float* Ab = As + buf * BP * LDA;
         const float* Db = Ds + buf * BP * LDD;
 #pragma unroll
@@ -238,11 +265,35 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (do_bias && tid < BCO) {
-            float s = 0.f;
+            float sb = 0.f;
 #pragma unroll 8
-            for (int p = 0; p < BP; ++p) s += Db[p * LDD + tid];
-            bsum += s;
+            for (int p = 0; p < BP; ++p) sb += Db[p * LDD + tid];
+            bsum += sb;
         }
+        store_chunk(std::integral_constant<int, (S + 1) % NS>{}, buf ^ 1);   // chunk it_no + 1
+        next_addrs();
+        ++it_no;
+        __syncthreads();
+    };
+    next_addrs();
+    issue_loads(J0{});
+    next_addrs();
+    issue_loads(J1{});
+    next_addrs();
+    issue_loads(J2{});
+    next_addrs();
+    store_chunk(J0{}, 0);
+    __syncthreads();
+    {
+        const int n_it = ch_end - ch_begin;
+        int i = 0;
+        for (; i + 2 < n_it; i += 3) {
+            iteration(J0{});
+            iteration(J1{});
+            iteration(J2{});
+        }
+        if (i < n_it) iteration(J0{});
+        if (i + 1 < n_it) iteration(J1{});
     }
 
     // ---- combine: fp32 atomics into the gradient buffer ----
@@ -297,8 +348,11 @@ static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
     }
     dim3 grid(sgw_cdiv(maxK, BKC), sgw_cdiv(P.Cout, BCO), z);
     const size_t lds = (size_t)(2 * 32 * LDD + 2 * 32 * LDA + 2 * P.Cin) * 4;
+    bool pro = P.pro_act != SGAN_ACT_NONE;
+    for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
     sg_prof_begin(st);
-    hipLaunchKernelGGL((sg_wgrad_kernel<BCO, BKC, WGC, WGK>), grid, dim3(256), lds, st, P);
+    if (pro) hipLaunchKernelGGL((sg_wgrad_kernel<BCO, BKC, WGC, WGK, true>), grid, dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((sg_wgrad_kernel<BCO, BKC, WGC, WGK, false>), grid, dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = BCO == 64 ? "sg_wgrad_kernel<64,64,2,2>" : BCO == 32 ? "sg_wgrad_kernel<32,64,1,4>"
                                                                             : "sg_wgrad_kernel<16,128,1,4>";

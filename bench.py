@@ -188,6 +188,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("SGAN_FORCE_DEVICE"):     # rehearsal of N ranks on a 1-GPU box (gloo): all ranks share one card
+        local = int(os.environ["SGAN_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 

@@ -58,6 +58,8 @@ typedef struct sgan_norm_desc {
     float eps;
     int32_t act;         /* SGAN_ACT_NONE / RELU / LRELU */
     float slope;         /* LeakyReLU slope */
+    int32_t sq_stride;   /* distance (in doubles) from sum[c] to sumsq[c]; 0 = C.  Lets `stats` point into the
+                          * statistics of a wider concat buffer (U-Net skip: [up half | skip half]) */
 } sgan_norm_desc;
 
 /* Geometry of one Conv2d / ConvTranspose2d layer (square kernel, symmetric stride/pad). */
@@ -124,6 +126,7 @@ typedef struct sgan_conv_fwd_job {
     const float* w; const float* bias;
     float* out; int32_t out_ld;
     double* out_stats;
+    int32_t out_stats_sq_stride;  /* distance from sum[n] to sumsq[n] in out_stats; 0 = Cout */
 } sgan_conv_fwd_job;
 typedef struct sgan_conv_dgrad_job {
     const sgan_conv_desc* d;
@@ -132,6 +135,8 @@ typedef struct sgan_conv_dgrad_job {
     float* din; int32_t din_ld;
     const float* x; int32_t x_ld; const sgan_norm_desc* x_norm;
     double* bwd_sums;
+    int32_t bwd_sums_sq_stride;   /* distance from s1[n] to s2[n] in bwd_sums; 0 = Cin */
+    int32_t accumulate;           /* 1: din += result (a tensor with two forward consumers, e.g. a U-Net skip) */
 } sgan_conv_dgrad_job;
 typedef struct sgan_conv_wgrad_job {
     const sgan_conv_desc* d;
@@ -157,8 +162,8 @@ int sgan_conv_wgrad(const sgan_conv_desc* d, const float* in, int32_t in_ld, con
  * dgamma += s2, dbeta += s1 when non-NULL.  M = npix.
  * Replaces: native_batch_norm_backward of nn.InstanceNorm2d / nn.BatchNorm2d. */
 int sgan_norm_bwd_apply(float* dy, int32_t dy_ld, const float* x, int32_t x_ld, int32_t npix, int32_t C,
-                        const sgan_norm_desc* x_norm, const double* bwd_sums, float* dgamma, float* dbeta,
-                        void* stream);
+                        const sgan_norm_desc* x_norm, const double* bwd_sums, int32_t bwd_sums_sq_stride /* 0 = C */,
+                        float* dgamma, float* dbeta, void* stream);
 
 /* ---- BatchNorm running statistics (momentum update, unbiased variance), n layers per launch --
  * Replaces the running_mean / running_var side effect of nn.BatchNorm2d.forward in train mode. */
@@ -215,6 +220,29 @@ int sgan_gan_loss_multi_bwd(const sgan_gan_loss_job* jobs, int32_t n, int32_t mo
 int sgan_sigmoid_fwd(const float* x, int32_t ld, int32_t npix, float* p, int32_t pld, void* stream);
 int sgan_sigmoid_bwd(const float* dp, int32_t dpld, const float* p, int32_t pld, int32_t npix, float* dx,
                      int32_t dxld, void* stream);
+
+/* ---- U-Net up path: normalise (+ dropout) (+ additive Gaussian noise) into a concat slice --------------
+ * t[p][c] = (u[p][c] - mean_c) * rstd_c * (mask ? mask[p][c] : 1) + (noise ? sigma * noise[p][c] : 0)
+ * mask holds 0 or 1/(1-p) (nn.Dropout(0.5) => 0 or 2).  Replaces norm_layer + nn.Dropout + the `y + noise` of
+ * UnetSkipConnectionBlock (models/networks.py:387-403,414-419); `t` is written straight into the up half
+ * of the concat buffer the next ConvTranspose2d reads (torch.cat, :417-419, never materialises).
+ * Backward, first pass: dt <- dt * mask in place and bwd_sums += (sum dt, sum dt * uhat); then
+ * sgan_norm_bwd_apply(dt, u, ...) finishes the normalisation backward. */
+int sgan_norm_apply_fwd(const float* u, int32_t u_ld, const sgan_norm_desc* u_norm, const float* mask, const float* noise,
+                        float sigma, float* t, int32_t t_ld, int32_t npix, int32_t C, void* stream);
+int sgan_norm_apply_bwd_sums(float* dt, int32_t dt_ld, const float* mask, const float* u, int32_t u_ld,
+                             const sgan_norm_desc* u_norm, double* bwd_sums, int32_t npix, int32_t C, void* stream);
+/* mask[i] = uniform(Philox(seed, *offset_dev + i)) < p ? 0 : 1/(1-p); advances *offset_dev (nn.Dropout). */
+int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* offset_dev, void* stream);
+
+/* ---- weighted L1 (cgan): loss = lambda * mean(|x - y| * w), w = 1 + sum_i ((a_i + 1)/2) * (weights_i - 1) over the
+ * first nweights channels of the label image `a` (w = 1 when a == NULL).  Also writes g = dloss/dx (unscaled by
+ * the incoming gradient); the backward is dx = gout * g.  Replaces WeightedL1Loss (models/networks.py:205-214)
+ * and the weight-map construction in CGANModel.backward_G (models/cgan_model.py:196-207). */
+int sgan_l1w_fwd(const float* x, int32_t x_ld, const float* y, int32_t y_ld, int32_t npix, int32_t C,
+                 const float* a, int32_t a_ld, const float* weights_dev, int32_t nweights, float lambda,
+                 float* loss_out, float* g, int32_t g_ld, void* stream);
+int sgan_scale(const float* gout, const float* g, float* dx, int64_t n, void* stream);   /* dx = gout[0] * g */
 
 /* ---- elementwise helpers ---------------------------------------------------------------------
  * tanh backward: dx = dy * (1 - y*y)                                   (nn.Tanh, networks.py:540)

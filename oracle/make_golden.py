@@ -7,7 +7,9 @@ none of which touch arithmetic:
     Python-2 code (models/networks.py:127-129, :808-811 compute sigma = scale_factor / 2);
   * `--which_model_netG fcgan` (README's `deconv` alias is rejected by define_G);
   * noise tensors are injected (Tensor.normal_ is patched to pop from a numpy-seeded queue
-    for the latent shape) so the vectors do not depend on torch's RNG stream.
+    for the latent shape) so the vectors do not depend on torch's RNG stream; for the U-Net the
+    Dropout(0.5) masks and the optional Gaussian noise are injected the same way (F.dropout /
+    Tensor.normal_ patched to numpy-seeded tensors keyed on the shape).
 
 Usage:  python oracle/make_golden.py            (writes tests/golden/)
 """
@@ -286,9 +288,157 @@ def golden_step(name, cfg: O.FCGANConfig, seed: int, nsteps: int, full_params: b
         save(name, **arrs)
 
 
+# ---------------------------------------------------------------------------------------
+# U-Net generator / cgan
+# ---------------------------------------------------------------------------------------
+class UnetRandomInjector:
+    """Dropout masks and Gaussian noise of the U-Net from numpy (same generators as the oracle)."""
+    def __init__(self, mask_seed, noise_seed):
+        self.mask_seed, self.noise_seed = mask_seed, noise_seed
+        self._orig_dropout = torch.nn.functional.dropout
+        self._orig_normal = torch.Tensor.normal_
+
+    def __enter__(self):
+        inj = self
+
+        def dropout(x, p=0.5, training=True, inplace=False):
+            assert p == 0.5 and training
+            return x * O.dropout_mask_np(inj.mask_seed, x.shape)
+
+        def normal_(t, mean=0.0, std=1.0, *a, **k):
+            if t.dim() == 4 and t.shape[2] > 1 and mean == 0 and std == 1:
+                t.copy_(O.gauss_noise_np(inj.noise_seed, t.shape))
+                return t
+            return inj._orig_normal(t, mean, std, *a, **k)
+        torch.nn.functional.dropout = dropout
+        torch.Tensor.normal_ = normal_
+        return self
+
+    def __exit__(self, *exc):
+        torch.nn.functional.dropout = self._orig_dropout
+        torch.Tensor.normal_ = self._orig_normal
+
+
+def golden_unet_small():
+    """unet_128 (7 downs) at 256x256, ngf=8: all skips + dropout; and 4 skips + Gaussian noise, no dropout."""
+    for tag, kw in (("skipall_dropout", dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False)),
+                    ("skip4_noise", dict(use_dropout=False, num_skips=4, add_gaussian_noise=True))):
+        ngf, in_nc, out_nc, hw = 8, 2, 1, 256
+        sd = O.init_unet(31, 7, in_nc, out_nc, ngf, kw["num_skips"])
+        g = RN.define_G(in_nc, out_nc, ngf, "unet_128", "instance", kw["use_dropout"], n_layers_G_skip=kw["num_skips"],
+                        add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, gpu_ids=[])
+        load_sd(g, sd)
+        x = O.np_uniform(301, (1, in_nc, hw, hw)).requires_grad_(True)
+        r = O.np_normal(302, (1, out_nc, hw, hw))
+        with UnetRandomInjector(40, 50):
+            y = g.forward(x)
+        loss = (y * r).sum()
+        loss.backward()
+        arrs = {"y": y.detach().numpy(), "dx": x.grad.numpy(), "loss": np.float64(loss.item())}
+        for k, p in g.named_parameters():
+            arrs["grad/" + k] = p.grad.numpy()
+        save(f"unet_small_{tag}.npz", **arrs)
+
+
+def build_ref_cgan(cfg: "O.CGANConfig", seed: int, tmpdir: str):
+    from options.train_options import TrainOptions
+    from models.cgan_model import CGANModel
+    netG = {7: "unet_128", 8: "unet_256"}[cfg.num_downs]
+    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "cgan", "--which_direction", "AtoB",
+            "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize), "--batchSize", "1",
+            "--which_model_netG", netG, "--ngf", str(cfg.ngf), "--which_model_netD", "n_layers",
+            "--n_layers_D", *map(str, cfg.n_layers_D), "--ndf", str(cfg.ndf), "--scale_factor", *map(str, cfg.scale_factor),
+            "--lambda_D", *map(str, cfg.lambda_D), "--lambda_A", str(cfg.lambda_A), "--norm", "instance",
+            "--which_channel", "rg_b", "--gpu_ids", "-1", "--display_id", "0", "--checkpoints_dir", tmpdir,
+            "--pool_size", str(cfg.pool_size), "--n_layers_G_skip", str(cfg.n_layers_G_skip)]
+    if not cfg.use_dropout:
+        argv.append("--no_dropout")
+    if cfg.no_lsgan:
+        argv.append("--no_lsgan")
+    if cfg.add_gaussian_noise:
+        argv += ["--add_gaussian_noise", "--gaussian_sigma", str(cfg.gaussian_sigma)]
+    if cfg.weights is not None:
+        argv += ["--weights", *map(str, cfg.weights)]
+    old = sys.argv
+    sys.argv = argv
+    try:
+        opt = TrainOptions().parse()
+    finally:
+        sys.argv = old
+    opt.scale_factor = [Py2Int(s) if s > 1 else s for s in opt.scale_factor]
+    model = CGANModel()
+    model.initialize(opt)
+    load_sd(model.netG, O.init_unet(seed + 1, cfg.num_downs, cfg.input_nc, cfg.output_nc, cfg.ngf, cfg.n_layers_G_skip))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D, cfg.scale_factor)):
+        load_sd(model.netD[i], O.init_nlayer_d(seed + 2 + i, cfg.input_nc + cfg.output_nc, cfg.ndf, nl, sf))
+    return model
+
+
+def cgan_batch(cfg, step):
+    """The synthetic aligned pair of step `step` (3-channel A and B images; `rg_b` picks A[rg] -> B[b])."""
+    return {"A": O.np_uniform(7100 + step, (1, 3, cfg.fineSize, cfg.fineSize)),
+            "B": O.np_uniform(7200 + step, (1, 3, cfg.fineSize, cfg.fineSize)), "A_paths": ["synthetic"], "B_paths": ["synthetic"]}
+
+
+def golden_cgan_step(name, cfg: "O.CGANConfig", seed: int, nsteps: int):
+    import random
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        random.seed(1234)           # ImagePool's coin flips (util/image_pool.py:27-37)
+        model = build_ref_cgan(cfg, seed, tmp)
+        arrs = {}
+        losses = []
+        for step in range(nsteps):
+            model.set_input(cgan_batch(cfg, step))
+            with UnetRandomInjector(9000 + 100 * step, 9500 + 100 * step):
+                if step > 0:
+                    model.optimize_parameters()
+                else:
+                    model.forward()
+                    fake1 = model.fake_B.detach()
+                    arrs["step1/fake_summary"] = np.asarray(O.tensor_summary(fake1))
+                    arrs["step1/fake_crop"] = fake1[:, :, :64, :64].numpy().copy()
+                    model.optimizer_D.zero_grad()
+                    model.backward_D()
+                    for i, d in enumerate(model.netD):
+                        capture_grads(arrs, f"step1/gradD_{i}", d)
+                    arrs["step1/loss_D"] = np.asarray([float(model.loss_D_real), float(model.loss_D_fake)])
+                    model.optimizer_D.step()
+                    model.optimizer_G.zero_grad()
+                    model.backward_G()
+                    arrs["step1/loss_G"] = np.asarray([float(model.loss_G), float(model.loss_G_L1)])
+                    model.optimizer_G.step()
+            losses.append([float(model.loss_G), float(model.loss_G_L1), float(model.loss_D_real), float(model.loss_D_fake)])
+        arrs["losses"] = np.asarray(losses, dtype=np.float64)
+        probe = build_ref_cgan(cfg, seed, tmp)
+        probe.set_input(cgan_batch(cfg, 0))
+        with UnetRandomInjector(9000, 9500):
+            probe.forward()
+            probe.optimizer_G.zero_grad()
+            probe.optimizer_D.zero_grad()
+            probe.backward_G()
+        capture_grads(arrs, "probeG/gradG", probe.netG)
+        for i, d in enumerate(probe.netD):
+            capture_grads(arrs, f"probeG/gradD_{i}", d)
+        arrs["probeG/loss_G"] = np.asarray([float(probe.loss_G), float(probe.loss_G_L1)])
+        for label, net in [("G", model.netG)] + [(f"D_{i}", d) for i, d in enumerate(model.netD)]:
+            for k, v in net.state_dict().items():
+                if v.is_floating_point():
+                    arrs[f"summary/{label}/{k}"] = np.asarray(O.tensor_summary(v))
+        save(name, **arrs)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    only = sys.argv[1:]
+    if not only or "cgan" in only:
+        golden_unet_small()
+        golden_cgan_step("cgan_step_small.npz", O.CGANConfig(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0)),
+                         seed=0, nsteps=3)
+        golden_cgan_step("cgan_step_full.npz", O.CGANConfig(), seed=0, nsteps=2)   # BASELINE configs[2]
+    if only and "fcgan" not in only:
+        return
     golden_gauss()
     golden_g_small()
     golden_d_small()

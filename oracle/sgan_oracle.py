@@ -22,6 +22,8 @@ Reference map (paths relative to /root/reference):
   define_D gaussian init (py2 int division)   models/networks.py:124-129
   GANLoss                                     models/networks.py:152-185
   WeightedL1Loss                              models/networks.py:205-214
+  UnetGenerator / UnetSkipConnectionBlock     models/networks.py:318-419
+  CGANModel step recipe                       models/cgan_model.py:134-226
   FCGANModel step recipe                      models/fcgan_model.py:124-193
   Adam hyper-parameters                       models/fcgan_model.py:98-109, options/train_options.py:16-17
   ImagePool                                   util/image_pool.py:6-42
@@ -405,6 +407,231 @@ class FCGANOracle:
     def losses(self):
         return {"G_GAN": float(self.loss_G.detach()), "D_real": float(self.loss_D_real.detach()),
                 "D_fake": float(self.loss_D_fake.detach())}
+
+
+# ----------------------------------------------------------------------------------
+# U-Net generator (models/networks.py:318-419)
+# ----------------------------------------------------------------------------------
+def unet_plan(num_downs: int, ngf: int, input_nc: int, output_nc: int, num_skips: int = -1, use_dropout: bool = False):
+    """The convs of UnetGenerator as a list of levels.  Level l = 0..n-1: `down` conv producing x_l
+    (c_l channels at H/2^(l+1)), `up` transposed conv of the block that wraps x_l.  Level 0 is the bare
+    downconv/upconv pair of UnetGenerator.model (:356-358); levels 1..n-1 are UnetSkipConnectionBlocks,
+    n-1 the innermost one (:330-354).  `skip[l]`: block l returns cat([y, x]) (:419)."""
+    n = num_downs
+    if num_skips < 0:
+        num_skips = n
+    c = [ngf * min(2 ** l, 8) for l in range(n)]
+    skip = [False] + [num_skips >= n - l for l in range(1, n)]
+    levels = []
+    for l in range(n):
+        prefix = "model.1" + ".model.3" * (l - 1) if l >= 1 else None
+        innermost = l == n - 1
+        if l == 0:
+            down_key, up_key = "model.0", "model.3"
+            up_in = c[0] * (2 if skip[1] else 1)
+            lv = dict(down=(down_key, input_nc, c[0]), up=(up_key, up_in, output_nc), down_norm=False, up_norm=False)
+        else:
+            down_key = prefix + ".model.1"
+            up_key = prefix + (".model.3" if innermost else ".model.5")
+            up_in = c[l] if innermost else c[l] * (2 if skip[l + 1] else 1)
+            lv = dict(down=(down_key, c[l - 1], c[l]), up=(up_key, up_in, c[l - 1]), down_norm=not innermost, up_norm=True)
+        lv["dropout"] = bool(use_dropout and 4 <= l <= n - 2)      # the `num_downs - 5` ngf*8 blocks (:333-339)
+        lv["skip"] = skip[l]
+        lv["innermost"] = innermost
+        levels.append(lv)
+    return levels
+
+
+def init_unet(seed: int, num_downs: int, input_nc: int, output_nc: int, ngf: int = 64, num_skips: int = -1):
+    """numpy-seeded state dict with UnetGenerator's keys/shapes; N(0, 0.02) conv weights (weights_init
+    :13-19), torch-default uniform biases."""
+    sd = OrderedDict()
+    k = 0
+    for lv in unet_plan(num_downs, ngf, input_nc, output_nc, num_skips):
+        key, ci, co = lv["down"]
+        sd[key + ".weight"] = np_normal(seed * 1000 + k, (co, ci, 4, 4), 0.0, 0.02)
+        b = 1.0 / math.sqrt(ci * 16)
+        sd[key + ".bias"] = np_uniform(seed * 1000 + k + 1, (co,), -b, b)
+        key, ci, co = lv["up"]
+        sd[key + ".weight"] = np_normal(seed * 1000 + k + 2, (ci, co, 4, 4), 0.0, 0.02)
+        b = 1.0 / math.sqrt(co * 16)            # torch computes fan_in from weight.size(1) for ConvTranspose2d
+        sd[key + ".bias"] = np_uniform(seed * 1000 + k + 3, (co,), -b, b)
+        k += 4
+    return sd
+
+
+def dropout_mask_np(seed: int, shape) -> torch.Tensor:
+    """Deterministic Dropout(0.5) keep-mask (0 or 2), keyed on the tensor shape (make_golden.py injects
+    the same masks into the reference)."""
+    rs = np.random.RandomState(seed + int(shape[1]) * 7 + int(shape[2]))
+    return torch.from_numpy((rs.uniform(size=tuple(shape)) >= 0.5).astype(np.float32) * 2.0)
+
+
+def gauss_noise_np(seed: int, shape) -> torch.Tensor:
+    return np_normal(seed + int(shape[1]) * 131 + int(shape[2]), shape)
+
+
+def unet_forward(sd, x, num_downs: int, ngf: int, num_skips: int = -1, use_dropout: bool = False, mask_seed: int = 0,
+                 add_gaussian_noise: bool = False, gaussian_sigma: float = 0.1, noise_seed: int = 0, tanh: bool = True):
+    """UnetGenerator.forward (:362-367) with UnetSkipConnectionBlock.forward (:409-419) inlined."""
+    input_nc = sd["model.0.weight"].shape[1]
+    output_nc = sd["model.3.weight"].shape[1]
+    levels = unet_plan(num_downs, ngf, input_nc, output_nc, num_skips, use_dropout)
+
+    def block(l, xin):
+        lv = levels[l]
+        dk, uk = lv["down"][0], lv["up"][0]
+        h = F.leaky_relu(xin, 0.2)
+        h = F.conv2d(h, sd[dk + ".weight"], sd[dk + ".bias"], stride=2, padding=1)
+        if not lv["innermost"]:
+            h = F.instance_norm(h, eps=IN_EPS)
+            h = block(l + 1, h)
+        h = F.relu(h)
+        h = F.conv_transpose2d(h, sd[uk + ".weight"], sd[uk + ".bias"], stride=2, padding=1)
+        h = F.instance_norm(h, eps=IN_EPS)
+        if lv["dropout"]:
+            h = h * dropout_mask_np(mask_seed, h.shape)
+        if add_gaussian_noise:
+            h = h + gaussian_sigma * gauss_noise_np(noise_seed, h.shape)
+        return torch.cat([h, xin], 1) if lv["skip"] else h
+
+    h = F.conv2d(x, sd["model.0.weight"], sd["model.0.bias"], stride=2, padding=1)
+    h = block(1, h)
+    h = F.relu(h)
+    h = F.conv_transpose2d(h, sd["model.3.weight"], sd["model.3.bias"], stride=2, padding=1)
+    return torch.tanh(h) if tanh else h
+
+
+def norm_cancelled_keys_unet(num_downs: int, ngf: int = 64, num_skips: int = -1):
+    """Conv biases of the U-Net that feed an InstanceNorm (analytically zero gradient, see
+    norm_cancelled_keys_g)."""
+    keys = set()
+    for lv in unet_plan(num_downs, ngf, 1, 1, num_skips):
+        if lv["down_norm"]:
+            keys.add(lv["down"][0] + ".bias")
+        if lv["up_norm"]:
+            keys.add(lv["up"][0] + ".bias")
+    return keys
+
+
+# ----------------------------------------------------------------------------------
+# the cgan training step (models/cgan_model.py:134-226)
+# ----------------------------------------------------------------------------------
+class CGANConfig:
+    """cgan flags: unet G (`--which_model_netG unet_128|unet_256`), n_layers discriminators on cat(A, B)."""
+    def __init__(self, num_downs=8, input_nc=2, output_nc=1, ngf=64, ndf=64, n_layers_D=(3, 4), scale_factor=(1, 2),
+                 lambda_D=(1.0, 1.0), lambda_A=10.0, weights=None, use_dropout=True, n_layers_G_skip=-1,
+                 add_gaussian_noise=False, gaussian_sigma=0.1, fineSize=512, lr=2e-4, beta1=0.5, pool_size=50,
+                 no_lsgan=False, no_logD_trick=False, no_cgan=False):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+class CGANOracle:
+    """CGANModel restated (initialize :18-117, forward :134-139, backward_D :158-182, backward_G :184-210,
+    optimize_parameters :212-226 with n_update_D = n_update_G = 1)."""
+
+    def __init__(self, cfg: CGANConfig, seed: int = 0):
+        self.cfg = cfg
+        c = cfg
+        self.G = init_unet(seed + 1, c.num_downs, c.input_nc, c.output_nc, c.ngf, c.n_layers_G_skip)
+        d_nc = c.output_nc if c.no_cgan else c.output_nc + c.input_nc
+        self.D = [init_nlayer_d(seed + 2 + i, d_nc, c.ndf, nl, sf) for i, (nl, sf) in enumerate(zip(c.n_layers_D, c.scale_factor))]
+        for v in self.G.values():
+            v.requires_grad_(True)
+        for d in self.D:
+            for v in d.values():
+                if v.is_floating_point():
+                    v.requires_grad_(True)
+        self.opt_G = Adam(list(self.G.values()), c.lr, c.beta1)
+        self.opt_D = Adam([v for d in self.D for k, v in d.items() if k.startswith("model.")], c.lr, c.beta1)
+        self.pool = ImagePool(c.pool_size)
+        self.step = 0
+
+    def forward(self):
+        c = self.cfg
+        self.fake_B = unet_forward(self.G, self.real_A, c.num_downs, c.ngf, c.n_layers_G_skip, c.use_dropout,
+                                   mask_seed=9000 + 100 * self.step, add_gaussian_noise=c.add_gaussian_noise,
+                                   gaussian_sigma=c.gaussian_sigma, noise_seed=9500 + 100 * self.step)
+
+    def _d(self, i, x):
+        c = self.cfg
+        return nlayer_d_forward(self.D[i], x, c.n_layers_D[i], c.scale_factor[i], use_sigmoid=c.no_lsgan)
+
+    def backward_D(self):
+        c = self.cfg
+        fake = self.fake_B if c.no_cgan else torch.cat((self.real_A, self.fake_B), 1)
+        fake = self.pool.query(fake)
+        self.loss_D_fake = sum(gan_loss(self._d(i, fake.detach()), False, not c.no_lsgan) for i in range(len(self.D)))
+        real = self.real_B if c.no_cgan else torch.cat((self.real_A, self.real_B), 1)
+        self.loss_D_real = sum(gan_loss(self._d(i, real), True, not c.no_lsgan) for i in range(len(self.D)))
+        self.loss_D = (self.loss_D_fake + self.loss_D_real) * 0.5
+        self.loss_D.backward()
+
+    def backward_G(self):
+        c = self.cfg
+        fake = self.fake_B if c.no_cgan else torch.cat((self.real_A, self.fake_B), 1)
+        loss = 0
+        for i, lam in enumerate(c.lambda_D):
+            pred = self._d(i, fake)
+            if not c.no_logD_trick:
+                loss = loss + gan_loss(pred, True, not c.no_lsgan) * lam
+            else:
+                loss = loss - gan_loss(pred, False, not c.no_lsgan) * lam
+        weight = None
+        if c.weights is not None:
+            weight = torch.ones(1, 1, c.fineSize, c.fineSize)
+            a01 = (self.real_A.detach() + 1) / 2
+            for i, wv in enumerate(c.weights):
+                weight = weight + a01.narrow(1, i, 1) * (wv - 1.0)
+        self.loss_G_L1 = weighted_l1(self.fake_B, self.real_B, weight) * c.lambda_A
+        self.loss_G = loss + self.loss_G_L1
+        self.loss_G.backward()
+
+    def set_input(self, real_A, real_B):
+        self.real_A, self.real_B = real_A, real_B
+
+    def optimize_parameters(self):
+        self.forward()
+        self.opt_D.zero_grad()
+        self.backward_D()
+        self.opt_D.step()
+        self.opt_G.zero_grad()
+        self.backward_G()
+        self.opt_G.step()
+        self.step += 1
+
+    def _gradD(self):
+        return [{k: v.grad.detach().clone() for k, v in d.items() if k.startswith("model.") and v.grad is not None} for d in self.D]
+
+    def step1_with_captures(self):
+        cap = {}
+        self.forward()
+        cap["fake"] = self.fake_B.detach().clone()
+        self.opt_D.zero_grad()
+        self.backward_D()
+        cap["gradD"] = self._gradD()
+        cap["loss_D"] = [float(self.loss_D_real.detach()), float(self.loss_D_fake.detach())]
+        self.opt_D.step()
+        self.opt_G.zero_grad()
+        self.backward_G()
+        cap["loss_G"] = [float(self.loss_G.detach()), float(self.loss_G_L1.detach())]
+        self.opt_G.step()
+        self.step += 1
+        return cap
+
+    def probe_G(self):
+        """forward() + backward_G() on the initial weights."""
+        self.forward()
+        self.opt_G.zero_grad()
+        self.opt_D.zero_grad()
+        self.backward_G()
+        return {"fake": self.fake_B.detach().clone(), "gradG": {k: v.grad.detach().clone() for k, v in self.G.items()},
+                "gradD": self._gradD(), "loss_G": [float(self.loss_G.detach()), float(self.loss_G_L1.detach())]}
+
+    def losses(self):
+        return {"G_GAN": float(self.loss_G.detach()), "G_L1": float(self.loss_G_L1.detach()),
+                "D_real": float(self.loss_D_real.detach()), "D_fake": float(self.loss_D_fake.detach())}
 
 
 def norm_cancelled_keys_g(n_layers: int = 5):

@@ -13,7 +13,7 @@ CONV, CONVT = 0, 1
 
 class NormDesc(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("count", C.c_int32), ("eps", C.c_float), ("act", C.c_int32), ("slope", C.c_float)]
+                ("count", C.c_int32), ("eps", C.c_float), ("act", C.c_int32), ("slope", C.c_float), ("sq_stride", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -24,13 +24,15 @@ class ConvDesc(C.Structure):
 
 class ConvFwdJob(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("inp", C.c_void_p), ("in_ld", C.c_int32), ("in_norm", C.POINTER(NormDesc)),
-                ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_stats", C.c_void_p)]
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_stats", C.c_void_p),
+                ("out_stats_sq_stride", C.c_int32)]
 
 
 class ConvDgradJob(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("w", C.c_void_p),
                 ("din", C.c_void_p), ("din_ld", C.c_int32), ("x", C.c_void_p), ("x_ld", C.c_int32),
-                ("x_norm", C.POINTER(NormDesc)), ("bwd_sums", C.c_void_p)]
+                ("x_norm", C.POINTER(NormDesc)), ("bwd_sums", C.c_void_p), ("bwd_sums_sq_stride", C.c_int32),
+                ("accumulate", C.c_int32)]
 
 
 class ConvWgradJob(C.Structure):
@@ -61,7 +63,12 @@ SIGNATURES = {
     "sgan_conv_fwd_grouped": [C.POINTER(ConvFwdJob), _I, _I, _P, _L, _P],
     "sgan_conv_dgrad_grouped": [C.POINTER(ConvDgradJob), _I, _P, _L, _P],
     "sgan_conv_wgrad_grouped": [C.POINTER(ConvWgradJob), _I, _P],
-    "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _P, _P, _P],
+    "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
+    "sgan_norm_apply_fwd": [_P, _I, C.POINTER(NormDesc), _P, _P, _F, _P, _I, _I, _I, _P],
+    "sgan_norm_apply_bwd_sums": [_P, _I, _P, _P, _I, C.POINTER(NormDesc), _P, _I, _I, _P],
+    "sgan_dropout_mask": [_P, _L, _F, C.c_uint64, _P, _P],
+    "sgan_l1w_fwd": [_P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _F, _P, _P, _I, _P],
+    "sgan_scale": [_P, _P, _P, _L, _P],
     "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],
     "sgan_gauss_down_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "sgan_gauss_down_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],

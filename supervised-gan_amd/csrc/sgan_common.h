@@ -66,16 +66,17 @@ struct SgNorm {  // device-side copy of sgan_norm_desc
     float eps;
     int32_t act;
     float slope;
+    int32_t sq_stride;  // 0 = C
 };
 
 static inline SgNorm sg_norm_from(const sgan_norm_desc* d) {
     SgNorm n;
     if (d) {
         n.stats = d->stats; n.gamma = d->gamma; n.beta = d->beta;
-        n.count = d->count; n.eps = d->eps; n.act = d->act; n.slope = d->slope;
+        n.count = d->count; n.eps = d->eps; n.act = d->act; n.slope = d->slope; n.sq_stride = d->sq_stride;
     } else {
         n.stats = nullptr; n.gamma = nullptr; n.beta = nullptr;
-        n.count = 1; n.eps = 0.f; n.act = SGAN_ACT_NONE; n.slope = 0.f;
+        n.count = 1; n.eps = 0.f; n.act = SGAN_ACT_NONE; n.slope = 0.f; n.sq_stride = 0;
     }
     return n;
 }
@@ -87,7 +88,7 @@ int sg_build_phases(const sgan_conv_desc* d, bool dgrad, SgPhase* ph, int* nphas
 
 // mean / rstd of channel c from accumulated (sum, sumsq) statistics (biased variance)
 __device__ __forceinline__ void sg_mean_rstd(const SgNorm& n, int C, int c, float& mean, float& rstd) {
-    double s = n.stats[c], q = n.stats[C + c];
+    double s = n.stats[c], q = n.stats[(n.sq_stride ? n.sq_stride : C) + c];
     double inv = 1.0 / (double)n.count;
     double m = s * inv;
     double var = q * inv - m * m;

@@ -75,7 +75,7 @@ static inline int ew_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b);
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(float* dy, int dy_ld, const float* x, int x_ld,
                                                                 int npix, int C, SgNorm xn, const double* sums,
-                                                                float* dgamma, float* dbeta) {
+                                                                int sums_sq, float* dgamma, float* dbeta) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* cA = reinterpret_cast<float*>(smem);  // gamma * rstd
     float* cMean = cA + C;
@@ -91,9 +91,9 @@ __global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(float* dy, int d
         cMean[c] = mean;
         cRstd[c] = rstd;
         cS1[c] = (float)(sums[c] * invM);
-        cS2[c] = (float)(sums[C + c] * invM);
+        cS2[c] = (float)(sums[sums_sq + c] * invM);
         if (blockIdx.x == 0) {
-            if (dgamma) atomicAdd(&dgamma[c], (float)sums[C + c]);   // concurrent chains may share the buffer
+            if (dgamma) atomicAdd(&dgamma[c], (float)sums[sums_sq + c]);   // concurrent chains may share the buffer
             if (dbeta) atomicAdd(&dbeta[c], (float)sums[c]);
         }
     }
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(float* dy, int d
 }
 
 extern "C" int sgan_norm_bwd_apply(float* dy, int32_t dy_ld, const float* x, int32_t x_ld, int32_t npix, int32_t C,
-                                   const sgan_norm_desc* x_norm, const double* bwd_sums, float* dgamma, float* dbeta,
-                                   void* stream) {
+                                   const sgan_norm_desc* x_norm, const double* bwd_sums, int32_t bwd_sums_sq_stride,
+                                   float* dgamma, float* dbeta, void* stream) {
     SGAN_CHECK(dy && x && x_norm && x_norm->stats && bwd_sums, "null argument");
     SGAN_CHECK((C & 3) == 0 && C > 0 && C <= 4096 && dy_ld >= C && x_ld >= C && (dy_ld & 3) == 0 && (x_ld & 3) == 0, "bad dims");
     const int64_t total = (int64_t)npix * (C >> 2);
@@ -123,7 +123,166 @@ extern "C" int sgan_norm_bwd_apply(float* dy, int32_t dy_ld, const float* x, int
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sg_norm_bwd_apply_kernel, dim3(blocks), dim3(256), (size_t)5 * C * 4, (hipStream_t)stream, dy, dy_ld,
-                       x, x_ld, npix, C, sg_norm_from(x_norm), bwd_sums, dgamma, dbeta);
+                       x, x_ld, npix, C, sg_norm_from(x_norm), bwd_sums, bwd_sums_sq_stride ? bwd_sums_sq_stride : C, dgamma, dbeta);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// U-Net up path: normalise (+ dropout) (+ noise) into a concat slice; and the first backward pass
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_norm_apply_fwd_kernel(const float* u, int u_ld, SgNorm un, const float* mask,
+                                                                const float* noise, float sigma, float* t, int t_ld, int npix,
+                                                                int C) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cMean = reinterpret_cast<float*>(smem);
+    float* cRstd = cMean + C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mean = 0.f, rstd = 1.f;
+        if (un.stats) sg_mean_rstd(un, C, c, mean, rstd);
+        cMean[c] = mean;
+        cRstd[c] = rstd;
+    }
+    __syncthreads();
+    const int CQ = C >> 2;
+    const int64_t total = (int64_t)npix * CQ;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int p = (int)(e / CQ), c = (int)(e - (int64_t)p * CQ) * 4;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(u + (int64_t)p * u_ld + c);
+        f32x4 m = (f32x4){1.f, 1.f, 1.f, 1.f}, nz = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (mask) m = *reinterpret_cast<const f32x4*>(mask + (int64_t)p * C + c);
+        if (noise) nz = *reinterpret_cast<const f32x4*>(noise + (int64_t)p * C + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (x[j] - cMean[c + j]) * cRstd[c + j] * m[j] + sigma * nz[j];
+        *reinterpret_cast<f32x4*>(t + (int64_t)p * t_ld + c) = o;
+    }
+}
+
+// thread t always works on channel group t % (C/4) (host: 256 % (C/4) == 0 or the generic path below)
+__global__ __launch_bounds__(256) void sg_norm_apply_bwd_sums_kernel(float* dt, int dt_ld, const float* mask, const float* u,
+                                                                     int u_ld, SgNorm un, double* sums, int npix, int C) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cMean = reinterpret_cast<float*>(smem);
+    float* cRstd = cMean + C;
+    float* red = cRstd + C;  // [2C]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mean = 0.f, rstd = 1.f;
+        if (un.stats) sg_mean_rstd(un, C, c, mean, rstd);
+        cMean[c] = mean;
+        cRstd[c] = rstd;
+    }
+    for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const int CQ = C >> 2;
+    const int64_t total = (int64_t)npix * CQ;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int p = (int)(e / CQ), c = (int)(e - (int64_t)p * CQ) * 4;
+        f32x4 d = *reinterpret_cast<const f32x4*>(dt + (int64_t)p * dt_ld + c);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(u + (int64_t)p * u_ld + c);
+        if (mask) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (int64_t)p * C + c);
+            d *= m;
+            *reinterpret_cast<f32x4*>(dt + (int64_t)p * dt_ld + c) = d;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xhat = (x[j] - cMean[c + j]) * cRstd[c + j];
+            atomicAdd(&red[c + j], d[j]);
+            atomicAdd(&red[C + c + j], d[j] * xhat);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(&sums[c], (double)red[c]);
+        atomicAdd(&sums[C + c], (double)red[C + c]);
+    }
+}
+
+extern "C" int sgan_norm_apply_fwd(const float* u, int32_t u_ld, const sgan_norm_desc* u_norm, const float* mask,
+                                   const float* noise, float sigma, float* t, int32_t t_ld, int32_t npix, int32_t C, void* stream) {
+    SGAN_CHECK(u && t && npix > 0 && C > 0 && (C & 3) == 0 && u_ld >= C && t_ld >= C && (u_ld & 3) == 0 && (t_ld & 3) == 0, "bad argument");
+    const int64_t total = (int64_t)npix * (C >> 2);
+    int blocks = ew_cdiv(total, 256 * 2);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sg_norm_apply_fwd_kernel, dim3(blocks), dim3(256), (size_t)2 * C * 4, (hipStream_t)stream, u, u_ld,
+                       sg_norm_from(u_norm), mask, noise, sigma, t, t_ld, npix, C);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_norm_apply_bwd_sums(float* dt, int32_t dt_ld, const float* mask, const float* u, int32_t u_ld,
+                                        const sgan_norm_desc* u_norm, double* bwd_sums, int32_t npix, int32_t C, void* stream) {
+    SGAN_CHECK(dt && u && bwd_sums && npix > 0 && C > 0 && (C & 3) == 0 && u_ld >= C && dt_ld >= C, "bad argument");
+    const int64_t total = (int64_t)npix * (C >> 2);
+    int blocks = ew_cdiv(total, 256 * 8);
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sg_norm_apply_bwd_sums_kernel, dim3(blocks), dim3(256), (size_t)4 * C * 4, (hipStream_t)stream, dt, dt_ld,
+                       mask, u, u_ld, sg_norm_from(u_norm), bwd_sums, npix, C);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// weighted L1, scalar scale
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sg_l1w_fwd_kernel(const float* x, int x_ld, const float* y, int y_ld, int npix, int C,
+                                                          const float* a, int a_ld, const float* wts, int nw, float lambda,
+                                                          float* loss_out, float* g, int g_ld) {
+    __shared__ double wsum[16];
+    const double inv = 1.0 / ((double)npix * (double)C);
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < npix; p += 1024) {
+        float w = 1.f;
+        if (a)
+            for (int i = 0; i < nw; ++i) w += (a[(int64_t)p * a_ld + i] + 1.f) * 0.5f * (wts[i] - 1.f);
+        for (int c = 0; c < g_ld; ++c) {
+            float gv = 0.f;
+            if (c < C) {
+                const float d = x[(int64_t)p * x_ld + c] - y[(int64_t)p * y_ld + c];
+                acc += (double)(fabsf(d) * w);
+                gv = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w * lambda * (float)inv;
+            }
+            g[(int64_t)p * g_ld + c] = gv;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += wsum[i];
+        loss_out[0] = (float)(t * inv * (double)lambda);
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_scale_kernel(const float* gout, const float* g, float* dx, int64_t n4) {
+    const float s = gout[0];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(g)[e];
+        v *= s;
+        reinterpret_cast<f32x4*>(dx)[e] = v;
+    }
+}
+
+extern "C" int sgan_l1w_fwd(const float* x, int32_t x_ld, const float* y, int32_t y_ld, int32_t npix, int32_t C, const float* a,
+                            int32_t a_ld, const float* weights_dev, int32_t nweights, float lambda, float* loss_out, float* g,
+                            int32_t g_ld, void* stream) {
+    SGAN_CHECK(x && y && loss_out && g && npix > 0 && C > 0 && g_ld >= C && x_ld >= C && y_ld >= C, "bad argument");
+    SGAN_CHECK(!a || (weights_dev && nweights > 0 && a_ld >= nweights), "weights need the label image");
+    hipLaunchKernelGGL(sg_l1w_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, x_ld, y, y_ld, npix, C, a, a_ld,
+                       weights_dev, nweights, lambda, loss_out, g, g_ld);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_scale(const float* gout, const float* g, float* dx, int64_t n, void* stream) {
+    SGAN_CHECK(gout && g && dx && n > 0 && (n & 3) == 0, "bad argument");
+    int blocks = ew_cdiv(n / 4, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sg_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gout, g, dx, n / 4);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
 }
@@ -630,6 +789,34 @@ __global__ __launch_bounds__(256) void sg_normal_fill_kernel(float* dst, int64_t
 }
 
 __global__ void sg_rng_advance_kernel(uint64_t* offset, uint64_t by) { offset[0] += by; }
+
+__global__ __launch_bounds__(256) void sg_dropout_mask_kernel(float* mask, int64_t n, float p, float keep_scale, uint64_t seed,
+                                                              const uint64_t* offset) {
+    const uint64_t off = offset ? offset[0] : 0;
+    const int64_t nq = (n + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+        const uint64_t ctr = off + (uint64_t)q;
+        uint32_t r[4];
+        sg_philox((uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) mask[q * 4 + j] = ((float)(r[j] >> 8) * (1.0f / 16777216.0f) < p) ? 0.f : keep_scale;
+    }
+}
+
+extern "C" int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* offset_dev, void* stream) {
+    SGAN_CHECK(mask && n > 0 && p >= 0.f && p < 1.f, "bad argument");
+    const int64_t nq = (n + 3) >> 2;
+    int blocks = ew_cdiv(nq, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sg_dropout_mask_kernel, dim3(blocks), dim3(256), 0, st, mask, n, p, 1.f / (1.f - p), seed, offset_dev);
+    SGAN_LAUNCH_CHECK();
+    if (offset_dev) {
+        hipLaunchKernelGGL(sg_rng_advance_kernel, dim3(1), dim3(1), 0, st, offset_dev, (uint64_t)nq);
+        SGAN_LAUNCH_CHECK();
+    }
+    return SGAN_OK;
+}
 
 extern "C" int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, void* stream) {
     SGAN_CHECK(dst && n > 0, "bad argument");

@@ -51,6 +51,9 @@ struct SgProb {
     int32_t Hin, Win, in_ld;     // gathered tensor geometry
     int32_t Hout, Wout, out_ld;  // result tensor geometry
     int32_t xref_ld, pro_count, xn_count;
+    int32_t pro_sq, xn_sq;   // sum -> sumsq distance of the two norm statistics (0 = channel count)
+    int32_t stats_sq;        // same for the statistics this launch accumulates (0 = N)
+    int32_t accum;           // out += result (backward-data into a tensor with two forward consumers)
     int32_t Hp[SGAN_MAX_PHASES], Wp[SGAN_MAX_PHASES];
     int32_t tile0[SGAN_MAX_PHASES];  // first blockIdx.x of (this problem, phase)
 };
@@ -76,6 +79,7 @@ struct SgLocal {
     const float* in; float* out; const float* w; const float* bias; const float* xref; double* stats;
     int32_t Hin, Win, Ck, in_ld, Hout, Wout, N, out_ld, xref_ld, is, os, w_ns, w_ks, out_act, ksplit;
     float* slab; int64_t slab_stride;
+    int32_t stats_sq, accum;
     SgNorm pro, xn;
 };
 
@@ -87,9 +91,10 @@ __device__ __forceinline__ SgLocal sg_local(const SgIgemmParams& G, int g) {
     P.out_ld = Q.out_ld; P.xref_ld = Q.xref_ld; P.is = G.is; P.os = G.os; P.w_ns = G.w_ns; P.w_ks = G.w_ks;
     P.out_act = G.out_act; P.ksplit = G.ksplit; P.slab = G.slab; P.slab_stride = G.slab_stride;
     P.pro.stats = Q.pro_stats; P.pro.gamma = Q.pro_gamma; P.pro.beta = Q.pro_beta; P.pro.count = Q.pro_count;
-    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope;
+    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope; P.pro.sq_stride = Q.pro_sq;
+    P.stats_sq = Q.stats_sq ? Q.stats_sq : G.N; P.accum = Q.accum;
     P.xn.stats = Q.xn_stats; P.xn.gamma = Q.xn_gamma; P.xn.beta = Q.xn_beta; P.xn.count = Q.xn_count;
-    P.xn.eps = G.xn_eps; P.xn.act = G.xn_act; P.xn.slope = G.xn_slope;
+    P.xn.eps = G.xn_eps; P.xn.act = G.xn_act; P.xn.slope = G.xn_slope; P.xn.sq_stride = Q.xn_sq;
     return P;
 }
 
@@ -486,6 +491,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
                         s2 += v * v;
                         if (P.out_act == SGAN_ACT_TANH) v = tanhf(v);
                     }
+                    if (P.accum) v += P.out[pix * P.out_ld + n];
                     P.out[pix * P.out_ld + n] = v;
                 }
             }
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
         __syncthreads();
         if (tid < BN && n0 + tid < N) {
             atomicAdd(&P.stats[n0 + tid], (double)red[tid]);
-            atomicAdd(&P.stats[N + n0 + tid], (double)red[BN + tid]);
+            atomicAdd(&P.stats[P.stats_sq + n0 + tid], (double)red[BN + tid]);
         }
     }
 }
@@ -715,6 +721,7 @@ __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmPa
                 if (P.out_act == SGAN_ACT_TANH) v[j] = tanhf(v[j]);
             }
         }
+        if (P.accum) v += *reinterpret_cast<const f32x4*>(P.out + pix * P.out_ld + n);
         *reinterpret_cast<f32x4*>(P.out + pix * P.out_ld + n) = v;
     }
     if (want_stats) {
@@ -726,7 +733,7 @@ __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmPa
         __syncthreads();
         for (int c = threadIdx.x; c < N; c += 256) {
             atomicAdd(&P.stats[c], (double)red[c]);
-            atomicAdd(&P.stats[N + c], (double)red[N + c]);
+            atomicAdd(&P.stats[P.stats_sq + c], (double)red[N + c]);
         }
     }
 }
@@ -905,7 +912,7 @@ static void sg_pick_tile(const SgIgemmParams& P, int* BM, int* BN) {
 static bool sg_use_small_n(const SgIgemmParams& P) {
     if (P.N != 4) return false;
     for (int g = 0; g < P.nprob; ++g)
-        if (P.q[g].xref || P.q[g].stats || (P.q[g].out_ld & 3)) return false;
+        if (P.q[g].xref || P.q[g].stats || (P.q[g].out_ld & 3) || P.q[g].accum) return false;
     return true;
 }
 
@@ -974,11 +981,13 @@ static int sg_group_geometry(SgIgemmParams& P, const sgan_conv_desc* const* desc
     return SGAN_OK;
 }
 
-static void sg_set_norm(const sgan_norm_desc* d, const double** stats, const float** gamma, const float** beta, int32_t* count) {
+static void sg_set_norm(const sgan_norm_desc* d, const double** stats, const float** gamma, const float** beta, int32_t* count,
+                        int32_t* sq) {
     *stats = d ? d->stats : nullptr;
     *gamma = d ? d->gamma : nullptr;
     *beta = d ? d->beta : nullptr;
     *count = d ? d->count : 1;
+    *sq = d ? d->sq_stride : 0;
 }
 
 extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, int32_t out_act, void* workspace,
@@ -1005,8 +1014,9 @@ extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, i
         SgProb& Q = P.q[g];
         Q.in = J.in; Q.out = J.out; Q.w = J.w; Q.bias = J.bias; Q.xref = nullptr; Q.stats = J.out_stats;
         Q.Hin = J.d->Hin; Q.Win = J.d->Win; Q.in_ld = J.in_ld; Q.Hout = J.d->Hout; Q.Wout = J.d->Wout; Q.out_ld = J.out_ld;
-        sg_set_norm(J.in_norm, &Q.pro_stats, &Q.pro_gamma, &Q.pro_beta, &Q.pro_count);
+        sg_set_norm(J.in_norm, &Q.pro_stats, &Q.pro_gamma, &Q.pro_beta, &Q.pro_count, &Q.pro_sq);
         Q.xn_count = 1;
+        Q.stats_sq = J.out_stats_sq_stride;
     }
     if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)
     return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
@@ -1041,7 +1051,9 @@ extern "C" int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t 
         Q.Hin = J.d->Hout; Q.Win = J.d->Wout; Q.in_ld = J.dout_ld; Q.Hout = J.d->Hin; Q.Wout = J.d->Win; Q.out_ld = J.din_ld;
         Q.xref_ld = J.x_ld;
         Q.pro_count = 1;
-        sg_set_norm(xn, &Q.xn_stats, &Q.xn_gamma, &Q.xn_beta, &Q.xn_count);
+        sg_set_norm(xn, &Q.xn_stats, &Q.xn_gamma, &Q.xn_beta, &Q.xn_count, &Q.xn_sq);
+        Q.stats_sq = J.bwd_sums_sq_stride;
+        Q.accum = J.accumulate;
     }
     if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)
     return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
@@ -1051,7 +1063,7 @@ extern "C" int sgan_conv_fwd(const sgan_conv_desc* d, const float* in, int32_t i
                              const float* w, const float* bias, float* out, int32_t out_ld, int32_t out_act,
                              double* out_stats, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
-    sgan_conv_fwd_job j = {d, in, in_ld, in_norm, w, bias, out, out_ld, out_stats};
+    sgan_conv_fwd_job j = {d, in, in_ld, in_norm, w, bias, out, out_ld, out_stats, 0};
     return sgan_conv_fwd_grouped(&j, 1, out_act, workspace, workspace_bytes, stream);
 }
 
@@ -1059,6 +1071,6 @@ extern "C" int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32
                                float* din, int32_t din_ld, const float* x, int32_t x_ld, const sgan_norm_desc* x_norm,
                                double* bwd_sums, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
-    sgan_conv_dgrad_job j = {d, dout, dout_ld, w, din, din_ld, x, x_ld, x_norm, bwd_sums};
+    sgan_conv_dgrad_job j = {d, dout, dout_ld, w, din, din_ld, x, x_ld, x_norm, bwd_sums, 0, 0};
     return sgan_conv_dgrad_grouped(&j, 1, workspace, workspace_bytes, stream);
 }

@@ -31,7 +31,7 @@ struct SgWgradProb {
     const float* pro_beta;
     int32_t Hin, Win, in_ld;
     int32_t Hout, Wout, dout_ld;
-    int32_t pro_count;
+    int32_t pro_count, pro_sq;
     int32_t nsplit;  // pixel-range splits of this problem
     int32_t z0;      // first blockIdx.z of this problem (z = z0 + phase * nsplit + split)
     int32_t Hp[SGAN_MAX_PHASES], Wp[SGAN_MAX_PHASES];
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     P.Hin = Q.Hin; P.Win = Q.Win; P.Cin = G.Cin; P.in_ld = Q.in_ld; P.Hout = Q.Hout; P.Wout = Q.Wout; P.Cout = G.Cout;
     P.dout_ld = Q.dout_ld; P.is = G.is; P.os = G.os; P.w_ns = G.w_ns; P.nsplit = Q.nsplit;
     P.pro.stats = Q.pro_stats; P.pro.gamma = Q.pro_gamma; P.pro.beta = Q.pro_beta; P.pro.count = Q.pro_count;
-    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope;
+    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope; P.pro.sq_stride = Q.pro_sq;
     const int zl = blockIdx.z - Q.z0;
     const int phz = zl / P.nsplit, split = zl % P.nsplit;
     const int Hp = Q.Hp[phz], Wp = Q.Wp[phz], M = Hp * Wp, ktot = G.ktot[phz];
@@ -398,6 +398,7 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
         Q.pro_gamma = J.in_norm ? J.in_norm->gamma : nullptr;
         Q.pro_beta = J.in_norm ? J.in_norm->beta : nullptr;
         Q.pro_count = J.in_norm ? J.in_norm->count : 1;
+        Q.pro_sq = J.in_norm ? J.in_norm->sq_stride : 0;
     }
     P.Cin = d0->Cin; P.Cout = d0->Cout; P.w_ns = d0->Cin;
     hipStream_t st = (hipStream_t)stream;

@@ -39,11 +39,13 @@ def conv_desc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s):
     return L.ConvDesc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s)
 
 
-def norm_desc(stats=None, gamma=None, beta=None, count=1, eps=1e-5, act=ACT_NONE, slope=0.0):
-    """None when the read is a plain one (no norm, no activation)."""
+def norm_desc(stats=None, gamma=None, beta=None, count=1, eps=1e-5, act=ACT_NONE, slope=0.0, sq_stride=0):
+    """None when the read is a plain one (no norm, no activation).  `sq_stride`: distance from a channel's sum to its
+    sum of squares inside `stats` (0 = the channel count of the tensor being read; wider when `stats` is a slice)."""
     if stats is None and act == ACT_NONE:
         return None
-    d = L.NormDesc(_ptr(stats).value, _ptr(gamma).value, _ptr(beta).value, int(count), float(eps), int(act), float(slope))
+    d = L.NormDesc(_ptr(stats).value, _ptr(gamma).value, _ptr(beta).value, int(count), float(eps), int(act), float(slope),
+                   int(sq_stride))
     d._keep = (stats, gamma, beta)
     return d
 
@@ -59,14 +61,19 @@ def _workspace(kib, device):
     return torch.empty(kib * 256, dtype=torch.float32, device=device) if kib > 0 else None
 
 
-def conv_fwd(desc, x, in_norm, w, bias, out, out_act=ACT_NONE, out_stats=None):
+def conv_fwd(desc, x, in_norm, w, bias, out, out_act=ACT_NONE, out_stats=None, stats_sq=0):
+    if stats_sq:
+        return conv_fwd_grouped([(desc, x, in_norm, w, bias, out, out_stats, stats_sq)], out_act)
     args = (C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(w), _ptr(bias), _ptr(_act(out)), out.stride(1),
             out_act, _ptr(out_stats))
     ws = _workspace(L.lib().sgan_conv_fwd(*args, None, -1, None), x.device)
     L.check(L.lib().sgan_conv_fwd(*args, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "sgan_conv_fwd")
 
 
-def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None):
+def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None, sums_sq=0, accumulate=False):
+    """accumulate: din += result (a tensor with two consumers); sums_sq: see norm_desc."""
+    if sums_sq or accumulate:
+        return conv_dgrad_grouped([(desc, dout, w, din, x, x_norm, bwd_sums, sums_sq, accumulate)])
     args = (C.byref(desc), _ptr(_act(dout)), dout.stride(1), _ptr(w), _ptr(_act(din)), din.stride(1),
             _ptr(x), x.stride(1) if x is not None else 0, _nd(x_norm), _ptr(bwd_sums))
     ws = _workspace(L.lib().sgan_conv_dgrad(*args, None, -1, None), dout.device)
@@ -83,22 +90,25 @@ def _pn(d):
 
 
 def conv_fwd_grouped(jobs, out_act=ACT_NONE):
-    """jobs: list of (desc, x, in_norm, w, bias, out, out_stats) of the same layer type -> one launch."""
+    """jobs: list of (desc, x, in_norm, w, bias, out, out_stats[, stats_sq]) of the same layer type -> one launch."""
     arr = (L.ConvFwdJob * len(jobs))()
-    for i, (desc, x, in_norm, w, bias, out, st) in enumerate(jobs):
+    for i, job in enumerate(jobs):
+        desc, x, in_norm, w, bias, out, st = job[:7]
         arr[i] = L.ConvFwdJob(C.pointer(desc), _ptr(_act(x)).value, x.stride(1), _pn(in_norm), _ptr(w).value, _ptr(bias).value,
-                              _ptr(_act(out)).value, out.stride(1), _ptr(st).value)
+                              _ptr(_act(out)).value, out.stride(1), _ptr(st).value, int(job[7]) if len(job) > 7 else 0)
     ws = _workspace(L.lib().sgan_conv_fwd_grouped(arr, len(jobs), out_act, None, -1, None), jobs[0][1].device)
     L.check(L.lib().sgan_conv_fwd_grouped(arr, len(jobs), out_act, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_fwd_grouped")
 
 
 def conv_dgrad_grouped(jobs):
-    """jobs: list of (desc, dout, w, din, x, x_norm, bwd_sums)."""
+    """jobs: list of (desc, dout, w, din, x, x_norm, bwd_sums[, sums_sq, accumulate])."""
     arr = (L.ConvDgradJob * len(jobs))()
-    for i, (desc, dout, w, din, x, x_norm, sums) in enumerate(jobs):
+    for i, job in enumerate(jobs):
+        desc, dout, w, din, x, x_norm, sums = job[:7]
         arr[i] = L.ConvDgradJob(C.pointer(desc), _ptr(_act(dout)).value, dout.stride(1), _ptr(w).value, _ptr(_act(din)).value,
-                                din.stride(1), _ptr(x).value, x.stride(1) if x is not None else 0, _pn(x_norm), _ptr(sums).value)
+                                din.stride(1), _ptr(x).value, x.stride(1) if x is not None else 0, _pn(x_norm), _ptr(sums).value,
+                                int(job[7]) if len(job) > 7 else 0, int(bool(job[8])) if len(job) > 8 else 0)
     ws = _workspace(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device)
     L.check(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_dgrad_grouped")
@@ -113,10 +123,41 @@ def conv_wgrad_grouped(jobs):
     L.check(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), _stream()), "sgan_conv_wgrad_grouped")
 
 
-def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None):
+def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None, sums_sq=0):
     H, W, Cs = dy.shape
     L.check(L.lib().sgan_norm_bwd_apply(_ptr(_act(dy)), dy.stride(1), _ptr(_act(x)), x.stride(1), H * W, Cs, _nd(x_norm),
-                                        _ptr(bwd_sums), _ptr(dgamma), _ptr(dbeta), _stream()), "sgan_norm_bwd_apply")
+                                        _ptr(bwd_sums), int(sums_sq), _ptr(dgamma), _ptr(dbeta), _stream()), "sgan_norm_bwd_apply")
+
+
+def norm_apply_fwd(u, u_norm, t, mask=None, noise=None, sigma=0.0):
+    """t = norm(u) * mask + sigma * noise  (U-Net up path: upnorm -> Dropout -> + Gaussian noise, into a concat slice)."""
+    H, W, Cs = u.shape
+    L.check(L.lib().sgan_norm_apply_fwd(_ptr(_act(u)), u.stride(1), _nd(u_norm), _ptr(mask), _ptr(noise), float(sigma),
+                                        _ptr(_act(t)), t.stride(1), H * W, Cs, _stream()), "sgan_norm_apply_fwd")
+
+
+def norm_apply_bwd_sums(dt, u, u_norm, bwd_sums, mask=None):
+    """dt *= mask (in place), bwd_sums += (sum dt, sum dt * norm(u)) per channel."""
+    H, W, Cs = dt.shape
+    L.check(L.lib().sgan_norm_apply_bwd_sums(_ptr(_act(dt)), dt.stride(1), _ptr(mask), _ptr(_act(u)), u.stride(1), _nd(u_norm),
+                                             _ptr(bwd_sums), H * W, Cs, _stream()), "sgan_norm_apply_bwd_sums")
+
+
+def dropout_mask(mask, p, seed, offset_dev=None):
+    L.check(L.lib().sgan_dropout_mask(_ptr(mask), mask.numel(), float(p), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(offset_dev),
+                                      _stream()), "sgan_dropout_mask")
+
+
+def l1w_fwd(x, y, Creal, a, weights_dev, nweights, lam, loss_out, g):
+    H, W, _ = x.shape
+    L.check(L.lib().sgan_l1w_fwd(_ptr(_act(x)), x.stride(1), _ptr(_act(y)), y.stride(1), H * W, Creal,
+                                 _ptr(a), a.stride(1) if a is not None else 0, _ptr(weights_dev), nweights, float(lam),
+                                 _ptr(loss_out), _ptr(_act(g)), g.stride(1), _stream()), "sgan_l1w_fwd")
+
+
+def scale(gout, g, dx):
+    assert g.is_contiguous() and dx.is_contiguous()
+    L.check(L.lib().sgan_scale(_ptr(gout), _ptr(g), _ptr(dx), g.numel(), _stream()), "sgan_scale")
 
 
 def bn_running_update(layers, momentum=0.1):

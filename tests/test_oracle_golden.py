@@ -201,3 +201,85 @@ def test_fcgan_step(golden_dir, name, kw):
         m.optimize_parameters(real_batch(cfg, step))
         losses.append(list(m.losses().values()))
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 1e-3, (losses, g["losses"])
+
+
+# ------------------------------------------------------------------------------------------------
+# U-Net generator and the cgan step (BASELINE configs[2])
+# ------------------------------------------------------------------------------------------------
+UNET_SMALL = {"skipall_dropout": dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False),
+              "skip4_noise": dict(use_dropout=False, num_skips=4, add_gaussian_noise=True)}
+
+
+def unet_small_inputs():
+    return O.np_uniform(301, (1, 2, 256, 256)), O.np_normal(302, (1, 1, 256, 256))
+
+
+@pytest.mark.parametrize("tag", list(UNET_SMALL))
+def test_unet_small(golden_dir, tag):
+    g = load(golden_dir, f"unet_small_{tag}.npz")
+    kw = UNET_SMALL[tag]
+    sd = O.init_unet(31, 7, 2, 1, 8, kw["num_skips"])
+    for v in sd.values():
+        v.requires_grad_(True)
+    x, r = unet_small_inputs()
+    x.requires_grad_(True)
+    y = O.unet_forward(sd, x, 7, 8, kw["num_skips"], kw["use_dropout"], mask_seed=40,
+                       add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, noise_seed=50)
+    (y * r).sum().backward()
+    assert rel(y, g["y"]) < TIGHT * 5
+    assert rel(x.grad, g["dx"]) < 1e-4
+    undet = O.norm_cancelled_keys_unet(7, 8, kw["num_skips"])
+    for k, v in sd.items():
+        if k in undet:
+            assert float(v.grad.abs().max()) <= 1e-3 * float(sd[k.replace(".bias", ".weight")].grad.abs().max())
+        else:
+            assert rel(v.grad, g["grad/" + k]) < 1e-4, k
+
+
+def cgan_batch(cfg, step):
+    A = O.np_uniform(7100 + step, (1, 3, cfg.fineSize, cfg.fineSize))
+    B = O.np_uniform(7200 + step, (1, 3, cfg.fineSize, cfg.fineSize))
+    return A[:, :2].contiguous(), B[:, 2:3].contiguous()       # --which_channel rg_b
+
+
+def cgan_undet_D(cfg, i):
+    return O.norm_cancelled_keys_d(cfg.input_nc + cfg.output_nc, cfg.ndf, cfg.n_layers_D[i])
+
+
+def check_cgan_step1(cap, g, cfg, tol=TOL, robust=False, tally=None):
+    check_forward(cap, g, tol)
+    for i, gd in enumerate(cap["gradD"]):
+        check_grads(gd, g, f"step1/gradD_{i}", cgan_undet_D(cfg, i), tol, robust, tally)
+
+
+def check_cgan_probe(pr, g, cfg, tol=TOL, robust=False, tally=None):
+    assert np.abs(np.asarray(pr["loss_G"]) - g["probeG/loss_G"]).max() < tol * max(1.0, float(g["probeG/loss_G"][0]))
+    check_grads(pr["gradG"], g, "probeG/gradG", O.norm_cancelled_keys_unet(cfg.num_downs, cfg.ngf, cfg.n_layers_G_skip),
+                tol, robust, tally)
+    for i, gd in enumerate(pr["gradD"]):
+        check_grads(gd, g, f"probeG/gradD_{i}", cgan_undet_D(cfg, i), tol, robust, tally)
+
+
+CGAN_CASES = [("cgan_step_small.npz", dict(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0))),
+              ("cgan_step_full.npz", dict())]                   # BASELINE configs[2]: unet_256 + D 3 4 @512x512
+
+
+@pytest.mark.parametrize("name,kw", CGAN_CASES)
+def test_cgan_step(golden_dir, name, kw):
+    import random
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    g = load(golden_dir, name)
+    cfg = O.CGANConfig(**kw)
+    pr = O.CGANOracle(cfg, seed=0)
+    pr.set_input(*cgan_batch(cfg, 0))
+    check_cgan_probe(pr.probe_G(), g, cfg, tol=1e-4)
+    random.seed(1234)
+    m = O.CGANOracle(cfg, seed=0)
+    m.set_input(*cgan_batch(cfg, 0))
+    check_cgan_step1(m.step1_with_captures(), g, cfg, tol=1e-4)
+    losses = [list(m.losses().values())]
+    for step in range(1, g["losses"].shape[0]):
+        m.set_input(*cgan_batch(cfg, step))
+        m.optimize_parameters()
+        losses.append(list(m.losses().values()))
+    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])

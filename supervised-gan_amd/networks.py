@@ -8,7 +8,7 @@ hand-written gfx950 kernels (include/sgan_hip.h); normalisation and activations 
 separate passes (they are applied while the consumer conv stages its input) and the whole net is
 one autograd node.
 
-Implemented: which_model_netG in {fcgan, deconv (README alias)}, which_model_netD in
+Implemented: which_model_netG in {fcgan, deconv (README alias), unet_128, unet_256}, which_model_netD in
 {n_layers, basic}.  Other names raise NotImplementedError like the reference does for unknown
 names (models/networks.py:95,123)."""
 from __future__ import annotations
@@ -152,7 +152,7 @@ class ChainNet(nn.Module):
             box = _ParamBox("conv")
             box.weight = nn.Parameter(torch.empty(0))
             box.bias = nn.Parameter(torch.empty(0)) if L.bias else None
-            self.model.add_module(L.key, box)
+            self._add_box(L.key, box)
             if L.norm == "bn":
                 nb = _ParamBox("bn")
                 nb.weight = nn.Parameter(torch.empty(0))
@@ -166,6 +166,24 @@ class ChainNet(nn.Module):
         self._default_bias_init()
         self.compute_param_grads = True   # trainers may clear this while only dX is wanted (G step)
         self._geom_cache = {}
+
+    # ---- module tree ---------------------------------------------------------------------------
+    def _add_box(self, key, box):
+        """Register `box` under self.model at a dotted path ("1.model.3.model.1"), creating plain containers on
+        the way, so state_dict() keys equal the reference's nested nn.Sequential names."""
+        node = self.model
+        parts = key.split(".")
+        for part in parts[:-1]:
+            if part not in node._modules:
+                node.add_module(part, nn.Module())
+            node = node._modules[part]
+        node.add_module(parts[-1], box)
+
+    def _box(self, L: LayerSpec):
+        node = self.model
+        for part in L.key.split("."):
+            node = node._modules[part]
+        return node
 
     # ---- storage <-> Parameter views -------------------------------------------------------
     def _views(self, flat, L: LayerSpec):
@@ -181,7 +199,7 @@ class ChainNet(nn.Module):
 
     def _rebind(self):
         for L in self.layers:
-            box = getattr(self.model, L.key)
+            box = self._box(L)
             w, b, g, be = self._views(self._flat, L)
             gw, gb, gg, gbe = self._views(self._gflat, L)
             box.weight.data = w
@@ -205,12 +223,12 @@ class ChainNet(nn.Module):
             if L.bias:
                 fan_in = (L.cin if L.kind == CONV else L.cout) * L.k * L.k
                 bound = 1.0 / math.sqrt(fan_in)
-                getattr(self.model, L.key).bias.data.uniform_(-bound, bound)
+                self._box(L).bias.data.uniform_(-bound, bound)
 
     def _ensure_grads(self):
         """Re-attach .grad views if someone set them to None (torch's zero_grad(set_to_none=True))."""
         for L in self.layers:
-            box = getattr(self.model, L.key)
+            box = self._box(L)
             gw, gb, gg, gbe = self._views(self._gflat, L)
             pairs = [(box.weight, gw)]
             if L.bias:
@@ -620,6 +638,308 @@ class FCGANGenerator(ChainNet):
         return y
 
 
+class UnetGenerator(ChainNet):
+    """UnetGenerator + UnetSkipConnectionBlock (models/networks.py:318-419) as a layer program over a DAG.
+
+    Level l = 0..n-1: `down[l]` Conv(k4,s2,p1) produces x_l (c_l channels at H/2^(l+1)); `up[l]` ConvT(k4,s2,p1) is the
+    transposed conv of the block wrapping x_l.  Block l (1..n-1) computes
+        y_l = Dropout?(IN(up[l](ReLU(sub)))) [+ sigma * noise],   returns cat([y_l, x_{l-1}]) if skip_l else y_l
+    with sub = IN(down[l](LeakyReLU(x_{l-1}))) fed to block l+1 (innermost: no IN, no sub-block).
+
+    MI355X layout: cat([y_l, x_{l-1}]) is never assembled -- `down[l-1]` writes its raw output straight into the
+    right half of the concat buffer (pixel stride 2c) with its InstanceNorm statistics in a slice of the buffer's
+    statistics, and one pass (`norm_apply_fwd`) writes y_l into the left half.  Consumers normalise on load with
+    per-channel statistics (left half: identity entries), so the skip tensors exist once and IN/LeakyReLU/ReLU
+    never run as passes.  Backward: the two consumers of x_{l-1} (ReLU via the concat, LeakyReLU via down[l])
+    accumulate into one gradient buffer (dgrad `accumulate`), then one `norm_bwd_apply`."""
+    final_act = ACT_TANH
+
+    def __init__(self, input_nc, output_nc, num_downs, ngf=64, norm="instance", use_dropout=False, use_residual=False,
+                 add_gaussian_noise=False, gaussian_sigma=0.1, num_skips=-1, gpu_ids=[]):
+        if norm != "instance":
+            raise NotImplementedError("UnetGenerator on the MI355X path implements --norm instance (the reference default)")
+        if use_residual:
+            raise NotImplementedError("UnetGenerator --use_residual is not on the MI355X path")
+        if num_downs < 5:
+            raise ValueError("UnetGenerator needs num_downs >= 5")
+        n = num_downs
+        if num_skips < 0:
+            num_skips = n
+        self.n = n
+        self.c = [ngf * min(2 ** l, 8) for l in range(n)]
+        self.skip = [False] + [num_skips >= n - l for l in range(1, n)]
+        self.use_dropout = bool(use_dropout)
+        self.drop = [bool(use_dropout and 4 <= l <= n - 2) for l in range(n)]
+        self.add_gauss, self.gauss_sigma = bool(add_gaussian_noise), float(gaussian_sigma)
+        self.input_nc, self.output_nc = input_nc, output_nc
+        c, skip = self.c, self.skip
+        self.down, self.up = [], []
+        for l in range(n):
+            inner = l == n - 1
+            if l == 0:
+                dk, uk = "0", "3"
+                d = LayerSpec(dk, CONV, 4, 2, 1, input_nc, c[0], True, None, ACT_NONE)
+                u = LayerSpec(uk, CONVT, 4, 2, 1, c[0] * (2 if skip[1] else 1), output_nc, True, None, ACT_NONE)
+            else:
+                prefix = "1" + ".model.3" * (l - 1)
+                dk, uk = prefix + ".model.1", prefix + (".model.3" if inner else ".model.5")
+                d = LayerSpec(dk, CONV, 4, 2, 1, c[l - 1], c[l], True, None if inner else "in", ACT_NONE)
+                u = LayerSpec(uk, CONVT, 4, 2, 1, c[l] if inner else c[l] * (2 if skip[l + 1] else 1), c[l - 1], True, "in", ACT_NONE)
+            self.down.append(d)
+            self.up.append(u)
+        # parameter order = the reference's nn.Sequential traversal: down[0], (down[1], (down[2] ... up[2]), up[1]), up[0]
+        super().__init__(self.down + self.up[::-1])
+        self.gpu_ids = gpu_ids
+        self._rng_seed = 0
+        self._rng_offset = None
+        self.mask_override = None     # tests: {level: [h, w, c] keep-mask (0 / 2)}
+        self.noise_override = None    # tests: {level: [h, w, c] N(0,1) tensor}
+
+    # ---- geometry / buffers ---------------------------------------------------------------------
+    def _unet_geometry(self, H, W):
+        key = ("unet", H, W)
+        if key not in self._geom_cache:
+            n = self.n
+            if H % (1 << n) or W % (1 << n):
+                raise SganError(f"UnetGenerator with {n} downsamplings needs H, W divisible by {1 << n}, got {H}x{W}")
+            hw = [(H >> (l + 1), W >> (l + 1)) for l in range(n)]
+            dn, upd = [], []
+            for l in range(n):
+                hi, wi = (H, W) if l == 0 else hw[l - 1]
+                ho, wo = hw[l]
+                d, u = self.down[l], self.up[l]
+                dn.append(ops.conv_desc(CONV, 4, 2, 1, hi, wi, d.cin_s, ho, wo, d.cout_s))
+                upd.append(ops.conv_desc(CONVT, 4, 2, 1, ho, wo, u.cin_s, hi, wi, u.cout_s))
+            self._geom_cache[key] = (hw, dn, upd)
+        return self._geom_cache[key]
+
+    def _stat_layout(self, hw):
+        """Offsets inside one float64 arena: per concat buffer [2 * width], per up-conv output [2 * c]; and the
+        template holding the identity entries (sum 0, sumsq count * (1 - eps) => mean 0, rstd 1)."""
+        n, c, skip = self.n, self.c, self.skip
+        off, lay = 0, {}
+        for l in range(1, n):
+            wdt = c[l - 1] * (2 if skip[l] else 1)
+            lay[("cat", l)] = (off, wdt)
+            off += 2 * wdt
+            lay[("u", l)] = (off, c[l - 1])
+            off += 2 * c[l - 1]
+        for l in range(1, n - 1):
+            if not skip[l + 1]:       # normalised x_l that is not part of a concat buffer
+                lay[("x", l)] = (off, c[l])
+                off += 2 * c[l]
+        return lay, off
+
+    def _stat_template(self, hw, dev):
+        key = ("tmpl", hw[0], str(dev))
+        if key not in self._geom_cache:
+            lay, total = self._stat_layout(hw)
+            t = torch.zeros(total, dtype=torch.float64)
+            one_minus_eps = 1.0 - float(np.float32(IN_EPS))
+            for l in range(1, self.n):
+                o, wdt = lay[("cat", l)]
+                cnt = hw[l - 1][0] * hw[l - 1][1]
+                cy = self.c[l - 1]
+                t[o + wdt: o + wdt + cy] = cnt * one_minus_eps              # y half: already normalised
+                if self.skip[l] and l - 1 == 0:
+                    t[o + wdt + cy: o + 2 * wdt] = cnt * one_minus_eps      # x_0 has no norm
+            self._geom_cache[key] = (lay, total, t.to(dev))
+        return self._geom_cache[key]
+
+    def _wb(self, L):
+        return super()._wb(L)
+
+    def _x_norm(self, l, hw, xstat, act, slope=0.0):
+        """How a consumer reads x_l from its raw conv output."""
+        if l == 0 or l == self.n - 1:
+            return ops.norm_desc(None, None, None, 1, 0.0, act, slope)
+        st, sq = xstat[l]
+        return ops.norm_desc(st, None, None, hw[l][0] * hw[l][1], IN_EPS, act, slope, sq)
+
+    def _cat_norm(self, l, hw, catstat):
+        """ReLU(cat_l) as read by up[l-1]: identity for y_l (and x_0), InstanceNorm statistics for x_{l-1}."""
+        if l == 1 or not self.skip[l]:
+            return ops.norm_desc(None, None, None, 1, 0.0, ACT_RELU, 0.0)
+        return ops.norm_desc(catstat[l], None, None, hw[l - 1][0] * hw[l - 1][1], IN_EPS, ACT_RELU, 0.0, 0)
+
+    def _random(self, l, shape, dev):
+        mask = noise = None
+        if self.drop[l]:
+            if self.mask_override is not None:
+                mask = self.mask_override[l]
+            else:
+                mask = torch.empty(shape, dtype=torch.float32, device=dev)
+                ops.dropout_mask(mask, 0.5, self._rng_seed + 2 * l, self._rng_offset)
+        if self.add_gauss:
+            if self.noise_override is not None:
+                noise = self.noise_override[l]
+            else:
+                noise = torch.empty(shape, dtype=torch.float32, device=dev)
+                ops.normal_fill(noise, self._rng_seed + 2 * l + 1, self._rng_offset)
+        return mask, noise
+
+    # ---- programs -------------------------------------------------------------------------------
+    def run_forward(self, x, update_running=True):
+        ops.require_gpu(x, type(self).__name__)
+        if self._flat.device != x.device:
+            raise SganError(f"module parameters are on {self._flat.device}, input on {x.device}")
+        H, W, Cs = x.shape
+        assert Cs == self.down[0].cin_s, (Cs, self.down[0].cin_s)
+        n, c, skip = self.n, self.c, self.skip
+        dev = x.device
+        hw, dn, upd = self._unet_geometry(H, W)
+        if self._rng_offset is None or self._rng_offset.device != dev:
+            self._rng_offset = torch.zeros(1, dtype=torch.int64, device=dev)
+        lay, total, tmpl = self._stat_template(hw, dev)
+        arena = tmpl.clone()
+        catw = [0] * (n + 1)
+        cat, catstat, ustat = [None] * (n + 1), [None] * (n + 1), [None] * (n + 1)
+        for l in range(1, n):
+            o, wdt = lay[("cat", l)]
+            catw[l] = wdt
+            cat[l] = torch.empty(hw[l - 1] + (wdt,), dtype=torch.float32, device=dev)
+            catstat[l] = arena[o: o + 2 * wdt]
+            o, cu = lay[("u", l)]
+            ustat[l] = arena[o: o + 2 * cu]
+        xr, xstat = [None] * n, [None] * n
+        for l in range(n):
+            if l + 1 <= n - 1 and skip[l + 1]:
+                xr[l] = cat[l + 1][:, :, c[l]:]
+                xstat[l] = (catstat[l + 1][c[l]:], catw[l + 1])
+            else:
+                xr[l] = torch.empty(hw[l] + (c[l],), dtype=torch.float32, device=dev)
+                if ("x", l) in lay:
+                    o, cx = lay[("x", l)]
+                    xstat[l] = (arena[o: o + 2 * cx], 0)
+        # encoder
+        for l in range(n):
+            L = self.down[l]
+            wt, b = self._wb(L)
+            src = x if l == 0 else xr[l - 1]
+            in_norm = None if l == 0 else self._x_norm(l - 1, hw, xstat, ACT_LRELU, 0.2)
+            if 1 <= l <= n - 2:
+                st, sq = xstat[l]
+                ops.conv_fwd(dn[l], src, in_norm, wt, b, xr[l], ACT_NONE, st, sq)
+            else:
+                ops.conv_fwd(dn[l], src, in_norm, wt, b, xr[l], ACT_NONE, None)
+        # decoder
+        u, masks = [None] * n, [None] * n
+        for l in range(n - 1, 0, -1):
+            L = self.up[l]
+            wt, b = self._wb(L)
+            if l == n - 1:
+                src, in_norm = xr[l], ops.norm_desc(None, None, None, 1, 0.0, ACT_RELU, 0.0)
+            else:
+                src, in_norm = cat[l + 1], self._cat_norm(l + 1, hw, catstat)
+            u[l] = torch.empty(hw[l - 1] + (c[l - 1],), dtype=torch.float32, device=dev)
+            ops.conv_fwd(upd[l], src, in_norm, wt, b, u[l], ACT_NONE, ustat[l])
+            mask, noise = self._random(l, u[l].shape, dev)
+            masks[l] = mask
+            un = ops.norm_desc(ustat[l], None, None, hw[l - 1][0] * hw[l - 1][1], IN_EPS, ACT_NONE, 0.0)
+            ops.norm_apply_fwd(u[l], un, cat[l][:, :, :c[l - 1]], mask, noise, self.gauss_sigma if noise is not None else 0.0)
+        L = self.up[0]
+        wt, b = self._wb(L)
+        out = torch.empty((H, W, L.cout_s), dtype=torch.float32, device=dev)
+        ops.conv_fwd(upd[0], cat[1], self._cat_norm(1, hw, catstat), wt, b, out, self.final_act, None)
+        saved = dict(x=x, hw=hw, cat=cat, catw=catw, catstat=catstat, ustat=ustat, xr=xr, xstat=xstat, u=u, masks=masks,
+                     out=out, lay=lay, total=total)
+        return [out], saved
+
+    def run_backward(self, x, outs, S, dout, need_dx, want_wgrad):
+        n, c, skip = self.n, self.c, self.skip
+        dev = x.device
+        hw, dn, upd = self._unet_geometry(x.shape[0], x.shape[1])
+        cat, catw, catstat, ustat, xr, xstat, u, masks = (S[k] for k in ("cat", "catw", "catstat", "ustat", "xr", "xstat", "u", "masks"))
+        if want_wgrad:
+            self._ensure_grads()
+        d0 = torch.empty_like(S["out"])
+        ops.tanh_bwd(dout.contiguous(), S["out"], d0)
+        lay = S["lay"]
+        arena = torch.zeros(S["total"], dtype=torch.float64, device=dev)
+        csum, usum, xsum = [None] * (n + 1), [None] * (n + 1), [None] * n
+        for l in range(1, n):
+            o, wdt = lay[("cat", l)]
+            csum[l] = arena[o: o + 2 * wdt]
+            o, cu = lay[("u", l)]
+            usum[l] = arena[o: o + 2 * cu]
+        for l in range(1, n - 1):
+            if skip[l + 1]:
+                xsum[l] = (csum[l + 1][c[l]:], catw[l + 1])
+            else:
+                o, cx = lay[("x", l)]
+                xsum[l] = (arena[o: o + 2 * cx], 0)
+        dcat = [None] * (n + 1)
+        for l in range(1, n):
+            dcat[l] = torch.empty_like(cat[l])
+
+        def wgrad(L, desc, src, nrm, dy):
+            if want_wgrad:
+                gw, gb = self._gwb(L)
+                ops.conv_wgrad(desc, src, nrm, dy, gw, gb)
+
+        # final transposed conv: gradient of ReLU(cat_1)
+        nrm = self._cat_norm(1, hw, catstat)
+        wgrad(self.up[0], upd[0], cat[1], nrm, d0)
+        ops.conv_dgrad(upd[0], d0, self._wb(self.up[0])[0], dcat[1], cat[1], nrm, None)
+        # decoder, outermost block first
+        d_inner = None
+        for l in range(1, n):
+            dy = dcat[l][:, :, :c[l - 1]]
+            un = ops.norm_desc(ustat[l], None, None, hw[l - 1][0] * hw[l - 1][1], IN_EPS, ACT_NONE, 0.0)
+            ops.norm_apply_bwd_sums(dy, u[l], un, usum[l], masks[l])
+            ops.norm_bwd_apply(dy, u[l], un, usum[l])                       # dy is now d(up[l] output)
+            if l == n - 1:
+                src, nrm = xr[l], ops.norm_desc(None, None, None, 1, 0.0, ACT_RELU, 0.0)
+                d_inner = torch.empty(hw[l] + (c[l],), dtype=torch.float32, device=dev)
+                din, sums = d_inner, None
+            else:
+                src, nrm = cat[l + 1], self._cat_norm(l + 1, hw, catstat)
+                din = dcat[l + 1]
+                sums = csum[l + 1] if (skip[l + 1] and l + 1 > 1) else None
+            wgrad(self.up[l], upd[l], src, nrm, dy)
+            ops.conv_dgrad(upd[l], dy, self._wb(self.up[l])[0], din, src, nrm, sums)
+        # encoder, innermost first: dr = gradient w.r.t. the raw output of down[l]
+        dr = d_inner
+        for l in range(n - 1, 0, -1):
+            src = xr[l - 1]
+            nrm = self._x_norm(l - 1, hw, xstat, ACT_LRELU, 0.2)
+            wgrad(self.down[l], dn[l], src, nrm, dr)
+            normed = 1 <= l - 1 <= n - 2
+            sums, sq = xsum[l - 1] if normed else (None, 0)
+            if skip[l]:
+                din = dcat[l][:, :, c[l - 1]:]
+                ops.conv_dgrad(dn[l], dr, self._wb(self.down[l])[0], din, src, nrm, sums, sq, accumulate=True)
+            else:
+                din = torch.empty(hw[l - 1] + (c[l - 1],), dtype=torch.float32, device=dev)
+                ops.conv_dgrad(dn[l], dr, self._wb(self.down[l])[0], din, src, nrm, sums, sq)
+            if normed:
+                ops.norm_bwd_apply(din, src, nrm, sums, None, None, sq)
+            dr = din
+        wgrad(self.down[0], dn[0], x, None, dr)
+        dx = None
+        if need_dx:
+            dx = torch.empty_like(x)
+            ops.conv_dgrad(dn[0], dr, self._wb(self.down[0])[0], dx, None, None, None)
+        return dx
+
+    # ---- module protocol ---------------------------------------------------------------------------
+    def _prepare_input(self, x):
+        return {"chain_in": ops.as_nhwc(x)}
+
+    def _finish_input_grad(self, xb, dchain):
+        return ops.logical_view(dchain, self.input_nc)
+
+    def forward(self, x, noise=None, activation=None):
+        """`noise` is accepted and ignored like in the reference (models/networks.py:362)."""
+        if activation is not None and not isinstance(activation, nn.Tanh):
+            raise NotImplementedError("only the default Tanh output activation is implemented")
+        params = list(self.model.parameters())
+        return _ChainFn.apply(self, x, *params)
+
+    def _wrap_output(self, y):
+        return y
+
+
 class NLayerDiscriminator(ChainNet):
     """NLayerDiscriminator (models/networks.py:798-847): [gauss prefilter + stride pick] ->
     Conv(k4,s2,p2)+LReLU -> (Conv s2 + norm + LReLU) x (n-1) -> Conv s1 + norm + LReLU -> Conv s1 [-> Sigmoid]."""
@@ -812,8 +1132,11 @@ def define_G(input_nc, output_nc, ngf, which_model_netG, norm='batch', use_dropo
     if which_model_netG in ('fcgan', 'deconv'):   # README spells it `deconv` (README.md:33)
         netG = FCGANGenerator(noise_nc, input_nc, ngf, n_layers=n_layers_G, use_dropout=use_dropout, use_fcn=use_fcn,
                               gpu_ids=gpu_ids)
-    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks', 'unet_128', 'unet_256', 'autoencoder', 'crn',
-                              'fcgan_star', 'dcgan'):
+    elif which_model_netG in ('unet_128', 'unet_256'):
+        netG = UnetGenerator(input_nc, output_nc, 7 if which_model_netG == 'unet_128' else 8, ngf, norm=norm,
+                             use_dropout=use_dropout, use_residual=use_residual, add_gaussian_noise=add_gaussian_noise,
+                             gaussian_sigma=gaussian_sigma, num_skips=n_layers_G_skip, gpu_ids=gpu_ids)
+    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks', 'autoencoder', 'crn', 'fcgan_star', 'dcgan'):
         raise NotImplementedError('Generator model name [%s] is not on the MI355X path yet' % which_model_netG)
     else:
         raise NotImplementedError('Generator model name [%s] is not recognized' % which_model_netG)

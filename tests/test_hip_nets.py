@@ -172,3 +172,76 @@ def test_grouped_chains_equal_individual_chains(N):
     assert all(float(d._gflat.abs().max()) == 0.0 for d in Ds)
     for d in Ds:
         d.compute_param_grads = True
+
+
+# ------------------------------------------------------------------------------------------------
+# U-Net generator (models/networks.py:318-419)
+# ------------------------------------------------------------------------------------------------
+UNET_SMALL = {"skipall_dropout": dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False),
+              "skip4_noise": dict(use_dropout=False, num_skips=4, add_gaussian_noise=True)}
+
+
+def inject_unet_random(G, H, mask_seed, noise_seed):
+    """Give the HIP U-Net the numpy-seeded dropout masks / Gaussian noise the golden vectors were made with."""
+    masks, noises = {}, {}
+    for l in range(1, G.n):
+        h = H >> l
+        shape = (1, G.c[l - 1], h, h)
+        if G.drop[l]:
+            masks[l] = O.dropout_mask_np(mask_seed, shape)[0].permute(1, 2, 0).contiguous().cuda()
+        if G.add_gauss:
+            noises[l] = O.gauss_noise_np(noise_seed, shape)[0].permute(1, 2, 0).contiguous().cuda()
+    G.mask_override = masks if G.use_dropout else None
+    G.noise_override = noises if G.add_gauss else None
+
+
+@pytest.mark.parametrize("tag", list(UNET_SMALL))
+def test_unet_small(N, golden_dir, tag):
+    g = load(golden_dir, f"unet_small_{tag}.npz")
+    kw = UNET_SMALL[tag]
+    G = N.define_G(2, 1, 8, "unet_128", "instance", kw["use_dropout"], n_layers_G_skip=kw["num_skips"],
+                   add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, gpu_ids=[0])
+    sd = O.init_unet(31, 7, 2, 1, 8, kw["num_skips"])
+    assert set(G.state_dict().keys()) == set(sd.keys())
+    assert list(G.state_dict().keys())[:3] == ['model.0.weight', 'model.0.bias', 'model.1.model.1.weight']     # nn.Sequential order
+    assert list(G.state_dict().keys())[-2:] == ['model.3.weight', 'model.3.bias']
+    G.load_state_dict(sd)
+    inject_unet_random(G, 256, 40, 50)
+    x = O.np_uniform(301, (1, 2, 256, 256)).cuda().requires_grad_(True)
+    r = O.np_normal(302, (1, 1, 256, 256)).cuda()
+    y = G.forward(x)
+    assert y.shape == (1, 1, 256, 256)
+    (y * r).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, g["y"]) < TOL
+    assert rel(x.grad, g["dx"]) < TOL
+    params = dict(G.named_parameters())
+    undet = O.norm_cancelled_keys_unet(7, 8, kw["num_skips"])
+    for k in g.files:
+        if not k.startswith("grad/"):
+            continue
+        name = k[5:]
+        if name in undet:
+            scale = np.abs(params[name.replace(".bias", ".weight")].grad.cpu().numpy()).max()
+            assert np.abs(params[name].grad.cpu().numpy()).max() < TOL * scale, name
+        else:
+            assert rel(params[name].grad, g[k]) < TOL, name
+
+
+def test_unet_own_dropout_and_noise(N):
+    """Without injected tensors the masks come from the Philox kernel: half the entries kept (scaled by 2), a fresh
+    mask per forward."""
+    from supervised_gan_amd import ops
+    m = torch.empty(64, 64, 32, device="cuda")
+    off = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.dropout_mask(m, 0.5, 7, off)
+    m2 = torch.empty_like(m)
+    ops.dropout_mask(m2, 0.5, 7, off)
+    torch.cuda.synchronize()
+    assert set(m.unique().tolist()) == {0.0, 2.0}
+    assert abs(float(m.mean()) - 1.0) < 0.02
+    assert float((m != m2).float().mean()) > 0.4
+    G = N.define_G(2, 1, 8, "unet_128", "instance", True, add_gaussian_noise=True, gpu_ids=[0])
+    x = O.np_uniform(1, (1, 2, 256, 256)).cuda()
+    y1, y2 = G.forward(x), G.forward(x)
+    assert torch.isfinite(y1).all() and float((y1 - y2).detach().abs().max()) > 0

@@ -324,3 +324,121 @@ def test_full_size_adjoint_identities(hip, layer):
     scale = float(y.double().norm() * r.double().norm())
     assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
     assert float((db.double() - r.double().sum((0, 1))).abs().max()) <= 1e-4 * float(r.double().abs().sum((0, 1)).max())
+
+
+# ------------------------------------------------------------------------------------------------
+# U-Net / cgan elementwise kernels
+# ------------------------------------------------------------------------------------------------
+def test_norm_apply_fwd_bwd(hip):
+    """y = IN(u) * mask + sigma * noise into a channel slice; backward sums then norm_bwd_apply == autograd."""
+    from hip_utils import from_buf, master_weight, pad_vec, rel, stats_of, to_buf
+    import sgan_oracle as O
+    ops = hip
+    torch.manual_seed(0)
+    C, H = 16, 12
+    u = torch.randn(1, C, H, H) * 2 + 0.5
+    mask = (torch.rand(1, C, H, H) >= 0.5).float() * 2
+    noise = torch.randn(1, C, H, H)
+    r = torch.randn(1, C, H, H)
+    ur = u.clone().requires_grad_(True)
+    y = torch.nn.functional.instance_norm(ur, eps=1e-5) * mask + 0.1 * noise
+    (y * r).sum().backward()
+    ub = to_buf(u)
+    wide = torch.zeros(H, H, 2 * C, device="cuda")
+    st = stats_of(u)
+    un = ops.norm_desc(st, None, None, H * H, 1e-5, 0, 0.0)
+    hw = lambda t: t[0].permute(1, 2, 0).contiguous().cuda()
+    ops.norm_apply_fwd(ub, un, wide[:, :, :C], hw(mask), hw(noise), 0.1)
+    assert rel(from_buf(wide[:, :, :C].contiguous(), C), y) < 1e-5
+    assert float(wide[:, :, C:].abs().max()) == 0.0
+    dwide = torch.zeros(H, H, 2 * C, device="cuda")
+    dwide[:, :, :C] = hw(r)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    ops.norm_apply_bwd_sums(dwide[:, :, :C], ub, un, sums, hw(mask))
+    ops.norm_bwd_apply(dwide[:, :, :C], ub, un, sums)
+    assert rel(from_buf(dwide[:, :, :C].contiguous(), C), ur.grad) < 1e-4
+
+
+def test_stat_slices_and_accumulate(hip):
+    """A conv writing into the right half of a wider buffer with its statistics in a slice (sq_stride), and a dgrad
+    accumulating into a slice: equal to the plain calls."""
+    from hip_utils import from_buf, master_weight, pad_vec, rel, stats_of, to_buf
+    import sgan_oracle as O
+    ops = hip
+    torch.manual_seed(1)
+    cin, cout, H = 8, 16, 20
+    x = torch.randn(1, cin, H, H)
+    w = torch.randn(cout, cin, 4, 4) * 0.1
+    b = torch.randn(cout)
+    desc = ops.conv_desc(0, 4, 2, 1, H, H, cin, H // 2, H // 2, cout)
+    xb, wm, bb = to_buf(x), master_weight(w, False), pad_vec(b)
+    plain = torch.empty(H // 2, H // 2, cout, device="cuda")
+    st = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+    ops.conv_fwd(desc, xb, None, wm, bb, plain, 0, st)
+    wide = torch.zeros(H // 2, H // 2, 3 * cout, device="cuda")
+    stw = torch.zeros(2 * 3 * cout, dtype=torch.float64, device="cuda")
+    ops.conv_fwd(desc, xb, None, wm, bb, wide[:, :, cout:2 * cout], 0, stw[cout:], 3 * cout)
+    torch.cuda.synchronize()
+    assert torch.equal(wide[:, :, cout:2 * cout], plain)
+    assert float(wide[:, :, :cout].abs().max()) == 0 and float(wide[:, :, 2 * cout:].abs().max()) == 0
+    assert rel(stw[cout:2 * cout], st[:cout]) < 1e-6 and rel(stw[4 * cout:5 * cout], st[cout:]) < 1e-6   # fp32 partial sums, atomic order
+    # consumer reads the slice with the sliced statistics: same result as reading the plain tensor
+    desc2 = ops.conv_desc(0, 4, 2, 1, H // 2, H // 2, cout, H // 4, H // 4, cout)
+    w2 = master_weight(torch.randn(cout, cout, 4, 4) * 0.1, False)
+    n_plain = ops.norm_desc(st, None, None, (H // 2) ** 2, 1e-5, 2, 0.2)
+    n_slice = ops.norm_desc(stw[cout:], None, None, (H // 2) ** 2, 1e-5, 2, 0.2, 3 * cout)
+    o1 = torch.empty(H // 4, H // 4, cout, device="cuda")
+    o2 = torch.empty_like(o1)
+    ops.conv_fwd(desc2, plain, n_plain, w2, None, o1, 0, None)
+    ops.conv_fwd(desc2, wide[:, :, cout:2 * cout], n_slice, w2, None, o2, 0, None)
+    assert rel(o2, o1) < 1e-5
+    # accumulate
+    dy = torch.randn(H // 4, H // 4, cout, device="cuda")
+    d1 = torch.empty_like(plain)
+    s1 = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+    ops.conv_dgrad(desc2, dy, w2, d1, plain, n_plain, s1)
+    base = torch.randn(H // 2, H // 2, 3 * cout, device="cuda")
+    dw = base.clone()
+    sw = torch.zeros(2 * 3 * cout, dtype=torch.float64, device="cuda")
+    ops.conv_dgrad(desc2, dy, w2, dw[:, :, cout:2 * cout], wide[:, :, cout:2 * cout], n_slice, sw[cout:], 3 * cout, accumulate=True)
+    torch.cuda.synchronize()
+    assert rel(dw[:, :, cout:2 * cout], base[:, :, cout:2 * cout] + d1) < 1e-5
+    assert torch.equal(dw[:, :, :cout], base[:, :, :cout]) and torch.equal(dw[:, :, 2 * cout:], base[:, :, 2 * cout:])
+    assert rel(sw[cout:2 * cout], s1[:cout]) < 1e-5 and rel(sw[4 * cout:5 * cout], s1[cout:]) < 1e-5
+    # norm_bwd_apply on the slice with sliced sums == on the plain tensor
+    d1c = d1.clone()
+    ops.norm_bwd_apply(d1c, plain, n_plain, s1)
+    dz = torch.zeros(H // 2, H // 2, 3 * cout, device="cuda")
+    dz[:, :, cout:2 * cout] = d1
+    ops.norm_bwd_apply(dz[:, :, cout:2 * cout], wide[:, :, cout:2 * cout], n_slice, sw[cout:], None, None, 3 * cout)
+    assert rel(dz[:, :, cout:2 * cout], d1c) < 1e-5
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_weighted_l1(hip, weighted):
+    from hip_utils import from_buf, master_weight, pad_vec, rel, stats_of, to_buf
+    import sgan_oracle as O
+    ops = hip
+    torch.manual_seed(2)
+    H = 64
+    x = torch.randn(1, 1, H, H, requires_grad=True)
+    y = torch.randn(1, 1, H, H)
+    A = torch.rand(1, 2, H, H) * 2 - 1
+    wts = [2.0, 5.0]
+    w = None
+    if weighted:
+        w = torch.ones(1, 1, H, H)
+        for i, wv in enumerate(wts):
+            w = w + (A.narrow(1, i, 1) + 1) / 2 * (wv - 1.0)
+    loss = O.weighted_l1(x, y, w) * 10.0
+    (loss * 0.7).backward()
+    xb, yb, ab = to_buf(x.detach()), to_buf(y), to_buf(A)
+    out = torch.empty((), device="cuda")
+    g = torch.empty_like(xb)
+    wd = torch.tensor(wts, device="cuda")
+    ops.l1w_fwd(xb, yb, 1, ab if weighted else None, wd if weighted else None, 2 if weighted else 0, 10.0, out, g)
+    dx = torch.empty_like(xb)
+    ops.scale(torch.tensor(0.7, device="cuda"), g, dx)
+    assert abs(float(out) - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
+    assert rel(from_buf(dx, 1), x.grad) < 1e-5
+    assert float(dx[:, :, 1:].abs().max()) == 0

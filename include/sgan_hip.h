@@ -236,7 +236,8 @@ int sgan_norm_apply_bwd_sums(float* dt, int32_t dt_ld, const float* mask, const 
 int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* offset_dev, void* stream);
 
 /* ---- weighted L1 (cgan): loss = lambda * mean(|x - y| * w), w = 1 + sum_i ((a_i + 1)/2) * (weights_i - 1) over the
- * first nweights channels of the label image `a` (w = 1 when a == NULL).  Also writes g = dloss/dx (unscaled by
+ * first nweights channels of the label image `a` (w = 1 when a == NULL; with nweights == 0, `a` is the weight map
+ * itself, one value per pixel).  Also writes g = dloss/dx (unscaled by
  * the incoming gradient); the backward is dx = gout * g.  Replaces WeightedL1Loss (models/networks.py:205-214)
  * and the weight-map construction in CGANModel.backward_G (models/cgan_model.py:196-207). */
 int sgan_l1w_fwd(const float* x, int32_t x_ld, const float* y, int32_t y_ld, int32_t npix, int32_t C,

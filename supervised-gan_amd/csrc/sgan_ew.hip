@@ -236,8 +236,10 @@ __global__ __launch_bounds__(1024) void sg_l1w_fwd_kernel(const float* x, int x_
     double acc = 0.0;
     for (int p = threadIdx.x; p < npix; p += 1024) {
         float w = 1.f;
-        if (a)
+        if (a) {
+            if (nw == 0) w = a[(int64_t)p * a_ld];   // explicit per-pixel weight map
             for (int i = 0; i < nw; ++i) w += (a[(int64_t)p * a_ld + i] + 1.f) * 0.5f * (wts[i] - 1.f);
+        }
         for (int c = 0; c < g_ld; ++c) {
             float gv = 0.f;
             if (c < C) {
@@ -271,7 +273,7 @@ extern "C" int sgan_l1w_fwd(const float* x, int32_t x_ld, const float* y, int32_
                             int32_t a_ld, const float* weights_dev, int32_t nweights, float lambda, float* loss_out, float* g,
                             int32_t g_ld, void* stream) {
     SGAN_CHECK(x && y && loss_out && g && npix > 0 && C > 0 && g_ld >= C && x_ld >= C && y_ld >= C, "bad argument");
-    SGAN_CHECK(!a || (weights_dev && nweights > 0 && a_ld >= nweights), "weights need the label image");
+    SGAN_CHECK(!a || nweights == 0 || (weights_dev && nweights > 0 && a_ld >= nweights), "weights need the label image");
     hipLaunchKernelGGL(sg_l1w_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, x_ld, y, y_ld, npix, C, a, a_ld,
                        weights_dev, nweights, lambda, loss_out, g, g_ld);
     SGAN_LAUNCH_CHECK();

@@ -5,9 +5,12 @@ def create_model(opt):
     if opt.model == 'fcgan':
         from .fcgan_model import FCGANModel
         model = FCGANModel()
-    elif opt.model in ('cgan', 'cgan2', 'cgan_cycle', 'cgan2_cycle', 'twostage', 'twostage_cycle', 'twostage_factd',
+    elif opt.model == 'cgan':
+        from .cgan_model import CGANModel
+        model = CGANModel()
+    elif opt.model in ('cgan2', 'cgan_cycle', 'cgan2_cycle', 'twostage', 'twostage_cycle', 'twostage_factd',
                        'test', 'segmentation', 'segmentation_cycle'):
-        raise NotImplementedError("model [%s] is not on the MI355X path yet (fcgan is; see DESIGN.md scope)" % opt.model)
+        raise NotImplementedError("model [%s] is not on the MI355X path yet (fcgan and cgan are; see DESIGN.md scope)" % opt.model)
     else:
         raise ValueError("Model [%s] not recognized." % opt.model)
     model.initialize(opt)

@@ -584,19 +584,33 @@ class _MultiChainFn(torch.autograd.Function):
 
 
 def multi_forward(jobs):
-    """[(net, x)] -> [net.forward(x)] with one kernel launch per layer for all jobs (same-architecture nets,
-    <= 8 jobs); anything else falls back to one call per job."""
+    """[(net, x)] -> [net.forward(x)].  Jobs are partitioned into sets of same-architecture nets (<= 8 each) and every
+    set runs with one kernel launch per layer; a net alone in its set is called on its own."""
     jobs = list(jobs)
-    nets = [n for n, _ in jobs]
-    if not can_group(nets):
-        return [n.forward(x) for n, x in jobs]
-    params, seen = [], set()
-    for n in nets:
-        if id(n) not in seen:
-            seen.add(id(n))
-            params += list(n.model.parameters())
-    outs = _MultiChainFn.apply(nets, *[x for _, x in jobs], *params)
-    return [n._wrap_output(o) for n, o in zip(nets, outs)]
+    groups = []
+    for idx, (n, _) in enumerate(jobs):
+        for grp in groups:
+            if len(grp) < 8 and _same_architecture(jobs[grp[0]][0], n):
+                grp.append(idx)
+                break
+        else:
+            groups.append([idx])
+    results = [None] * len(jobs)
+    for grp in groups:
+        if len(grp) == 1:
+            n, x = jobs[grp[0]]
+            results[grp[0]] = n.forward(x)
+            continue
+        nets = [jobs[i][0] for i in grp]
+        params, seen = [], set()
+        for n in nets:
+            if id(n) not in seen:
+                seen.add(id(n))
+                params += list(n.model.parameters())
+        outs = _MultiChainFn.apply(nets, *[jobs[i][1] for i in grp], *params)
+        for i, n, o in zip(grp, nets, outs):
+            results[i] = n._wrap_output(o)
+    return results
 
 
 class FCGANGenerator(ChainNet):
@@ -1116,11 +1130,45 @@ class GANLoss(nn.Module):
                                      *[self._logits_of(i) for i in inputs])
 
 
+class _L1Fn(torch.autograd.Function):
+    """lambda * mean(|x - y| * w) with w = 1 + sum_i (A_i + 1) / 2 * (weights_i - 1), or w a per-pixel map, or 1."""
+
+    @staticmethod
+    def forward(ctx, x, y, a, wts, nw, lam):
+        xb = ops.as_nhwc(x)
+        yb = ops.as_nhwc(y)
+        ab = None
+        if a is not None:
+            ab = ops.as_nhwc(a)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        g = torch.empty_like(xb)
+        ops.l1w_fwd(xb, yb, x.shape[1], ab, wts, nw, lam, loss, g)
+        ctx.g, ctx.C = g, x.shape[1]
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        dx = torch.empty_like(ctx.g)
+        ops.scale(gout.contiguous(), ctx.g, dx)
+        return ops.logical_view(dx, ctx.C), None, None, None, None, None
+
+
 class WeightedL1Loss(nn.Module):
-    """WeightedL1Loss (models/networks.py:205-214) -- cgan path, not on the fcgan hot path yet."""
+    """WeightedL1Loss (models/networks.py:205-214): mean(|x - y| * w).  One forward kernel (which also writes the
+    gradient for a unit upstream) and one scaling kernel in backward."""
 
     def __call__(self, x, y, w=None):
-        raise NotImplementedError("WeightedL1Loss: cgan path is scheduled after the fcgan path (SURVEY 8f)")
+        return _L1Fn.apply(x, y, w, None, 0, 1.0)
+
+    def from_labels(self, x, y, real_A, weights, lam=1.0):
+        """lam * self(x, y, w) with the weight map of CGANModel.backward_G (models/cgan_model.py:198-207),
+        w = 1 + sum_i (real_A[:, i] + 1) / 2 * (weights[i] - 1), evaluated inside the kernel."""
+        if weights is None:
+            return _L1Fn.apply(x, y, None, None, 0, float(lam))
+        wts = getattr(self, "_wts", None)
+        if wts is None or wts.device != x.device or wts.numel() != len(weights):
+            wts = self._wts = torch.tensor([float(v) for v in weights], dtype=torch.float32, device=x.device)
+        return _L1Fn.apply(x, y, real_A, wts, len(weights), float(lam))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -64,6 +64,7 @@ class BaseOptions:
         a('--no_share_label_block_weights', action='store_true')
         a('--n_layers_CRN_block', type=int, default=1)
         a('--pretrained_model_dir', type=str, default='')
+        a('--transform_1to2', type=str, default='None')
         # MI355X path extras (not in the reference)
         a('--skip_wasted_D_wgrad', action='store_true',
           help='do not compute discriminator weight gradients during the G step (the reference computes and discards them)')

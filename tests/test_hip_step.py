@@ -153,3 +153,88 @@ def test_checkpoint_roundtrip_with_oracle(tmp_path):
     sdD["model.3.running_mean"] = torch.zeros(16)
     sdD["model.3.running_var"] = torch.ones(16)
     load_state_dict_compat(m.netD[2], sdD)
+
+
+# ------------------------------------------------------------------------------------------------
+# cgan: unet G + n_layers D (3, 4) + weighted L1  (BASELINE configs[2])
+# ------------------------------------------------------------------------------------------------
+from test_hip_nets import inject_unet_random  # noqa: E402
+from test_oracle_golden import CGAN_CASES, check_cgan_probe, check_cgan_step1  # noqa: E402
+
+
+def build_cgan(cfg, extra=()):
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")
+    from supervised_gan_amd.models import create_model
+    from supervised_gan_amd.options import TrainOptions
+    argv = ["--name", "t", "--model", "cgan", "--which_direction", "AtoB", "--dataset_mode", "aligned",
+            "--fineSize", str(cfg.fineSize), "--which_model_netG", {7: "unet_128", 8: "unet_256"}[cfg.num_downs],
+            "--ngf", str(cfg.ngf), "--which_model_netD", "n_layers", "--n_layers_D", *map(str, cfg.n_layers_D),
+            "--ndf", str(cfg.ndf), "--scale_factor", *map(str, cfg.scale_factor), "--lambda_D", *map(str, cfg.lambda_D),
+            "--lambda_A", str(cfg.lambda_A), "--norm", "instance", "--which_channel", "rg_b", "--gpu_ids", "0",
+            "--checkpoints_dir", "/tmp/sgan_ckpt", *extra]
+    if cfg.weights is not None:
+        argv += ["--weights", *map(str, cfg.weights)]
+    opt = TrainOptions().parse(argv, save=False, verbose=False)
+    m = create_model(opt)
+    m.netG.load_state_dict(O.init_unet(1, cfg.num_downs, cfg.input_nc, cfg.output_nc, cfg.ngf, cfg.n_layers_G_skip))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D, cfg.scale_factor)):
+        m.netD[i].load_state_dict(O.init_nlayer_d(2 + i, cfg.input_nc + cfg.output_nc, cfg.ndf, nl, sf))
+    return m
+
+
+def cgan_input(cfg, step):
+    return {"A": O.np_uniform(7100 + step, (1, 3, cfg.fineSize, cfg.fineSize)),
+            "B": O.np_uniform(7200 + step, (1, 3, cfg.fineSize, cfg.fineSize)), "A_paths": ["synthetic"], "B_paths": ["synthetic"]}
+
+
+def _grads(net, prefix="model."):
+    return {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("name,kw", CGAN_CASES)
+def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
+    import random
+    g = np.load(os.path.join(golden_dir, name))
+    cfg = O.CGANConfig(**kw)
+    full = cfg.fineSize >= 512
+    tally = []
+    # (1) G step (GAN + weighted L1) through the initial discriminators
+    p = build_cgan(cfg)
+    p.set_input(cgan_input(cfg, 0))
+    inject_unet_random(p.netG, cfg.fineSize, 9000, 9500)
+    p.forward()
+    p.optimizer_G.zero_grad()
+    p.optimizer_D.zero_grad()
+    p.backward_G()
+    torch.cuda.synchronize()
+    pr = {"gradG": _grads(p.netG), "gradD": [_grads(d) for d in p.netD], "loss_G": [float(p.loss_G), float(p.loss_G_L1)]}
+    check_cgan_probe(pr, g, cfg, tol=1e-3, robust=full, tally=tally)
+    # (2) step 1: fake_B, D losses, D gradients before the optimizer acts
+    random.seed(1234)
+    m = build_cgan(cfg)
+    m.set_input(cgan_input(cfg, 0))
+    inject_unet_random(m.netG, cfg.fineSize, 9000, 9500)
+    m.forward()
+    cap = {"fake": m.fake_B.detach().cpu().clone()}
+    m.optimizer_D.zero_grad()
+    m.backward_D()
+    cap["gradD"] = [_grads(d) for d in m.netD]
+    cap["loss_D"] = [float(m.loss_D_real), float(m.loss_D_fake)]
+    check_cgan_step1(cap, g, cfg, tol=1e-3, robust=full, tally=tally)
+    m.optimizer_D.step()
+    m.optimizer_G.zero_grad()
+    m.backward_G()
+    m.optimizer_G.step()
+    strict = sum(1 for _, _, e_max, _ in tally if e_max <= 1e-3)
+    worst = max(tally, key=lambda t: t[3])
+    print(f"{name}: {strict}/{len(tally)} gradient tensors within 1e-3 (max-abs/max|g|); worst rel-L2 {worst[3]:.2e} at {worst[0]}/{worst[1]}")
+    assert float(np.median([t[3] for t in tally])) <= 5e-3, tally
+    # (3) trajectory through the losses
+    losses = [list(m.get_current_errors().values())]
+    for step in range(1, g["losses"].shape[0]):
+        m.set_input(cgan_input(cfg, step))
+        inject_unet_random(m.netG, cfg.fineSize, 9000 + 100 * step, 9500 + 100 * step)
+        m.optimize_parameters()
+        losses.append(list(m.get_current_errors().values()))
+    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])

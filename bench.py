@@ -23,9 +23,33 @@ import torch  # noqa: E402
 GMAC_G, GMAC_D = 1.9483, 4.7386
 
 
-def flops_per_image(n_update_G):
+# cgan (BASELINE configs[2]): unet_256 ngf64 forward 23.86 GMAC, D n_layers 3 + 4 (ndf 64, scale 1) 13.77 + 11.74
+GMAC_G_CGAN, GMAC_D_CGAN = 23.86, 25.51
+
+
+def flops_per_image(n_update_G, workload="fcgan"):
+    g, d = (GMAC_G, GMAC_D) if workload == "fcgan" else (GMAC_G_CGAN, GMAC_D_CGAN)
     g_f, g_b, d_f, d_b = (3, 2, 4, 4) if n_update_G == 2 else (1, 1, 3, 3)
-    return 2.0 * 1e9 * (g_f * GMAC_G + 2 * g_b * GMAC_G + d_f * GMAC_D + 2 * d_b * GMAC_D)
+    return 2.0 * 1e9 * (g_f * g + 2 * g_b * g + d_f * d + 2 * d_b * d)
+
+
+def build_cgan(args, rank):
+    """README.md:38: unet_256 ngf64 with dropout + Gaussian noise, D n_layers 3 4 ndf64 scale 1 1,
+    lambda_D .5 .5, lambda_A 10, L1 weights 2 4, no_lsgan, n_update_G 2, which_channel rg_b."""
+    from supervised_gan_amd.models import create_model
+    from supervised_gan_amd.options import TrainOptions
+    argv = ["--name", "bench", "--model", "cgan", "--which_direction", "AtoB", "--dataset_mode", "single",
+            "--loadSize", "1024", "--fineSize", "512", "--batchSize", "1", "--input_nc", "2", "--output_nc", "1",
+            "--which_model_netG", "unet_256", "--ngf", "64", "--which_model_netD", "n_layers", "--n_layers_D", "3", "4",
+            "--ndf", "64", "--scale_factor", "1", "1", "--lambda_D", "0.5", "0.5", "--lambda_A", "10", "--noise_nc", "8",
+            "--noiseSize", "4", "--norm", "instance", "--n_update_G", str(args.n_update_G), "--weights", "2", "4",
+            "--no_lsgan", "--manualSeed", str(rank), "--add_gaussian_noise", "--which_channel", "rg_b",
+            "--gpu_ids", str(torch.cuda.current_device()), "--checkpoints_dir", "/tmp/sgan_bench_ckpt"]
+    if args.skip_wasted_D_wgrad:
+        argv.append("--skip_wasted_D_wgrad")
+    opt = TrainOptions().parse(argv, save=False, verbose=False)
+    torch.manual_seed(0)
+    return create_model(opt)
 
 
 def build_model(args, rank):
@@ -57,7 +81,7 @@ def synthetic_ring(n, rank, device):
     return [{"A": (torch.rand(1, 3, 512, 512, generator=g) * 2 - 1).to(device), "A_paths": ["synthetic"]} for _ in range(n)]
 
 
-def profile_kernels(model, ring, reps=3):
+def profile_kernels(model, ring, reps=3, workload="fcgan"):
     """Per-kernel-instantiation time and algorithmic flops of the conv kernels, measured live.
 
     Every sgan_conv_* call of one eager training step is recorded (descriptor + tensors), then the whole list
@@ -70,9 +94,14 @@ def profile_kernels(model, ring, reps=3):
     lib = _lib.lib()
     calls = []
 
-    def flops(desc):   # stored 4 channels <- logical {1, 2} on this net (2-channel image, 1-channel logits)
-        cin = desc.Cin if desc.Cin > 4 else 2
-        cout = desc.Cout if desc.Cout > 4 else (2 if desc.kind == 1 else 1)
+    def flops(desc):   # stored 4 channels <- logical channels: fcgan 2-channel image / 1-channel logits; cgan 2-channel label
+        # (U-Net, pad 1), 3-channel pair (discriminators, pad 2), 1-channel image and logits
+        if workload == "fcgan":
+            cin = desc.Cin if desc.Cin > 4 else 2
+            cout = desc.Cout if desc.Cout > 4 else (2 if desc.kind == 1 else 1)
+        else:
+            cin = desc.Cin if desc.Cin > 4 else (2 if desc.pad == 1 else 3)
+            cout = desc.Cout if desc.Cout > 4 else 1
         pix = desc.Hout * desc.Wout if desc.kind == 0 else desc.Hin * desc.Win
         return 2.0 * pix * cin * cout * desc.k * desc.k
 
@@ -88,7 +117,7 @@ def profile_kernels(model, ring, reps=3):
 
     names = {"conv_fwd": False, "conv_dgrad": False, "conv_wgrad": False,
              "conv_fwd_grouped": True, "conv_dgrad_grouped": True, "conv_wgrad_grouped": True}
-    saved_streams, model._streams = model._streams, []     # one stream: kernels are timed one at a time
+    saved_streams, model._streams = getattr(model, "_streams", []), []     # one stream: kernels are timed one at a time
     try:
         for i in range(2):      # untimed: code-object loads and allocator growth are not kernel time
             model.set_input(ring[i % len(ring)])
@@ -126,12 +155,43 @@ def profile_kernels(model, ring, reps=3):
             a_[1] += max(m - overhead, 1e-4)
             a_[2] += calls[i % len(calls)][3]
         agg["_event_pair_overhead_us"] = [1, overhead, 0.0]
+        if os.environ.get("SGAN_BENCH_CALLS"):     # tuning aid: one line per conv call of the step
+            with open(os.environ["SGAN_BENCH_CALLS"], "w") as f:
+                for ci, (fn, a, k, fl) in enumerate(calls):
+                    ts = [recs[2 * (r * len(calls) + ci)] for r in range(reps)]
+                    us = 1e3 * (sum(t for _, t in ts) / reps - overhead)
+                    first = a[0]
+                    descs = [j[0] for j in first] if isinstance(first, list) else [first]
+                    shape = " ".join(f"{'T' if d.kind else 'C'}k{d.k}s{d.stride} {d.Cin}->{d.Cout} {d.Hin}x{d.Win}->{d.Hout}x{d.Wout}" for d in descs[:2])
+                    f.write(f"{ci:3d} {getattr(fn, '__name__', '?'):20s} {ts[0][0]:36s} n={len(descs)} {fl / 1e9:8.3f} GF {us:8.1f} us {fl / us / 1e6:6.1f} TF  {shape}\n")
     finally:
         lib.sgan_profile_enable(0)
         model._streams = saved_streams
     calls.clear()
     return {k: {"launches_per_step": v[0] / reps, "avg_us": 1e3 * v[1] / v[0], "ms_per_step": v[1] / reps,
                 "tflops": v[2] / (v[1] * 1e-3) / 1e12, "gflop_per_launch": v[2] / v[0] / 1e9} for k, v in agg.items()}
+
+
+def cpu_baseline_cgan(n_update_G, budget_s=25.0):
+    """The CPU oracle's cgan step (same README config) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import sgan_oracle as O
+    cores = int(os.environ.get("SGAN_CPU_THREADS", min(16, os.cpu_count() or 1)))
+    torch.set_num_threads(cores)
+    cfg = O.CGANConfig(**dict(O.CGAN_README, n_update_G=n_update_G))
+    m = O.CGANOracle(cfg, seed=0)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    m.set_input(x[:, :2].contiguous(), x[:, 2:3].contiguous())
+    m.optimize_parameters()                          # warm-up
+    n, t0 = 0, time.perf_counter()
+    while n < 1 or (time.perf_counter() - t0 < budget_s and n < 20):
+        m.optimize_parameters()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of the same cgan unet_256 512x512 bs=1 n_update_G={n_update_G} workload after 1 warm-up step, "
+                      f"torch {torch.__version__} fp32 CPU oracle, {cores} threads"}
 
 
 def cpu_baseline(n_update_G, budget_s=20.0):
@@ -181,6 +241,8 @@ def main():
     ap.add_argument("--no_group", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_profile", action="store_true")
+    ap.add_argument("--workload", default="fcgan", choices=["fcgan", "cgan"],
+                    help="fcgan = the headline metric (BASELINE configs[1]); cgan = BASELINE configs[2], reported under its own metric name")
     args = ap.parse_args()
 
     from supervised_gan_amd import dist as sdist
@@ -193,7 +255,8 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
-    model = build_model(args, rank)
+    cgan = args.workload == "cgan"
+    model = build_cgan(args, rank) if cgan else build_model(args, rank)
     sdist.broadcast_parameters([model.netG] + model.netD)
     if world > 1:
         model.grad_sync = sdist.GradAverager()
@@ -201,15 +264,15 @@ def main():
 
     kern = None
     if rank == 0 and not args.no_kernel_profile:
-        kern = profile_kernels(model, ring)
+        kern = profile_kernels(model, ring, workload=args.workload)
 
     if args.eager:
         def step(i):
             model.set_input(ring[i % len(ring)])
             model.optimize_parameters()
     else:
-        from supervised_gan_amd.graph_step import GraphedFCGANStep
-        gs = GraphedFCGANStep(model)
+        from supervised_gan_amd.graph_step import GraphedStep
+        gs = GraphedStep(model)
         gs.capture(ring[0])
 
         def step(i):
@@ -237,14 +300,19 @@ def main():
 
     if rank == 0:
         ips = world * args.steps / dt
-        fl = flops_per_image(args.n_update_G)
+        fl = flops_per_image(args.n_update_G, args.workload)
+        workload = ("fcgan deconv-G(ngf32, z 8x8x8) + 3x PatchGAN-D(ndf32, n_layers 3, scale 1/2/4) 512x512 bs=1, "
+                    f"n_update_D=1 n_update_G={args.n_update_G}, Adam, pool 50 (BASELINE configs[1] shape, fp32 compute)")
+        if cgan:
+            workload = ("cgan unet_256-G(ngf64, 2->1 ch, dropout, gaussian noise) + PatchGAN-D n_layers 3 and 4 (ndf64, scale 1 1) "
+                        f"512x512 bs=1, GAN + weighted L1 (lambda_A 10, weights 2 4), n_update_D=1 n_update_G={args.n_update_G}, "
+                        "Adam, pool 50 (BASELINE configs[2], fp32 compute)")
         out = {
-            "metric": "train-step images/sec, fcgan 512x512 bs=1/GPU",
+            "metric": "train-step images/sec, cgan unet_256 512x512 bs=1/GPU" if cgan else "train-step images/sec, fcgan 512x512 bs=1/GPU",
             "value": ips, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "fcgan deconv-G(ngf32, z 8x8x8) + 3x PatchGAN-D(ndf32, n_layers 3, scale 1/2/4) 512x512 bs=1, "
-                                   f"n_update_D=1 n_update_G={args.n_update_G}, Adam, pool 50 (BASELINE configs[1] shape, fp32 compute)",
+            "config": {"workload": workload,
                        "parallelism": f"dp{world}", "global_batch": world, "hip_graph": not args.eager,
                        "skip_wasted_D_wgrad": bool(args.skip_wasted_D_wgrad),
                        "gflop_per_image_reference_executed": fl / 1e9,
@@ -271,7 +339,7 @@ def main():
                                "event_pair_overhead_us": ovh}
             out["kernels"] = {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kern.items())}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.n_update_G)
+            out["cpu_baseline"] = cpu_baseline_cgan(args.n_update_G) if cgan else cpu_baseline(args.n_update_G)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

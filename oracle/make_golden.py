@@ -292,11 +292,23 @@ def golden_step(name, cfg: O.FCGANConfig, seed: int, nsteps: int, full_params: b
 # U-Net generator / cgan
 # ---------------------------------------------------------------------------------------
 class UnetRandomInjector:
-    """Dropout masks and Gaussian noise of the U-Net from numpy (same generators as the oracle)."""
+    """Dropout masks and Gaussian noise of the U-Net from numpy (same generators as the oracle).  `count_forwards(net)`
+    makes the seeds advance by 100 with every call of net.forward (the oracle's per-forward seeding)."""
     def __init__(self, mask_seed, noise_seed):
         self.mask_seed, self.noise_seed = mask_seed, noise_seed
+        self.nfwd = 0
         self._orig_dropout = torch.nn.functional.dropout
         self._orig_normal = torch.Tensor.normal_
+
+    def count_forwards(self, net):
+        inner = net.forward
+        m0, n0 = self.mask_seed, self.noise_seed
+
+        def fwd(*a, **k):
+            self.mask_seed, self.noise_seed = m0 + 100 * self.nfwd, n0 + 100 * self.nfwd
+            self.nfwd += 1
+            return inner(*a, **k)
+        net.forward = fwd
 
     def __enter__(self):
         inj = self
@@ -350,7 +362,8 @@ def build_ref_cgan(cfg: "O.CGANConfig", seed: int, tmpdir: str):
             "--n_layers_D", *map(str, cfg.n_layers_D), "--ndf", str(cfg.ndf), "--scale_factor", *map(str, cfg.scale_factor),
             "--lambda_D", *map(str, cfg.lambda_D), "--lambda_A", str(cfg.lambda_A), "--norm", "instance",
             "--which_channel", "rg_b", "--gpu_ids", "-1", "--display_id", "0", "--checkpoints_dir", tmpdir,
-            "--pool_size", str(cfg.pool_size), "--n_layers_G_skip", str(cfg.n_layers_G_skip)]
+            "--pool_size", str(cfg.pool_size), "--n_layers_G_skip", str(cfg.n_layers_G_skip),
+            "--n_update_G", str(cfg.n_update_G)]
     if not cfg.use_dropout:
         argv.append("--no_dropout")
     if cfg.no_lsgan:
@@ -388,9 +401,10 @@ def golden_cgan_step(name, cfg: "O.CGANConfig", seed: int, nsteps: int):
         model = build_ref_cgan(cfg, seed, tmp)
         arrs = {}
         losses = []
-        for step in range(nsteps):
-            model.set_input(cgan_batch(cfg, step))
-            with UnetRandomInjector(9000 + 100 * step, 9500 + 100 * step):
+        with UnetRandomInjector(9000, 9500) as inj:
+            inj.count_forwards(model.netG)
+            for step in range(nsteps):
+                model.set_input(cgan_batch(cfg, step))
                 if step > 0:
                     model.optimize_parameters()
                 else:
@@ -404,11 +418,13 @@ def golden_cgan_step(name, cfg: "O.CGANConfig", seed: int, nsteps: int):
                         capture_grads(arrs, f"step1/gradD_{i}", d)
                     arrs["step1/loss_D"] = np.asarray([float(model.loss_D_real), float(model.loss_D_fake)])
                     model.optimizer_D.step()
-                    model.optimizer_G.zero_grad()
-                    model.backward_G()
-                    arrs["step1/loss_G"] = np.asarray([float(model.loss_G), float(model.loss_G_L1)])
-                    model.optimizer_G.step()
-            losses.append([float(model.loss_G), float(model.loss_G_L1), float(model.loss_D_real), float(model.loss_D_fake)])
+                    for _ in range(cfg.n_update_G):
+                        model.optimizer_G.zero_grad()
+                        model.backward_G()
+                        model.optimizer_G.step()
+                        if cfg.n_update_G > 1:
+                            model.sample_noise()
+                losses.append([float(model.loss_G), float(model.loss_G_L1), float(model.loss_D_real), float(model.loss_D_fake)])
         arrs["losses"] = np.asarray(losses, dtype=np.float64)
         probe = build_ref_cgan(cfg, seed, tmp)
         probe.set_input(cgan_batch(cfg, 0))
@@ -436,7 +452,7 @@ def main():
         golden_unet_small()
         golden_cgan_step("cgan_step_small.npz", O.CGANConfig(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0)),
                          seed=0, nsteps=3)
-        golden_cgan_step("cgan_step_full.npz", O.CGANConfig(), seed=0, nsteps=2)   # BASELINE configs[2]
+        golden_cgan_step("cgan_step_full.npz", O.CGANConfig(**O.CGAN_README), seed=0, nsteps=2)   # BASELINE configs[2]
     if only and "fcgan" not in only:
         return
     golden_gauss()

@@ -522,14 +522,23 @@ class CGANConfig:
     def __init__(self, num_downs=8, input_nc=2, output_nc=1, ngf=64, ndf=64, n_layers_D=(3, 4), scale_factor=(1, 2),
                  lambda_D=(1.0, 1.0), lambda_A=10.0, weights=None, use_dropout=True, n_layers_G_skip=-1,
                  add_gaussian_noise=False, gaussian_sigma=0.1, fineSize=512, lr=2e-4, beta1=0.5, pool_size=50,
-                 no_lsgan=False, no_logD_trick=False, no_cgan=False):
+                 no_lsgan=False, no_logD_trick=False, no_cgan=False, n_update_G=1):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
 
+# BASELINE configs[2] / SURVEY 8d "Config 3" (README.md:38): unet_256 ngf 64 with dropout and Gaussian noise, two scale-1
+# discriminators (n_layers 3 and 4, ndf 64), weighted L1, two generator updates per discriminator update.
+CGAN_README = dict(num_downs=8, ngf=64, ndf=64, n_layers_D=(3, 4), scale_factor=(1, 1), lambda_D=(0.5, 0.5), lambda_A=10.0,
+                   weights=(2.0, 4.0), use_dropout=True, add_gaussian_noise=True, gaussian_sigma=0.1, fineSize=512, n_update_G=2,
+                   no_lsgan=True)
+
+
 class CGANOracle:
     """CGANModel restated (initialize :18-117, forward :134-139, backward_D :158-182, backward_G :184-210,
-    optimize_parameters :212-226 with n_update_D = n_update_G = 1)."""
+    optimize_parameters :212-226 with n_update_D = 1).  Dropout masks / Gaussian noise of the k-th generator
+    forward since construction are the numpy tensors seeded 9000 + 100 k / 9500 + 100 k (make_golden.py injects the
+    same ones into the reference)."""
 
     def __init__(self, cfg: CGANConfig, seed: int = 0):
         self.cfg = cfg
@@ -546,13 +555,14 @@ class CGANOracle:
         self.opt_G = Adam(list(self.G.values()), c.lr, c.beta1)
         self.opt_D = Adam([v for d in self.D for k, v in d.items() if k.startswith("model.")], c.lr, c.beta1)
         self.pool = ImagePool(c.pool_size)
-        self.step = 0
+        self.nfwd = 0
 
     def forward(self):
         c = self.cfg
         self.fake_B = unet_forward(self.G, self.real_A, c.num_downs, c.ngf, c.n_layers_G_skip, c.use_dropout,
-                                   mask_seed=9000 + 100 * self.step, add_gaussian_noise=c.add_gaussian_noise,
-                                   gaussian_sigma=c.gaussian_sigma, noise_seed=9500 + 100 * self.step)
+                                   mask_seed=9000 + 100 * self.nfwd, add_gaussian_noise=c.add_gaussian_noise,
+                                   gaussian_sigma=c.gaussian_sigma, noise_seed=9500 + 100 * self.nfwd)
+        self.nfwd += 1
 
     def _d(self, i, x):
         c = self.cfg
@@ -591,15 +601,20 @@ class CGANOracle:
     def set_input(self, real_A, real_B):
         self.real_A, self.real_B = real_A, real_B
 
+    def _g_steps(self):
+        for _ in range(self.cfg.n_update_G):
+            self.opt_G.zero_grad()
+            self.backward_G()
+            self.opt_G.step()
+            if self.cfg.n_update_G > 1:
+                self.forward()          # sample_noise (:141-144): fresh dropout masks / noise
+
     def optimize_parameters(self):
         self.forward()
         self.opt_D.zero_grad()
         self.backward_D()
         self.opt_D.step()
-        self.opt_G.zero_grad()
-        self.backward_G()
-        self.opt_G.step()
-        self.step += 1
+        self._g_steps()
 
     def _gradD(self):
         return [{k: v.grad.detach().clone() for k, v in d.items() if k.startswith("model.") and v.grad is not None} for d in self.D]
@@ -613,11 +628,7 @@ class CGANOracle:
         cap["gradD"] = self._gradD()
         cap["loss_D"] = [float(self.loss_D_real.detach()), float(self.loss_D_fake.detach())]
         self.opt_D.step()
-        self.opt_G.zero_grad()
-        self.backward_G()
-        cap["loss_G"] = [float(self.loss_G.detach()), float(self.loss_G_L1.detach())]
-        self.opt_G.step()
-        self.step += 1
+        self._g_steps()
         return cap
 
     def probe_G(self):

@@ -102,6 +102,10 @@ class CGANModel(BaseModel):
 
     sample_noise = forward
 
+    def _pool_source(self):
+        """What the reference hands to ImagePool.query (cgan_model.py:160-163)."""
+        return self.fake_B if self.opt.no_cgan else torch.cat((self.real_A, self.fake_B), 1)
+
     def test(self):
         with torch.no_grad():
             self.real_A = self.input_A
@@ -117,11 +121,7 @@ class CGANModel(BaseModel):
 
     def backward_D(self):
         """loss_D = 0.5 * (sum_i GAN(D_i(fake), 0) + sum_i GAN(D_i(real), 1))   (cgan_model.py:158-182)"""
-        if self._pool_override is not None:
-            fake = self._pool_override
-        else:
-            fake = self.fake_B if self.opt.no_cgan else torch.cat((self.real_A, self.fake_B), 1)
-            fake = self.fake_pool.query(fake)
+        fake = self._pool_override if self._pool_override is not None else self.fake_pool.query(self._pool_source())
         fake = fake.detach()
         real = self.real_B if self.opt.no_cgan else torch.cat((self.real_A, self.real_B), 1)
         n = self.n_netD

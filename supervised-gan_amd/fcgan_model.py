@@ -111,6 +111,9 @@ class FCGANModel(BaseModel):
 
     sample_noise = forward
 
+    def _pool_source(self):
+        return self.fake
+
     def test(self):
         with torch.no_grad():
             self.noise = self._draw_noise()

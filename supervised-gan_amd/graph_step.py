@@ -1,9 +1,10 @@
-"""hipGraph capture of FCGANModel.optimize_parameters (models/fcgan_model.py:178-193).
+"""hipGraph capture of FCGANModel.optimize_parameters (models/fcgan_model.py:178-193) and
+CGANModel.optimize_parameters (models/cgan_model.py:212-226).
 
-A bs=1 fcgan step is ~300 short kernels; launched eagerly from Python the host is the bottleneck.
+A bs=1 step is a few hundred short kernels; launched eagerly from Python the host is the bottleneck.
 The step is therefore captured once into hipGraphs and replayed:
 
-    graph A : forward()                      latent fill + G forward -> static `fake`
+    graph A : forward()                      latent fill + G forward -> static `fake` (cgan: cat(real_A, fake_B))
     host    : ImagePool.query(fake)          the reference's python-random history policy, one D2D copy
     graph B : D step, then the G step(s)     zero_grad / backward / Adam, loss scalars left on device
 
@@ -16,7 +17,10 @@ import torch
 from . import ops
 
 
-class GraphedFCGANStep:
+class GraphedStep:
+    """Works on any trainer exposing optimizer_D/G, backward_D/G, forward, sample_noise, fake_pool, `_pool_source()`
+    (what the reference feeds ImagePool.query) and `_pool_override`."""
+
     def __init__(self, model, warmup_steps=2):
         self.m = model
         opt = model.opt
@@ -38,7 +42,7 @@ class GraphedFCGANStep:
 
     def capture(self, example_input):
         m = self.m
-        assert m.noise_source is None, "graphed step draws its latents on the device"
+        assert getattr(m, "noise_source", None) is None, "graphed step draws its latents on the device"
         for _ in range(self._warmup_steps):   # lazy state (optimizer moments, caches) must exist before capture
             m.set_input(example_input)
             m.optimize_parameters()
@@ -46,12 +50,13 @@ class GraphedFCGANStep:
         m.optimizer_G.sync_lr()
         torch.cuda.synchronize()
         H = W = m.opt.fineSize
-        self.fake_for_D = torch.zeros((H, W, ops.pad4(m.opt.input_nc)), dtype=torch.float32, device=m.device)
-        m._pool_override = ops.logical_view(self.fake_for_D, m.opt.input_nc)
+        nc = m._pool_source().shape[1]
+        self.fake_for_D = torch.zeros((H, W, ops.pad4(nc)), dtype=torch.float32, device=m.device)
+        m._pool_override = ops.logical_view(self.fake_for_D, nc)
         self.gA = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gA):
             m.forward()
-        self._fakeA = m.fake
+            self._fakeA = m._pool_source()
         pool = self.gA.pool()
         self.segs = []
         merged = []
@@ -77,7 +82,7 @@ class GraphedFCGANStep:
         return g
 
     def step(self, data=None):
-        """One training step == FCGANModel.optimize_parameters() (set_input first when data is given)."""
+        """One training step == model.optimize_parameters() (set_input first when data is given)."""
         m = self.m
         if data is not None:
             m.set_input(data)
@@ -89,3 +94,6 @@ class GraphedFCGANStep:
                 obj.replay()
             else:
                 m.grad_sync(obj)
+
+
+GraphedFCGANStep = GraphedStep

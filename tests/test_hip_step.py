@@ -175,11 +175,24 @@ def build_cgan(cfg, extra=()):
             "--checkpoints_dir", "/tmp/sgan_ckpt", *extra]
     if cfg.weights is not None:
         argv += ["--weights", *map(str, cfg.weights)]
+    if cfg.add_gaussian_noise:
+        argv += ["--add_gaussian_noise", "--gaussian_sigma", str(cfg.gaussian_sigma)]
+    if cfg.no_lsgan:
+        argv.append("--no_lsgan")
+    argv += ["--n_update_G", str(cfg.n_update_G)]
     opt = TrainOptions().parse(argv, save=False, verbose=False)
     m = create_model(opt)
     m.netG.load_state_dict(O.init_unet(1, cfg.num_downs, cfg.input_nc, cfg.output_nc, cfg.ngf, cfg.n_layers_G_skip))
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D, cfg.scale_factor)):
         m.netD[i].load_state_dict(O.init_nlayer_d(2 + i, cfg.input_nc + cfg.output_nc, cfg.ndf, nl, sf))
+    # the k-th generator forward uses the numpy dropout masks / noise seeded 9000 + 100 k / 9500 + 100 k (as the goldens)
+    inner, ctr = m.netG.forward, {"k": 0}
+
+    def fwd(*a, **k):
+        inject_unet_random(m.netG, cfg.fineSize, 9000 + 100 * ctr["k"], 9500 + 100 * ctr["k"])
+        ctr["k"] += 1
+        return inner(*a, **k)
+    m.netG.forward = fwd
     return m
 
 
@@ -202,7 +215,6 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
     # (1) G step (GAN + weighted L1) through the initial discriminators
     p = build_cgan(cfg)
     p.set_input(cgan_input(cfg, 0))
-    inject_unet_random(p.netG, cfg.fineSize, 9000, 9500)
     p.forward()
     p.optimizer_G.zero_grad()
     p.optimizer_D.zero_grad()
@@ -214,7 +226,6 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
     random.seed(1234)
     m = build_cgan(cfg)
     m.set_input(cgan_input(cfg, 0))
-    inject_unet_random(m.netG, cfg.fineSize, 9000, 9500)
     m.forward()
     cap = {"fake": m.fake_B.detach().cpu().clone()}
     m.optimizer_D.zero_grad()
@@ -223,9 +234,12 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
     cap["loss_D"] = [float(m.loss_D_real), float(m.loss_D_fake)]
     check_cgan_step1(cap, g, cfg, tol=1e-3, robust=full, tally=tally)
     m.optimizer_D.step()
-    m.optimizer_G.zero_grad()
-    m.backward_G()
-    m.optimizer_G.step()
+    for _ in range(cfg.n_update_G):
+        m.optimizer_G.zero_grad()
+        m.backward_G()
+        m.optimizer_G.step()
+        if cfg.n_update_G > 1:
+            m.sample_noise()
     strict = sum(1 for _, _, e_max, _ in tally if e_max <= 1e-3)
     worst = max(tally, key=lambda t: t[3])
     print(f"{name}: {strict}/{len(tally)} gradient tensors within 1e-3 (max-abs/max|g|); worst rel-L2 {worst[3]:.2e} at {worst[0]}/{worst[1]}")
@@ -234,7 +248,6 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
     losses = [list(m.get_current_errors().values())]
     for step in range(1, g["losses"].shape[0]):
         m.set_input(cgan_input(cfg, step))
-        inject_unet_random(m.netG, cfg.fineSize, 9000 + 100 * step, 9500 + 100 * step)
         m.optimize_parameters()
         losses.append(list(m.get_current_errors().values()))
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])

@@ -261,7 +261,7 @@ def check_cgan_probe(pr, g, cfg, tol=TOL, robust=False, tally=None):
 
 
 CGAN_CASES = [("cgan_step_small.npz", dict(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0))),
-              ("cgan_step_full.npz", dict())]                   # BASELINE configs[2]: unet_256 + D 3 4 @512x512
+              ("cgan_step_full.npz", O.CGAN_README)]            # BASELINE configs[2]: unet_256 + D 3 4 @512x512
 
 
 @pytest.mark.parametrize("name,kw", CGAN_CASES)

@@ -148,14 +148,19 @@ int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, int32_t out_
                           int64_t workspace_bytes, void* stream);
 int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t n, void* workspace, int64_t workspace_bytes,
                             void* stream);
-int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* stream);
+int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* workspace, int64_t workspace_bytes,
+                            void* stream);
 
 /* ---- backward-weight ---------------------------------------------------------------------------
  * dw += act(norm(in))^T (x) dout over all pixels (master layout), dbias += sum_pixels dout.
  * Accumulates (atomics) into caller-owned gradient buffers.
+ * `workspace` (same protocol as sgan_conv_fwd: workspace_bytes == -1 returns the KiB needed) lets the thin-layer
+ * kernel (stored Cin == 4 or Cout == 4) combine its pixel splits in two stages instead of with contended atomics;
+ * optional -- without it the result is the same, only slower.
  * Replaces: convolution_backward (weight / bias grad). */
 int sgan_conv_wgrad(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
-                    const float* dout, int32_t dout_ld, float* dw, float* dbias, void* stream);
+                    const float* dout, int32_t dout_ld, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
+                    void* stream);
 
 /* ---- InstanceNorm / BatchNorm(batch 1) backward, in place ------------------------------------
  * dy[p][c] <- gamma_c * rstd_c * ( dy - s1_c/M - xhat * s2_c/M ), xhat = (x - mean_c) * rstd_c.
@@ -164,6 +169,17 @@ int sgan_conv_wgrad(const sgan_conv_desc* d, const float* in, int32_t in_ld, con
 int sgan_norm_bwd_apply(float* dy, int32_t dy_ld, const float* x, int32_t x_ld, int32_t npix, int32_t C,
                         const sgan_norm_desc* x_norm, const double* bwd_sums, int32_t bwd_sums_sq_stride /* 0 = C */,
                         float* dgamma, float* dbeta, void* stream);
+
+/* Several independent tensors in one launch (the matching layer of grouped discriminator chains). */
+typedef struct sgan_norm_bwd_job {
+    float* dy; int32_t dy_ld;
+    const float* x; int32_t x_ld;
+    int32_t npix, C;
+    const sgan_norm_desc* x_norm;
+    const double* bwd_sums; int32_t bwd_sums_sq_stride;
+    float* dgamma; float* dbeta;
+} sgan_norm_bwd_job;
+int sgan_norm_bwd_apply_multi(const sgan_norm_bwd_job* jobs, int32_t n /* 1..8 */, void* stream);
 
 /* ---- BatchNorm running statistics (momentum update, unbiased variance), n layers per launch --
  * Replaces the running_mean / running_var side effect of nn.BatchNorm2d.forward in train mode. */

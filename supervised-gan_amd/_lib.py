@@ -40,6 +40,12 @@ class ConvWgradJob(C.Structure):
                 ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("dw", C.c_void_p), ("dbias", C.c_void_p)]
 
 
+class NormBwdJob(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("dy_ld", C.c_int32), ("x", C.c_void_p), ("x_ld", C.c_int32), ("npix", C.c_int32),
+                ("C", C.c_int32), ("x_norm", C.POINTER(NormDesc)), ("bwd_sums", C.c_void_p), ("bwd_sums_sq_stride", C.c_int32),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
 class GanLossJob(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("ld", C.c_int32), ("npix", C.c_int32), ("target", C.c_float), ("weight", C.c_float),
                 ("dlogits", C.c_void_p), ("dld", C.c_int32)]
@@ -59,11 +65,12 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "sgan_conv_fwd": [C.POINTER(ConvDesc), _P, _I, C.POINTER(NormDesc), _P, _P, _P, _I, _I, _P, _P, _L, _P],
     "sgan_conv_dgrad": [C.POINTER(ConvDesc), _P, _I, _P, _P, _I, _P, _I, C.POINTER(NormDesc), _P, _P, _L, _P],
-    "sgan_conv_wgrad": [C.POINTER(ConvDesc), _P, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
+    "sgan_conv_wgrad": [C.POINTER(ConvDesc), _P, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P, _L, _P],
     "sgan_conv_fwd_grouped": [C.POINTER(ConvFwdJob), _I, _I, _P, _L, _P],
     "sgan_conv_dgrad_grouped": [C.POINTER(ConvDgradJob), _I, _P, _L, _P],
-    "sgan_conv_wgrad_grouped": [C.POINTER(ConvWgradJob), _I, _P],
+    "sgan_conv_wgrad_grouped": [C.POINTER(ConvWgradJob), _I, _P, _L, _P],
     "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
+    "sgan_norm_bwd_apply_multi": [C.POINTER(NormBwdJob), _I, _P],
     "sgan_norm_apply_fwd": [_P, _I, C.POINTER(NormDesc), _P, _P, _F, _P, _I, _I, _I, _P],
     "sgan_norm_apply_bwd_sums": [_P, _I, _P, _P, _I, C.POINTER(NormDesc), _P, _I, _I, _P],
     "sgan_dropout_mask": [_P, _L, _F, C.c_uint64, _P, _P],

@@ -73,59 +73,89 @@ static inline int ew_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b);
 // ------------------------------------------------------------------------------------------
 // InstanceNorm / BatchNorm(batch 1) backward, in place on dy
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(float* dy, int dy_ld, const float* x, int x_ld,
-                                                                int npix, int C, SgNorm xn, const double* sums,
-                                                                int sums_sq, float* dgamma, float* dbeta) {
+struct SgNormBwdJob {
+    float* dy; const float* x; const double* sums; float* dgamma; float* dbeta;
+    SgNorm xn;
+    int32_t dy_ld, x_ld, npix, C, sums_sq, blocks;
+};
+struct SgNormBwdTable { SgNormBwdJob j[8]; };
+
+// blockIdx.y = job; every job strides over its own elements with its own block count (<= gridDim.x)
+__global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(const SgNormBwdTable T) {
+    const SgNormBwdJob& J = T.j[blockIdx.y];
+    if ((int)blockIdx.x >= J.blocks) return;
+    const int C = J.C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* cA = reinterpret_cast<float*>(smem);  // gamma * rstd
     float* cMean = cA + C;
     float* cRstd = cMean + C;
     float* cS1 = cRstd + C;  // s1 / M
     float* cS2 = cS1 + C;    // s2 / M
-    const double invM = 1.0 / (double)npix;
+    const double invM = 1.0 / (double)J.npix;
     for (int c = threadIdx.x; c < C; c += 256) {
         float mean, rstd;
-        sg_mean_rstd(xn, C, c, mean, rstd);
-        const float g = xn.gamma ? xn.gamma[c] : 1.f;
+        sg_mean_rstd(J.xn, C, c, mean, rstd);
+        const float g = J.xn.gamma ? J.xn.gamma[c] : 1.f;
         cA[c] = g * rstd;
         cMean[c] = mean;
         cRstd[c] = rstd;
-        cS1[c] = (float)(sums[c] * invM);
-        cS2[c] = (float)(sums[sums_sq + c] * invM);
+        cS1[c] = (float)(J.sums[c] * invM);
+        cS2[c] = (float)(J.sums[J.sums_sq + c] * invM);
         if (blockIdx.x == 0) {
-            if (dgamma) atomicAdd(&dgamma[c], (float)sums[sums_sq + c]);   // concurrent chains may share the buffer
-            if (dbeta) atomicAdd(&dbeta[c], (float)sums[c]);
+            if (J.dgamma) atomicAdd(&J.dgamma[c], (float)J.sums[J.sums_sq + c]);   // concurrent chains may share the buffer
+            if (J.dbeta) atomicAdd(&J.dbeta[c], (float)J.sums[c]);
         }
     }
     __syncthreads();
     const int CQ = C >> 2;
-    const int64_t total = (int64_t)npix * CQ;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t total = (int64_t)J.npix * CQ;
+    float* dy = J.dy;
+    const float* x = J.x;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)J.blocks * 256) {
         const int p = (int)(e / CQ), c = (int)(e - (int64_t)p * CQ) * 4;
-        f32x4 d = *reinterpret_cast<const f32x4*>(dy + (int64_t)p * dy_ld + c);
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)p * x_ld + c);
+        f32x4 d = *reinterpret_cast<const f32x4*>(dy + (int64_t)p * J.dy_ld + c);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)p * J.x_ld + c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xhat = (xv[j] - cMean[c + j]) * cRstd[c + j];
             d[j] = cA[c + j] * (d[j] - cS1[c + j] - xhat * cS2[c + j]);
         }
-        *reinterpret_cast<f32x4*>(dy + (int64_t)p * dy_ld + c) = d;
+        *reinterpret_cast<f32x4*>(dy + (int64_t)p * J.dy_ld + c) = d;
     }
+}
+
+extern "C" int sgan_norm_bwd_apply_multi(const sgan_norm_bwd_job* jobs, int32_t n, void* stream) {
+    SGAN_CHECK(jobs && n >= 1 && n <= 8, "1..8 jobs");
+    SgNormBwdTable T;
+    int maxb = 1, maxC = 4;
+    for (int i = 0; i < n; ++i) {
+        const sgan_norm_bwd_job& S = jobs[i];
+        SGAN_CHECK(S.dy && S.x && S.x_norm && S.x_norm->stats && S.bwd_sums, "null argument in job %d", i);
+        SGAN_CHECK((S.C & 3) == 0 && S.C > 0 && S.C <= 4096 && S.dy_ld >= S.C && S.x_ld >= S.C && (S.dy_ld & 3) == 0 &&
+                       (S.x_ld & 3) == 0 && S.npix > 0, "bad dims in job %d", i);
+        SgNormBwdJob& J = T.j[i];
+        J.dy = S.dy; J.x = S.x; J.sums = S.bwd_sums; J.dgamma = S.dgamma; J.dbeta = S.dbeta;
+        J.xn = sg_norm_from(S.x_norm);
+        J.dy_ld = S.dy_ld; J.x_ld = S.x_ld; J.npix = S.npix; J.C = S.C;
+        J.sums_sq = S.bwd_sums_sq_stride ? S.bwd_sums_sq_stride : S.C;
+        const int64_t total = (int64_t)S.npix * (S.C >> 2);
+        int blocks = ew_cdiv(total, 256 * 4);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        J.blocks = blocks;
+        if (blocks > maxb) maxb = blocks;
+        if (S.C > maxC) maxC = S.C;
+    }
+    hipLaunchKernelGGL(sg_norm_bwd_apply_kernel, dim3(maxb, n), dim3(256), (size_t)5 * maxC * 4, (hipStream_t)stream, T);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
 }
 
 extern "C" int sgan_norm_bwd_apply(float* dy, int32_t dy_ld, const float* x, int32_t x_ld, int32_t npix, int32_t C,
                                    const sgan_norm_desc* x_norm, const double* bwd_sums, int32_t bwd_sums_sq_stride,
                                    float* dgamma, float* dbeta, void* stream) {
-    SGAN_CHECK(dy && x && x_norm && x_norm->stats && bwd_sums, "null argument");
-    SGAN_CHECK((C & 3) == 0 && C > 0 && C <= 4096 && dy_ld >= C && x_ld >= C && (dy_ld & 3) == 0 && (x_ld & 3) == 0, "bad dims");
-    const int64_t total = (int64_t)npix * (C >> 2);
-    int blocks = ew_cdiv(total, 256 * 4);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sg_norm_bwd_apply_kernel, dim3(blocks), dim3(256), (size_t)5 * C * 4, (hipStream_t)stream, dy, dy_ld,
-                       x, x_ld, npix, C, sg_norm_from(x_norm), bwd_sums, bwd_sums_sq_stride ? bwd_sums_sq_stride : C, dgamma, dbeta);
-    SGAN_LAUNCH_CHECK();
-    return SGAN_OK;
+    sgan_norm_bwd_job j = {dy, dy_ld, x, x_ld, npix, C, x_norm, bwd_sums, bwd_sums_sq_stride, dgamma, dbeta};
+    return sgan_norm_bwd_apply_multi(&j, 1, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -326,57 +356,66 @@ extern "C" int sgan_bn_running_update(const sgan_bn_running_desc* layers, int32_
 // ------------------------------------------------------------------------------------------
 // Gaussian pre-filter: depthwise (diagonal of the dense reference weight), strided outputs only
 // ------------------------------------------------------------------------------------------
+// one thread per (pixel, channel quad): 16-byte loads, the k x k taps of the channel's Gaussian from LDS
 __global__ __launch_bounds__(256) void sg_gauss_fwd_kernel(const float* in, int in_ld, int H, int W, int C, int Creal,
                                                            const float* g, int gcs, int k, int pad, int s, float* out,
                                                            int out_ld, int Ho, int Wo) {
-    const int64_t total = (int64_t)Ho * Wo * C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gs = reinterpret_cast<float*>(smem);   // [k*k][C] (zero for padding channels)
+    for (int i = threadIdx.x; i < k * k * C; i += 256) {
+        const int c = i % C, t = i / C;
+        gs[i] = c < Creal ? g[(int64_t)c * gcs + t] : 0.f;
+    }
+    __syncthreads();
+    const int CQ = C >> 2;
+    const int64_t total = (int64_t)Ho * Wo * CQ;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const int64_t pix = e / C;
+        const int c = (int)(e % CQ) * 4;
+        const int64_t pix = e / CQ;
         const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
-        float acc = 0.f;
-        if (c < Creal) {
-            const float* gc = g + (int64_t)c * gcs;
-            for (int ky = 0; ky < k; ++ky) {
-                const int iy = oy * s + ky - pad;
-                if ((unsigned)iy >= (unsigned)H) continue;
-                for (int kx = 0; kx < k; ++kx) {
-                    const int ix = ox * s + kx - pad;
-                    if ((unsigned)ix >= (unsigned)W) continue;
-                    acc += gc[ky * k + kx] * in[((int64_t)iy * W + ix) * in_ld + c];
-                }
-            }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ky0 = max(0, pad - oy * s), ky1 = min(k, H + pad - oy * s);
+        const int kx0 = max(0, pad - ox * s), kx1 = min(k, W + pad - ox * s);
+        for (int ky = ky0; ky < ky1; ++ky) {
+            const float* row = in + ((int64_t)(oy * s + ky - pad) * W + (ox * s - pad)) * in_ld + c;
+            for (int kx = kx0; kx < kx1; ++kx)
+                acc += *reinterpret_cast<const f32x4*>(gs + (ky * k + kx) * C + c) * *reinterpret_cast<const f32x4*>(row + (int64_t)kx * in_ld);
         }
-        out[pix * out_ld + c] = acc;
+        *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = acc;
     }
 }
 
+// transpose of the above: only the taps with (iy + pad - ky) % s == 0 reach an output row (ceil(k/s) per axis)
 __global__ __launch_bounds__(256) void sg_gauss_bwd_kernel(const float* dout, int dout_ld, int Ho, int Wo, int C, int Creal,
                                                            const float* g, int gcs, int k, int pad, int s, float* din,
                                                            int din_ld, int H, int W) {
-    const int64_t total = (int64_t)H * W * C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gs = reinterpret_cast<float*>(smem);
+    for (int i = threadIdx.x; i < k * k * C; i += 256) {
+        const int c = i % C, t = i / C;
+        gs[i] = c < Creal ? g[(int64_t)c * gcs + t] : 0.f;
+    }
+    __syncthreads();
+    const int CQ = C >> 2;
+    const int64_t total = (int64_t)H * W * CQ;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const int64_t pix = e / C;
+        const int c = (int)(e % CQ) * 4;
+        const int64_t pix = e / CQ;
         const int ix = (int)(pix % W), iy = (int)(pix / W);
-        float acc = 0.f;
-        if (c < Creal) {
-            const float* gc = g + (int64_t)c * gcs;
-            for (int ky = 0; ky < k; ++ky) {
-                const int ry = iy + pad - ky;
-                if (ry < 0 || ry % s != 0) continue;
-                const int oy = ry / s;
-                if (oy >= Ho) continue;
-                for (int kx = 0; kx < k; ++kx) {
-                    const int rx = ix + pad - kx;
-                    if (rx < 0 || rx % s != 0) continue;
-                    const int ox = rx / s;
-                    if (ox >= Wo) continue;
-                    acc += gc[ky * k + kx] * dout[((int64_t)oy * Wo + ox) * dout_ld + c];
-                }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ky = (iy + pad) % s; ky < k; ky += s) {
+            const int oy = (iy + pad - ky) / s;          // exact; decreasing in ky
+            if (iy + pad - ky < 0) break;
+            if (oy >= Ho) continue;
+            for (int kx = (ix + pad) % s; kx < k; kx += s) {
+                const int ox = (ix + pad - kx) / s;
+                if (ix + pad - kx < 0) break;
+                if (ox >= Wo) continue;
+                acc += *reinterpret_cast<const f32x4*>(gs + (ky * k + kx) * C + c) *
+                       *reinterpret_cast<const f32x4*>(dout + ((int64_t)oy * Wo + ox) * dout_ld + c);
             }
         }
-        din[pix * din_ld + c] = acc;
+        *reinterpret_cast<f32x4*>(din + pix * din_ld + c) = acc;
     }
 }
 
@@ -384,11 +423,12 @@ extern "C" int sgan_gauss_down_fwd(const float* in, int32_t in_ld, int32_t H, in
                                    const float* g, int32_t g_chan_stride, int32_t k, int32_t pad, int32_t s, float* out,
                                    int32_t out_ld, int32_t Ho, int32_t Wo, void* stream) {
     SGAN_CHECK(in && g && out && k > 0 && s > 0 && Creal <= C, "bad argument");
+    SGAN_CHECK((C & 3) == 0 && (in_ld & 3) == 0 && (out_ld & 3) == 0 && in_ld >= C && out_ld >= C && k * k * C * 4 <= 60000, "bad channel layout");
     SGAN_CHECK(Ho == (H + 2 * pad - k) / s + 1 && Wo == (W + 2 * pad - k) / s + 1, "gauss geometry mismatch");
-    const int64_t total = (int64_t)Ho * Wo * C;
+    const int64_t total = (int64_t)Ho * Wo * (C >> 2);
     int blocks = ew_cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sg_gauss_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, in_ld, H, W, C, Creal, g,
+    hipLaunchKernelGGL(sg_gauss_fwd_kernel, dim3(blocks), dim3(256), (size_t)k * k * C * 4, (hipStream_t)stream, in, in_ld, H, W, C, Creal, g,
                        g_chan_stride, k, pad, s, out, out_ld, Ho, Wo);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
@@ -398,11 +438,12 @@ extern "C" int sgan_gauss_down_bwd(const float* dout, int32_t dout_ld, int32_t H
                                    const float* g, int32_t g_chan_stride, int32_t k, int32_t pad, int32_t s, float* din,
                                    int32_t din_ld, int32_t H, int32_t W, void* stream) {
     SGAN_CHECK(dout && g && din && k > 0 && s > 0 && Creal <= C, "bad argument");
+    SGAN_CHECK((C & 3) == 0 && (din_ld & 3) == 0 && (dout_ld & 3) == 0 && din_ld >= C && dout_ld >= C && k * k * C * 4 <= 60000, "bad channel layout");
     SGAN_CHECK(Ho == (H + 2 * pad - k) / s + 1 && Wo == (W + 2 * pad - k) / s + 1, "gauss geometry mismatch");
-    const int64_t total = (int64_t)H * W * C;
+    const int64_t total = (int64_t)H * W * (C >> 2);
     int blocks = ew_cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sg_gauss_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, dout_ld, Ho, Wo, C, Creal,
+    hipLaunchKernelGGL(sg_gauss_bwd_kernel, dim3(blocks), dim3(256), (size_t)k * k * C * 4, (hipStream_t)stream, dout, dout_ld, Ho, Wo, C, Creal,
                        g, g_chan_stride, k, pad, s, din, din_ld, H, W);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;

@@ -360,7 +360,366 @@ static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
     return SGAN_OK;
 }
 
-extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* stream) {
+// ------------------------------------------------------------------------------------------
+// Thin layers: one side of the conv has only 4 stored channels (image-side first convs, image / logits
+// heads).  dW is then a [rows][16 taps x 4] matrix reduced over up to 10^6 pixels -- bandwidth-bound
+// streaming, not a GEMM worth tiling.  Both cases are one kernel:
+//   SWAP = false (stored Cin == 4):  rows = co,  dense operand = dOut[p][co],
+//                                    gathered operand = x[p*s + tap][0..3]          (walk over output pixels p)
+//   SWAP = true  (stored Cout == 4): rows = ci,  dense operand = act(norm(x[q][ci])),
+//                                    gathered operand = dOut[q (+) tap][0..3]       (walk over INPUT pixels q)
+// so the MFMA N dimension is always the 64 (tap, thin channel) pairs and no MFMA row is wasted on padding.
+// Every wave owns a pixel range, feeds the MFMA straight from global memory (no LDS staging, no barriers in
+// the loop) and keeps its whole 16*MB x 64 partial in accumulators:
+//   * B operand, lane (fr, fq): tap fr of pixel p + fq, its 4 channels = one 16-byte load;
+//   * A operand, lane (fr, fq): rows r0 + fr*MB + i (i < MB) of the same pixel = consecutive floats;
+//   * the four waves of a workgroup combine their partials through LDS; the workgroup's tile goes to the
+//     caller's workspace and a second small kernel adds the tiles of all pixel splits into dW (hundreds of
+//     workgroups adding into the same few thousand addresses would serialise in the memory-side atomic units).
+// (The row permutation relative to the wide kernel is only a relabelling of MFMA tiles.)
+// ------------------------------------------------------------------------------------------
+#ifndef SG_THIN_U
+#define SG_THIN_U 2
+#endif
+
+template <int MB, bool PRO, bool SWAP>
+__global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams G, float* ws) {
+    constexpr int ROWS = 16 * MB, COLS = 64, NB = 4;
+    static_assert(MB == 1 || MB == 2 || MB == 4, "operand widths");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][ROWS][COLS]
+    float* redb = red + 4 * ROWS * COLS;           // [4 waves][ROWS]
+    float* pss = redb + 4 * ROWS;                  // [2 * Cin] prologue scale | shift
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    int g = 0;
+    for (int gi = 1; gi < G.nprob; ++gi)
+        if ((int)blockIdx.z >= G.q[gi].z0) g = gi;
+    const SgWgradProb& Q = G.q[g];
+    const int zl = blockIdx.z - Q.z0;
+    const int phz = zl / Q.nsplit, split = zl % Q.nsplit;
+    const int Hp = Q.Hp[phz], Wp = Q.Wp[phz], M = Hp * Wp;
+    if (M == 0) return;
+    const int rows_total = SWAP ? G.Cin : G.Cout;
+    const int r0 = blockIdx.y * ROWS;
+    // this wave's pixel range: the workgroup's share of M, cut into 4 (multiples of 4 pixels)
+    const int per_wg = ((M + Q.nsplit - 1) / Q.nsplit + 15) & ~15;
+    const int per_wave = per_wg >> 2;
+    const int m_begin = split * per_wg + wid * per_wave;
+    const int m_end = min(M, m_begin + per_wave);
+
+    // lane constants: column group = tap fr, rows r0 + fr*MB + i
+    const bool kok = fr < G.ntaps[phz];
+    const int tdy = kok ? (int)G.taps[phz][fr].dy : 0, tdx = kok ? (int)G.taps[phz][fr].dx : 0;
+    const int row_l = r0 + fr * MB;
+    const bool rok = row_l < rows_total;
+    const int gs = G.is, os = G.os, oa = G.oa[phz], ob = G.ob[phz];
+    const float* gat = SWAP ? Q.dout : Q.in;
+    const float* den = SWAP ? Q.in : Q.dout;
+    const int gat_H = SWAP ? Q.Hout : Q.Hin, gat_W = SWAP ? Q.Wout : Q.Win, gat_ld = SWAP ? Q.dout_ld : Q.in_ld;
+    const int den_W = SWAP ? Q.Win : Q.Wout, den_ld = SWAP ? Q.in_ld : Q.dout_ld;
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gat), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(den), 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int OOB = (int)0x80000000u;
+    constexpr int NP = SWAP ? MB : NB;      // channels of x this lane touches
+    float psc[NP], psh[NP];
+    float pro_neg = 1.f;
+    if constexpr (PRO) {
+        // per-channel scale / shift once per workgroup (fp64 divide + sqrt per channel), then each lane picks its own
+        SgNorm pn;
+        pn.stats = Q.pro_stats; pn.gamma = Q.pro_gamma; pn.beta = Q.pro_beta; pn.count = Q.pro_count;
+        pn.eps = G.pro_eps; pn.act = G.pro_act; pn.slope = G.pro_slope; pn.sq_stride = Q.pro_sq;
+        pro_neg = G.pro_act == SGAN_ACT_NONE ? 1.f : (G.pro_act == SGAN_ACT_RELU ? 0.f : G.pro_slope);
+        for (int c = tid; c < G.Cin; c += 256) {
+            float sc = 1.f, sh = 0.f;
+            if (pn.stats) {
+                float mean, rstd;
+                sg_mean_rstd(pn, G.Cin, c, mean, rstd);
+                const float gm = pn.gamma ? pn.gamma[c] : 1.f;
+                const float bt = pn.beta ? pn.beta[c] : 0.f;
+                sc = gm * rstd;
+                sh = bt - mean * sc;
+            }
+            pss[c] = sc;
+            pss[G.Cin + c] = sh;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int c = SWAP ? row_l + j : j;
+            const bool cv = c < G.Cin;
+            psc[j] = cv ? pss[c] : 1.f;
+            psh[j] = cv ? pss[G.Cin + c] : 0.f;
+        }
+    }
+    const bool do_bias = !SWAP && Q.dbias != nullptr;
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) bsum[i] = 0.f;
+
+    // pixel walk of this lane: m = m_begin + fq, advancing by 4 per step (no division in the loop)
+    int m = m_begin + fq;
+    int py = m / Wp, px = m - py * Wp;
+    const int adv_y = 4 / Wp, adv_x = 4 - adv_y * Wp;
+
+    constexpr int U = SG_THIN_U;     // steps per group; group k+1 is in flight while group k feeds the MFMAs
+    f32x4 xb[2][U];
+    float da[2][U][MB];
+    bool gok[2][U], dok[2][U];
+    auto load_group = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool valid = m < m_end;
+            const int gy = py * gs + tdy, gx = px * gs + tdx;
+            const bool ok = valid && kok && (unsigned)gy < (unsigned)gat_H && (unsigned)gx < (unsigned)gat_W;
+            xb[slot][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, ok ? ((gy * gat_W + gx) * gat_ld) << 2 : OOB, 0, 0));
+            gok[slot][u] = ok;
+            const int pix = (py * os + oa) * den_W + (px * os + ob);
+            const int dof = (valid && rok) ? (pix * den_ld + row_l) << 2 : OOB;
+            dok[slot][u] = valid && rok;
+            if constexpr (MB == 1) {
+                da[slot][u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, dof, 0, 0));
+            } else if constexpr (MB == 2) {
+                da[slot][u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, dof, 0, 0));
+                da[slot][u][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, dof, 4, 0));
+            } else {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, dof, 0, 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) da[slot][u][i] = v[i];
+            }
+            m += 4;
+            py += adv_y;
+            px += adv_x;
+            while (px >= Wp) { px -= Wp; ++py; }
+        }
+    };
+    auto compute_group = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float b[NB], a[MB];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = xb[slot][u][e];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) a[i] = da[slot][u][i];
+            if constexpr (PRO && !SWAP) {   // x is the gathered operand: zero padding applies after norm + activation
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float y = b[j] * psc[j] + psh[j];
+                    b[j] = gok[slot][u] ? (y > 0.f ? y : y * pro_neg) : 0.f;
+                }
+            }
+            if constexpr (PRO && SWAP) {    // x is the dense operand
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const float y = a[i] * psc[i] + psh[i];
+                    a[i] = dok[slot][u] ? (y > 0.f ? y : y * pro_neg) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                bsum[i] += a[i];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    const int nsteps = (max(m_end - m_begin, 0) + 3) >> 2;
+    const int ngroups = (nsteps + U - 1) / U;
+    // branch-free body (loads past the range carry the out-of-range offset and return zeros): a conditional load
+    // would make the compiler wait for ALL outstanding loads at the join, serialising the two slots
+    load_group(0);
+    for (int gk = 0; gk < ngroups; gk += 2) {
+        load_group(1);
+        compute_group(0);
+        load_group(0);
+        compute_group(1);
+    }
+
+    // ---- combine the four waves through LDS (plain stores, then every thread sums 4 partials per element) ----
+    {
+        float* mine = red + wid * ROWS * COLS;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][e][r];
+                *reinterpret_cast<f32x4*>(mine + ((fq * 4 + r) * MB + i) * COLS + fr * NB) = v;
+            }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            float b = bsum[i];
+            b += __shfl_xor(b, 16);
+            b += __shfl_xor(b, 32);
+            if (fq == 0) redb[wid * ROWS + fr * MB + i] = b;
+        }
+    }
+    __syncthreads();
+    float* part = ws ? ws + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (ROWS * COLS + ROWS) : nullptr;
+    for (int e = tid; e < ROWS * COLS; e += 256) {
+        const float v = (red[e] + red[ROWS * COLS + e]) + (red[2 * ROWS * COLS + e] + red[3 * ROWS * COLS + e]);
+        if (part) {
+            part[e] = v;
+        } else {   // no workspace: straight to dW (same result, contended atomics)
+            const int rl = e / COLS, kl = e - rl * COLS, t = kl >> 2, c4 = kl & 3;
+            const int row = r0 + rl;
+            if (row < rows_total && t < G.ntaps[phz] && c4 < (SWAP ? G.Cout : G.Cin))
+                atomicAdd(Q.dw + G.taps[phz][t].w_off + (SWAP ? (int64_t)c4 * G.w_ns + row : (int64_t)row * G.w_ns + c4), v);
+        }
+    }
+    if (tid < ROWS) {
+        const float b = (redb[tid] + redb[ROWS + tid]) + (redb[2 * ROWS + tid] + redb[3 * ROWS + tid]);
+        if (part) part[ROWS * COLS + tid] = do_bias ? b : 0.f;
+        else if (do_bias && r0 + tid < rows_total) atomicAdd(Q.dbias + r0 + tid, b);
+    }
+}
+
+// second stage: dW[tile element] += sum over the pixel splits of one (problem, phase, row block).  A workgroup is
+// 32 elements x 8 split lanes of 16 splits each; the 8 lanes meet in LDS and one atomic per element leaves.
+// SWAP launches carry extra z-slices (one per problem) that sum dOut over all pixels into dbias.
+template <int ROWS, bool SWAP>
+__global__ __launch_bounds__(256) void sg_wgrad_thin_reduce_kernel(const SgWgradParams G, const float* ws, int nrb) {
+    constexpr int COLS = 64, PS = ROWS * COLS + ROWS, CH = 16;
+    __shared__ float sred[8][33];
+    const int ngroups = G.nprob * G.nphase * nrb;
+    if ((int)blockIdx.z >= ngroups) {
+        if constexpr (SWAP) {   // bias gradient of a thin-Cout layer: sum of dOut over its pixels (<= 4 channels)
+            const SgWgradProb& Q = G.q[blockIdx.z - ngroups];
+            if (!Q.dbias) return;
+            const int npix = Q.Hout * Q.Wout;
+            const int nb = min((int)gridDim.x, 16);      // few workgroups: every one ends in an atomic on the same address
+            if (blockIdx.y != 0 || (int)blockIdx.x >= nb) return;
+            f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += nb * 256)
+                s4 += *reinterpret_cast<const f32x4*>(Q.dout + (int64_t)p * Q.dout_ld);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = s4[c];
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][c] = v;
+            }
+            __syncthreads();
+            if (threadIdx.x < 4 && (int)threadIdx.x < G.Cout)
+                atomicAdd(Q.dbias + threadIdx.x, (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]));
+        }
+        return;
+    }
+    int t = blockIdx.z;
+    const int rb = t % nrb; t /= nrb;     // t = problem * nphase + phase
+    const int g = t / G.nphase, phz = t - g * G.nphase;
+    const SgWgradProb& Q = G.q[g];
+    if (Q.Hp[phz] * Q.Wp[phz] == 0) return;
+    const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    const int sp0 = (blockIdx.y * 8 + cl) * CH;
+    if (blockIdx.y * 8 * CH >= Q.nsplit) return;
+    float sum = 0.f;
+    if (e < PS) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int sp = sp0 + u;
+            if (sp < Q.nsplit) sum += ws[((int64_t)(Q.z0 + phz * Q.nsplit + sp) * nrb + rb) * PS + e];
+        }
+    }
+    sred[cl][el] = sum;
+    __syncthreads();
+    if (cl != 0 || e >= PS) return;
+#pragma unroll
+    for (int c = 1; c < 8; ++c) sum += sred[c][el];
+    const int rows_total = SWAP ? G.Cin : G.Cout;
+    if (e < ROWS * COLS) {
+        const int rl = e / COLS, kl = e - rl * COLS, tp = kl >> 2, c4 = kl & 3;
+        const int row = rb * ROWS + rl;
+        if (row < rows_total && tp < G.ntaps[phz] && c4 < (SWAP ? G.Cout : G.Cin))
+            atomicAdd(Q.dw + G.taps[phz][tp].w_off + (SWAP ? (int64_t)c4 * G.w_ns + row : (int64_t)row * G.w_ns + c4), sum);
+    } else if (!SWAP && Q.dbias && rb * ROWS + (e - ROWS * COLS) < rows_total) {
+        atomicAdd(Q.dbias + rb * ROWS + (e - ROWS * COLS), sum);
+    }
+}
+
+template <int MB, bool SWAP>
+static int sg_launch_wgrad_thin(SgWgradParams& P, hipStream_t st, const char* name, void* workspace, int64_t workspace_bytes) {
+    constexpr int ROWS = 16 * MB, COLS = 64, PS = ROWS * COLS + ROWS;
+    const int nrb = sgw_cdiv(SWAP ? P.Cin : P.Cout, ROWS);
+    // ~4 waves per SIMD over the whole launch (1024 workgroups), >= 128 pixels per workgroup
+    long pix_total = 0;
+    for (int g = 0; g < P.nprob; ++g)
+        for (int i = 0; i < P.nphase; ++i) pix_total += (long)P.q[g].Hp[i] * P.q[g].Wp[i];
+    if (pix_total == 0) return workspace_bytes == -1 ? 0 : SGAN_OK;
+    const char* want_env = getenv("SGAN_THIN_WANT");        // tuning knobs
+    const int min_pix = getenv("SGAN_THIN_MINPIX") ? atoi(getenv("SGAN_THIN_MINPIX")) : 128;
+    const double want = (want_env ? atof(want_env) : 1024.0) / (double)nrb;
+    int z = 0, max_split = 1;
+    for (int g = 0; g < P.nprob; ++g) {
+        long pg = 0;
+        int maxM = 0;
+        for (int i = 0; i < P.nphase; ++i) {
+            pg += (long)P.q[g].Hp[i] * P.q[g].Wp[i];
+            maxM = max(maxM, P.q[g].Hp[i] * P.q[g].Wp[i]);
+        }
+        int nsplit = (int)(want * ((double)pg / (double)pix_total) / P.nphase + 0.5);
+        if (nsplit > maxM / min_pix) nsplit = maxM / min_pix;
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > 1024) nsplit = 1024;
+        P.q[g].nsplit = nsplit;
+        P.q[g].z0 = z;
+        z += P.nphase * nsplit;
+        max_split = max(max_split, nsplit);
+    }
+    const int64_t need = (int64_t)z * nrb * PS * 4;
+    if (workspace_bytes == -1) return (int)((need + 1023) >> 10);   // query (KiB)
+    float* ws = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
+    if (SWAP && !ws) return 1;    // the bias of a thin-Cout layer rides on the second stage: caller falls back to the tiled kernel
+    dim3 grid(1, nrb, z);
+    const size_t lds = (size_t)(4 * PS + 2 * P.Cin) * 4;
+    bool pro = P.pro_act != SGAN_ACT_NONE;
+    for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
+    sg_prof_begin(st);
+    if (pro) hipLaunchKernelGGL((sg_wgrad_thin_kernel<MB, true, SWAP>), grid, dim3(256), lds, st, P, ws);
+    else hipLaunchKernelGGL((sg_wgrad_thin_kernel<MB, false, SWAP>), grid, dim3(256), lds, st, P, ws);
+    SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = name;
+    sg_prof_end(st, g_sgan_last_kernel);
+    if (ws) {
+        dim3 g2(sgw_cdiv(PS, 32), sgw_cdiv(max_split, 128), P.nprob * P.nphase * nrb + (SWAP ? P.nprob : 0));
+        hipLaunchKernelGGL((sg_wgrad_thin_reduce_kernel<ROWS, SWAP>), g2, dim3(256), 0, st, P, ws, nrb);
+        SGAN_LAUNCH_CHECK();
+    }
+    return SGAN_OK;
+}
+
+// thin-Cout layers walk the INPUT pixels: one "phase", the k*k taps gather dOut at q*gs + (dy, dx)
+static void sg_thin_swap_geometry(SgWgradParams& P, const sgan_conv_desc* d0, const sgan_conv_wgrad_job* jobs, int n) {
+    const int k = d0->k, p = d0->pad;
+    const bool tr = d0->kind == SGAN_CONVT;
+    P.nphase = 1;
+    P.is = tr ? d0->stride : 1;
+    P.os = 1;
+    P.oa[0] = P.ob[0] = 0;
+    P.ntaps[0] = k * k;
+    P.ktot[0] = 64;
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx) {
+            SgTap& t = P.taps[0][ky * k + kx];
+            t.dy = (int16_t)(tr ? ky - p : p - ky);
+            t.dx = (int16_t)(tr ? kx - p : p - kx);
+            t.w_off = (ky * k + kx) * d0->Cout * d0->Cin;
+        }
+    for (int g = 0; g < n; ++g) {
+        P.q[g].Hp[0] = jobs[g].d->Hin;
+        P.q[g].Wp[0] = jobs[g].d->Win;
+    }
+}
+
+extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* workspace, int64_t workspace_bytes,
+                                       void* stream) {
     SGAN_CHECK(jobs && n >= 1 && n <= SGW_MAX_PROB, "1..%d jobs", SGW_MAX_PROB);
     SgWgradParams P;
     memset(&P, 0, sizeof(P));
@@ -402,13 +761,31 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
     }
     P.Cin = d0->Cin; P.Cout = d0->Cout; P.w_ns = d0->Cin;
     hipStream_t st = (hipStream_t)stream;
+    if (!getenv("SGAN_NO_THIN_WGRAD") && d0->k * d0->k <= 16) {
+        if (d0->Cin == 4 && P.nphase == 1) {      // conv-form gather of a 4-channel image
+            if (d0->Cout <= 16) return sg_launch_wgrad_thin<1, false>(P, st, "sg_wgrad_thin_kernel<1,cin4>", workspace, workspace_bytes);
+            if (d0->Cout <= 32) return sg_launch_wgrad_thin<2, false>(P, st, "sg_wgrad_thin_kernel<2,cin4>", workspace, workspace_bytes);
+            return sg_launch_wgrad_thin<4, false>(P, st, "sg_wgrad_thin_kernel<4,cin4>", workspace, workspace_bytes);
+        }
+        if (d0->Cout == 4 && d0->Cin >= 16 && (d0->kind == SGAN_CONVT || d0->stride == 1) &&
+            (workspace_bytes == -1 || workspace != nullptr)) {
+            SgWgradParams S = P;
+            sg_thin_swap_geometry(S, d0, jobs, n);
+            int rc;
+            if (d0->Cin <= 32) rc = sg_launch_wgrad_thin<2, true>(S, st, "sg_wgrad_thin_kernel<2,cout4>", workspace, workspace_bytes);
+            else rc = sg_launch_wgrad_thin<4, true>(S, st, "sg_wgrad_thin_kernel<4,cout4>", workspace, workspace_bytes);
+            if (rc != 1 || workspace_bytes == -1) return rc;
+        }
+    }
+    if (workspace_bytes == -1) return 0;   // the tiled kernel combines its splits with atomics: no workspace
     if (d0->Cout <= 16) return sg_launch_wgrad<16, 128, 1, 4>(P, st);
     if (d0->Cout <= 32) return sg_launch_wgrad<32, 64, 1, 4>(P, st);
     return sg_launch_wgrad<64, 64, 2, 2>(P, st);
 }
 
 extern "C" int sgan_conv_wgrad(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
-                               const float* dout, int32_t dout_ld, float* dw, float* dbias, void* stream) {
+                               const float* dout, int32_t dout_ld, float* dw, float* dbias, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
     sgan_conv_wgrad_job j = {d, in, in_ld, in_norm, dout, dout_ld, dw, dbias};
-    return sgan_conv_wgrad_grouped(&j, 1, stream);
+    return sgan_conv_wgrad_grouped(&j, 1, workspace, workspace_bytes, stream);
 }

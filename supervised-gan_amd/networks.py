@@ -118,6 +118,20 @@ class _ParamBox(nn.Module):
         return ", ".join(f"{n}={tuple(p.shape)}" for n, p in self._parameters.items() if p is not None)
 
 
+class _BwdArena:
+    """Zeroed fp64 scratch for the backward sums, carved from the same fill as the forward statistics.  A second
+    backward through the same forward (retain_graph) gets a fresh zeroed buffer."""
+
+    def __init__(self, buf):
+        self.buf, self.dev = buf, buf.device
+
+    def take(self, n):
+        buf, self.buf = self.buf, None
+        if buf is None or buf.numel() < n:
+            return torch.zeros(n, dtype=torch.float64, device=self.dev)
+        return buf[:n]
+
+
 class ChainNet(nn.Module):
     """A sequential conv net as a layer program over flat fp32 storage.
 
@@ -314,7 +328,8 @@ class ChainNet(nn.Module):
         assert Cs == self.layers[0].cin_s, (Cs, self.layers[0].cin_s)
         geo = self._geometry(H, W)
         n_stats = sum(2 * L.cout_s for L in self.layers if L.norm)
-        arena = torch.zeros(max(n_stats, 1), dtype=torch.float64, device=x.device)
+        # one zero-fill serves the forward statistics and the backward sums (second half, consumed by run_backward)
+        arena = torch.zeros(max(2 * n_stats, 1), dtype=torch.float64, device=x.device)
         stats, o = [], 0
         for L in self.layers:
             if L.norm:
@@ -322,6 +337,7 @@ class ChainNet(nn.Module):
                 o += 2 * L.cout_s
             else:
                 stats.append(None)
+        stats.append(_BwdArena(arena[n_stats:]))
         outs = []
         cur = x
         for li, L in enumerate(self.layers):
@@ -356,7 +372,7 @@ class ChainNet(nn.Module):
             ops.tanh_bwd(dcur.contiguous(), outs[-1], d2)
             dcur = d2
         n_sums = sum(2 * L.cout_s for L in self.layers if L.norm)
-        arena = torch.zeros(max(n_sums, 1), dtype=torch.float64, device=dev)
+        arena = stats[-1].take(max(n_sums, 1))
         sums, o = [], 0
         for L in self.layers:
             if L.norm:
@@ -451,7 +467,8 @@ def _grouped_forward(nets, xs):
     J = len(nets)
     geos = [n._geometry(x.shape[0], x.shape[1]) for n, x in zip(nets, xs)]
     per_job = sum(2 * L.cout_s for L in nets[0].layers if L.norm)
-    arena = torch.zeros(max(per_job * J, 1), dtype=torch.float64, device=dev)
+    arena = torch.zeros(max(2 * per_job * J, 1), dtype=torch.float64, device=dev)   # forward statistics | backward sums
+    bwd = _BwdArena(arena[per_job * J:])
     stats = []
     for j in range(J):
         st, o = [], j * per_job
@@ -461,6 +478,7 @@ def _grouped_forward(nets, xs):
                 o += 2 * L.cout_s
             else:
                 st.append(None)
+        st.append(bwd)
         stats.append(st)
     outs = [[] for _ in range(J)]
     cur = list(xs)
@@ -504,7 +522,7 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
             ops.tanh_bwd(dcur[j].contiguous(), outs[j][-1], d2)
             dcur[j] = d2
     per_job = sum(2 * L.cout_s for L in nets[0].layers if L.norm)
-    arena = torch.zeros(max(per_job * J, 1), dtype=torch.float64, device=dev)
+    arena = stats[0][-1].take(max(per_job * J, 1))
     sums = []
     for j in range(J):
         sm, o = [], j * per_job
@@ -531,14 +549,17 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
                 dins.append(din)
                 jobs.append((desc, dcur[j], net._wb(net.layers[li])[0], din, srcs[j], norms[j], sums[j][li - 1]))
             ops.conv_dgrad_grouped(jobs)
+            nb = []
             for j, net in enumerate(nets):
                 Pv = net.layers[li - 1]
                 if Pv.norm:
                     bn = Pv.norm == "bn" and want_wgrad[j]
                     dg = net._gflat[Pv.g_off: Pv.g_off + Pv.cout_s] if bn else None
                     db = net._gflat[Pv.be_off: Pv.be_off + Pv.cout_s] if bn else None
-                    ops.norm_bwd_apply(dins[j], srcs[j], norms[j], sums[j][li - 1], dg, db)
+                    nb.append((dins[j], srcs[j], norms[j], sums[j][li - 1], dg, db))
                 dcur[j] = dins[j]
+            if nb:
+                ops.norm_bwd_apply_multi(nb)
         else:
             dj = [j for j in range(J) if need_dx[j]]
             if dj:
@@ -748,7 +769,7 @@ class UnetGenerator(ChainNet):
         key = ("tmpl", hw[0], str(dev))
         if key not in self._geom_cache:
             lay, total = self._stat_layout(hw)
-            t = torch.zeros(total, dtype=torch.float64)
+            t = torch.zeros(2 * total, dtype=torch.float64)      # forward statistics | backward sums (zeros)
             one_minus_eps = 1.0 - float(np.float32(IN_EPS))
             for l in range(1, self.n):
                 o, wdt = lay[("cat", l)]
@@ -856,7 +877,7 @@ class UnetGenerator(ChainNet):
         out = torch.empty((H, W, L.cout_s), dtype=torch.float32, device=dev)
         ops.conv_fwd(upd[0], cat[1], self._cat_norm(1, hw, catstat), wt, b, out, self.final_act, None)
         saved = dict(x=x, hw=hw, cat=cat, catw=catw, catstat=catstat, ustat=ustat, xr=xr, xstat=xstat, u=u, masks=masks,
-                     out=out, lay=lay, total=total)
+                     out=out, lay=lay, total=total, bwd=_BwdArena(arena[total:]))
         return [out], saved
 
     def run_backward(self, x, outs, S, dout, need_dx, want_wgrad):
@@ -869,7 +890,7 @@ class UnetGenerator(ChainNet):
         d0 = torch.empty_like(S["out"])
         ops.tanh_bwd(dout.contiguous(), S["out"], d0)
         lay = S["lay"]
-        arena = torch.zeros(S["total"], dtype=torch.float64, device=dev)
+        arena = S["bwd"].take(S["total"])
         csum, usum, xsum = [None] * (n + 1), [None] * (n + 1), [None] * n
         for l in range(1, n):
             o, wdt = lay[("cat", l)]

@@ -81,8 +81,9 @@ def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None, sums_sq=0
 
 
 def conv_wgrad(desc, x, in_norm, dout, dw, dbias):
-    L.check(L.lib().sgan_conv_wgrad(C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(_act(dout)), dout.stride(1),
-                                    _ptr(dw), _ptr(dbias), _stream()), "sgan_conv_wgrad")
+    args = (C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(_act(dout)), dout.stride(1), _ptr(dw), _ptr(dbias))
+    ws = _workspace(L.lib().sgan_conv_wgrad(*args, None, -1, None), x.device) if min(desc.Cin, desc.Cout) <= 4 else None
+    L.check(L.lib().sgan_conv_wgrad(*args, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "sgan_conv_wgrad")
 
 
 def _pn(d):
@@ -120,13 +121,29 @@ def conv_wgrad_grouped(jobs):
     for i, (desc, x, in_norm, dout, dw, dbias) in enumerate(jobs):
         arr[i] = L.ConvWgradJob(C.pointer(desc), _ptr(_act(x)).value, x.stride(1), _pn(in_norm), _ptr(_act(dout)).value,
                                 dout.stride(1), _ptr(dw).value, _ptr(dbias).value)
-    L.check(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), _stream()), "sgan_conv_wgrad_grouped")
+    d0 = jobs[0][0]
+    ws = _workspace(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device) if min(d0.Cin, d0.Cout) <= 4 else None
+    L.check(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
+            "sgan_conv_wgrad_grouped")
 
 
 def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None, sums_sq=0):
     H, W, Cs = dy.shape
     L.check(L.lib().sgan_norm_bwd_apply(_ptr(_act(dy)), dy.stride(1), _ptr(_act(x)), x.stride(1), H * W, Cs, _nd(x_norm),
                                         _ptr(bwd_sums), int(sums_sq), _ptr(dgamma), _ptr(dbeta), _stream()), "sgan_norm_bwd_apply")
+
+
+def norm_bwd_apply_multi(jobs):
+    """jobs: list of (dy, x, x_norm, bwd_sums, dgamma, dbeta[, sums_sq]) -> one launch (<= 8 per launch)."""
+    for i0 in range(0, len(jobs), 8):
+        part = jobs[i0:i0 + 8]
+        arr = (L.NormBwdJob * len(part))()
+        for i, job in enumerate(part):
+            dy, x, x_norm, sums, dg, db = job[:6]
+            H, W, Cs = dy.shape
+            arr[i] = L.NormBwdJob(_ptr(_act(dy)).value, dy.stride(1), _ptr(_act(x)).value, x.stride(1), H * W, Cs, C.pointer(x_norm),
+                                  _ptr(sums).value, int(job[6]) if len(job) > 6 else 0, _ptr(dg).value, _ptr(db).value)
+        L.check(L.lib().sgan_norm_bwd_apply_multi(arr, len(part), _stream()), "sgan_norm_bwd_apply_multi")
 
 
 def norm_apply_fwd(u, u_norm, t, mask=None, noise=None, sigma=0.0):

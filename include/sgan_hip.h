@@ -251,6 +251,22 @@ int sgan_norm_apply_bwd_sums(float* dt, int32_t dt_ld, const float* mask, const 
 /* mask[i] = uniform(Philox(seed, *offset_dev + i)) < p ? 0 : 1/(1-p); advances *offset_dev (nn.Dropout). */
 int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* offset_dev, void* stream);
 
+/* ---- CRN building blocks (models/networks.py:642-794) --------------------------------------------
+ * sgan_bilinear_up2_fwd: nn.Upsample(scale_factor=2, mode='bilinear') (align_corners = False) of an [H, W, C] tensor
+ * into [2H, 2W, C], accumulating the (sum, sumsq) statistics of the result for the InstanceNorm that follows it
+ * (CrnUpsampleBlock :741-746).  sgan_bilinear_up2_bwd is its adjoint (din [H, W, C] from dout [2H, 2W, C]).
+ * sgan_avgpool_pyramid_fwd: the six label maps AvgPool2d(2^(s+1)) (label), s = 0..5, of
+ * CascadedRefinementNetwork.forward (:709-731) in one launch (4 stored channels; H, W divisible by 64);
+ * sgan_avgpool_pyramid_bwd: dlabel (+)= sum_s upsample(dlevels[s]) / 4^(s+1) (NULL levels are skipped). */
+int sgan_bilinear_up2_fwd(const float* in, int32_t in_ld, int32_t H, int32_t W, int32_t C, float* out, int32_t out_ld,
+                          double* out_stats, int32_t out_stats_sq_stride, void* stream);
+int sgan_bilinear_up2_bwd(const float* dout, int32_t dout_ld, int32_t H, int32_t W, int32_t C, float* din, int32_t din_ld,
+                          void* stream);
+int sgan_avgpool_pyramid_fwd(const float* label, int32_t ld, int32_t H, int32_t W, float* const* levels,
+                             const int32_t* level_ld, void* stream);
+int sgan_avgpool_pyramid_bwd(const float* const* dlevels, const int32_t* level_ld, int32_t H, int32_t W, float* dlabel,
+                             int32_t ld, int32_t accumulate, void* stream);
+
 /* ---- weighted L1 (cgan): loss = lambda * mean(|x - y| * w), w = 1 + sum_i ((a_i + 1)/2) * (weights_i - 1) over the
  * first nweights channels of the label image `a` (w = 1 when a == NULL; with nweights == 0, `a` is the weight map
  * itself, one value per pixel).  Also writes g = dloss/dx (unscaled by

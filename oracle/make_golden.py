@@ -352,6 +352,28 @@ def golden_unet_small():
         save(f"unet_small_{tag}.npz", **arrs)
 
 
+def golden_crn_small():
+    """crn at 128x128 (label 2 ch, noise 8 x 2 x 2), ngf 8: ConvTranspose upsampling with 1-layer blocks, and the README's
+    bilinear upsampling with 2-layer blocks; shared label block."""
+    for tag, mode, nlb in (("convt_b1", "convt", 1), ("bilinear_b2", "bilinear", 2)):
+        in_nc, out_nc, nz, ngf, hw = 2, 1, 8, 8, 128
+        sd = O.init_crn(41, in_nc, out_nc, nz, ngf, mode, nlb, True)
+        g = RN.define_G(in_nc, out_nc, ngf, "crn", "instance", False, n_layers_G=5, noise_nc=nz, upsample_mode=mode,
+                        n_layers_CRN_block=nlb, share_label_weights=True, gpu_ids=[])
+        assert list(g.state_dict().keys()) == list(sd.keys()), (list(g.state_dict().keys()), list(sd.keys()))
+        load_sd(g, sd)
+        label = O.np_uniform(401, (1, in_nc, hw, hw)).requires_grad_(True)
+        z = O.np_normal(402, (1, nz, hw // 64, hw // 64)).requires_grad_(True)
+        r = O.np_normal(403, (1, out_nc, hw, hw))
+        y = g.forward(label, z)
+        loss = (y * r).sum()
+        loss.backward()
+        arrs = {"y": y.detach().numpy(), "dlabel": label.grad.numpy(), "dz": z.grad.numpy(), "loss": np.float64(loss.item())}
+        for k, p in g.named_parameters():
+            arrs["grad/" + k] = p.grad.numpy()
+        save(f"crn_small_{tag}.npz", **arrs)
+
+
 def build_ref_cgan(cfg: "O.CGANConfig", seed: int, tmpdir: str):
     from options.train_options import TrainOptions
     from models.cgan_model import CGANModel
@@ -448,6 +470,8 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
+    if not only or "crn" in only:
+        golden_crn_small()
     if not only or "cgan" in only:
         golden_unet_small()
         golden_cgan_step("cgan_step_small.npz", O.CGANConfig(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0)),

@@ -23,6 +23,7 @@ Reference map (paths relative to /root/reference):
   GANLoss                                     models/networks.py:152-185
   WeightedL1Loss                              models/networks.py:205-214
   UnetGenerator / UnetSkipConnectionBlock     models/networks.py:318-419
+  CascadedRefinementNetwork / Crn*Block       models/networks.py:642-794
   CGANModel step recipe                       models/cgan_model.py:134-226
   FCGANModel step recipe                      models/fcgan_model.py:124-193
   Adam hyper-parameters                       models/fcgan_model.py:98-109, options/train_options.py:16-17
@@ -511,6 +512,86 @@ def norm_cancelled_keys_unet(num_downs: int, ngf: int = 64, num_skips: int = -1)
             keys.add(lv["down"][0] + ".bias")
         if lv["up_norm"]:
             keys.add(lv["up"][0] + ".bias")
+    return keys
+
+
+# ----------------------------------------------------------------------------------
+# Cascaded refinement network (models/networks.py:642-794)
+# ----------------------------------------------------------------------------------
+def crn_plan(input_nc: int, output_nc: int, noise_nc: int, ngf: int, upsample_mode: str = "convt", n_layers_block: int = 1,
+             share_label_weights: bool = True):
+    """[(key, kind, cin, cout, bias)] of every conv of CascadedRefinementNetwork in the reference's module order
+    (blockh5 .. blockh0, then the label block(s)); kind 'conv3' = Conv2d(k3,s1,p1), 'convt' = ConvTranspose2d(k4,s2,p1)."""
+    convs = []
+    for s in range(5, -1, -1):
+        cin = noise_nc + input_nc if s == 5 else 2 * ngf
+        if upsample_mode == "convt":
+            convs.append((f"blockh{s}.0.model.0", "convt", cin, ngf, False))            # :736-740
+        elif upsample_mode == "bilinear":
+            convs.append((f"blockh{s}.0.model.0", "conv3", cin, ngf, True))             # :741-746
+        else:
+            raise NotImplementedError(upsample_mode)
+        for i in range(1, n_layers_block):                                              # CrnInterBlock :760-779
+            convs.append((f"blockh{s}.1.model.{3 * (i - 1) + 1}", "conv3", ngf, ngf, True))
+        convs.append((f"blockh{s}.1.model.{3 * (n_layers_block - 1) + 1}", "conv3", ngf, output_nc if s == 0 else ngf, True))
+    if share_label_weights:
+        convs.append(("blockl.0", "conv3", input_nc, ngf, True))                        # :684-688
+    else:
+        for s in range(4, -1, -1):
+            convs.append((f"blockl{s}.0", "conv3", input_nc, ngf, True))
+    return convs
+
+
+def init_crn(seed: int, input_nc: int, output_nc: int, noise_nc: int, ngf: int = 64, upsample_mode: str = "convt",
+             n_layers_block: int = 1, share_label_weights: bool = True):
+    sd = OrderedDict()
+    for k, (key, kind, cin, cout, bias) in enumerate(crn_plan(input_nc, output_nc, noise_nc, ngf, upsample_mode, n_layers_block,
+                                                              share_label_weights)):
+        if kind == "convt":
+            sd[key + ".weight"] = np_normal(seed * 1000 + 2 * k, (cin, cout, 4, 4), 0.0, 0.02)
+        else:
+            sd[key + ".weight"] = np_normal(seed * 1000 + 2 * k, (cout, cin, 3, 3), 0.0, 0.02)
+            if bias:
+                b = 1.0 / math.sqrt(cin * 9)
+                sd[key + ".bias"] = np_uniform(seed * 1000 + 2 * k + 1, (cout,), -b, b)
+    return sd
+
+
+def crn_forward(sd, label, noise, ngf: int, upsample_mode: str = "convt", n_layers_block: int = 1,
+                share_label_weights: bool = True, tanh: bool = True):
+    """CascadedRefinementNetwork.forward (:708-733) with CrnUpsampleBlock (:737-757) and CrnInterBlock (:760-787)
+    inlined; InstanceNorm2d(affine=False), no Gaussian noise."""
+    def conv3(x, key):
+        return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=1, padding=1)
+
+    def block(s, x):
+        k0 = f"blockh{s}.0.model.0"
+        if upsample_mode == "convt":
+            h = F.conv_transpose2d(x, sd[k0 + ".weight"], None, stride=2, padding=1)
+        else:
+            h = F.interpolate(conv3(x, k0), scale_factor=2, mode="bilinear", align_corners=False)
+        h = F.instance_norm(h, eps=IN_EPS)
+        for i in range(n_layers_block):
+            h = conv3(F.relu(h), f"blockh{s}.1.model.{3 * i + 1}")
+            if not (s == 0 and i == n_layers_block - 1):
+                h = F.instance_norm(h, eps=IN_EPS)
+        return h
+
+    h = block(5, torch.cat([F.avg_pool2d(label, 64, 64), noise], 1))
+    for s in range(4, -1, -1):
+        l = F.avg_pool2d(label, 2 ** (s + 1), 2 ** (s + 1))
+        l = F.instance_norm(conv3(l, "blockl.0" if share_label_weights else f"blockl{s}.0"), eps=IN_EPS)
+        h = block(s, torch.cat([l, h], 1))
+    return torch.tanh(h) if tanh else h
+
+
+def norm_cancelled_keys_crn(input_nc, output_nc, noise_nc, ngf, upsample_mode="convt", n_layers_block=1, share_label_weights=True):
+    keys = set()
+    plan = crn_plan(input_nc, output_nc, noise_nc, ngf, upsample_mode, n_layers_block, share_label_weights)
+    last = f"blockh0.1.model.{3 * (n_layers_block - 1) + 1}"
+    for key, kind, cin, cout, bias in plan:
+        if bias and key != last:
+            keys.add(key + ".bias")
     return keys
 
 

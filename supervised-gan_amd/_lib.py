@@ -71,6 +71,10 @@ SIGNATURES = {
     "sgan_conv_wgrad_grouped": [C.POINTER(ConvWgradJob), _I, _P, _L, _P],
     "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
     "sgan_norm_bwd_apply_multi": [C.POINTER(NormBwdJob), _I, _P],
+    "sgan_bilinear_up2_fwd": [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
+    "sgan_bilinear_up2_bwd": [_P, _I, _I, _I, _I, _P, _I, _P],
+    "sgan_avgpool_pyramid_fwd": [_P, _I, _I, _I, _P, _P, _P],
+    "sgan_avgpool_pyramid_bwd": [_P, _P, _I, _I, _P, _I, _I, _P],
     "sgan_norm_apply_fwd": [_P, _I, C.POINTER(NormDesc), _P, _P, _F, _P, _I, _I, _I, _P],
     "sgan_norm_apply_bwd_sums": [_P, _I, _P, _P, _I, C.POINTER(NormDesc), _P, _I, _I, _P],
     "sgan_dropout_mask": [_P, _L, _F, C.c_uint64, _P, _P],

@@ -12,7 +12,7 @@ from collections import OrderedDict
 
 import torch
 
-from . import networks
+from . import networks, ops
 from .base_model import BaseModel
 from .image_pool import ImagePool
 from .optim import FusedAdam
@@ -38,6 +38,10 @@ class CGANModel(BaseModel):
         self.input_A = self.Tensor(opt.batchSize, opt.input_nc, opt.fineSize, opt.fineSize)
         self.input_B = self.Tensor(opt.batchSize, opt.output_nc, opt.fineSize, opt.fineSize)
         self.noise = None
+        self.noise_ = self.Tensor(opt.batchSize, opt.noise_nc, opt.noiseSize, opt.noiseSize)
+        self._rng_seed = 0 if opt.manualSeed is None else int(opt.manualSeed)
+        self._rng_offset = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.noise_source = None    # optional callable() -> z tensor (tests inject latents)
 
         self.netG = networks.define_G(opt.input_nc, opt.output_nc, opt.ngf, opt.which_model_netG, opt.norm,
                                       not opt.no_dropout, n_layers_G=opt.n_layers_G, use_residual=opt.use_residual,
@@ -95,9 +99,20 @@ class CGANModel(BaseModel):
         self.input_B.resize_(b.size()).copy_(b)
         self.image_paths = input.get('A_paths' if AtoB else 'B_paths')
 
+    def _draw_noise(self):
+        """z ~ N(0, 1) [1, noise_nc, noiseSize, noiseSize] (cgan_model.py:137-138); only the CRN generator reads it."""
+        if not hasattr(self.netG, 'noise_nc'):
+            return None
+        if self.noise_source is not None:
+            self.noise_.copy_(self.noise_source())
+        else:
+            ops.normal_fill(self.noise_, self._rng_seed + 977, self._rng_offset)
+        return self.noise_
+
     def forward(self):
         self.real_A = self.input_A
         self.real_B = self.input_B
+        self.noise = self._draw_noise()
         self.fake_B = self.netG.forward(self.real_A, self.noise)
 
     sample_noise = forward
@@ -109,6 +124,7 @@ class CGANModel(BaseModel):
     def test(self):
         with torch.no_grad():
             self.real_A = self.input_A
+            self.noise = self._draw_noise()
             self.fake_B = self.netG.forward(self.real_A, self.noise)
 
     def get_image_paths(self):

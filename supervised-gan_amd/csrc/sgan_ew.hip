@@ -450,6 +450,190 @@ extern "C" int sgan_gauss_down_bwd(const float* dout, int32_t dout_ld, int32_t H
 }
 
 // ------------------------------------------------------------------------------------------
+// CRN: bilinear x2 upsampling (align_corners = False) with the statistics of its result, its adjoint,
+// and the label pyramid AvgPool2d(2^(s+1)), s = 0..5
+// ------------------------------------------------------------------------------------------
+// out[2i + a] = 0.25 * in[clamp(i - 1 + 2a)] + 0.75 * in[i]   (a = 0: neighbour i-1, a = 1: neighbour i+1), separable.
+// Thread t always works on channel quad t % (C/4) (host: 256 % (C/4) == 0), so the per-channel sums stay in registers.
+__global__ __launch_bounds__(256) void sg_bilinear_up2_fwd_kernel(const float* in, int in_ld, int H, int W, int C, float* out,
+                                                                  int out_ld, double* stats, int stats_sq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem);   // [2C], fp64 from the first add (see sg_igemm_kernel)
+    for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.0;
+    __syncthreads();
+    const int CQ = C >> 2, Wo = 2 * W;
+    const int64_t total = (int64_t)4 * H * W * CQ;
+    const int c = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % CQ) * 4;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t pix = e / CQ;
+        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+        const int iy = oy >> 1, ix = ox >> 1;
+        const int ny = min(max(iy - 1 + 2 * (oy & 1), 0), H - 1), nx = min(max(ix - 1 + 2 * (ox & 1), 0), W - 1);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(in + ((int64_t)iy * W + ix) * in_ld + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(in + ((int64_t)iy * W + nx) * in_ld + c);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(in + ((int64_t)ny * W + ix) * in_ld + c);
+        const f32x4 f = *reinterpret_cast<const f32x4*>(in + ((int64_t)ny * W + nx) * in_ld + c);
+        const f32x4 v = 0.75f * (0.75f * a + 0.25f * b) + 0.25f * (0.75f * d + 0.25f * f);
+        *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s1[j] += (double)v[j];
+            s2[j] += (double)v[j] * (double)v[j];
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&red[c + j], s1[j]);
+            atomicAdd(&red[C + c + j], s2[j]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += 256) {
+            atomicAdd(&stats[i], red[i]);
+            atomicAdd(&stats[stats_sq + i], red[C + i]);
+        }
+    }
+}
+
+// din[i] = sum over output rows {2i-1, 2i, 2i+1, 2i+2} (clamped into the image) with weights {.25, .75, .75, .25}, separable
+__global__ __launch_bounds__(256) void sg_bilinear_up2_bwd_kernel(const float* dout, int dout_ld, int H, int W, int C, float* din,
+                                                                  int din_ld) {
+    const int CQ = C >> 2, Ho = 2 * H, Wo = 2 * W;
+    const int64_t total = (int64_t)H * W * CQ;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % CQ) * 4;
+        const int64_t pix = e / CQ;
+        const int ix = (int)(pix % W), iy = (int)(pix / W);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oy = min(max(2 * iy - 1 + a, 0), Ho - 1);
+            const float wy = (a == 0 || a == 3) ? 0.25f : 0.75f;
+            f32x4 row = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int ox = min(max(2 * ix - 1 + b, 0), Wo - 1);
+                const float wx = (b == 0 || b == 3) ? 0.25f : 0.75f;
+                row += wx * *reinterpret_cast<const f32x4*>(dout + ((int64_t)oy * Wo + ox) * dout_ld + c);
+            }
+            acc += wy * row;
+        }
+        *reinterpret_cast<f32x4*>(din + pix * din_ld + c) = acc;
+    }
+}
+
+extern "C" int sgan_bilinear_up2_fwd(const float* in, int32_t in_ld, int32_t H, int32_t W, int32_t C, float* out, int32_t out_ld,
+                                     double* out_stats, int32_t out_stats_sq_stride, void* stream) {
+    SGAN_CHECK(in && out && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && in_ld >= C && out_ld >= C && (in_ld & 3) == 0 &&
+                   (out_ld & 3) == 0, "bad argument");
+    SGAN_CHECK(256 % (C >> 2) == 0, "channel count must be 4 * a divisor of 256");
+    const int64_t total = (int64_t)4 * H * W * (C >> 2);
+    int blocks = ew_cdiv(total, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sg_bilinear_up2_fwd_kernel, dim3(blocks), dim3(256), (size_t)2 * C * 8, (hipStream_t)stream, in, in_ld, H, W,
+                       C, out, out_ld, out_stats, out_stats_sq_stride ? out_stats_sq_stride : C);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_bilinear_up2_bwd(const float* dout, int32_t dout_ld, int32_t H, int32_t W, int32_t C, float* din,
+                                     int32_t din_ld, void* stream) {
+    SGAN_CHECK(dout && din && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && din_ld >= C && dout_ld >= C && (din_ld & 3) == 0 &&
+                   (dout_ld & 3) == 0, "bad argument");
+    const int64_t total = (int64_t)H * W * (C >> 2);
+    int blocks = ew_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sg_bilinear_up2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, dout_ld, H, W, C, din,
+                       din_ld);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+struct SgPyramid { float* l[6]; int32_t ld[6]; };
+
+// one workgroup per 64x64 tile of the label image: level s = mean over 2^(s+1) x 2^(s+1) pixels, built level by level in LDS
+__global__ __launch_bounds__(256) void sg_avgpool_pyramid_fwd_kernel(const float* label, int ld, int H, int W, SgPyramid P) {
+    __shared__ f32x4 lv[32 * 32];
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int y = i >> 5, x = i & 31;
+        const float* p = label + ((int64_t)(ty0 + 2 * y) * W + (tx0 + 2 * x)) * ld;
+        const f32x4 v = 0.25f * ((*reinterpret_cast<const f32x4*>(p) + *reinterpret_cast<const f32x4*>(p + ld)) +
+                                 (*reinterpret_cast<const f32x4*>(p + (int64_t)W * ld) + *reinterpret_cast<const f32x4*>(p + (int64_t)W * ld + ld)));
+        lv[i] = v;
+        *reinterpret_cast<f32x4*>(P.l[0] + ((int64_t)(ty0 / 2 + y) * (W / 2) + (tx0 / 2 + x)) * P.ld[0]) = v;
+    }
+    int n = 32;   // side of the level held in lv[] (row pitch stays 32)
+    for (int s = 1; s < 6; ++s) {
+        __syncthreads();
+        const int m = n >> 1;
+        f32x4 v[4];
+        int cnt = 0;
+        for (int i = threadIdx.x; i < m * m; i += 256, ++cnt) {
+            const int y = i / m, x = i % m;
+            v[cnt] = 0.25f * ((lv[(2 * y) * 32 + 2 * x] + lv[(2 * y) * 32 + 2 * x + 1]) + (lv[(2 * y + 1) * 32 + 2 * x] + lv[(2 * y + 1) * 32 + 2 * x + 1]));
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int i = threadIdx.x; i < m * m; i += 256, ++cnt) {
+            const int y = i / m, x = i % m;
+            lv[y * 32 + x] = v[cnt];
+            const int Ws = W >> (s + 1);
+            *reinterpret_cast<f32x4*>(P.l[s] + ((int64_t)((ty0 >> (s + 1)) + y) * Ws + ((tx0 >> (s + 1)) + x)) * P.ld[s]) = v[cnt];
+        }
+        n = m;
+    }
+}
+
+// dlabel[p] (+)= sum_s dl_s[p >> (s+1)] / 4^(s+1)
+__global__ __launch_bounds__(256) void sg_avgpool_pyramid_bwd_kernel(SgPyramid D, int H, int W, float* dlabel, int ld, int accumulate) {
+    const int64_t total = (int64_t)H * W;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
+        const int x = (int)(p % W), y = (int)(p / W);
+        f32x4 acc = accumulate ? *reinterpret_cast<const f32x4*>(dlabel + p * ld) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        float sc = 0.25f;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            if (D.l[s]) acc += sc * *reinterpret_cast<const f32x4*>(D.l[s] + ((int64_t)(y >> (s + 1)) * (W >> (s + 1)) + (x >> (s + 1))) * D.ld[s]);
+            sc *= 0.25f;
+        }
+        *reinterpret_cast<f32x4*>(dlabel + p * ld) = acc;
+    }
+}
+
+extern "C" int sgan_avgpool_pyramid_fwd(const float* label, int32_t ld, int32_t H, int32_t W, float* const* levels,
+                                        const int32_t* level_ld, void* stream) {
+    SGAN_CHECK(label && levels && level_ld && H > 0 && W > 0 && H % 64 == 0 && W % 64 == 0 && ld >= 4 && (ld & 3) == 0,
+               "label must be a 4-channel (stored) image with sides divisible by 64");
+    SgPyramid P;
+    for (int s = 0; s < 6; ++s) {
+        SGAN_CHECK(levels[s] && level_ld[s] >= 4 && (level_ld[s] & 3) == 0, "bad level %d", s);
+        P.l[s] = levels[s];
+        P.ld[s] = level_ld[s];
+    }
+    hipLaunchKernelGGL(sg_avgpool_pyramid_fwd_kernel, dim3(W / 64, H / 64), dim3(256), 0, (hipStream_t)stream, label, ld, H, W, P);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_avgpool_pyramid_bwd(const float* const* dlevels, const int32_t* level_ld, int32_t H, int32_t W, float* dlabel,
+                                        int32_t ld, int32_t accumulate, void* stream) {
+    SGAN_CHECK(dlevels && level_ld && dlabel && H % 64 == 0 && W % 64 == 0 && H > 0 && W > 0 && ld >= 4 && (ld & 3) == 0, "bad argument");
+    SgPyramid P;
+    for (int s = 0; s < 6; ++s) {
+        P.l[s] = const_cast<float*>(dlevels[s]);
+        P.ld[s] = level_ld[s];
+    }
+    int blocks = ew_cdiv((int64_t)H * W, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sg_avgpool_pyramid_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, H, W, dlabel, ld, accumulate);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // GAN loss on the logits map (one workgroup; the maps are <= 67x67)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sg_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }

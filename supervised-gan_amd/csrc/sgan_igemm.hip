@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);  // [2][BM*32]
     float* Bs = As + 2 * BM * 32;                // [2][BN*32]
-    float* red = Bs + 2 * BN * 32;               // [2*BN]
+    // statistics are accumulated in fp64 from the first add on: var = E[x^2] - mean^2 cancels catastrophically in fp32
+    // partial sums as soon as |mean| >> std (conv of a near-constant map plus its bias, e.g. the CRN label branch)
+    double* red = reinterpret_cast<double*>(Bs + 2 * BN * 32);   // [2*BN]
     int4* ttab = reinterpret_cast<int4*>(red + 2 * BN);  // [16] {dy, dx, gather offset, weight slab offset}
     float* pscale = reinterpret_cast<float*>(ttab + SGAN_MAX_TAPS);  // [Ck]
     float* pshift = pscale + G.Ck;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
         const int dy = v ? (int)G.taps[phz][tid].dy : 0, dx = v ? (int)G.taps[phz][tid].dx : 0;
         ttab[tid] = make_int4(dy, dx, (dy * P.Win + dx) * P.in_ld, v ? G.taps[phz][tid].w_off : 0);
     }
-    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
+    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.0;
     {   // always present (identity when there is no prologue) so the main loop is branch-free
         for (int c = tid; c < Ck; c += 256) {
             float sc = 1.f, sh = 0.f;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
             x_b = P.xn.beta ? P.xn.beta[n] : 0.f;
         }
         const float xn_neg = P.xn.act == SGAN_ACT_NONE ? 1.f : (P.xn.act == SGAN_ACT_RELU ? 0.f : P.xn.slope);
-        float s1 = 0.f, s2 = 0.f;
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
 #pragma unroll
@@ -484,11 +486,11 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
                         const float xhat = (x - x_mean) * x_rstd;
                         const float y = xnorm ? (x_g * xhat + x_b) : x;
                         v *= (y > 0.f ? 1.f : xn_neg);
-                        s1 += v;
-                        s2 += v * xhat;
+                        s1 += (double)v;
+                        s2 += (double)(v * xhat);
                     } else {
-                        s1 += v;
-                        s2 += v * v;
+                        s1 += (double)v;
+                        s2 += (double)v * (double)v;
                         if (P.out_act == SGAN_ACT_TANH) v = tanhf(v);
                     }
                     if (P.accum) v += P.out[pix * P.out_ld + n];
@@ -510,8 +512,8 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
     if (want_stats) {
         __syncthreads();
         if (tid < BN && n0 + tid < N) {
-            atomicAdd(&P.stats[n0 + tid], (double)red[tid]);
-            atomicAdd(&P.stats[P.stats_sq + n0 + tid], (double)red[BN + tid]);
+            atomicAdd(&P.stats[n0 + tid], red[tid]);
+            atomicAdd(&P.stats[P.stats_sq + n0 + tid], red[BN + tid]);
         }
     }
 }
@@ -664,15 +666,15 @@ __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmPa
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SgLocal P = sg_local(G, 0);   // split-K is single-problem
     const int N = P.N, NQ = N >> 2;
-    float* red = reinterpret_cast<float*>(smem);  // [2N]
-    float* cMean = red + 2 * N;                  // [N] (dact with norm)
+    double* red = reinterpret_cast<double*>(smem);               // [2N], fp64 (see sg_igemm_kernel)
+    float* cMean = reinterpret_cast<float*>(red + 2 * N);        // [N] (dact with norm)
     float* cRstd = cMean + N;
     float* cG = cRstd + N;
     float* cB = cG + N;
     const bool dact = P.xref != nullptr;
     const bool xnorm = dact && P.xn.stats != nullptr;
     const bool want_stats = P.stats != nullptr;
-    for (int i = threadIdx.x; i < 2 * N; i += 256) red[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * N; i += 256) red[i] = 0.0;
     for (int c = threadIdx.x; c < N; c += 256) {
         float mean = 0.f, rstd = 1.f;
         if (xnorm) sg_mean_rstd(P.xn, N, c, mean, rstd);
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmPa
     const int n = (int)(e0 % NQ) * 4;
     f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (P.bias) bias = *reinterpret_cast<const f32x4*>(P.bias + n);
-    f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     for (int64_t e = e0; e < total; e += stride) {
         const int64_t pix = e / NQ;
         f32x4 v = bias;
@@ -710,14 +712,14 @@ __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmPa
                 const float xhat = (x[j] - cMean[n + j]) * cRstd[n + j];
                 const float y = xnorm ? (cG[n + j] * xhat + cB[n + j]) : x[j];
                 v[j] *= (y > 0.f ? 1.f : xn_neg);
-                s1[j] += v[j];
-                s2[j] += v[j] * xhat;
+                s1[j] += (double)v[j];
+                s2[j] += (double)(v[j] * xhat);
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s1[j] += v[j];
-                s2[j] += v[j] * v[j];
+                s1[j] += (double)v[j];
+                s2[j] += (double)v[j] * (double)v[j];
                 if (P.out_act == SGAN_ACT_TANH) v[j] = tanhf(v[j]);
             }
         }
@@ -732,8 +734,8 @@ __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmPa
         }
         __syncthreads();
         for (int c = threadIdx.x; c < N; c += 256) {
-            atomicAdd(&P.stats[c], (double)red[c]);
-            atomicAdd(&P.stats[P.stats_sq + c], (double)red[N + c]);
+            atomicAdd(&P.stats[c], red[c]);
+            atomicAdd(&P.stats[P.stats_sq + c], red[N + c]);
         }
     }
 }
@@ -871,7 +873,7 @@ static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t 
     P.slab = ks > 1 ? ws : nullptr;
     P.slab_stride = slab;
     dim3 grid(tiles * sg_cdiv(P.N, BN), 1, ks);
-    const size_t lds = (size_t)(2 * BM * 32 + 2 * BN * 32 + 2 * BN) * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
+    const size_t lds = (size_t)(2 * BM * 32 + 2 * BN * 32 + 4 * BN) * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
     if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
     sg_prof_begin(st);
     bool pro = P.pro_act != SGAN_ACT_NONE;
@@ -893,7 +895,7 @@ static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t 
         const int64_t total = (int64_t)P.q[0].Hout * P.q[0].Wout * NQ;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 1024) blocks = 1024;   // 256 % NQ == 0, so blocks * 256 is a multiple of NQ
-        const size_t elds = (size_t)6 * P.N * 4;
+        const size_t elds = (size_t)8 * P.N * 4;
         hipLaunchKernelGGL(sg_splitk_epilogue_kernel, dim3(blocks), dim3(256), elds, st, P);
         SGAN_LAUNCH_CHECK();
     }

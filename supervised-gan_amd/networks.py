@@ -8,7 +8,7 @@ hand-written gfx950 kernels (include/sgan_hip.h); normalisation and activations 
 separate passes (they are applied while the consumer conv stages its input) and the whole net is
 one autograd node.
 
-Implemented: which_model_netG in {fcgan, deconv (README alias), unet_128, unet_256}, which_model_netD in
+Implemented: which_model_netG in {fcgan, deconv (README alias), unet_128, unet_256, crn}, which_model_netD in
 {n_layers, basic}.  Other names raise NotImplementedError like the reference does for unknown
 names (models/networks.py:95,123)."""
 from __future__ import annotations
@@ -185,7 +185,7 @@ class ChainNet(nn.Module):
     def _add_box(self, key, box):
         """Register `box` under self.model at a dotted path ("1.model.3.model.1"), creating plain containers on
         the way, so state_dict() keys equal the reference's nested nn.Sequential names."""
-        node = self.model
+        node = self._param_root()
         parts = key.split(".")
         for part in parts[:-1]:
             if part not in node._modules:
@@ -193,8 +193,13 @@ class ChainNet(nn.Module):
             node = node._modules[part]
         node.add_module(parts[-1], box)
 
+    def _param_root(self):
+        """Module under which the parameter boxes live: `self.model` mirrors the reference nets that keep their layers
+        in `self.model`; nets whose blocks are direct attributes (CRN) return self."""
+        return self.model
+
     def _box(self, L: LayerSpec):
-        node = self.model
+        node = self._param_root()
         for part in L.key.split("."):
             node = node._modules[part]
         return node
@@ -975,6 +980,266 @@ class UnetGenerator(ChainNet):
         return y
 
 
+class CascadedRefinementNetwork(ChainNet):
+    """CascadedRefinementNetwork + CrnUpsampleBlock + CrnInterBlock (models/networks.py:642-794), n_layers = 5:
+    six stages from H/64 to H.  Stage s reads cat([label branch l_s, h_{s+1}]) (stage 5: cat([AvgPool64(label), noise])),
+    upsamples by 2 (ConvT k4 s2 p1 + IN, or Conv3x3 + bilinear + IN) and applies n_layers_block x (ReLU, Conv3x3, IN);
+    the last stage ends in Conv3x3 -> Tanh.  l_s = IN(Conv3x3(AvgPool_{2^(s+1)}(label))) with one shared conv.
+
+    MI355X layout: as in the U-Net, cat([l_s, h]) is never assembled -- the label conv and the previous stage's last
+    conv write their raw outputs into the two halves of one buffer, their InstanceNorm statistics into the two
+    halves of one statistics array, and the stage's first conv normalises on load.  The six label maps come from one
+    pyramid kernel; the bilinear kernel accumulates the statistics of its own output."""
+    final_act = ACT_TANH
+
+    def __init__(self, input_nc, output_nc, noise_nc, ngf=64, n_layers=5, norm="instance", upsample_mode='convt',
+                 add_gaussian_noise=False, gaussian_sigma=0.1, share_label_weights=True, n_layers_block=1, gpu_ids=[]):
+        assert n_layers == 5
+        if norm != "instance":
+            raise NotImplementedError("CascadedRefinementNetwork on the MI355X path implements --norm instance")
+        if add_gaussian_noise:
+            raise NotImplementedError("CascadedRefinementNetwork --add_gaussian_noise is not on the MI355X path")
+        if upsample_mode not in ('convt', 'bilinear'):
+            raise NotImplementedError('UpsampleBlock mode [%s] is not recognized' % upsample_mode)
+        if input_nc > 4:
+            raise NotImplementedError("label images with more than 4 channels are not on the MI355X path")
+        self.input_nc, self.output_nc, self.noise_nc, self.ngf = input_nc, output_nc, noise_nc, ngf
+        self.mode, self.nlb, self.share = upsample_mode, n_layers_block, share_label_weights
+        self.up, self.inter, self.lab = {}, {}, {}
+        layers = []
+        for s in range(5, -1, -1):
+            cin = noise_nc + input_nc if s == 5 else 2 * ngf
+            if upsample_mode == 'convt':
+                u = LayerSpec(f"blockh{s}.0.model.0", CONVT, 4, 2, 1, cin, ngf, False, "in", ACT_NONE)
+            else:
+                u = LayerSpec(f"blockh{s}.0.model.0", CONV, 3, 1, 1, cin, ngf, True, "in", ACT_NONE)
+            self.up[s] = u
+            layers.append(u)
+            self.inter[s] = []
+            for i in range(n_layers_block):
+                last = s == 0 and i == n_layers_block - 1
+                L = LayerSpec(f"blockh{s}.1.model.{3 * i + 1}", CONV, 3, 1, 1, ngf, output_nc if last else ngf, True,
+                              None if last else "in", ACT_NONE)
+                self.inter[s].append(L)
+                layers.append(L)
+        if share_label_weights:
+            L = LayerSpec("blockl.0", CONV, 3, 1, 1, input_nc, ngf, True, "in", ACT_NONE)
+            layers.append(L)
+            for s in range(5):
+                self.lab[s] = L
+        else:
+            for s in range(4, -1, -1):
+                self.lab[s] = LayerSpec(f"blockl{s}.0", CONV, 3, 1, 1, input_nc, ngf, True, "in", ACT_NONE)
+                layers.append(self.lab[s])
+        super().__init__(layers)
+        del self.model          # the reference keeps its blocks as direct attributes: no `model.` prefix in state_dict keys
+        self.gpu_ids = gpu_ids
+
+    def _param_root(self):
+        return self
+
+    # ---- programs -------------------------------------------------------------------------------
+    def _desc(self, L, h, w):
+        key = ("crn", L.key, h, w)
+        if key not in self._geom_cache:
+            ho, wo = L.out_hw(h, w)
+            self._geom_cache[key] = ops.conv_desc(L.kind, L.k, L.stride, L.pad, h, w, L.cin_s, ho, wo, L.cout_s)
+        return self._geom_cache[key]
+
+    def run_forward(self, x, update_running=True):
+        """x: dict(label=[H, W, 4] buffer, first=[H/64, W/64, pad4(input_nc + noise_nc)] buffer = cat([AvgPool64(label), noise]))
+        -- the caller (forward) builds `first` because its channel order interleaves two tensors."""
+        label = x["label"]
+        ops.require_gpu(label, type(self).__name__)
+        if self._flat.device != label.device:
+            raise SganError(f"module parameters are on {self._flat.device}, input on {label.device}")
+        H, W, _ = label.shape
+        dev = label.device
+        ngf, nlb = self.ngf, self.nlb
+        C2 = 2 * ngf
+        # statistics arena: per stage s <= 4 the concat statistics [2 * C2]; per stage the upsampled tensor [2 * ngf] and
+        # the inner inter-block convs [2 * ngf] each; doubled for the backward sums
+        lay, off = {}, 0
+        for s in range(5, -1, -1):
+            if s <= 4:
+                lay[("cat", s)] = off
+                off += 2 * C2
+            lay[("u", s)] = off
+            off += 2 * ngf
+            for i in range(nlb - 1):
+                lay[("t", s, i)] = off
+                off += 2 * ngf
+        arena = torch.zeros(2 * off, dtype=torch.float64, device=dev)
+        st = lambda k, n: arena[lay[k]: lay[k] + n]
+        res = {s: (H >> (s + 1), W >> (s + 1)) for s in range(6)}
+        cat = {s: torch.empty(res[s] + (C2,), dtype=torch.float32, device=dev) for s in range(5)}
+        # label branch: pyramid, then the (shared) label conv into the left halves
+        lv = [torch.empty(res[s] + (4,), dtype=torch.float32, device=dev) for s in range(5)] + [x["pool64"]]
+        ops.avgpool_pyramid_fwd(label, lv)
+        if x.get("first") is None:
+            x["first"] = x["first_fn"]()
+        for s in range(5):
+            L = self.lab[s]
+            wt, b = self._wb(L)
+            ops.conv_fwd(self._desc(L, *res[s]), lv[s], None, wt, b, cat[s][:, :, :ngf], ACT_NONE, st(("cat", s), 2 * C2), C2)
+        saved = dict(label=label, first=x["first"], lv=lv, cat=cat, c={}, u={}, t={}, arena=arena, lay=lay, off=off, res=res)
+        out = None
+        for s in range(5, -1, -1):
+            h, w = res[s]
+            U = self.up[s]
+            wt, b = self._wb(U)
+            src = x["first"] if s == 5 else cat[s]
+            nrm = None if s == 5 else ops.norm_desc(st(("cat", s), 2 * C2), None, None, h * w, IN_EPS, ACT_NONE, 0.0)
+            u = torch.empty((2 * h, 2 * w, ngf), dtype=torch.float32, device=dev)
+            ustat = st(("u", s), 2 * ngf)
+            if self.mode == 'convt':
+                ops.conv_fwd(self._desc(U, h, w), src, nrm, wt, b, u, ACT_NONE, ustat)
+            else:
+                c = torch.empty((h, w, ngf), dtype=torch.float32, device=dev)
+                ops.conv_fwd(self._desc(U, h, w), src, nrm, wt, b, c, ACT_NONE, None)
+                ops.bilinear_up2_fwd(c, u, ustat)
+                saved["c"][s] = c
+            saved["u"][s] = u
+            cur, cur_stat = u, ustat
+            for i, L in enumerate(self.inter[s]):
+                wt, b = self._wb(L)
+                nrm = ops.norm_desc(cur_stat, None, None, 4 * h * w, IN_EPS, ACT_RELU, 0.0)
+                last_i = i == nlb - 1
+                if last_i and s == 0:
+                    out = torch.empty((2 * h, 2 * w, L.cout_s), dtype=torch.float32, device=dev)
+                    ops.conv_fwd(self._desc(L, 2 * h, 2 * w), cur, nrm, wt, b, out, self.final_act, None)
+                elif last_i:   # feeds the next stage: right half of its concat buffer, statistics into the matching slice
+                    dst = cat[s - 1][:, :, ngf:]
+                    ops.conv_fwd(self._desc(L, 2 * h, 2 * w), cur, nrm, wt, b, dst, ACT_NONE, st(("cat", s - 1), 2 * C2)[ngf:], C2)
+                else:
+                    t = torch.empty((2 * h, 2 * w, ngf), dtype=torch.float32, device=dev)
+                    tstat = st(("t", s, i), 2 * ngf)
+                    ops.conv_fwd(self._desc(L, 2 * h, 2 * w), cur, nrm, wt, b, t, ACT_NONE, tstat)
+                    saved["t"][(s, i)] = t
+                    cur, cur_stat = t, tstat
+        saved["out"] = out
+        return [out], saved
+
+    def run_backward(self, x, outs, S, dout, need_dx, want_wgrad):
+        """Returns (dlabel buffer or None, dfirst buffer or None)."""
+        dev = dout.device
+        ngf, nlb = self.ngf, self.nlb
+        C2 = 2 * ngf
+        res, cat, lay, off, arena = S["res"], S["cat"], S["lay"], S["off"], S["arena"]
+        st = lambda k, n: arena[lay[k]: lay[k] + n]
+        sm = lambda k, n: arena[off + lay[k]: off + lay[k] + n]          # backward sums live in the arena's second half
+        if want_wgrad:
+            self._ensure_grads()
+
+        def wgrad(L, desc, src, nrm, dy):
+            if want_wgrad:
+                gw, gb = self._gwb(L)
+                ops.conv_wgrad(desc, src, nrm, dy, gw, gb)
+
+        d = torch.empty_like(S["out"])
+        ops.tanh_bwd(dout.contiguous(), S["out"], d)
+        dcat_next = None        # gradient w.r.t. cat[s - 1] produced while walking stage s - 1; consumed by stage s
+        dlv = [None] * 6
+        dfirst = None
+        for s in range(0, 6):
+            h, w = res[s]
+            u, ustat = S["u"][s], st(("u", s), 2 * ngf)
+            # inter block, last conv first: `d` is the gradient w.r.t. the raw output of inter[s][-1]
+            for i in range(nlb - 1, -1, -1):
+                L = self.inter[s][i]
+                src = u if i == 0 else S["t"][(s, i - 1)]
+                sstat = ustat if i == 0 else st(("t", s, i - 1), 2 * ngf)
+                ssum = sm(("u", s), 2 * ngf) if i == 0 else sm(("t", s, i - 1), 2 * ngf)
+                nrm = ops.norm_desc(sstat, None, None, 4 * h * w, IN_EPS, ACT_RELU, 0.0)
+                desc = self._desc(L, 2 * h, 2 * w)
+                wgrad(L, desc, src, nrm, d)
+                din = torch.empty((2 * h, 2 * w, ngf), dtype=torch.float32, device=dev)
+                ops.conv_dgrad(desc, d, self._wb(L)[0], din, src, nrm, ssum)
+                ops.norm_bwd_apply(din, src, nrm, ssum)
+                d = din
+            # d = gradient w.r.t. u_s (raw, before its InstanceNorm)
+            U = self.up[s]
+            desc = self._desc(U, h, w)
+            if self.mode == 'bilinear':
+                dc = torch.empty((h, w, ngf), dtype=torch.float32, device=dev)
+                ops.bilinear_up2_bwd(d, dc)
+                d = dc
+            src = S["first"] if s == 5 else cat[s]
+            nrm = None if s == 5 else ops.norm_desc(st(("cat", s), 2 * C2), None, None, h * w, IN_EPS, ACT_NONE, 0.0)
+            wgrad(U, desc, src, nrm, d)
+            if s == 5:
+                if need_dx:
+                    dfirst = torch.empty_like(S["first"])
+                    ops.conv_dgrad(desc, d, self._wb(U)[0], dfirst, None, None, None)
+                break
+            dc_ = torch.empty_like(cat[s])
+            csum = sm(("cat", s), 2 * C2)
+            ops.conv_dgrad(desc, d, self._wb(U)[0], dc_, cat[s], nrm, csum)
+            ops.norm_bwd_apply(dc_, cat[s], nrm, csum)          # both halves at once: raw gradients of l_s and of h_{s+1}
+            # label branch of this stage
+            Ll = self.lab[s]
+            ldesc = self._desc(Ll, h, w)
+            wgrad(Ll, ldesc, S["lv"][s], None, dc_[:, :, :ngf])
+            if need_dx:
+                dlv[s] = torch.empty(res[s] + (4,), dtype=torch.float32, device=dev)
+                ops.conv_dgrad(ldesc, dc_[:, :, :ngf], self._wb(Ll)[0], dlv[s], None, None, None)
+            d = dc_[:, :, ngf:]      # gradient w.r.t. the raw output of stage s + 1's last conv
+        dlabel = None
+        if need_dx:
+            dlabel = torch.empty_like(S["label"])
+            ops.avgpool_pyramid_bwd(dlv, dlabel, accumulate=False)     # level 5 travels with `dfirst`
+        return dlabel, dfirst
+
+    # ---- module protocol ---------------------------------------------------------------------------
+    def forward(self, label, noise, activation=None):
+        if activation is not None and not isinstance(activation, nn.Tanh):
+            raise NotImplementedError("only the default Tanh output activation is implemented")
+        params = list(self.parameters())
+        return _CrnFn.apply(self, label, noise, *params)
+
+    def _wrap_output(self, y):
+        return y
+
+
+class _CrnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, label, noise, *params):
+        lb = ops.as_nhwc(label)
+        H, W, _ = lb.shape
+        if H % 64 or W % 64:
+            raise SganError(f"CascadedRefinementNetwork needs H, W divisible by 64, got {H}x{W}")
+        if tuple(noise.shape[2:]) != (H // 64, W // 64):
+            raise SganError(f"noise must be {H // 64}x{W // 64} for a {H}x{W} label, got {tuple(noise.shape[2:])}")
+        pool64 = torch.empty((H // 64, W // 64, 4), dtype=torch.float32, device=lb.device)
+        x = {"label": lb, "pool64": pool64, "first": None}
+        # cat([AvgPool64(label), noise], 1) interleaves two tensors channel-wise: assembled by torch on the 8x8 map.
+        # The pyramid kernel has to run first, so the generator's first buffer is filled right after it.
+        net_first = lambda: ops.as_nhwc(torch.cat([ops.logical_view(pool64, net.input_nc), noise], 1))
+        x["first_fn"] = net_first
+        outs, saved = net.run_forward(x)
+        ctx.net, ctx.saved = net, saved
+        ctx.need_dlabel, ctx.need_dnoise = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        ctx.want_wgrad = net.compute_param_grads and any(ctx.needs_input_grad[3:])
+        return ops.logical_view(outs[-1], net.output_nc)
+
+    @staticmethod
+    def backward(ctx, gout):
+        net = ctx.net
+        need_dx = ctx.need_dlabel or ctx.need_dnoise
+        dlabel, dfirst = net.run_backward(None, None, ctx.saved, ops.as_nhwc(gout), need_dx, ctx.want_wgrad)
+        gl = gn = None
+        if need_dx:
+            dfl = ops.logical_view(dfirst, net.input_nc + net.noise_nc)
+            if ctx.need_dnoise:
+                gn = dfl[:, net.input_nc:]
+            if ctx.need_dlabel:
+                # level 5 of the pyramid: its gradient is the first input_nc channels of dfirst
+                d5 = ops.as_nhwc(dfl[:, :net.input_nc])
+                ops.avgpool_pyramid_bwd([None] * 5 + [d5], dlabel, accumulate=True)
+                gl = ops.logical_view(dlabel, net.input_nc)
+        return (None, gl, gn) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
 class NLayerDiscriminator(ChainNet):
     """NLayerDiscriminator (models/networks.py:798-847): [gauss prefilter + stride pick] ->
     Conv(k4,s2,p2)+LReLU -> (Conv s2 + norm + LReLU) x (n-1) -> Conv s1 + norm + LReLU -> Conv s1 [-> Sigmoid]."""
@@ -1205,7 +1470,12 @@ def define_G(input_nc, output_nc, ngf, which_model_netG, norm='batch', use_dropo
         netG = UnetGenerator(input_nc, output_nc, 7 if which_model_netG == 'unet_128' else 8, ngf, norm=norm,
                              use_dropout=use_dropout, use_residual=use_residual, add_gaussian_noise=add_gaussian_noise,
                              gaussian_sigma=gaussian_sigma, num_skips=n_layers_G_skip, gpu_ids=gpu_ids)
-    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks', 'autoencoder', 'crn', 'fcgan_star', 'dcgan'):
+    elif which_model_netG == 'crn':
+        netG = CascadedRefinementNetwork(input_nc, output_nc, noise_nc, ngf=ngf, n_layers=n_layers_G, norm=norm,
+                                         upsample_mode=upsample_mode, add_gaussian_noise=add_gaussian_noise,
+                                         gaussian_sigma=gaussian_sigma, share_label_weights=share_label_weights,
+                                         n_layers_block=n_layers_CRN_block, gpu_ids=gpu_ids)
+    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks', 'autoencoder', 'fcgan_star', 'dcgan'):
         raise NotImplementedError('Generator model name [%s] is not on the MI355X path yet' % which_model_netG)
     else:
         raise NotImplementedError('Generator model name [%s] is not recognized' % which_model_netG)

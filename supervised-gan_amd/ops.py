@@ -160,6 +160,38 @@ def norm_apply_bwd_sums(dt, u, u_norm, bwd_sums, mask=None):
                                              _ptr(bwd_sums), H * W, Cs, _stream()), "sgan_norm_apply_bwd_sums")
 
 
+def bilinear_up2_fwd(x, out, out_stats=None, stats_sq=0):
+    H, W, Cs = x.shape
+    L.check(L.lib().sgan_bilinear_up2_fwd(_ptr(_act(x)), x.stride(1), H, W, Cs, _ptr(_act(out)), out.stride(1), _ptr(out_stats),
+                                          int(stats_sq), _stream()), "sgan_bilinear_up2_fwd")
+
+
+def bilinear_up2_bwd(dout, din):
+    H, W, Cs = din.shape
+    L.check(L.lib().sgan_bilinear_up2_bwd(_ptr(_act(dout)), dout.stride(1), H, W, Cs, _ptr(_act(din)), din.stride(1), _stream()),
+            "sgan_bilinear_up2_bwd")
+
+
+def _level_table(levels):
+    ptrs = (C.c_void_p * 6)(*[t.data_ptr() if t is not None else None for t in levels])
+    lds = (C.c_int32 * 6)(*[t.stride(1) if t is not None else 4 for t in levels])
+    return ptrs, lds
+
+
+def avgpool_pyramid_fwd(label, levels):
+    """levels[s]: [H >> (s+1), W >> (s+1), 4] buffers (or channel slices), s = 0..5."""
+    H, W, _ = label.shape
+    ptrs, lds = _level_table(levels)
+    L.check(L.lib().sgan_avgpool_pyramid_fwd(_ptr(_act(label)), label.stride(1), H, W, ptrs, lds, _stream()), "sgan_avgpool_pyramid_fwd")
+
+
+def avgpool_pyramid_bwd(dlevels, dlabel, accumulate=False):
+    H, W, _ = dlabel.shape
+    ptrs, lds = _level_table(dlevels)
+    L.check(L.lib().sgan_avgpool_pyramid_bwd(ptrs, lds, H, W, _ptr(_act(dlabel)), dlabel.stride(1), int(accumulate), _stream()),
+            "sgan_avgpool_pyramid_bwd")
+
+
 def dropout_mask(mask, p, seed, offset_dev=None):
     L.check(L.lib().sgan_dropout_mask(_ptr(mask), mask.numel(), float(p), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(offset_dev),
                                       _stream()), "sgan_dropout_mask")

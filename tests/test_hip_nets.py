@@ -245,3 +245,41 @@ def test_unet_own_dropout_and_noise(N):
     x = O.np_uniform(1, (1, 2, 256, 256)).cuda()
     y1, y2 = G.forward(x), G.forward(x)
     assert torch.isfinite(y1).all() and float((y1 - y2).detach().abs().max()) > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# Cascaded refinement network (models/networks.py:642-794)
+# ------------------------------------------------------------------------------------------------
+CRN_SMALL = {"convt_b1": ("convt", 1), "bilinear_b2": ("bilinear", 2)}
+
+
+@pytest.mark.parametrize("tag", list(CRN_SMALL))
+def test_crn_small(N, golden_dir, tag):
+    g = load(golden_dir, f"crn_small_{tag}.npz")
+    mode, nlb = CRN_SMALL[tag]
+    G = N.define_G(2, 1, 8, "crn", "instance", False, n_layers_G=5, noise_nc=8, upsample_mode=mode, n_layers_CRN_block=nlb,
+                   share_label_weights=True, gpu_ids=[0])
+    sd = O.init_crn(41, 2, 1, 8, 8, mode, nlb, True)
+    assert list(G.state_dict().keys()) == list(sd.keys())          # the reference's module order, no `model.` prefix
+    G.load_state_dict(sd)
+    label = O.np_uniform(401, (1, 2, 128, 128)).cuda().requires_grad_(True)
+    z = O.np_normal(402, (1, 8, 2, 2)).cuda().requires_grad_(True)
+    r = O.np_normal(403, (1, 1, 128, 128)).cuda()
+    y = G.forward(label, z)
+    assert y.shape == (1, 1, 128, 128)
+    (y * r).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, g["y"]) < TOL
+    assert rel(label.grad, g["dlabel"]) < TOL
+    assert rel(z.grad, g["dz"]) < TOL
+    params = dict(G.named_parameters())
+    undet = O.norm_cancelled_keys_crn(2, 1, 8, 8, mode, nlb, True)
+    for k in g.files:
+        if not k.startswith("grad/"):
+            continue
+        name = k[5:]
+        if name in undet:
+            scale = np.abs(params[name.replace(".bias", ".weight")].grad.cpu().numpy()).max()
+            assert np.abs(params[name].grad.cpu().numpy()).max() < TOL * scale, name
+        else:
+            assert rel(params[name].grad, g[k]) < TOL, name

@@ -49,6 +49,10 @@ CASES = [
     ("conv", 4, 2, 1, 64, 128, 16, 16, "in", 2),    # unet down
     ("conv", 4, 2, 2, 3, 64, 64, 64, None, 0),      # cgan D first layer (3 channels)
     ("conv", 4, 2, 2, 64, 128, 129, 129, "in", 2),  # > 1 split, odd
+    ("conv", 3, 1, 1, 8, 1, 20, 22, "in", 1),       # CRN output conv: k3, Cout = 1 (K = 9 taps x 4: a partial k-tile in dgrad)
+    ("conv", 3, 1, 1, 16, 8, 12, 12, "in", 0),      # CRN stage conv: norm without activation on load
+    ("conv", 3, 1, 1, 2, 8, 16, 16, None, 0),       # CRN label conv
+    ("convT", 4, 2, 1, 16, 8, 6, 6, "in", 0),       # CRN ConvT upsampling, norm without activation on load
 ]
 
 
@@ -442,3 +446,37 @@ def test_weighted_l1(hip, weighted):
     assert abs(float(out) - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
     assert rel(from_buf(dx, 1), x.grad) < 1e-5
     assert float(dx[:, :, 1:].abs().max()) == 0
+
+
+def test_bilinear_up2_and_pyramid(hip):
+    from hip_utils import from_buf, rel, to_buf
+    ops = hip
+    torch.manual_seed(3)
+    C, H, W = 8, 10, 14
+    x = torch.randn(1, C, H, W, requires_grad=True)
+    y = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    r = torch.randn_like(y)
+    (y * r).sum().backward()
+    out = torch.empty(2 * H, 2 * W, C, device="cuda")
+    st = torch.zeros(2 * C, dtype=torch.float64, device="cuda")
+    ops.bilinear_up2_fwd(to_buf(x.detach()), out, st)
+    din = torch.empty(H, W, C, device="cuda")
+    ops.bilinear_up2_bwd(to_buf(r), din)
+    torch.cuda.synchronize()
+    assert rel(from_buf(out, C), y) < 1e-6
+    assert rel(from_buf(din, C), x.grad) < 1e-5
+    yd = y.detach().double()
+    assert rel(st[:C], yd.sum((0, 2, 3))) < 1e-5 and rel(st[C:], (yd * yd).sum((0, 2, 3))) < 1e-5
+    # label pyramid: AvgPool2d(2^(s+1)), s = 0..5, and its adjoint
+    lab = torch.rand(1, 2, 128, 192, requires_grad=True)
+    lvl = [F.avg_pool2d(lab, 2 ** (s + 1), 2 ** (s + 1)) for s in range(6)]
+    rs = [torch.randn_like(t) for t in lvl]
+    sum((a * b).sum() for a, b in zip(lvl, rs)).backward()
+    bufs = [torch.empty(128 >> (s + 1), 192 >> (s + 1), 4, device="cuda") for s in range(6)]
+    ops.avgpool_pyramid_fwd(to_buf(lab.detach()), bufs)
+    dl = torch.empty(128, 192, 4, device="cuda")
+    ops.avgpool_pyramid_bwd([to_buf(t) for t in rs], dl)
+    torch.cuda.synchronize()
+    for s in range(6):
+        assert rel(from_buf(bufs[s], 2), lvl[s]) < 5e-6, s    # hierarchical vs flat summation order
+    assert rel(from_buf(dl, 2), lab.grad) < 1e-6

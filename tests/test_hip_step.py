@@ -251,3 +251,35 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
         m.optimize_parameters()
         losses.append(list(m.get_current_errors().values()))
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+
+
+def test_cgan_with_crn_generator():
+    """`--model cgan --which_model_netG crn` (the G2 of BASELINE configs[4]) trains through the same trainer: the generator
+    output equals the CPU oracle on the same weights / latent, and a few optimizer steps keep every loss finite."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")
+    from supervised_gan_amd.models import create_model
+    from supervised_gan_amd.options import TrainOptions
+    argv = ["--name", "t", "--model", "cgan", "--which_direction", "AtoB", "--dataset_mode", "aligned", "--fineSize", "128",
+            "--which_model_netG", "crn", "--upsample_mode", "bilinear", "--n_layers_CRN_block", "2", "--ngf", "8", "--noise_nc", "8",
+            "--noiseSize", "2", "--which_model_netD", "n_layers", "--n_layers_D", "3", "--ndf", "8", "--scale_factor", "1",
+            "--lambda_D", "1.0", "--norm", "instance", "--which_channel", "rg_b", "--gpu_ids", "0", "--no_dropout",
+            "--checkpoints_dir", "/tmp/sgan_ckpt"]
+    m = create_model(TrainOptions().parse(argv, save=False, verbose=False))
+    sd = O.init_crn(51, 2, 1, 8, 8, "bilinear", 2, True)
+    m.netG.load_state_dict(sd)
+    z = O.np_normal(52, (1, 8, 2, 2))
+    m.noise_source = lambda: z
+    cfg = O.CGANConfig(fineSize=128)
+    m.set_input(cgan_input(cfg, 0))
+    m.forward()
+    A = O.np_uniform(7100, (1, 3, 128, 128))[:, :2].contiguous()
+    y_ref = O.crn_forward({k: v.clone() for k, v in sd.items()}, A, z, 8, "bilinear", 2, True)
+    assert O.rel_err(m.fake_B, y_ref) < 1e-3
+    m.noise_source = None
+    for step in range(3):
+        m.set_input(cgan_input(cfg, step))
+        m.optimize_parameters()
+    errs = m.get_current_errors()
+    assert all(np.isfinite(v) for v in errs.values()), errs
+    assert m.optimizer_G.step_count == 3 and m.optimizer_D.step_count == 3

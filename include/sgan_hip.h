@@ -251,6 +251,12 @@ int sgan_norm_apply_bwd_sums(float* dt, int32_t dt_ld, const float* mask, const 
 /* mask[i] = uniform(Philox(seed, *offset_dev + i)) < p ? 0 : 1/(1-p); advances *offset_dev (nn.Dropout). */
 int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* offset_dev, void* stream);
 
+/* ---- BCELoss on rescaled tanh outputs (two-stage trainers): loss = mean BCE((x + 1) / 2, (t + 1) / 2) over npix * C
+ * with torch's -100 log clamp; g = dloss/dx for a unit upstream gradient (backward: dx = gout * g, sgan_scale).
+ * Replaces: torch.nn.BCELoss()((x + 1) / 2, (t + 1) / 2) at models/twostage_cycle_model.py:398-403. */
+int sgan_bce01_fwd(const float* x, int32_t x_ld, const float* t, int32_t t_ld, int32_t npix, int32_t C, float* loss_out,
+                   float* g, int32_t g_ld, void* stream);
+
 /* ---- CRN building blocks (models/networks.py:642-794) --------------------------------------------
  * sgan_bilinear_up2_fwd: nn.Upsample(scale_factor=2, mode='bilinear') (align_corners = False) of an [H, W, C] tensor
  * into [2H, 2W, C], accumulating the (sum, sumsq) statistics of the result for the InstanceNorm that follows it

@@ -466,12 +466,138 @@ def golden_cgan_step(name, cfg: "O.CGANConfig", seed: int, nsteps: int):
         save(name, **arrs)
 
 
+# ---------------------------------------------------------------------------------------
+# twostage_cycle (DSGAN)
+# ---------------------------------------------------------------------------------------
+class TwoNoiseInjector:
+    """Latents of G1 / G2 from numpy: the k-th draw of shape1 is np_normal(5000 + k), of shape2 np_normal(6000 + k)."""
+    def __init__(self, shape1, shape2):
+        self.shapes = {tuple(shape1): [5000, 0], tuple(shape2): [6000, 0]}
+        self._orig = torch.Tensor.normal_
+
+    def __enter__(self):
+        inj = self
+
+        def patched(t, mean=0.0, std=1.0, *a, **k):
+            ent = inj.shapes.get(tuple(t.shape))
+            if ent is not None and mean == 0 and std == 1:
+                t.copy_(O.np_normal(ent[0] + ent[1], tuple(t.shape)))
+                ent[1] += 1
+                return t
+            return inj._orig(t, mean, std, *a, **k)
+        torch.Tensor.normal_ = patched
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.normal_ = self._orig
+
+
+def build_ref_twostage(cfg: "O.TwoStageConfig", seed: int, tmpdir: str):
+    from options.train_options import TrainOptions
+    from models.twostage_cycle_model import TwoStageCycleModel
+    L = lambda xs: [str(x) for x in xs]
+    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "twostage_cycle", "--which_direction", "AtoB",
+            "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize), "--transform_1to2", cfg.transform_1to2, "--batchSize", "1",
+            "--which_channel", "rg_b", "--which_model_netG1", "fcgan", "--n_layers_G1", str(cfg.n_layers_G1), "--ngf1", str(cfg.ngf1),
+            "--which_model_netD1", "n_layers", "--n_layers_D1", *L(cfg.n_layers_D1), "--ndf1", str(cfg.ndf1),
+            "--scale_factor1", *L(cfg.scale_factor1), "--lambda_D1", *L(cfg.lambda_D1), "--which_model_netG2", "crn",
+            "--ngf2", str(cfg.ngf2), "--upsample_mode2", cfg.upsample_mode2, "--n_layers_CRN_block2", str(cfg.n_layers_CRN_block2),
+            "--which_model_netF2", "unet_128", "--nff2", str(cfg.nff2), "--which_model_netD2", "n_layers",
+            "--n_layers_D2", *L(cfg.n_layers_D2), "--ndf2", str(cfg.ndf2), "--scale_factor2", *L(cfg.scale_factor2),
+            "--lambda_D2", *L(cfg.lambda_D2), "--lambda_A", str(cfg.lambda_A), "--lambda_B", str(cfg.lambda_B),
+            "--lambda_A_cycle", str(cfg.lambda_A_cycle), "--lambda_fake_cycle", str(cfg.lambda_fake_cycle),
+            "--noise_nc1", str(cfg.noise_nc1), "--noiseSize1", str(cfg.noiseSize1), "--noise_nc2", str(cfg.noise_nc2),
+            "--noiseSize2", str(cfg.noiseSize2), "--norm", "instance", "--no_dropout1", "--no_dropout2", "--n_update_G", "1",
+            "--GAN_losses_D2", *cfg.GAN_losses_D2, "--GAN_losses_G2", *cfg.GAN_losses_G2, "--pool_size", str(cfg.pool_size),
+            "--gpu_ids", "-1", "--display_id", "0", "--checkpoints_dir", tmpdir]
+    if cfg.no_lsgan1:
+        argv.append("--no_lsgan1")
+    if cfg.no_lsgan2:
+        argv.append("--no_lsgan2")
+    if cfg.weights is not None:
+        argv += ["--weights", *L(cfg.weights)]
+    old = sys.argv
+    sys.argv = argv
+    try:
+        opt = TrainOptions().parse()
+    finally:
+        sys.argv = old
+    opt.scale_factor1 = [Py2Int(s) if s > 1 else s for s in opt.scale_factor1]
+    opt.scale_factor2 = [Py2Int(s) if s > 1 else s for s in opt.scale_factor2]
+    model = TwoStageCycleModel()
+    model.initialize(opt)
+    load_sd(model.netG1, O.init_fcgan_g(seed + 1, cfg.noise_nc1, cfg.input_nc, cfg.ngf1, cfg.n_layers_G1))
+    load_sd(model.netG2, O.init_crn(seed + 2, cfg.input_nc, cfg.output_nc, cfg.noise_nc2, cfg.ngf2, cfg.upsample_mode2,
+                                    cfg.n_layers_CRN_block2, True))
+    load_sd(model.netF2, O.init_unet(seed + 3, 7, cfg.output_nc, cfg.input_nc, cfg.nff2, -1))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D1, cfg.scale_factor1)):
+        load_sd(model.netD1[i], O.init_nlayer_d(seed + 10 + i, cfg.input_nc, cfg.ndf1, nl, sf))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D2, cfg.scale_factor2)):
+        load_sd(model.netD2[i], O.init_nlayer_d(seed + 20 + i, cfg.input_nc + cfg.output_nc, cfg.ndf2, nl, sf))
+    return model
+
+
+def golden_twostage(name, cfg: "O.TwoStageConfig", seed: int, nsteps: int):
+    import random
+    import tempfile
+    z1 = (1, cfg.noise_nc1, cfg.noiseSize1, cfg.noiseSize1)
+    z2 = (1, cfg.noise_nc2, cfg.noiseSize2, cfg.noiseSize2)
+    assert z1 != z2
+    errs = lambda m: [float(m.loss_G2_GAN), float(m.loss_G2_real_cycle), float(m.loss_G2_fake_cycle), float(m.loss_D2),
+                      float(m.loss_G1_GAN), float(m.loss_D1)]
+    with tempfile.TemporaryDirectory() as tmp:
+        arrs = {}
+        # probe: every gradient of the step on the initial weights
+        random.seed(1234)
+        with TwoNoiseInjector(z1, z2):
+            m = build_ref_twostage(cfg, seed, tmp)
+            m.set_input(cgan_batch(cfg, 0))
+            m.forward()
+            for key, t in (("fake_A", m.fake_A), ("fake_B_from_fake_A", m.fake_B_from_fake_A), ("recon_fake_A", m.recon_fake_A)):
+                arrs[f"probe/{key}_summary"] = np.asarray(O.tensor_summary(t))
+                arrs[f"probe/{key}_crop"] = t.detach()[:, :, :64, :64].numpy().copy()
+            m.optimizer_D1.zero_grad()
+            m.backward_D1()
+            for i, d in enumerate(m.netD1):
+                capture_grads(arrs, f"probe/gradD1_{i}", d)
+            m.optimizer_D2.zero_grad()
+            m.backward_D2()
+            for i, d in enumerate(m.netD2):
+                capture_grads(arrs, f"probe/gradD2_{i}", d)
+            m.optimizer_G.zero_grad()
+            m.backward_G()
+            for tag, net in (("G1", m.netG1), ("G2", m.netG2), ("F2", m.netF2)):
+                for k, p in net.named_parameters():
+                    gflat = p.grad.detach().reshape(-1)
+                    arrs[f"probe/grad{tag}/summary/{k}"] = np.asarray(O.tensor_summary(gflat))
+                    arrs[f"probe/grad{tag}/sample/{k}"] = gflat[torch.from_numpy(grad_sample_idx(gflat.numel()))].numpy()
+            arrs["probe/losses"] = np.asarray(errs(m))
+            arrs["probe/loss_G"] = np.float64(float(m.loss_G))
+        # trajectory
+        random.seed(1234)
+        with TwoNoiseInjector(z1, z2):
+            m = build_ref_twostage(cfg, seed, tmp)
+            losses = []
+            for step in range(nsteps):
+                m.set_input(cgan_batch(cfg, step))
+                m.optimize_parameters()
+                losses.append(errs(m))
+            arrs["losses"] = np.asarray(losses, dtype=np.float64)
+        save(name, **arrs)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
     if not only or "crn" in only:
         golden_crn_small()
+    if not only or "twostage" in only:
+        golden_twostage("twostage_small.npz", O.TwoStageConfig(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8,
+                                                               ndf2=8, GAN_losses_D2=("real_fake", "fake_fake"),
+                                                               GAN_losses_G2=("real_fake", "fake_fake"), weights=(2.0, 5.0)),
+                        seed=0, nsteps=3)
+        golden_twostage("twostage_full.npz", O.TwoStageConfig(), seed=0, nsteps=2)     # BASELINE configs[4], README.md:18
     if not only or "cgan" in only:
         golden_unet_small()
         golden_cgan_step("cgan_step_small.npz", O.CGANConfig(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0)),

@@ -25,6 +25,7 @@ Reference map (paths relative to /root/reference):
   UnetGenerator / UnetSkipConnectionBlock     models/networks.py:318-419
   CascadedRefinementNetwork / Crn*Block       models/networks.py:642-794
   CGANModel step recipe                       models/cgan_model.py:134-226
+  TwoStageCycleModel step recipe              models/twostage_cycle_model.py:193-438
   FCGANModel step recipe                      models/fcgan_model.py:124-193
   Adam hyper-parameters                       models/fcgan_model.py:98-109, options/train_options.py:16-17
   ImagePool                                   util/image_pool.py:6-42
@@ -724,6 +725,188 @@ class CGANOracle:
     def losses(self):
         return {"G_GAN": float(self.loss_G.detach()), "G_L1": float(self.loss_G_L1.detach()),
                 "D_real": float(self.loss_D_real.detach()), "D_fake": float(self.loss_D_fake.detach())}
+
+
+# ----------------------------------------------------------------------------------
+# the twostage_cycle (DSGAN) training step (models/twostage_cycle_model.py:193-438)
+# ----------------------------------------------------------------------------------
+class TwoStageConfig:
+    """README.md:18 flags (BASELINE configs[4]) by default; binary GAN objective, no dropout."""
+    def __init__(self, input_nc=2, output_nc=1, fineSize=512, ngf1=32, n_layers_G1=5, noise_nc1=8, noiseSize1=4,
+                 n_layers_D1=(3, 3), ndf1=32, scale_factor1=(1, 2), lambda_D1=(0.5, 0.4), ngf2=64, upsample_mode2="bilinear",
+                 n_layers_CRN_block2=2, noise_nc2=8, noiseSize2=8, nff2=32, n_layers_D2=(3, 4, 3, 4), ndf2=64,
+                 scale_factor2=(1, 1, 2, 2), lambda_D2=(0.3, 0.3, 0.2, 0.2), lambda_A=10.0, lambda_B=10.0, lambda_A_cycle=5.0,
+                 lambda_fake_cycle=1.0, weights=None, no_lsgan1=True, no_lsgan2=False, GAN_losses_D2=("real_fake",),
+                 GAN_losses_G2=("real_fake",), lr=2e-4, lr1=2e-4, lr2=2e-4, beta1=0.5, pool_size=50, transform_1to2="bilinear_2",
+                 detach_G1_from_G2_x=False, detach_G1_from_G2_y=False, no_logD_trick=False):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+    @property
+    def sizeA(self):        # side of G1's label map
+        return self.noiseSize1 * 2 ** (self.n_layers_G1 + 1)
+
+
+class TwoStageCycleOracle:
+    """TwoStageCycleModel restated (forward :193-211, backward_D1 :245-262, backward_D2_binary :264-299, backward_G :337-410,
+    optimize_parameters :412-438 with one update each); G1 = fcgan, G2 = crn, F2 = unet_128 without dropout."""
+
+    def __init__(self, cfg: TwoStageConfig, seed: int = 0):
+        c = self.cfg = cfg
+        self.G1 = init_fcgan_g(seed + 1, c.noise_nc1, c.input_nc, c.ngf1, c.n_layers_G1)
+        self.G2 = init_crn(seed + 2, c.input_nc, c.output_nc, c.noise_nc2, c.ngf2, c.upsample_mode2, c.n_layers_CRN_block2, True)
+        self.F2 = init_unet(seed + 3, 7, c.output_nc, c.input_nc, c.nff2, -1)
+        self.D1 = [init_nlayer_d(seed + 10 + i, c.input_nc, c.ndf1, nl, sf) for i, (nl, sf) in enumerate(zip(c.n_layers_D1, c.scale_factor1))]
+        self.D2 = [init_nlayer_d(seed + 20 + i, c.input_nc + c.output_nc, c.ndf2, nl, sf)
+                   for i, (nl, sf) in enumerate(zip(c.n_layers_D2, c.scale_factor2))]
+        for net in [self.G1, self.G2, self.F2] + self.D1 + self.D2:
+            for k, v in net.items():
+                if v.is_floating_point() and "running" not in k:
+                    v.requires_grad_(True)
+        gp = lambda net: [v for v in net.values() if v.requires_grad]
+        self.opt_G = [Adam(gp(self.G1), c.lr1, c.beta1), Adam(gp(self.G2), c.lr2, c.beta1), Adam(gp(self.F2), c.lr2, c.beta1)]
+        self.opt_D1 = Adam([v for d in self.D1 for k, v in d.items() if k.startswith("model.")], c.lr1, c.beta1)
+        self.opt_D2 = Adam([v for d in self.D2 for k, v in d.items() if k.startswith("model.")], c.lr2, c.beta1)
+        self.pool1, self.pool2 = ImagePool(c.pool_size), ImagePool(c.pool_size)
+        self.noise_iter = None      # iterator yielding (z1, z2) per forward()
+
+    def transform(self, x):
+        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) if self.cfg.transform_1to2 == "bilinear_2" else x
+
+    def transform_inverse(self, x):
+        return F.avg_pool2d(x, 2, 2) if self.cfg.transform_1to2 == "bilinear_2" else x
+
+    def _g2(self, label):
+        c = self.cfg
+        return crn_forward(self.G2, label, self.noise2, c.ngf2, c.upsample_mode2, c.n_layers_CRN_block2, True)
+
+    def _f2(self, img):
+        return unet_forward(self.F2, img, 7, self.cfg.nff2)
+
+    def set_input(self, real_A, real_B):
+        self.real_A, self.real_B = real_A, real_B
+
+    def forward(self):
+        c = self.cfg
+        self.noise1, self.noise2 = next(self.noise_iter)
+        self.fake_A = fcgan_g_forward(self.G1, self.noise1, c.n_layers_G1)
+        self.fake_A_from_real_B = self._f2(self.real_B)
+        self.fake_B_from_real_A = self._g2(self.real_A)
+        self.fake_B_from_fake_A = self._g2(self.transform(self.fake_A.detach() if c.detach_G1_from_G2_x else self.fake_A))
+        self.recon_real_A = self._f2(self.fake_B_from_real_A)
+        self.recon_fake_A = self._f2(self.fake_B_from_fake_A)
+
+    def _d(self, nets, cfg_nl, cfg_sf, i, x, sig):
+        return nlayer_d_forward(nets[i], x, cfg_nl[i], cfg_sf[i], use_sigmoid=sig)
+
+    def backward_D1(self):
+        c = self.cfg
+        fake = self.pool1.query(self.fake_A)
+        real = self.transform_inverse(self.real_A)
+        n = len(self.D1)
+        self.loss_D1_fake = sum(gan_loss(self._d(self.D1, c.n_layers_D1, c.scale_factor1, i, fake.detach(), c.no_lsgan1), False, not c.no_lsgan1) for i in range(n))
+        self.loss_D1_real = sum(gan_loss(self._d(self.D1, c.n_layers_D1, c.scale_factor1, i, real, c.no_lsgan1), True, not c.no_lsgan1) for i in range(n))
+        self.loss_D1 = (self.loss_D1_fake + self.loss_D1_real) * 0.5
+        self.loss_D1.backward()
+
+    def backward_D2(self):
+        c = self.cfg
+        n = len(self.D2)
+        d2 = lambda i, x: self._d(self.D2, c.n_layers_D2, c.scale_factor2, i, x, c.no_lsgan2)
+        self.loss_D2_fake, pairs = 0, 0
+        if "real_fake" in c.GAN_losses_D2:
+            fake = self.pool2.query(torch.cat([self.real_A, self.fake_B_from_real_A], 1))
+            pairs += 1
+            self.loss_D2_fake = self.loss_D2_fake + sum(gan_loss(d2(i, fake.detach()), False, not c.no_lsgan2) for i in range(n))
+        if "fake_fake" in c.GAN_losses_D2:
+            fake = self.pool2.query(torch.cat([self.transform(self.fake_A), self.fake_B_from_fake_A], 1))
+            pairs += 1
+            self.loss_D2_fake = self.loss_D2_fake + sum(gan_loss(d2(i, fake.detach()), False, not c.no_lsgan2) for i in range(n))
+        self.loss_D2_fake = self.loss_D2_fake / pairs
+        real = torch.cat([self.real_A, self.real_B], 1)
+        self.loss_D2_real = sum(gan_loss(d2(i, real), True, not c.no_lsgan2) for i in range(n))
+        self.loss_D2 = (self.loss_D2_fake + self.loss_D2_real) * 0.5
+        self.loss_D2.backward()
+
+    def backward_G(self):
+        c = self.cfg
+        bce01 = lambda x, t: F.binary_cross_entropy((x + 1) / 2, (t + 1) / 2)
+        g1 = 0
+        for i, lam in enumerate(c.lambda_D1):
+            pred = self._d(self.D1, c.n_layers_D1, c.scale_factor1, i, self.fake_A, c.no_lsgan1)
+            g1 = g1 + (gan_loss(pred, True, not c.no_lsgan1) * lam if not c.no_logD_trick else -gan_loss(pred, False, not c.no_lsgan1) * lam)
+        self.loss_G1_GAN = g1
+        g2, pairs = 0, 0
+        fakes = []
+        if "real_fake" in c.GAN_losses_G2:
+            fakes.append(torch.cat([self.real_A, self.fake_B_from_real_A], 1))
+        if "fake_fake" in c.GAN_losses_G2:
+            fa = self.fake_A.detach() if c.detach_G1_from_G2_y else self.fake_A
+            fakes.append(torch.cat([self.transform(fa), self.fake_B_from_fake_A], 1))
+        for fake in fakes:
+            pairs += 1
+            for i, lam in enumerate(c.lambda_D2):
+                pred = self._d(self.D2, c.n_layers_D2, c.scale_factor2, i, fake, c.no_lsgan2)
+                g2 = g2 + (gan_loss(pred, True, not c.no_lsgan2) * lam if not c.no_logD_trick else -gan_loss(pred, False, not c.no_lsgan2) * lam)
+        self.loss_G2_GAN = g2
+        if "real_fake" in c.GAN_losses_G2:
+            weight = None
+            if c.weights is not None:
+                weight = torch.ones(1, 1, c.fineSize, c.fineSize)
+                a01 = (self.real_A.detach() + 1) / 2
+                for i, wv in enumerate(c.weights):
+                    weight = weight + a01.narrow(1, i, 1) * (wv - 1.0)
+            self.loss_G2_L1 = weighted_l1(self.fake_B_from_real_A, self.real_B, weight)
+        else:
+            self.loss_G2_L1 = 0
+        self.loss_F2_CE = bce01(self.fake_A_from_real_B, self.real_A)
+        self.loss_G2_real_cycle = bce01(self.recon_real_A, self.real_A)
+        self.loss_G2_fake_cycle = bce01(self.recon_fake_A, self.transform(self.fake_A.detach()))
+        self.loss_G = self.loss_G1_GAN + self.loss_G2_GAN / pairs + self.loss_G2_L1 * c.lambda_A + self.loss_F2_CE * c.lambda_B \
+            + self.loss_G2_real_cycle * c.lambda_A_cycle + self.loss_G2_fake_cycle * c.lambda_A_cycle * c.lambda_fake_cycle
+        self.loss_G.backward()
+
+    def optimize_parameters(self):
+        self.forward()
+        self.opt_D1.zero_grad()
+        self.backward_D1()
+        self.opt_D1.step()
+        self.opt_D2.zero_grad()
+        self.backward_D2()
+        self.opt_D2.step()
+        for o in self.opt_G:
+            o.zero_grad()
+        self.backward_G()
+        for o in self.opt_G:
+            o.step()
+
+    def _grads(self, net, prefix=""):
+        return {k: v.grad.detach().clone() for k, v in net.items() if v.requires_grad and v.grad is not None and k.startswith(prefix)}
+
+    def probe(self):
+        """forward() + backward_D1() + backward_D2() + backward_G() on the initial weights, gradients captured after each
+        (the G step's wasted discriminator gradients are not part of the capture)."""
+        cap = {}
+        self.forward()
+        cap["fake_A"], cap["fake_B_from_fake_A"] = self.fake_A.detach().clone(), self.fake_B_from_fake_A.detach().clone()
+        cap["recon_fake_A"] = self.recon_fake_A.detach().clone()
+        self.opt_D1.zero_grad()
+        self.backward_D1()
+        cap["gradD1"] = [self._grads(d, "model.") for d in self.D1]
+        self.opt_D2.zero_grad()
+        self.backward_D2()
+        cap["gradD2"] = [self._grads(d, "model.") for d in self.D2]
+        for o in self.opt_G:
+            o.zero_grad()
+        self.backward_G()
+        cap["gradG1"], cap["gradG2"], cap["gradF2"] = self._grads(self.G1), self._grads(self.G2), self._grads(self.F2)
+        cap["losses"] = self.losses()
+        return cap
+
+    def losses(self):
+        f = lambda v: float(v.detach()) if torch.is_tensor(v) else float(v)
+        return {"G2_GAN": f(self.loss_G2_GAN), "G2_real_cycle": f(self.loss_G2_real_cycle), "G2_fake_cycle": f(self.loss_G2_fake_cycle),
+                "D2": f(self.loss_D2), "G1_GAN": f(self.loss_G1_GAN), "D1": f(self.loss_D1)}
 
 
 def norm_cancelled_keys_g(n_layers: int = 5):

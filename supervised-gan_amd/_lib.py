@@ -71,6 +71,7 @@ SIGNATURES = {
     "sgan_conv_wgrad_grouped": [C.POINTER(ConvWgradJob), _I, _P, _L, _P],
     "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
     "sgan_norm_bwd_apply_multi": [C.POINTER(NormBwdJob), _I, _P],
+    "sgan_bce01_fwd": [_P, _I, _P, _I, _I, _I, _P, _P, _I, _P],
     "sgan_bilinear_up2_fwd": [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "sgan_bilinear_up2_bwd": [_P, _I, _I, _I, _I, _P, _I, _P],
     "sgan_avgpool_pyramid_fwd": [_P, _I, _I, _I, _P, _P, _P],

@@ -299,6 +299,43 @@ __global__ __launch_bounds__(256) void sg_scale_kernel(const float* gout, const 
     }
 }
 
+// BCELoss((x + 1) / 2, (t + 1) / 2), mean over npix * C (torch's -100 log clamp); g = dloss/dx for a unit upstream
+// gradient (torch: dL/dp = (p - t) / max(p (1 - p), 1e-12), then dp/dx = 1/2)
+__global__ __launch_bounds__(1024) void sg_bce01_fwd_kernel(const float* x, int x_ld, const float* t, int t_ld, int npix, int C,
+                                                            float* loss_out, float* g, int g_ld) {
+    __shared__ double wsum[16];
+    const double inv = 1.0 / ((double)npix * (double)C);
+    double acc = 0.0;
+    for (int p = threadIdx.x; p < npix; p += 1024) {
+        for (int c = 0; c < g_ld; ++c) {
+            float gv = 0.f;
+            if (c < C) {
+                const float pr = (x[(int64_t)p * x_ld + c] + 1.f) * 0.5f, tg = (t[(int64_t)p * t_ld + c] + 1.f) * 0.5f;
+                const float lp = fmaxf(logf(pr), -100.f), lq = fmaxf(log1pf(-pr), -100.f);
+                acc += (double)(-(tg * lp + (1.f - tg) * lq));
+                gv = (pr - tg) / fmaxf(pr * (1.f - pr), 1e-12f) * 0.5f * (float)inv;
+            }
+            g[(int64_t)p * g_ld + c] = gv;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < 16; ++i) s += wsum[i];
+        loss_out[0] = (float)(s * inv);
+    }
+}
+
+extern "C" int sgan_bce01_fwd(const float* x, int32_t x_ld, const float* t, int32_t t_ld, int32_t npix, int32_t C, float* loss_out,
+                              float* g, int32_t g_ld, void* stream) {
+    SGAN_CHECK(x && t && loss_out && g && npix > 0 && C > 0 && g_ld >= C && x_ld >= C && t_ld >= C, "bad argument");
+    hipLaunchKernelGGL(sg_bce01_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, x_ld, t, t_ld, npix, C, loss_out, g, g_ld);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
 extern "C" int sgan_l1w_fwd(const float* x, int32_t x_ld, const float* y, int32_t y_ld, int32_t npix, int32_t C, const float* a,
                             int32_t a_ld, const float* weights_dev, int32_t nweights, float lambda, float* loss_out, float* g,
                             int32_t g_ld, void* stream) {

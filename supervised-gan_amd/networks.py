@@ -1439,6 +1439,54 @@ class _L1Fn(torch.autograd.Function):
         return ops.logical_view(dx, ctx.C), None, None, None, None, None
 
 
+class _Bce01Fn(torch.autograd.Function):
+    """BCELoss((x + 1) / 2, (t + 1) / 2), gradient w.r.t. x only."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        xb, tb = ops.as_nhwc(x), ops.as_nhwc(t)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        g = torch.empty_like(xb)
+        ops.bce01_fwd(xb, tb, x.shape[1], loss, g)
+        ctx.g, ctx.C = g, x.shape[1]
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        dx = torch.empty_like(ctx.g)
+        ops.scale(gout.contiguous(), ctx.g, dx)
+        return ops.logical_view(dx, ctx.C), None
+
+
+def bce_on_rescaled(x, t):
+    """torch.nn.BCELoss()((x + 1) / 2, (t + 1) / 2) of the two-stage trainers (twostage_cycle_model.py:398-403) as one
+    forward and one backward kernel; `t` is treated as a constant."""
+    return _Bce01Fn.apply(x, t.detach())
+
+
+class _Bilinear2xFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode='bilinear') on a logical [1, C, H, W] tensor (`--transform_1to2 bilinear_2`)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xb = ops.as_nhwc(x)
+        H, W, Cs = xb.shape
+        out = torch.empty((2 * H, 2 * W, Cs), dtype=torch.float32, device=x.device)
+        ops.bilinear_up2_fwd(xb, out, None)
+        ctx.shape, ctx.C = (H, W, Cs), x.shape[1]
+        return ops.logical_view(out, x.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        din = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        ops.bilinear_up2_bwd(ops.as_nhwc(g), din)
+        return ops.logical_view(din, ctx.C)
+
+
+def bilinear_upsample2x(x):
+    return _Bilinear2xFn.apply(x)
+
+
 class WeightedL1Loss(nn.Module):
     """WeightedL1Loss (models/networks.py:205-214): mean(|x - y| * w).  One forward kernel (which also writes the
     gradient for a unit upstream) and one scaling kernel in backward."""

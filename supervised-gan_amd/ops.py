@@ -204,6 +204,12 @@ def l1w_fwd(x, y, Creal, a, weights_dev, nweights, lam, loss_out, g):
                                  _ptr(loss_out), _ptr(_act(g)), g.stride(1), _stream()), "sgan_l1w_fwd")
 
 
+def bce01_fwd(x, t, Creal, loss_out, g):
+    H, W, _ = x.shape
+    L.check(L.lib().sgan_bce01_fwd(_ptr(_act(x)), x.stride(1), _ptr(_act(t)), t.stride(1), H * W, Creal, _ptr(loss_out),
+                                   _ptr(_act(g)), g.stride(1), _stream()), "sgan_bce01_fwd")
+
+
 def scale(gout, g, dx):
     assert g.is_contiguous() and dx.is_contiguous()
     L.check(L.lib().sgan_scale(_ptr(gout), _ptr(g), _ptr(dx), g.numel(), _stream()), "sgan_scale")

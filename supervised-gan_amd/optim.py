@@ -80,3 +80,36 @@ class FusedAdam:
     @property
     def step_count(self):
         return int(self._state[0].item()) if self._state is not None else 0
+
+
+class AdamGroups:
+    """`torch.optim.Adam([{'name':, 'params':, 'lr':}, ...], betas=)` as the two-stage trainers build it
+    (models/twostage_cycle_model.py:141-144): one FusedAdam per named group, stepped together."""
+
+    def __init__(self, groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.optimizers = []
+        self.param_groups = []
+        for g in groups:
+            o = FusedAdam(g["params"], lr=g.get("lr", lr), betas=betas, eps=eps)
+            o.param_groups[0]["name"] = g.get("name")
+            self.optimizers.append(o)
+            self.param_groups.append(o.param_groups[0])
+
+    def zero_grad(self, set_to_none=False):
+        for o in self.optimizers:
+            o.zero_grad()
+
+    def step(self):
+        for o in self.optimizers:
+            o.step()
+
+    def sync_lr(self):
+        for o in self.optimizers:
+            o.sync_lr()
+
+    def segments(self):
+        return [s for o in self.optimizers for s in o.segments()]
+
+    @property
+    def step_count(self):
+        return self.optimizers[0].step_count

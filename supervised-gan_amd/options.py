@@ -65,6 +65,43 @@ class BaseOptions:
         a('--n_layers_CRN_block', type=int, default=1)
         a('--pretrained_model_dir', type=str, default='')
         a('--transform_1to2', type=str, default='None')
+        # two-stage models (options/base_options.py:62-99)
+        a('--scale_factor1', type=int, default=[1], nargs='+')
+        a('--scale_factor2', type=int, default=[1], nargs='+')
+        a('--which_model_netD1', type=str, default='n_layers')
+        a('--which_model_netG1', type=str, default='fcgan')
+        a('--which_model_netF1', type=str, default='fcgan')
+        a('--ngf1', type=int, default=64)
+        a('--ndf1', type=int, default=64)
+        a('--nff1', type=int, default=64)
+        a('--n_layers_D1', type=int, default=[3], nargs='+')
+        a('--n_layers_G1', type=int, default=5)
+        a('--n_layers_F1', type=int, default=5)
+        a('--no_dropout1', action='store_true')
+        a('--noise_nc1', type=int, default=256)
+        a('--noiseSize1', type=int, default=1)
+        a('--which_model_netD2', type=str, default='n_layers')
+        a('--which_model_netG2', type=str, default='unet_128')
+        a('--which_model_netF2', type=str, default='unet_128')
+        a('--ngf2', type=int, default=64)
+        a('--ndf2', type=int, default=64)
+        a('--nff2', type=int, default=64)
+        a('--n_layers_D2', type=int, default=[3], nargs='+')
+        a('--n_layers_G2', type=int, default=5)
+        a('--n_layers_F2', type=int, default=5)
+        a('--no_dropout2', action='store_true')
+        a('--noise_nc2', type=int, default=256)
+        a('--noiseSize2', type=int, default=1)
+        a('--use_residual1', action='store_true')
+        a('--use_residual2', action='store_true')
+        a('--upsample_mode1', type=str, default='convt')
+        a('--no_share_label_block_weights1', action='store_true')
+        a('--n_layers_CRN_block1', type=int, default=1)
+        a('--upsample_mode2', type=str, default='convt')
+        a('--no_share_label_block_weights2', action='store_true')
+        a('--n_layers_CRN_block2', type=int, default=1)
+        a('--n_layers_G1_skip', type=int, default=-1)
+        a('--n_layers_G2_skip', type=int, default=-1)
         # MI355X path extras (not in the reference)
         a('--skip_wasted_D_wgrad', action='store_true',
           help='do not compute discriminator weight gradients during the G step (the reference computes and discards them)')
@@ -127,6 +164,27 @@ class TrainOptions(BaseOptions):
         a('--optimizer', type=str, default='adam')
         a('--pool_reject_prob', type=float, default=0.5)
         a('--no_logD_trick', action='store_true')
+        a('--lambda_fake_cycle', type=float, default=1.0)
+        a('--which_model_to_load', nargs='+', default=[''])
+        # two-stage models (options/train_options.py:42-64)
+        a('--lr1', type=float, default=0.0002)
+        a('--lr2', type=float, default=0.0002)
+        a('--lambda_D1', type=float, default=[1.0], nargs='+')
+        a('--no_lsgan1', action='store_true')
+        a('--n_update_D1', type=int, default=1)
+        a('--lambda_D2', type=float, default=[1.0], nargs='+')
+        a('--no_lsgan2', action='store_true')
+        a('--n_update_D2', type=int, default=1)
+        a('--sequential_train', action='store_true')
+        a('--which_epoch_sequential', type=str, default='seq')
+        a('--use_multi_class_GAN', action='store_true')
+        a('--detach_G1_from_G2_x', action='store_true')
+        a('--detach_G1_from_G2_y', action='store_true')
+        a('--GAN_losses_D2', nargs='+', default=['real_fake'])
+        a('--GAN_losses_G2', nargs='+', default=['real_fake'])
+        a('--lambda_A_cycle', type=float, default=10.0)
+        a('--lambda_B_cycle', type=float, default=10.0)
+        a('--use_fixed_noise1', action='store_true')
         self.isTrain = True
 
 

@@ -311,3 +311,63 @@ def test_crn_small(golden_dir, tag):
             assert float(v.grad.abs().max()) <= 1e-3 * float(sd[k.replace(".bias", ".weight")].grad.abs().max()), k
         else:
             assert rel(v.grad, g["grad/" + k]) < 1e-4, k
+
+
+# ------------------------------------------------------------------------------------------------
+# twostage_cycle (BASELINE configs[4]): G1 fcgan + G2 crn + F2 unet_128 + 2 x D1 + 4 x D2
+# ------------------------------------------------------------------------------------------------
+TWOSTAGE_CASES = [("twostage_small.npz", dict(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8, ndf2=8,
+                                             GAN_losses_D2=("real_fake", "fake_fake"), GAN_losses_G2=("real_fake", "fake_fake"),
+                                             weights=(2.0, 5.0))),
+                  ("twostage_full.npz", dict())]
+
+
+def twostage_noise(cfg):
+    k = 0
+    while True:
+        yield (O.np_normal(5000 + k, (1, cfg.noise_nc1, cfg.noiseSize1, cfg.noiseSize1)),
+               O.np_normal(6000 + k, (1, cfg.noise_nc2, cfg.noiseSize2, cfg.noiseSize2)))
+        k += 1
+
+
+def twostage_undet(cfg):
+    u = {"G1": O.norm_cancelled_keys_g(cfg.n_layers_G1),
+         "G2": O.norm_cancelled_keys_crn(cfg.input_nc, cfg.output_nc, cfg.noise_nc2, cfg.ngf2, cfg.upsample_mode2, cfg.n_layers_CRN_block2, True),
+         "F2": O.norm_cancelled_keys_unet(7, cfg.nff2, -1)}
+    u["D1"] = [O.norm_cancelled_keys_d(cfg.input_nc, cfg.ndf1, nl) for nl in cfg.n_layers_D1]
+    u["D2"] = [O.norm_cancelled_keys_d(cfg.input_nc + cfg.output_nc, cfg.ndf2, nl) for nl in cfg.n_layers_D2]
+    return u
+
+
+def check_twostage_probe(cap, g, cfg, tol=TOL, robust=False, tally=None):
+    for key in ("fake_A", "fake_B_from_fake_A", "recon_fake_A"):
+        assert rel(cap[key][:, :, :64, :64], g[f"probe/{key}_crop"]) < tol, key
+    assert np.abs(np.asarray(list(cap["losses"].values())) - g["probe/losses"]).max() < tol * max(1.0, np.abs(g["probe/losses"]).max())
+    u = twostage_undet(cfg)
+    for tag in ("G1", "G2", "F2"):
+        check_grads(cap["grad" + tag], g, f"probe/grad{tag}", u[tag], tol, robust, tally)
+    for tag in ("D1", "D2"):
+        for i, gd in enumerate(cap["grad" + tag]):
+            check_grads(gd, g, f"probe/grad{tag}_{i}", u[tag][i], tol, robust, tally)
+
+
+@pytest.mark.parametrize("name,kw", TWOSTAGE_CASES)
+def test_twostage_cycle_step(golden_dir, name, kw):
+    import random
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    g = load(golden_dir, name)
+    cfg = O.TwoStageConfig(**kw)
+    random.seed(1234)
+    p = O.TwoStageCycleOracle(cfg, seed=0)
+    p.noise_iter = twostage_noise(cfg)
+    p.set_input(*cgan_batch(cfg, 0))
+    check_twostage_probe(p.probe(), g, cfg, tol=1e-4)
+    random.seed(1234)
+    m = O.TwoStageCycleOracle(cfg, seed=0)
+    m.noise_iter = twostage_noise(cfg)
+    losses = []
+    for step in range(g["losses"].shape[0]):
+        m.set_input(*cgan_batch(cfg, step))
+        m.optimize_parameters()
+        losses.append(list(m.losses().values()))
+    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])

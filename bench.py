@@ -33,6 +33,29 @@ def flops_per_image(n_update_G, workload="fcgan"):
     return 2.0 * 1e9 * (g_f * g + 2 * g_b * g + d_f * d + 2 * d_b * d)
 
 
+def build_twostage(args, rank):
+    """README.md:18 (BASELINE configs[4]): G1 fcgan ngf32 (z 8x4x4 -> 256^2 labels), bilinear x2, G2 crn ngf64 bilinear 2-layer
+    blocks, F2 unet_128 nff32, D1 n_layers 3 3 scale 1 2, D2 n_layers 3 4 3 4 scale 1 1 2 2, no dropout."""
+    from supervised_gan_amd.models import create_model
+    from supervised_gan_amd.options import TrainOptions
+    argv = ["--name", "bench", "--model", "twostage_cycle", "--which_direction", "AtoB", "--dataset_mode", "single",
+            "--loadSize", "1024", "--fineSize", "512", "--transform_1to2", "bilinear_2", "--batchSize", "1", "--input_nc", "2",
+            "--output_nc", "1", "--which_channel", "rg_b", "--which_model_netG1", "fcgan", "--n_layers_G1", "5", "--ngf1", "32",
+            "--which_model_netD1", "n_layers", "--n_layers_D1", "3", "3", "--ndf1", "32", "--scale_factor1", "1", "2",
+            "--lambda_D1", "0.5", "0.4", "--which_model_netG2", "crn", "--ngf2", "64", "--upsample_mode2", "bilinear",
+            "--n_layers_CRN_block2", "2", "--which_model_netF2", "unet_128", "--nff2", "32", "--which_model_netD2", "n_layers",
+            "--n_layers_D2", "3", "4", "3", "4", "--ndf2", "64", "--scale_factor2", "1", "1", "2", "2",
+            "--lambda_D2", "0.3", "0.3", "0.2", "0.2", "--lambda_A", "10", "--lambda_B", "10", "--lambda_A_cycle", "5",
+            "--lambda_fake_cycle", "1", "--noise_nc1", "8", "--noiseSize1", "4", "--noise_nc2", "8", "--noiseSize2", "8",
+            "--norm", "instance", "--no_dropout1", "--no_dropout2", "--n_update_G", "1", "--no_lsgan1", "--manualSeed", str(rank),
+            "--gpu_ids", str(torch.cuda.current_device()), "--checkpoints_dir", "/tmp/sgan_bench_ckpt"]
+    if args.skip_wasted_D_wgrad:
+        argv.append("--skip_wasted_D_wgrad")
+    opt = TrainOptions().parse(argv, save=False, verbose=False)
+    torch.manual_seed(0)
+    return create_model(opt)
+
+
 def build_cgan(args, rank):
     """README.md:38: unet_256 ngf64 with dropout + Gaussian noise, D n_layers 3 4 ndf64 scale 1 1,
     lambda_D .5 .5, lambda_A 10, L1 weights 2 4, no_lsgan, n_update_G 2, which_channel rg_b."""
@@ -241,8 +264,9 @@ def main():
     ap.add_argument("--no_group", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_profile", action="store_true")
-    ap.add_argument("--workload", default="fcgan", choices=["fcgan", "cgan"],
-                    help="fcgan = the headline metric (BASELINE configs[1]); cgan = BASELINE configs[2], reported under its own metric name")
+    ap.add_argument("--workload", default="fcgan", choices=["fcgan", "cgan", "twostage_cycle"],
+                    help="fcgan = the headline metric (BASELINE configs[1]); cgan = BASELINE configs[2], twostage_cycle = configs[4], "
+                         "each reported under its own metric name (twostage_cycle runs eagerly, without the kernel profile)")
     args = ap.parse_args()
 
     from supervised_gan_amd import dist as sdist
@@ -256,8 +280,14 @@ def main():
     device = torch.device("cuda", local)
 
     cgan = args.workload == "cgan"
-    model = build_cgan(args, rank) if cgan else build_model(args, rank)
-    sdist.broadcast_parameters([model.netG] + model.netD)
+    two = args.workload == "twostage_cycle"
+    if two:
+        args.eager, args.no_kernel_profile, args.no_cpu_baseline = True, True, True
+        model = build_twostage(args, rank)
+        sdist.broadcast_parameters([model.netG1, model.netG2, model.netF2] + model.netD1 + model.netD2)
+    else:
+        model = build_cgan(args, rank) if cgan else build_model(args, rank)
+        sdist.broadcast_parameters([model.netG] + model.netD)
     if world > 1:
         model.grad_sync = sdist.GradAverager()
     ring = synthetic_ring(64, rank, device)
@@ -300,15 +330,20 @@ def main():
 
     if rank == 0:
         ips = world * args.steps / dt
-        fl = flops_per_image(args.n_update_G, args.workload)
+        fl = 990e9 if two else flops_per_image(args.n_update_G, args.workload)      # twostage_cycle ~ 990 GFLOP / image
         workload = ("fcgan deconv-G(ngf32, z 8x8x8) + 3x PatchGAN-D(ndf32, n_layers 3, scale 1/2/4) 512x512 bs=1, "
                     f"n_update_D=1 n_update_G={args.n_update_G}, Adam, pool 50 (BASELINE configs[1] shape, fp32 compute)")
         if cgan:
             workload = ("cgan unet_256-G(ngf64, 2->1 ch, dropout, gaussian noise) + PatchGAN-D n_layers 3 and 4 (ndf64, scale 1 1) "
                         f"512x512 bs=1, GAN + weighted L1 (lambda_A 10, weights 2 4), n_update_D=1 n_update_G={args.n_update_G}, "
                         "Adam, pool 50 (BASELINE configs[2], fp32 compute)")
+        if two:
+            workload = ("twostage_cycle: G1 fcgan(ngf32) + bilinear x2 + G2 crn(ngf64, bilinear, 2-layer blocks) + F2 unet_128(nff32) + "
+                        "D1 n_layers 3 3 (scale 1 2) + D2 n_layers 3 4 3 4 (scale 1 1 2 2) 512x512 bs=1, one D1, D2 and G update per "
+                        "step, Adam (BASELINE configs[4], fp32 compute, eager launches)")
         out = {
-            "metric": "train-step images/sec, cgan unet_256 512x512 bs=1/GPU" if cgan else "train-step images/sec, fcgan 512x512 bs=1/GPU",
+            "metric": ("train-step images/sec, twostage_cycle 512x512 bs=1/GPU" if two else
+                       "train-step images/sec, cgan unet_256 512x512 bs=1/GPU" if cgan else "train-step images/sec, fcgan 512x512 bs=1/GPU"),
             "value": ips, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

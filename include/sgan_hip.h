@@ -137,6 +137,9 @@ typedef struct sgan_conv_dgrad_job {
     double* bwd_sums;
     int32_t bwd_sums_sq_stride;   /* distance from s1[n] to s2[n] in bwd_sums; 0 = Cin */
     int32_t accumulate;           /* 1: din += result (a tensor with two forward consumers, e.g. a U-Net skip) */
+    int32_t w_transposed;         /* 1: `w` is the transposed master copy [kh*kw][Cin_s][Cout_s] (sgan_transpose_weights): the
+                                   * reduction channel (Cout) is then contiguous and backward-data stages its weights with
+                                   * 16-byte LDS stores like the forward pass */
 } sgan_conv_dgrad_job;
 typedef struct sgan_conv_wgrad_job {
     const sgan_conv_desc* d;
@@ -150,6 +153,12 @@ int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t n, void* wo
                             void* stream);
 int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* workspace, int64_t workspace_bytes,
                             void* stream);
+
+/* ---- transposed weight copy for backward-data ---------------------------------------------------
+ * flat_t[off + tap][ci][co] = flat[off + tap][co][ci] for every conv segment (bias / affine ranges of the flat
+ * parameter buffer are not touched).  Run after each optimizer step on the nets whose backward-data is needed. */
+typedef struct sgan_wt_seg { int64_t off; int32_t taps, cout, cin; } sgan_wt_seg;
+int sgan_transpose_weights(const float* flat, float* flat_t, const sgan_wt_seg* segs, int32_t n /* <= 64 */, void* stream);
 
 /* ---- backward-weight ---------------------------------------------------------------------------
  * dw += act(norm(in))^T (x) dout over all pixels (master layout), dbias += sum_pixels dout.

@@ -32,7 +32,11 @@ class ConvDgradJob(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("w", C.c_void_p),
                 ("din", C.c_void_p), ("din_ld", C.c_int32), ("x", C.c_void_p), ("x_ld", C.c_int32),
                 ("x_norm", C.POINTER(NormDesc)), ("bwd_sums", C.c_void_p), ("bwd_sums_sq_stride", C.c_int32),
-                ("accumulate", C.c_int32)]
+                ("accumulate", C.c_int32), ("w_transposed", C.c_int32)]
+
+
+class WtSeg(C.Structure):
+    _fields_ = [("off", C.c_int64), ("taps", C.c_int32), ("cout", C.c_int32), ("cin", C.c_int32)]
 
 
 class ConvWgradJob(C.Structure):
@@ -71,6 +75,7 @@ SIGNATURES = {
     "sgan_conv_wgrad_grouped": [C.POINTER(ConvWgradJob), _I, _P, _L, _P],
     "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
     "sgan_norm_bwd_apply_multi": [C.POINTER(NormBwdJob), _I, _P],
+    "sgan_transpose_weights": [_P, _P, C.POINTER(WtSeg), _I, _P],
     "sgan_bce01_fwd": [_P, _I, _P, _I, _I, _I, _P, _P, _I, _P],
     "sgan_bilinear_up2_fwd": [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "sgan_bilinear_up2_bwd": [_P, _I, _I, _I, _I, _P, _I, _P],

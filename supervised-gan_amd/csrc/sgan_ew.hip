@@ -357,6 +357,52 @@ extern "C" int sgan_scale(const float* gout, const float* g, float* dx, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// transposed master copy of the conv weights (backward-data wants the reduction channel contiguous)
+// ------------------------------------------------------------------------------------------
+struct SgWtTable { sgan_wt_seg s[64]; int64_t first[65]; int32_t n; };   // first[i]: first 32x32 tile of segment i
+
+__global__ __launch_bounds__(256) void sg_transpose_weights_kernel(const float* flat, float* flat_t, const SgWtTable T) {
+    __shared__ float tile[32][33];
+    int i = 0;
+    for (int k = 1; k < T.n; ++k)
+        if ((int64_t)blockIdx.x >= T.first[k]) i = k;
+    const sgan_wt_seg S = T.s[i];
+    int64_t t = blockIdx.x - T.first[i];
+    const int tc = (S.cin + 31) / 32, tr = (S.cout + 31) / 32;
+    const int bx = (int)(t % tc); t /= tc;
+    const int by = (int)(t % tr); t /= tr;      // t = tap
+    const float* src = flat + S.off + t * (int64_t)S.cout * S.cin;
+    float* dst = flat_t + S.off + t * (int64_t)S.cout * S.cin;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int r = ly; r < 32; r += 8) {
+        const int co = by * 32 + r, ci = bx * 32 + lx;
+        tile[r][lx] = (co < S.cout && ci < S.cin) ? src[(int64_t)co * S.cin + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int ci = bx * 32 + r, co = by * 32 + lx;
+        if (ci < S.cin && co < S.cout) dst[(int64_t)ci * S.cout + co] = tile[lx][r];
+    }
+}
+
+extern "C" int sgan_transpose_weights(const float* flat, float* flat_t, const sgan_wt_seg* segs, int32_t n, void* stream) {
+    SGAN_CHECK(flat && flat_t && segs && n >= 1 && n <= 64, "1..64 segments");
+    SgWtTable T;
+    T.n = n;
+    int64_t tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        SGAN_CHECK(segs[i].taps > 0 && segs[i].cout > 0 && segs[i].cin > 0, "bad segment %d", i);
+        T.s[i] = segs[i];
+        T.first[i] = tiles;
+        tiles += (int64_t)segs[i].taps * ((segs[i].cout + 31) / 32) * ((segs[i].cin + 31) / 32);
+    }
+    T.first[n] = tiles;
+    hipLaunchKernelGGL(sg_transpose_weights_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, flat, flat_t, T);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // BatchNorm running statistics for up to 16 layers in one launch
 // ------------------------------------------------------------------------------------------
 struct SgBnRunTable {

@@ -1034,7 +1034,8 @@ extern "C" int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t 
     if (rc) return rc;
     const sgan_conv_desc* d0 = jobs[0].d;
     P.Ck = d0->Cout; P.N = d0->Cin;
-    P.w_ns = 1; P.w_ks = d0->Cin;  // B[k=co][n=ci] = W[tap][co][ci]
+    if (jobs[0].w_transposed) { P.w_ns = d0->Cout; P.w_ks = 1; }   // B[k=co][n=ci] = Wt[tap][ci][co]: k contiguous
+    else { P.w_ns = 1; P.w_ks = d0->Cin; }                          // B[k=co][n=ci] = W[tap][co][ci]: n contiguous
     P.out_act = SGAN_ACT_NONE;
     P.pro_act = SGAN_ACT_NONE;
     const sgan_norm_desc* x0 = jobs[0].x ? jobs[0].x_norm : nullptr;
@@ -1046,6 +1047,7 @@ extern "C" int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t 
         SGAN_CHECK(!J.x || J.x_ld >= J.d->Cin, "bad x_ld in job %d", g);
         SGAN_CHECK(!(J.bwd_sums && !J.x), "bwd_sums needs x (job %d)", g);
         SGAN_CHECK((J.x != nullptr) == (jobs[0].x != nullptr), "grouped jobs must all have / all lack the forward tensor");
+        SGAN_CHECK((J.w_transposed != 0) == (jobs[0].w_transposed != 0), "grouped jobs must use the same weight layout");
         const sgan_norm_desc* xn = J.x ? J.x_norm : nullptr;
         SGAN_CHECK((xn ? xn->act : SGAN_ACT_NONE) == P.xn_act, "grouped jobs must share the activation");
         SgProb& Q = P.q[g];
@@ -1073,6 +1075,6 @@ extern "C" int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32
                                float* din, int32_t din_ld, const float* x, int32_t x_ld, const sgan_norm_desc* x_norm,
                                double* bwd_sums, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
-    sgan_conv_dgrad_job j = {d, dout, dout_ld, w, din, din_ld, x, x_ld, x_norm, bwd_sums, 0, 0};
+    sgan_conv_dgrad_job j = {d, dout, dout_ld, w, din, din_ld, x, x_ld, x_norm, bwd_sums, 0, 0, 0};
     return sgan_conv_dgrad_grouped(&j, 1, workspace, workspace_bytes, stream);
 }

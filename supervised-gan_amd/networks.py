@@ -306,6 +306,22 @@ class ChainNet(nn.Module):
         b = self._flat[L.b_off: L.b_off + L.cout_s] if L.bias else None
         return w, b
 
+    def _wt(self, L: LayerSpec):
+        """Weights of layer L from the transposed copy [tap][Cin][Cout] that backward-data reads (refreshed lazily: after an
+        optimizer step -- FusedAdam bumps `_wt_epoch` -- or any in-place torch write to the flat storage)."""
+        key = (self._flat.data_ptr(), self._flat._version, getattr(self, "_wt_epoch", 0))
+        if getattr(self, "_wt_key", None) != key:
+            if getattr(self, "_flat_t", None) is None or self._flat_t.shape != self._flat.shape or self._flat_t.device != self._flat.device:
+                self._flat_t = torch.zeros_like(self._flat)
+            segs, seen = [], set()
+            for Lx in self.layers:
+                if Lx.w_off not in seen:
+                    seen.add(Lx.w_off)
+                    segs.append((Lx.w_off, Lx.k * Lx.k, Lx.cout_s, Lx.cin_s))
+            ops.transpose_weights(self._flat, self._flat_t, segs)
+            self._wt_key = key
+        return self._flat_t[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s]
+
     def _gwb(self, L: LayerSpec):
         w = self._gflat[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s]
         b = self._gflat[L.b_off: L.b_off + L.cout_s] if L.bias else None
@@ -398,7 +414,7 @@ class ChainNet(nn.Module):
             if li > 0:
                 P = self.layers[li - 1]
                 din = torch.empty((h, w, P.cout_s), dtype=torch.float32, device=dev)
-                ops.conv_dgrad(desc, dcur, wt, din, src, in_norm, sums[li - 1])
+                ops.conv_dgrad(desc, dcur, self._wt(L), din, src, in_norm, sums[li - 1], w_transposed=True)
                 if P.norm:
                     dg = self._gflat[P.g_off: P.g_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
                     db = self._gflat[P.be_off: P.be_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
@@ -406,7 +422,7 @@ class ChainNet(nn.Module):
                 dcur = din
             elif need_dx:
                 dx = torch.empty((h, w, L.cin_s), dtype=torch.float32, device=dev)
-                ops.conv_dgrad(desc, dcur, wt, dx, None, None, None)
+                ops.conv_dgrad(desc, dcur, self._wt(L), dx, None, None, None, w_transposed=True)
         return dx
 
 
@@ -552,7 +568,7 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
                 desc, h, w, ho, wo = geos[j][li]
                 din = torch.empty((h, w, Pv.cout_s), dtype=torch.float32, device=dev)
                 dins.append(din)
-                jobs.append((desc, dcur[j], net._wb(net.layers[li])[0], din, srcs[j], norms[j], sums[j][li - 1]))
+                jobs.append((desc, dcur[j], net._wt(net.layers[li]), din, srcs[j], norms[j], sums[j][li - 1], 0, False, True))
             ops.conv_dgrad_grouped(jobs)
             nb = []
             for j, net in enumerate(nets):
@@ -573,7 +589,7 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
                     L = nets[j].layers[0]
                     desc, h, w, ho, wo = geos[j][0]
                     dxs[j] = torch.empty((h, w, L.cin_s), dtype=torch.float32, device=dev)
-                    jobs.append((desc, dcur[j], nets[j]._wb(L)[0], dxs[j], None, None, None))
+                    jobs.append((desc, dcur[j], nets[j]._wt(L), dxs[j], None, None, None, 0, False, True))
                 ops.conv_dgrad_grouped(jobs)
     return dxs
 
@@ -920,7 +936,7 @@ class UnetGenerator(ChainNet):
         # final transposed conv: gradient of ReLU(cat_1)
         nrm = self._cat_norm(1, hw, catstat)
         wgrad(self.up[0], upd[0], cat[1], nrm, d0)
-        ops.conv_dgrad(upd[0], d0, self._wb(self.up[0])[0], dcat[1], cat[1], nrm, None)
+        ops.conv_dgrad(upd[0], d0, self._wt(self.up[0]), dcat[1], cat[1], nrm, None, w_transposed=True)
         # decoder, outermost block first
         d_inner = None
         for l in range(1, n):
@@ -937,7 +953,7 @@ class UnetGenerator(ChainNet):
                 din = dcat[l + 1]
                 sums = csum[l + 1] if (skip[l + 1] and l + 1 > 1) else None
             wgrad(self.up[l], upd[l], src, nrm, dy)
-            ops.conv_dgrad(upd[l], dy, self._wb(self.up[l])[0], din, src, nrm, sums)
+            ops.conv_dgrad(upd[l], dy, self._wt(self.up[l]), din, src, nrm, sums, w_transposed=True)
         # encoder, innermost first: dr = gradient w.r.t. the raw output of down[l]
         dr = d_inner
         for l in range(n - 1, 0, -1):
@@ -948,10 +964,10 @@ class UnetGenerator(ChainNet):
             sums, sq = xsum[l - 1] if normed else (None, 0)
             if skip[l]:
                 din = dcat[l][:, :, c[l - 1]:]
-                ops.conv_dgrad(dn[l], dr, self._wb(self.down[l])[0], din, src, nrm, sums, sq, accumulate=True)
+                ops.conv_dgrad(dn[l], dr, self._wt(self.down[l]), din, src, nrm, sums, sq, accumulate=True, w_transposed=True)
             else:
                 din = torch.empty(hw[l - 1] + (c[l - 1],), dtype=torch.float32, device=dev)
-                ops.conv_dgrad(dn[l], dr, self._wb(self.down[l])[0], din, src, nrm, sums, sq)
+                ops.conv_dgrad(dn[l], dr, self._wt(self.down[l]), din, src, nrm, sums, sq, w_transposed=True)
             if normed:
                 ops.norm_bwd_apply(din, src, nrm, sums, None, None, sq)
             dr = din
@@ -959,7 +975,7 @@ class UnetGenerator(ChainNet):
         dx = None
         if need_dx:
             dx = torch.empty_like(x)
-            ops.conv_dgrad(dn[0], dr, self._wb(self.down[0])[0], dx, None, None, None)
+            ops.conv_dgrad(dn[0], dr, self._wt(self.down[0]), dx, None, None, None, w_transposed=True)
         return dx
 
     # ---- module protocol ---------------------------------------------------------------------------
@@ -1154,7 +1170,7 @@ class CascadedRefinementNetwork(ChainNet):
                 desc = self._desc(L, 2 * h, 2 * w)
                 wgrad(L, desc, src, nrm, d)
                 din = torch.empty((2 * h, 2 * w, ngf), dtype=torch.float32, device=dev)
-                ops.conv_dgrad(desc, d, self._wb(L)[0], din, src, nrm, ssum)
+                ops.conv_dgrad(desc, d, self._wt(L), din, src, nrm, ssum, w_transposed=True)
                 ops.norm_bwd_apply(din, src, nrm, ssum)
                 d = din
             # d = gradient w.r.t. u_s (raw, before its InstanceNorm)
@@ -1170,11 +1186,11 @@ class CascadedRefinementNetwork(ChainNet):
             if s == 5:
                 if need_dx:
                     dfirst = torch.empty_like(S["first"])
-                    ops.conv_dgrad(desc, d, self._wb(U)[0], dfirst, None, None, None)
+                    ops.conv_dgrad(desc, d, self._wt(U), dfirst, None, None, None, w_transposed=True)
                 break
             dc_ = torch.empty_like(cat[s])
             csum = sm(("cat", s), 2 * C2)
-            ops.conv_dgrad(desc, d, self._wb(U)[0], dc_, cat[s], nrm, csum)
+            ops.conv_dgrad(desc, d, self._wt(U), dc_, cat[s], nrm, csum, w_transposed=True)
             ops.norm_bwd_apply(dc_, cat[s], nrm, csum)          # both halves at once: raw gradients of l_s and of h_{s+1}
             # label branch of this stage
             Ll = self.lab[s]
@@ -1182,7 +1198,7 @@ class CascadedRefinementNetwork(ChainNet):
             wgrad(Ll, ldesc, S["lv"][s], None, dc_[:, :, :ngf])
             if need_dx:
                 dlv[s] = torch.empty(res[s] + (4,), dtype=torch.float32, device=dev)
-                ops.conv_dgrad(ldesc, dc_[:, :, :ngf], self._wb(Ll)[0], dlv[s], None, None, None)
+                ops.conv_dgrad(ldesc, dc_[:, :, :ngf], self._wt(Ll), dlv[s], None, None, None, w_transposed=True)
             d = dc_[:, :, ngf:]      # gradient w.r.t. the raw output of stage s + 1's last conv
         dlabel = None
         if need_dx:

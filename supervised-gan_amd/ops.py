@@ -70,10 +70,11 @@ def conv_fwd(desc, x, in_norm, w, bias, out, out_act=ACT_NONE, out_stats=None, s
     L.check(L.lib().sgan_conv_fwd(*args, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "sgan_conv_fwd")
 
 
-def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None, sums_sq=0, accumulate=False):
-    """accumulate: din += result (a tensor with two consumers); sums_sq: see norm_desc."""
-    if sums_sq or accumulate:
-        return conv_dgrad_grouped([(desc, dout, w, din, x, x_norm, bwd_sums, sums_sq, accumulate)])
+def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None, sums_sq=0, accumulate=False, w_transposed=False):
+    """accumulate: din += result (a tensor with two consumers); sums_sq: see norm_desc; w_transposed: `w` is the
+    [tap][Cin][Cout] copy made by transpose_weights."""
+    if sums_sq or accumulate or w_transposed:
+        return conv_dgrad_grouped([(desc, dout, w, din, x, x_norm, bwd_sums, sums_sq, accumulate, w_transposed)])
     args = (C.byref(desc), _ptr(_act(dout)), dout.stride(1), _ptr(w), _ptr(_act(din)), din.stride(1),
             _ptr(x), x.stride(1) if x is not None else 0, _nd(x_norm), _ptr(bwd_sums))
     ws = _workspace(L.lib().sgan_conv_dgrad(*args, None, -1, None), dout.device)
@@ -103,13 +104,14 @@ def conv_fwd_grouped(jobs, out_act=ACT_NONE):
 
 
 def conv_dgrad_grouped(jobs):
-    """jobs: list of (desc, dout, w, din, x, x_norm, bwd_sums[, sums_sq, accumulate])."""
+    """jobs: list of (desc, dout, w, din, x, x_norm, bwd_sums[, sums_sq, accumulate, w_transposed])."""
     arr = (L.ConvDgradJob * len(jobs))()
     for i, job in enumerate(jobs):
         desc, dout, w, din, x, x_norm, sums = job[:7]
         arr[i] = L.ConvDgradJob(C.pointer(desc), _ptr(_act(dout)).value, dout.stride(1), _ptr(w).value, _ptr(_act(din)).value,
                                 din.stride(1), _ptr(x).value, x.stride(1) if x is not None else 0, _pn(x_norm), _ptr(sums).value,
-                                int(job[7]) if len(job) > 7 else 0, int(bool(job[8])) if len(job) > 8 else 0)
+                                int(job[7]) if len(job) > 7 else 0, int(bool(job[8])) if len(job) > 8 else 0,
+                                int(bool(job[9])) if len(job) > 9 else 0)
     ws = _workspace(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device)
     L.check(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_dgrad_grouped")
@@ -125,6 +127,14 @@ def conv_wgrad_grouped(jobs):
     ws = _workspace(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device) if min(d0.Cin, d0.Cout) <= 4 else None
     L.check(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_wgrad_grouped")
+
+
+def transpose_weights(flat, flat_t, segs):
+    """segs: list of (off, taps, cout_s, cin_s) conv ranges of the flat parameter buffer."""
+    for i0 in range(0, len(segs), 64):
+        part = segs[i0:i0 + 64]
+        arr = (L.WtSeg * len(part))(*[L.WtSeg(int(o), int(t), int(co), int(ci)) for o, t, co, ci in part])
+        L.check(L.lib().sgan_transpose_weights(_ptr(flat), _ptr(flat_t), arr, len(part), _stream()), "sgan_transpose_weights")
 
 
 def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None, sums_sq=0):

@@ -20,12 +20,14 @@ class FusedAdam:
         # map every parameter to its range in an arena (a network's flat storage, or the shared arena
         # several networks were packed into) and merge adjacent ranges
         ranges = {}
+        self._nets = {}
         for p in params:
             seg = getattr(p, "_sgan_seg", None)
             if seg is None:
                 raise SganError("FusedAdam only handles parameters of supervised_gan_amd networks "
                                 "(use torch.optim.Adam for foreign parameters)")
             net, off, n = seg
+            self._nets[id(net)] = net
             arena_p, arena_g, base = net._arena
             ranges.setdefault(arena_p.data_ptr(), (arena_p, arena_g, []))[2].append((base + off, n))
         self._segs = []   # (param arena, grad arena, off, n)
@@ -76,6 +78,8 @@ class FusedAdam:
         segs = [(ap[off: off + n], ag[off: off + n], m, v, n)
                 for (ap, ag, off, n), m, v in zip(self._segs, self._m, self._v)]
         ops.adam_multi(segs, self._lr_dev, g["betas"][0], g["betas"][1], g["eps"], self._state)
+        for net in self._nets.values():     # the transposed weight copy backward-data reads is stale now
+            net._wt_epoch = getattr(net, "_wt_epoch", 0) + 1
 
     @property
     def step_count(self):

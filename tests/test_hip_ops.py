@@ -116,6 +116,17 @@ def test_conv_layer_fwd_bwd(hip, case):
     if norm == "bn":
         assert rel(dgam[:cin], gamma.grad) < TOL
         assert rel(dbet[:cin], beta.grad) < TOL
+    # same through the transposed weight copy [tap][Cin][Cout] (what the networks use: k-contiguous staging)
+    wt = torch.empty_like(wm)
+    ops.transpose_weights(wm, wt, [(0, k * k, pad4(cout), pad4(cin))])
+    assert torch.equal(wt.view(k * k, pad4(cin), pad4(cout)), wm.view(k * k, pad4(cout), pad4(cin)).transpose(1, 2))
+    din2 = torch.full((H, W, pad4(cin)), float("nan"), device="cuda")
+    sums2 = torch.zeros(2 * pad4(cin), dtype=torch.float64, device="cuda") if norm else None
+    ops.conv_dgrad(desc, Rb, wt, din2, xb, in_norm, sums2, w_transposed=True)
+    if norm:
+        ops.norm_bwd_apply(din2, xb, in_norm, sums2)
+    torch.cuda.synchronize()
+    assert rel(from_buf(din2, cin), x.grad) < TOL
 
     # ---- backward weight / bias (accumulating) ----
     dw = torch.zeros_like(wm)

@@ -128,13 +128,20 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
         pix = desc.Hout * desc.Wout if desc.kind == 0 else desc.Hin * desc.Win
         return 2.0 * pix * cin * cout * desc.k * desc.k
 
+    depth = [0]      # conv_fwd / conv_dgrad may delegate to their grouped form: record the outermost call only
+
     def wrap(name, grouped):
         orig = getattr(ops, name)
 
         def f(first, *a, **k):
-            fl = sum(flops(j[0]) for j in first) if grouped else flops(first)
-            calls.append((orig, (first,) + a, k, fl))
-            return orig(first, *a, **k)
+            if depth[0] == 0:
+                fl = sum(flops(j[0]) for j in first) if grouped else flops(first)
+                calls.append((orig, (first,) + a, k, fl))
+            depth[0] += 1
+            try:
+                return orig(first, *a, **k)
+            finally:
+                depth[0] -= 1
         setattr(ops, name, f)
         return orig
 

@@ -324,7 +324,8 @@ static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
     int maxK = 0;
     for (int i = 0; i < P.nphase; ++i) maxK = max(maxK, P.ktot[i]);
     const int tiles = sgw_cdiv(maxK, BKC) * sgw_cdiv(P.Cout, BCO);
-    // pixel-range split per problem: aim at ~1024 workgroups over the whole launch, >= 4 chunks of 32 pixels each
+    // pixel-range split per problem: ~1024 workgroups over the whole launch with the SAME number of 32-pixel chunks each
+    // (the longest workgroup is the critical path), >= 4 chunks per workgroup
     long chunks_total = 0;
     for (int g = 0; g < P.nprob; ++g) {
         int maxM = 0;
@@ -332,14 +333,15 @@ static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
         chunks_total += (long)sgw_cdiv(maxM, 32) * P.nphase;
     }
     if (chunks_total == 0) return SGAN_OK;
-    const double want_z = 1024.0 / tiles;   // total z extent we would like
+    const double want = getenv("SGAN_WGRAD_WANT") ? atof(getenv("SGAN_WGRAD_WANT")) : 1024.0;
+    int per = (int)((double)chunks_total * tiles / want + 0.999);
+    if (per < 4) per = 4;
     int z = 0;
     for (int g = 0; g < P.nprob; ++g) {
         int maxM = 0;
         for (int i = 0; i < P.nphase; ++i) maxM = max(maxM, P.q[g].Hp[i] * P.q[g].Wp[i]);
         const int nchunk = sgw_cdiv(maxM, 32);
-        int nsplit = (int)(want_z * ((double)nchunk * P.nphase / (double)chunks_total) / P.nphase + 0.5);
-        if (nsplit > nchunk / 4) nsplit = nchunk / 4;
+        int nsplit = sgw_cdiv(nchunk, per);
         if (nsplit < 1) nsplit = 1;
         if (nsplit > 512) nsplit = 512;
         P.q[g].nsplit = nsplit;

@@ -36,13 +36,14 @@ def jobs_conv(kind, k, s, p, cin, cout, sizes, norm):
 cases = {"D0 4->32 n=6": jobs_conv(0, 4, 2, 2, 4, 32, [512, 256, 128] * 2, False),
          "Dhead 256->4 n=6": jobs_conv(0, 4, 1, 2, 256, 4, [66, 34, 18] * 2, True),
          "G5 T 32->4": jobs_conv(1, 4, 2, 1, 32, 4, [256], True)}
-for want in sys.argv[1:] or ["1024"]:
-    w, mp = want.split(":") if ":" in want else (want, "256")
-    os.environ["SGAN_THIN_WANT"] = w; os.environ["SGAN_THIN_MINPIX"] = mp
-    for name, jobs in cases.items():
-        t = timeit(lambda: ops.conv_wgrad_grouped(jobs))
-        print(f"want {w:>5s} minpix {mp:>4s}  {name:18s} {t:8.1f} us  {_lib.lib().sgan_last_kernel().decode()}")
-os.environ["SGAN_NO_THIN_WGRAD"] = "1"
-for name, jobs in cases.items():
-    t = timeit(lambda: ops.conv_wgrad_grouped(jobs))
-    print(f"old kernel            {name:18s} {t:8.1f} us  {_lib.lib().sgan_last_kernel().decode()}")
+if __name__ == "__main__":
+  for want in sys.argv[1:] or ["1024"]:
+      w, mp = want.split(":") if ":" in want else (want, "256")
+      os.environ["SGAN_THIN_WANT"] = w; os.environ["SGAN_THIN_MINPIX"] = mp
+      for name, jobs in cases.items():
+          t = timeit(lambda: ops.conv_wgrad_grouped(jobs))
+          print(f"want {w:>5s} minpix {mp:>4s}  {name:18s} {t:8.1f} us  {_lib.lib().sgan_last_kernel().decode()}")
+  os.environ["SGAN_NO_THIN_WGRAD"] = "1"
+  for name, jobs in cases.items():
+      t = timeit(lambda: ops.conv_wgrad_grouped(jobs))
+      print(f"old kernel            {name:18s} {t:8.1f} us  {_lib.lib().sgan_last_kernel().decode()}")

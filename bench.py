@@ -9,6 +9,7 @@ One "step" = FCGANModel.optimize_parameters() of the README fcgan recipe (README
 n_update_G=2, pool_size=50) on one synthetic 2x512x512 batch that is already resident in HBM.
 Rank 0 prints ONE JSON line (contract in the task statement / DESIGN.md section "Measurement")."""
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -53,7 +54,8 @@ def build_twostage(args, rank):
         argv.append("--skip_wasted_D_wgrad")
     opt = TrainOptions().parse(argv, save=False, verbose=False)
     torch.manual_seed(0)
-    return create_model(opt)
+    with contextlib.redirect_stdout(sys.stderr):      # stdout carries exactly one JSON line
+        return create_model(opt)
 
 
 def build_cgan(args, rank):
@@ -72,7 +74,8 @@ def build_cgan(args, rank):
         argv.append("--skip_wasted_D_wgrad")
     opt = TrainOptions().parse(argv, save=False, verbose=False)
     torch.manual_seed(0)
-    return create_model(opt)
+    with contextlib.redirect_stdout(sys.stderr):
+        return create_model(opt)
 
 
 def build_model(args, rank):
@@ -368,8 +371,7 @@ def main():
             traffic = None     # HBM bytes per launch from the committed PMC passes (profiles/), same kernel
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                key = dom.replace(",", ", ")
-                traffic = pm[key]["hbm_bytes_per_launch"] if key in pm else None
+                traffic = pm[dom]["hbm_bytes_per_launch"] if dom in pm else None
             except Exception:
                 traffic = None
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": peak,

@@ -805,40 +805,40 @@ struct SgLossMulti {
     int32_t n, mode;
 };
 
+// 1024 threads = 8 groups of two waves; group j reduces term j, so all terms are in flight together
 __global__ __launch_bounds__(1024) void sg_gan_loss_multi_fwd_kernel(SgLossMulti J, float* each, float* total) {
-    __shared__ double wsum[16];
-    __shared__ double tot;
-    if (threadIdx.x == 0) tot = 0.0;
-    for (int j = 0; j < J.n; ++j) {
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < J.npix[j]; i += 1024) {
+    __shared__ double wsum[8][2];
+    const int j = threadIdx.x >> 7, lt = threadIdx.x & 127;
+    double acc = 0.0;
+    if (j < J.n) {
+        const float tg = J.target[j];
+        for (int i = lt; i < J.npix[j]; i += 128) {
             const float x = J.logits[j][(int64_t)i * J.ld[j]];
             float l;
             if (J.mode == 0) {
                 const float p = sg_sigmoid(x);
                 const float lp = fmaxf(logf(p), -100.f);
                 const float lq = fmaxf(log1pf(-p), -100.f);
-                l = -(J.target[j] * lp + (1.f - J.target[j]) * lq);
+                l = -(tg * lp + (1.f - tg) * lq);
             } else {
-                const float d = x - J.target[j];
+                const float d = x - tg;
                 l = d * d;
             }
             acc += (double)l;
         }
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-            for (int i = 0; i < 16; ++i) t += wsum[i];
-            const float m = (float)(t / (double)J.npix[j]);
-            each[j] = m;
-            tot += (double)J.weight[j] * (double)m;
-        }
     }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) wsum[j][(threadIdx.x >> 6) & 1] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) total[0] = (float)tot;
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int t = 0; t < J.n; ++t) {
+            const float m = (float)((wsum[t][0] + wsum[t][1]) / (double)J.npix[t]);
+            each[t] = m;
+            tot += (double)J.weight[t] * (double)m;
+        }
+        total[0] = (float)tot;
+    }
 }
 
 __global__ __launch_bounds__(256) void sg_gan_loss_multi_bwd_kernel(SgLossMulti J, const float* gout) {

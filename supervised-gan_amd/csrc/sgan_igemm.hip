@@ -884,10 +884,10 @@ static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t 
     else hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true, false>), grid, dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();
     if (bkc)
-        g_sgan_last_kernel = BM == 64 ? "sg_igemm_kernel<64,64,2,2,true>" : BN == 64 ? "sg_igemm_kernel<128,64,2,2,true>"
+        g_sgan_last_kernel = (BM == 64 && BN == 32) ? "sg_igemm_kernel<64,32,2,2,true>" : BM == 64 ? "sg_igemm_kernel<64,64,2,2,true>" : BN == 64 ? "sg_igemm_kernel<128,64,2,2,true>"
                              : BN == 32 ? "sg_igemm_kernel<128,32,4,1,true>" : "sg_igemm_kernel<128,16,4,1,true>";
     else
-        g_sgan_last_kernel = BM == 64 ? "sg_igemm_kernel<64,64,2,2,false>" : BN == 64 ? "sg_igemm_kernel<128,64,2,2,false>"
+        g_sgan_last_kernel = (BM == 64 && BN == 32) ? "sg_igemm_kernel<64,32,2,2,false>" : BM == 64 ? "sg_igemm_kernel<64,64,2,2,false>" : BN == 64 ? "sg_igemm_kernel<128,64,2,2,false>"
                              : BN == 32 ? "sg_igemm_kernel<128,32,4,1,false>" : "sg_igemm_kernel<128,16,4,1,false>";
     sg_prof_end(st, g_sgan_last_kernel);
     if (ks > 1) {
@@ -933,6 +933,15 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
     if (BN == 16) return sg_launch_igemm<128, 16, 4, 1>(P, st, ws, ws_bytes);
     if (BN == 32) return sg_launch_igemm<128, 32, 4, 1>(P, st, ws, ws_bytes);
     if (BM == 128) return sg_launch_igemm<128, 64, 2, 2>(P, st, ws, ws_bytes);
+    // short reductions on small grids: half-width tiles double the workgroups per CU, so one's pipeline fill / epilogue
+    // overlaps another's MFMA block (measured on the fcgan step: 3.70 -> 3.51 ms; thresholds from a sweep, env-tunable)
+    static const int half = getenv("SGAN_HALF_TILES") ? atoi(getenv("SGAN_HALF_TILES")) : 1024;
+    if (half && BM == 64) {
+        const long blocks = sg_total_tiles(P, 64) * sg_cdiv(P.N, 64);
+        const int nkt = sg_cdiv(sg_max_k(P), 32);
+        static const int half_nkt = getenv("SGAN_HALF_NKT") ? atoi(getenv("SGAN_HALF_NKT")) : 128;
+        if (blocks <= half && nkt <= half_nkt && sg_plan_ksplit(P, 64, 64) == 1) return sg_launch_igemm<64, 32, 2, 2>(P, st, ws, ws_bytes);
+    }
     return sg_launch_igemm<64, 64, 2, 2>(P, st, ws, ws_bytes);
 }
 

@@ -602,7 +602,8 @@ class _MultiChainFn(torch.autograd.Function):
     def forward(ctx, nets, *tensors):
         J = len(nets)
         xlog = tensors[:J]
-        xbs = [net._prepare_input(x) for net, x in zip(nets, xlog)]
+        memo = {}       # the same image goes to several discriminators: one layout conversion
+        xbs = [net._prepare_input(x, memo) for net, x in zip(nets, xlog)]
         outs, stats = _grouped_forward(nets, [xb["chain_in"] for xb in xbs])
         ctx.nets, ctx.xbs, ctx.outs, ctx.stats = nets, xbs, outs, stats
         ctx.need_dx = [bool(ctx.needs_input_grad[1 + j]) for j in range(J)]
@@ -678,7 +679,7 @@ class FCGANGenerator(ChainNet):
         super().__init__(layers)
         self.gpu_ids = gpu_ids
 
-    def _prepare_input(self, x):
+    def _prepare_input(self, x, memo=None):
         return {"chain_in": ops.as_nhwc(x)}
 
     def _finish_input_grad(self, xb, dchain):
@@ -979,7 +980,7 @@ class UnetGenerator(ChainNet):
         return dx
 
     # ---- module protocol ---------------------------------------------------------------------------
-    def _prepare_input(self, x):
+    def _prepare_input(self, x, memo=None):
         return {"chain_in": ops.as_nhwc(x)}
 
     def _finish_input_grad(self, xb, dchain):
@@ -1302,8 +1303,14 @@ class NLayerDiscriminator(ChainNet):
         kg, padg = self._gauss
         return wg, (self.input_nc + 1) * kg * kg, kg, padg
 
-    def _prepare_input(self, x):
-        xb = {"img": ops.as_nhwc(x)}
+    def _prepare_input(self, x, memo=None):
+        key = (x.data_ptr(), tuple(x.shape), x.stride())
+        img = memo.get(key) if memo is not None else None
+        if img is None:
+            img = ops.as_nhwc(x)
+            if memo is not None:
+                memo[key] = img
+        xb = {"img": img}
         if self.scale_factor > 1:
             wg, gcs, kg, padg = self._gauss_args()
             H, W, Cs = xb["img"].shape

@@ -905,9 +905,11 @@ static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t 
 static void sg_pick_tile(const SgIgemmParams& P, int* BM, int* BN) {
     if (P.N <= 16) { *BM = 128; *BN = 16; return; }
     if (P.N <= 32) { *BM = 128; *BN = 32; return; }
-    // 128x64 tiles only when they still fill the chip (256 CUs, 2 workgroups each)
+    // 128x64 tiles lose to 64x64 at every grid size measured (cgan step 19.4 -> 18.8 ms without them: the smaller tile
+    // keeps three workgroups per CU); kept selectable for tuning only
     const long blocks128 = sg_total_tiles(P, 128) * sg_cdiv(P.N, 64);
-    *BM = blocks128 >= 512 ? 128 : 64;
+    static const long min128 = getenv("SGAN_MIN128") ? atol(getenv("SGAN_MIN128")) : (1L << 60);
+    *BM = blocks128 >= min128 ? 128 : 64;
     *BN = 64;
 }
 

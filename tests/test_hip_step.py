@@ -374,3 +374,48 @@ def test_twostage_cycle_vs_reference_golden(golden_dir, name, kw):
         m.optimize_parameters()
         losses.append(list(m.get_current_errors().values()))
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+
+
+def test_checkpoints_cgan_and_twostage(tmp_path):
+    """save() / load_network() of the U-Net, CRN and two-stage trainers: the reference's file names (base_model.py:44-61,
+    cgan_model.py:246-249, twostage_cycle_model.py:466-475), its state_dict keys, and a fresh trainer that continues from
+    them reproduces the generator outputs bit for bit."""
+    from supervised_gan_amd.base_model import load_state_dict_compat
+    cfg = O.CGANConfig(num_downs=7, ngf=8, ndf=8, fineSize=256)
+    m = build_cgan(cfg)
+    m.save_dir = str(tmp_path / "cgan")
+    m.save("latest")
+    assert sorted(os.listdir(m.save_dir)) == ["latest_net_D_0.pth", "latest_net_D_1.pth", "latest_net_G.pth"]
+    sd = torch.load(os.path.join(m.save_dir, "latest_net_G.pth"))
+    ref = O.init_unet(1, 7, 2, 1, 8, -1)
+    assert set(sd.keys()) == set(ref.keys()) and all(sd[k].shape == ref[k].shape and sd[k].device.type == "cpu" for k in ref)
+    assert all(torch.equal(sd[k], ref[k].detach()) for k in ref)
+    m2 = build_cgan(cfg)
+    torch.nn.init.normal_(next(m2.netG.parameters()).data)      # perturb, then restore from the checkpoint
+    m2.save_dir = m.save_dir
+    m2.load_network(m2.netG, "G", "latest")
+    for mm in (m, m2):
+        mm.set_input(cgan_input(cfg, 0))
+        mm.test()
+    assert torch.equal(m.fake_B, m2.fake_B)
+
+    tcfg = O.TwoStageConfig(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8, ndf2=8)
+    t = build_twostage(tcfg)
+    t.save_dir = str(tmp_path / "two")
+    t.save("latest")
+    assert sorted(os.listdir(t.save_dir)) == ["latest_net_D1_0.pth", "latest_net_D1_1.pth", "latest_net_D2_0.pth", "latest_net_D2_1.pth",
+                                              "latest_net_D2_2.pth", "latest_net_D2_3.pth", "latest_net_F2.pth", "latest_net_G1.pth",
+                                              "latest_net_G2.pth"]
+    sdG2 = torch.load(os.path.join(t.save_dir, "latest_net_G2.pth"))
+    refG2 = O.init_crn(2, 2, 1, 8, 8, "bilinear", 2, True)
+    assert list(sdG2.keys()) == list(refG2.keys()) and all(torch.equal(sdG2[k], refG2[k].detach()) for k in refG2)
+    # the CPU oracle consumes the files directly and reproduces G2 on the HIP path
+    lab = O.np_uniform(91, (1, 2, 256, 256))
+    z = O.np_normal(92, (1, 8, 4, 4))
+    y_ref = O.crn_forward(sdG2, lab, z, 8, "bilinear", 2, True)
+    assert O.rel_err(t.netG2.forward(lab.cuda(), z.cuda()), y_ref) < 1e-3
+    # old-torch checkpoints carry InstanceNorm running stats: tolerated
+    sdF2 = torch.load(os.path.join(t.save_dir, "latest_net_F2.pth"))
+    sdF2["model.1.model.2.running_mean"] = torch.zeros(16)
+    sdF2["model.1.model.2.running_var"] = torch.ones(16)
+    load_state_dict_compat(t.netF2, sdF2)

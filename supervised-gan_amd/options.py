@@ -198,4 +198,5 @@ class TestOptions(BaseOptions):
         a('--phase', type=str, default='test')
         a('--which_epoch', type=str, default='latest')
         a('--how_many', type=int, default=50)
+        a('--save_as_single_image', action='store_true')
         self.isTrain = False

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Sampling driver with the reference's loop (test.py:10-60): load `<which_epoch>_net_*.pth`, run `model.test()` how_many
+times, write the visuals as PNGs under results_dir/name/<phase>_<which_epoch>/images/ (the HTML index page of the
+reference's util/html.py is not reproduced)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from supervised_gan_amd.models import create_model  # noqa: E402
+from supervised_gan_amd.options import TestOptions  # noqa: E402
+from supervised_gan_amd.synthetic_data import SyntheticDataset  # noqa: E402
+from supervised_gan_amd.util import save_image, tensor2im  # noqa: E402
+
+
+def main(argv=None):
+    opt = TestOptions().parse(argv, save=False)
+    opt.nThreads, opt.batchSize, opt.serial_batches, opt.no_flip, opt.no_rotate = 1, 1, True, True, True
+    model = create_model(opt)
+    img_dir = os.path.join(opt.results_dir, opt.name, '%s_%s' % (opt.phase, opt.which_epoch), 'images')
+    written = []
+
+    def dump(visuals, stem):
+        for label, t in visuals.items():
+            path = os.path.join(img_dir, '%s_%s.png' % (stem, label))
+            save_image(tensor2im(t), path)
+            written.append(path)
+
+    if opt.model.startswith('cgan'):       # only cgan needs a label image (test.py:27-41)
+        if opt.dataroot != 'synthetic':
+            raise NotImplementedError("only `--dataroot synthetic` ships with the MI355X path")
+        for i, data in enumerate(SyntheticDataset(opt, opt.how_many)):
+            model.set_input(data)
+            model.test()
+            print('process image... %s' % model.get_image_paths())
+            dump(model.get_current_visuals(save_as_single_image=opt.save_as_single_image), os.path.splitext(data['A_paths'][0])[0])
+    else:                                   # fcgan, twostage models (test.py:43-52)
+        for i in range(opt.how_many):
+            model.test()
+            print('produce image... %04d.png' % (i + 1))
+            dump(model.get_current_visuals(save_as_single_image=opt.save_as_single_image), '%04d' % (i + 1))
+    return written
+
+
+if __name__ == '__main__':
+    main()

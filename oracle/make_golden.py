@@ -495,8 +495,9 @@ class TwoNoiseInjector:
 def build_ref_twostage(cfg: "O.TwoStageConfig", seed: int, tmpdir: str):
     from options.train_options import TrainOptions
     from models.twostage_cycle_model import TwoStageCycleModel
+    from models.twostage_model import TwoStageModel
     L = lambda xs: [str(x) for x in xs]
-    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "twostage_cycle", "--which_direction", "AtoB",
+    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "twostage_cycle" if cfg.cycle else "twostage", "--which_direction", "AtoB",
             "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize), "--transform_1to2", cfg.transform_1to2, "--batchSize", "1",
             "--which_channel", "rg_b", "--which_model_netG1", "fcgan", "--n_layers_G1", str(cfg.n_layers_G1), "--ngf1", str(cfg.ngf1),
             "--which_model_netD1", "n_layers", "--n_layers_D1", *L(cfg.n_layers_D1), "--ndf1", str(cfg.ndf1),
@@ -516,6 +517,8 @@ def build_ref_twostage(cfg: "O.TwoStageConfig", seed: int, tmpdir: str):
         argv.append("--no_lsgan2")
     if cfg.weights is not None:
         argv += ["--weights", *L(cfg.weights)]
+    if not cfg.cycle:
+        argv += ["--lambda_G1", str(cfg.lambda_G1), "--lambda_G2", str(cfg.lambda_G2)]
     old = sys.argv
     sys.argv = argv
     try:
@@ -524,12 +527,13 @@ def build_ref_twostage(cfg: "O.TwoStageConfig", seed: int, tmpdir: str):
         sys.argv = old
     opt.scale_factor1 = [Py2Int(s) if s > 1 else s for s in opt.scale_factor1]
     opt.scale_factor2 = [Py2Int(s) if s > 1 else s for s in opt.scale_factor2]
-    model = TwoStageCycleModel()
+    model = TwoStageCycleModel() if cfg.cycle else TwoStageModel()
     model.initialize(opt)
     load_sd(model.netG1, O.init_fcgan_g(seed + 1, cfg.noise_nc1, cfg.input_nc, cfg.ngf1, cfg.n_layers_G1))
     load_sd(model.netG2, O.init_crn(seed + 2, cfg.input_nc, cfg.output_nc, cfg.noise_nc2, cfg.ngf2, cfg.upsample_mode2,
                                     cfg.n_layers_CRN_block2, True))
-    load_sd(model.netF2, O.init_unet(seed + 3, 7, cfg.output_nc, cfg.input_nc, cfg.nff2, -1))
+    if cfg.cycle:
+        load_sd(model.netF2, O.init_unet(seed + 3, 7, cfg.output_nc, cfg.input_nc, cfg.nff2, -1))
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D1, cfg.scale_factor1)):
         load_sd(model.netD1[i], O.init_nlayer_d(seed + 10 + i, cfg.input_nc, cfg.ndf1, nl, sf))
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D2, cfg.scale_factor2)):
@@ -543,8 +547,9 @@ def golden_twostage(name, cfg: "O.TwoStageConfig", seed: int, nsteps: int):
     z1 = (1, cfg.noise_nc1, cfg.noiseSize1, cfg.noiseSize1)
     z2 = (1, cfg.noise_nc2, cfg.noiseSize2, cfg.noiseSize2)
     assert z1 != z2
-    errs = lambda m: [float(m.loss_G2_GAN), float(m.loss_G2_real_cycle), float(m.loss_G2_fake_cycle), float(m.loss_D2),
-                      float(m.loss_G1_GAN), float(m.loss_D1)]
+    errs = lambda m: ([float(m.loss_G2_GAN), float(m.loss_G2_real_cycle), float(m.loss_G2_fake_cycle), float(m.loss_D2),
+                       float(m.loss_G1_GAN), float(m.loss_D1)] if cfg.cycle else
+                      [float(m.loss_G2_GAN), float(m.loss_D2), float(m.loss_G1_GAN), float(m.loss_D1)])
     with tempfile.TemporaryDirectory() as tmp:
         arrs = {}
         # probe: every gradient of the step on the initial weights
@@ -553,7 +558,8 @@ def golden_twostage(name, cfg: "O.TwoStageConfig", seed: int, nsteps: int):
             m = build_ref_twostage(cfg, seed, tmp)
             m.set_input(cgan_batch(cfg, 0))
             m.forward()
-            for key, t in (("fake_A", m.fake_A), ("fake_B_from_fake_A", m.fake_B_from_fake_A), ("recon_fake_A", m.recon_fake_A)):
+            outs = [("fake_A", m.fake_A), ("fake_B_from_fake_A", m.fake_B_from_fake_A)] + ([("recon_fake_A", m.recon_fake_A)] if cfg.cycle else [])
+            for key, t in outs:
                 arrs[f"probe/{key}_summary"] = np.asarray(O.tensor_summary(t))
                 arrs[f"probe/{key}_crop"] = t.detach()[:, :, :64, :64].numpy().copy()
             m.optimizer_D1.zero_grad()
@@ -566,7 +572,7 @@ def golden_twostage(name, cfg: "O.TwoStageConfig", seed: int, nsteps: int):
                 capture_grads(arrs, f"probe/gradD2_{i}", d)
             m.optimizer_G.zero_grad()
             m.backward_G()
-            for tag, net in (("G1", m.netG1), ("G2", m.netG2), ("F2", m.netF2)):
+            for tag, net in [("G1", m.netG1), ("G2", m.netG2)] + ([("F2", m.netF2)] if cfg.cycle else []):
                 for k, p in net.named_parameters():
                     gflat = p.grad.detach().reshape(-1)
                     arrs[f"probe/grad{tag}/summary/{k}"] = np.asarray(O.tensor_summary(gflat))
@@ -598,6 +604,10 @@ def main():
                                                                GAN_losses_G2=("real_fake", "fake_fake"), weights=(2.0, 5.0)),
                         seed=0, nsteps=3)
         golden_twostage("twostage_full.npz", O.TwoStageConfig(), seed=0, nsteps=2)     # BASELINE configs[4], README.md:18
+        golden_twostage("twostage_nocycle_small.npz", O.TwoStageConfig(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8,
+                                                                       ndf2=8, GAN_losses_D2=("real_fake", "fake_fake"),
+                                                                       GAN_losses_G2=("real_fake", "fake_fake"), cycle=False, lambda_G1=0.7,
+                                                                       lambda_G2=1.3), seed=0, nsteps=3)
     if not only or "cgan" in only:
         golden_unet_small()
         golden_cgan_step("cgan_step_small.npz", O.CGANConfig(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0)),

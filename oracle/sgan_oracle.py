@@ -738,7 +738,7 @@ class TwoStageConfig:
                  scale_factor2=(1, 1, 2, 2), lambda_D2=(0.3, 0.3, 0.2, 0.2), lambda_A=10.0, lambda_B=10.0, lambda_A_cycle=5.0,
                  lambda_fake_cycle=1.0, weights=None, no_lsgan1=True, no_lsgan2=False, GAN_losses_D2=("real_fake",),
                  GAN_losses_G2=("real_fake",), lr=2e-4, lr1=2e-4, lr2=2e-4, beta1=0.5, pool_size=50, transform_1to2="bilinear_2",
-                 detach_G1_from_G2_x=False, detach_G1_from_G2_y=False, no_logD_trick=False):
+                 detach_G1_from_G2_x=False, detach_G1_from_G2_y=False, no_logD_trick=False, cycle=True, lambda_G1=1.0, lambda_G2=1.0):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -749,7 +749,8 @@ class TwoStageConfig:
 
 class TwoStageCycleOracle:
     """TwoStageCycleModel restated (forward :193-211, backward_D1 :245-262, backward_D2_binary :264-299, backward_G :337-410,
-    optimize_parameters :412-438 with one update each); G1 = fcgan, G2 = crn, F2 = unet_128 without dropout."""
+    optimize_parameters :412-438 with one update each); G1 = fcgan, G2 = crn, F2 = unet_128 without dropout.
+    cfg.cycle = False is TwoStageModel (models/twostage_model.py:185-395): no F2, plain L1, lambda_G1 / lambda_G2."""
 
     def __init__(self, cfg: TwoStageConfig, seed: int = 0):
         c = self.cfg = cfg
@@ -764,7 +765,9 @@ class TwoStageCycleOracle:
                 if v.is_floating_point() and "running" not in k:
                     v.requires_grad_(True)
         gp = lambda net: [v for v in net.values() if v.requires_grad]
-        self.opt_G = [Adam(gp(self.G1), c.lr1, c.beta1), Adam(gp(self.G2), c.lr2, c.beta1), Adam(gp(self.F2), c.lr2, c.beta1)]
+        self.opt_G = [Adam(gp(self.G1), c.lr1, c.beta1), Adam(gp(self.G2), c.lr2, c.beta1)]
+        if c.cycle:
+            self.opt_G.append(Adam(gp(self.F2), c.lr2, c.beta1))
         self.opt_D1 = Adam([v for d in self.D1 for k, v in d.items() if k.startswith("model.")], c.lr1, c.beta1)
         self.opt_D2 = Adam([v for d in self.D2 for k, v in d.items() if k.startswith("model.")], c.lr2, c.beta1)
         self.pool1, self.pool2 = ImagePool(c.pool_size), ImagePool(c.pool_size)
@@ -790,11 +793,13 @@ class TwoStageCycleOracle:
         c = self.cfg
         self.noise1, self.noise2 = next(self.noise_iter)
         self.fake_A = fcgan_g_forward(self.G1, self.noise1, c.n_layers_G1)
-        self.fake_A_from_real_B = self._f2(self.real_B)
+        if c.cycle:
+            self.fake_A_from_real_B = self._f2(self.real_B)
         self.fake_B_from_real_A = self._g2(self.real_A)
         self.fake_B_from_fake_A = self._g2(self.transform(self.fake_A.detach() if c.detach_G1_from_G2_x else self.fake_A))
-        self.recon_real_A = self._f2(self.fake_B_from_real_A)
-        self.recon_fake_A = self._f2(self.fake_B_from_fake_A)
+        if c.cycle:
+            self.recon_real_A = self._f2(self.fake_B_from_real_A)
+            self.recon_fake_A = self._f2(self.fake_B_from_fake_A)
 
     def _d(self, nets, cfg_nl, cfg_sf, i, x, sig):
         return nlayer_d_forward(nets[i], x, cfg_nl[i], cfg_sf[i], use_sigmoid=sig)
@@ -851,7 +856,7 @@ class TwoStageCycleOracle:
         self.loss_G2_GAN = g2
         if "real_fake" in c.GAN_losses_G2:
             weight = None
-            if c.weights is not None:
+            if c.weights is not None and c.cycle:
                 weight = torch.ones(1, 1, c.fineSize, c.fineSize)
                 a01 = (self.real_A.detach() + 1) / 2
                 for i, wv in enumerate(c.weights):
@@ -859,6 +864,10 @@ class TwoStageCycleOracle:
             self.loss_G2_L1 = weighted_l1(self.fake_B_from_real_A, self.real_B, weight)
         else:
             self.loss_G2_L1 = 0
+        if not c.cycle:
+            self.loss_G = self.loss_G1_GAN * c.lambda_G1 + self.loss_G2_GAN / pairs * c.lambda_G2 + self.loss_G2_L1 * c.lambda_G2 * c.lambda_A
+            self.loss_G.backward()
+            return
         self.loss_F2_CE = bce01(self.fake_A_from_real_B, self.real_A)
         self.loss_G2_real_cycle = bce01(self.recon_real_A, self.real_A)
         self.loss_G2_fake_cycle = bce01(self.recon_fake_A, self.transform(self.fake_A.detach()))
@@ -889,7 +898,8 @@ class TwoStageCycleOracle:
         cap = {}
         self.forward()
         cap["fake_A"], cap["fake_B_from_fake_A"] = self.fake_A.detach().clone(), self.fake_B_from_fake_A.detach().clone()
-        cap["recon_fake_A"] = self.recon_fake_A.detach().clone()
+        if self.cfg.cycle:
+            cap["recon_fake_A"] = self.recon_fake_A.detach().clone()
         self.opt_D1.zero_grad()
         self.backward_D1()
         cap["gradD1"] = [self._grads(d, "model.") for d in self.D1]
@@ -899,12 +909,15 @@ class TwoStageCycleOracle:
         for o in self.opt_G:
             o.zero_grad()
         self.backward_G()
-        cap["gradG1"], cap["gradG2"], cap["gradF2"] = self._grads(self.G1), self._grads(self.G2), self._grads(self.F2)
+        cap["gradG1"], cap["gradG2"] = self._grads(self.G1), self._grads(self.G2)
+        cap["gradF2"] = self._grads(self.F2) if self.cfg.cycle else {}
         cap["losses"] = self.losses()
         return cap
 
     def losses(self):
         f = lambda v: float(v.detach()) if torch.is_tensor(v) else float(v)
+        if not self.cfg.cycle:
+            return {"G2_GAN": f(self.loss_G2_GAN), "D2": f(self.loss_D2), "G1_GAN": f(self.loss_G1_GAN), "D1": f(self.loss_D1)}
         return {"G2_GAN": f(self.loss_G2_GAN), "G2_real_cycle": f(self.loss_G2_real_cycle), "G2_fake_cycle": f(self.loss_G2_fake_cycle),
                 "D2": f(self.loss_D2), "G1_GAN": f(self.loss_G1_GAN), "D1": f(self.loss_D1)}
 

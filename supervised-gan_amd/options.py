@@ -185,6 +185,8 @@ class TrainOptions(BaseOptions):
         a('--lambda_A_cycle', type=float, default=10.0)
         a('--lambda_B_cycle', type=float, default=10.0)
         a('--use_fixed_noise1', action='store_true')
+        a('--lambda_G1', type=float, default=1)
+        a('--lambda_G2', type=float, default=1)
         self.isTrain = True
 
 

@@ -17,6 +17,8 @@ from .optim import AdamGroups, FusedAdam
 
 
 class TwoStageCycleModel(BaseModel):
+    cycle = True      # TwoStageModel (below) is the same trainer without F2 and the cycle terms
+
     def name(self):
         return 'TwoStageCycleModel'
 
@@ -59,12 +61,14 @@ class TwoStageCycleModel(BaseModel):
                                        gaussian_sigma=opt.gaussian_sigma, upsample_mode=opt.upsample_mode2,
                                        n_layers_CRN_block=opt.n_layers_CRN_block2,
                                        share_label_weights=not opt.no_share_label_block_weights2, gpu_ids=self.gpu_ids)
-        self.netF2 = networks.define_G(opt.output_nc, opt.input_nc, opt.nff2, opt.which_model_netF2, opt.norm,
-                                       not opt.no_dropout2, n_layers_G=opt.n_layers_F2, use_residual=opt.use_residual2,
-                                       use_fcn=False, noise_nc=opt.noise_nc2, add_gaussian_noise=opt.add_gaussian_noise,
-                                       gaussian_sigma=opt.gaussian_sigma, upsample_mode=opt.upsample_mode2,
-                                       n_layers_CRN_block=opt.n_layers_CRN_block2,
-                                       share_label_weights=not opt.no_share_label_block_weights2, gpu_ids=self.gpu_ids)
+        self.netF2 = None
+        if self.cycle:
+            self.netF2 = networks.define_G(opt.output_nc, opt.input_nc, opt.nff2, opt.which_model_netF2, opt.norm,
+                                           not opt.no_dropout2, n_layers_G=opt.n_layers_F2, use_residual=opt.use_residual2,
+                                           use_fcn=False, noise_nc=opt.noise_nc2, add_gaussian_noise=opt.add_gaussian_noise,
+                                           gaussian_sigma=opt.gaussian_sigma, upsample_mode=opt.upsample_mode2,
+                                           n_layers_CRN_block=opt.n_layers_CRN_block2,
+                                           share_label_weights=not opt.no_share_label_block_weights2, gpu_ids=self.gpu_ids)
         if 'bilinear' in opt.transform_1to2:
             sc = int(opt.transform_1to2.split('_')[1])
             if sc != 2:
@@ -93,7 +97,8 @@ class TwoStageCycleModel(BaseModel):
             if self.gpu_ids:
                 networks.pack_flat(self.netD1)
                 networks.pack_flat(self.netD2)
-        nets = [('G1', self.netG1), ('G2', self.netG2), ('F2', self.netF2)]
+        nets = [('G1', self.netG1), ('G2', self.netG2)] + ([('F2', self.netF2)] if self.cycle else [])
+        self._gnets = nets
         if self.isTrain and opt.sequential_train:
             for label, net in nets:
                 if label in opt.which_model_to_load:
@@ -121,10 +126,11 @@ class TwoStageCycleModel(BaseModel):
             self.criterionGAN2 = networks.GANLoss(use_lsgan=not opt.no_lsgan2)
             self.criterionL1 = networks.WeightedL1Loss()
             self.backward_D2 = self.backward_D2_binary
-            self.optimizer_G = AdamGroups([{'name': 'G1', 'params': self.netG1.parameters(), 'lr': opt.lr1},
-                                           {'name': 'G2', 'params': self.netG2.parameters(), 'lr': opt.lr2},
-                                           {'name': 'F2', 'params': self.netF2.parameters(), 'lr': opt.lr2}],
-                                          lr=opt.lr, betas=(opt.beta1, 0.999))
+            groups = [{'name': 'G1', 'params': self.netG1.parameters(), 'lr': opt.lr1},
+                      {'name': 'G2', 'params': self.netG2.parameters(), 'lr': opt.lr2}]
+            if self.cycle:
+                groups.append({'name': 'F2', 'params': self.netF2.parameters(), 'lr': opt.lr2})
+            self.optimizer_G = AdamGroups(groups, lr=opt.lr, betas=(opt.beta1, 0.999))
             self.optimizer_D1 = FusedAdam([p for d in self.netD1 for p in d.model.parameters()], lr=opt.lr1, betas=(opt.beta1, 0.999))
             self.optimizer_D2 = FusedAdam([p for d in self.netD2 for p in d.model.parameters()], lr=opt.lr2, betas=(opt.beta1, 0.999))
             self.grad_sync = None
@@ -156,12 +162,14 @@ class TwoStageCycleModel(BaseModel):
         """The six generator calls of forward() / sample_noise() (:193-226)."""
         o = self.opt
         self.fake_A = self.netG1.forward(self.noise1)
-        self.fake_A_from_real_B = self.netF2.forward(self.real_B, self.noise2)
+        if self.cycle:
+            self.fake_A_from_real_B = self.netF2.forward(self.real_B, self.noise2)
         self.fake_B_from_real_A = self.netG2.forward(self.real_A, self.noise2)
         src = self.fake_A.detach() if o.detach_G1_from_G2_x else self.fake_A
         self.fake_B_from_fake_A = self.netG2.forward(self.transform(src), self.noise2)
-        self.recon_real_A = self.netF2.forward(self.fake_B_from_real_A, self.noise2)
-        self.recon_fake_A = self.netF2.forward(self.fake_B_from_fake_A, self.noise2)
+        if self.cycle:
+            self.recon_real_A = self.netF2.forward(self.fake_B_from_real_A, self.noise2)
+            self.recon_fake_A = self.netF2.forward(self.fake_B_from_fake_A, self.noise2)
 
     def forward(self):
         self.real_A, self.real_B = self.input_A, self.input_B
@@ -252,9 +260,15 @@ class TwoStageCycleModel(BaseModel):
         for netD in self.netD1 + self.netD2:
             netD.compute_param_grads = True
         if 'real_fake' in o.GAN_losses_G2:
-            self.loss_G2_L1 = self.criterionL1.from_labels(self.fake_B_from_real_A, self.real_B, self.real_A, o.weights, 1.0)
+            self.loss_G2_L1 = self.criterionL1.from_labels(self.fake_B_from_real_A, self.real_B, self.real_A,
+                                                           o.weights if self.cycle else None, 1.0)
         else:
             self.loss_G2_L1 = 0
+        if not self.cycle:      # TwoStageModel.backward_G (twostage_model.py:369-377): plain L1Loss, lambda_G1 / lambda_G2
+            self.loss_G = self.loss_G1_GAN * o.lambda_G1 + self.loss_G2_GAN / num_fake_pairs * o.lambda_G2 \
+                + self.loss_G2_L1 * o.lambda_G2 * o.lambda_A
+            self.loss_G.backward()
+            return
         self.loss_F2_CE = networks.bce_on_rescaled(self.fake_A_from_real_B, self.real_A)
         self.loss_G2_real_cycle = networks.bce_on_rescaled(self.recon_real_A, self.real_A)
         self.loss_G2_fake_cycle = networks.bce_on_rescaled(self.recon_fake_A, self.transform(self.fake_A.detach()))
@@ -266,9 +280,10 @@ class TwoStageCycleModel(BaseModel):
     def optimize_parameters(self):
         o = self.opt
         self.forward()
-        for n_up, opt_, back in ((o.n_update_D1, self.optimizer_D1, self.backward_D1),
-                                 (o.n_update_D2, self.optimizer_D2, self.backward_D2),
-                                 (o.n_update_G, self.optimizer_G, self.backward_G)):
+        ups = (o.n_update_D1, o.n_update_D2, o.n_update_G) if self.cycle else (1, 1, 1)     # twostage_model.py:379-395: one each
+        for n_up, opt_, back in ((ups[0], self.optimizer_D1, self.backward_D1),
+                                 (ups[1], self.optimizer_D2, self.backward_D2),
+                                 (ups[2], self.optimizer_G, self.backward_G)):
             for _ in range(n_up):
                 opt_.zero_grad()
                 back()
@@ -280,6 +295,9 @@ class TwoStageCycleModel(BaseModel):
 
     def get_current_errors(self):
         f = lambda v: float(v.detach()) if torch.is_tensor(v) else float(v)
+        if not self.cycle:
+            return OrderedDict([('G2_GAN', f(self.loss_G2_GAN)), ('D2', f(self.loss_D2)), ('G1_GAN', f(self.loss_G1_GAN)),
+                                ('D1', f(self.loss_D1))])
         return OrderedDict([('G2_GAN', f(self.loss_G2_GAN)), ('G2_real_cycle', f(self.loss_G2_real_cycle)),
                             ('G2_fake_cycle', f(self.loss_G2_fake_cycle)), ('D2', f(self.loss_D2)),
                             ('G1_GAN', f(self.loss_G1_GAN)), ('D1', f(self.loss_D1))])
@@ -287,13 +305,14 @@ class TwoStageCycleModel(BaseModel):
     def get_current_visuals(self, save_as_single_image=False):
         out = OrderedDict([('fake_A', self.transform(self.fake_A).detach()), ('fake_B_fake_A', self.fake_B_from_fake_A.detach())])
         if self.isTrain:
-            out.update([('real_A', self.real_A), ('fake_B_real_A', self.fake_B_from_real_A.detach()),
-                        ('fake_A_real_B', self.fake_A_from_real_B.detach()), ('real_B', self.real_B),
-                        ('recon_real_A', self.recon_real_A.detach()), ('recon_fake_A', self.recon_fake_A.detach())])
+            out.update([('real_A', self.real_A), ('fake_B_real_A', self.fake_B_from_real_A.detach()), ('real_B', self.real_B)])
+            if self.cycle:
+                out.update([('fake_A_real_B', self.fake_A_from_real_B.detach()), ('recon_real_A', self.recon_real_A.detach()),
+                            ('recon_fake_A', self.recon_fake_A.detach())])
         return out
 
     def save(self, label):
-        for tag, net in (('G1', self.netG1), ('G2', self.netG2), ('F2', self.netF2)):
+        for tag, net in self._gnets:
             self.save_network(net, tag, label, gpu_ids=self.gpu_ids)
         for tag, ds in (('D1', self.netD1), ('D2', self.netD2)):
             for n, netD in enumerate(ds):
@@ -315,3 +334,12 @@ class TwoStageCycleModel(BaseModel):
             opt_.sync_lr()
         print('update learning rate: %f -> %f, %f -> %f' % (self.old_lr1, lr1, self.old_lr2, lr2))
         self.old_lr, self.old_lr1, self.old_lr2 = lr, lr1, lr2
+
+
+class TwoStageModel(TwoStageCycleModel):
+    """TwoStageModel (models/twostage_model.py:14-448): G1 + G2 with D1 / D2, no label reconstructor and no cycle terms;
+    loss_G = lambda_G1 G1_GAN + lambda_G2 (G2_GAN / num_pairs + lambda_A L1)."""
+    cycle = False
+
+    def name(self):
+        return 'TwoStageModel'

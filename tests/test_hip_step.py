@@ -297,7 +297,7 @@ def build_twostage(cfg):
     from supervised_gan_amd.models import create_model
     from supervised_gan_amd.options import TrainOptions
     L = lambda xs: [str(x) for x in xs]
-    argv = ["--name", "t", "--model", "twostage_cycle", "--which_direction", "AtoB", "--dataset_mode", "aligned",
+    argv = ["--name", "t", "--model", "twostage_cycle" if cfg.cycle else "twostage", "--which_direction", "AtoB", "--dataset_mode", "aligned",
             "--fineSize", str(cfg.fineSize), "--transform_1to2", cfg.transform_1to2, "--which_channel", "rg_b",
             "--which_model_netG1", "fcgan", "--n_layers_G1", str(cfg.n_layers_G1), "--ngf1", str(cfg.ngf1),
             "--which_model_netD1", "n_layers", "--n_layers_D1", *L(cfg.n_layers_D1), "--ndf1", str(cfg.ndf1),
@@ -317,10 +317,13 @@ def build_twostage(cfg):
         argv.append("--no_lsgan2")
     if cfg.weights is not None:
         argv += ["--weights", *L(cfg.weights)]
+    if not cfg.cycle:
+        argv += ["--lambda_G1", str(cfg.lambda_G1), "--lambda_G2", str(cfg.lambda_G2)]
     m = create_model(TrainOptions().parse(argv, save=False, verbose=False))
     m.netG1.load_state_dict(O.init_fcgan_g(1, cfg.noise_nc1, cfg.input_nc, cfg.ngf1, cfg.n_layers_G1))
     m.netG2.load_state_dict(O.init_crn(2, cfg.input_nc, cfg.output_nc, cfg.noise_nc2, cfg.ngf2, cfg.upsample_mode2, cfg.n_layers_CRN_block2, True))
-    m.netF2.load_state_dict(O.init_unet(3, 7, cfg.output_nc, cfg.input_nc, cfg.nff2, -1))
+    if cfg.cycle:
+        m.netF2.load_state_dict(O.init_unet(3, 7, cfg.output_nc, cfg.input_nc, cfg.nff2, -1))
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D1, cfg.scale_factor1)):
         m.netD1[i].load_state_dict(O.init_nlayer_d(10 + i, cfg.input_nc, cfg.ndf1, nl, sf))
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D2, cfg.scale_factor2)):
@@ -347,7 +350,7 @@ def test_twostage_cycle_vs_reference_golden(golden_dir, name, kw):
     p = build_twostage(cfg)
     p.set_input(cgan_input(cfg, 0))
     p.forward()
-    cap = {k: getattr(p, k).detach().cpu().clone() for k in ("fake_A", "fake_B_from_fake_A", "recon_fake_A")}
+    cap = {k: getattr(p, k).detach().cpu().clone() for k in ("fake_A", "fake_B_from_fake_A") + (("recon_fake_A",) if cfg.cycle else ())}
     p.optimizer_D1.zero_grad()
     p.backward_D1()
     cap["gradD1"] = [_grads(d) for d in p.netD1]
@@ -357,7 +360,8 @@ def test_twostage_cycle_vs_reference_golden(golden_dir, name, kw):
     p.optimizer_G.zero_grad()
     p.backward_G()
     torch.cuda.synchronize()
-    cap["gradG1"], cap["gradG2"], cap["gradF2"] = _grads(p.netG1), _grads(p.netG2, ""), _grads(p.netF2)
+    cap["gradG1"], cap["gradG2"] = _grads(p.netG1), _grads(p.netG2, "")
+    cap["gradF2"] = _grads(p.netF2) if cfg.cycle else {}
     cap["losses"] = p.get_current_errors()
     # G1's gradient arrives through seven networks (D1 x2, and via the bilinear transform G2, D2 x4, F2) and ends in a BatchNorm over
     # 4x4 samples, F2's inner blocks normalise 2x2 maps: the per-tensor criterion is the robust one (relative L2 <= 2e-2) at both sizes, the strict count is reported

@@ -319,7 +319,10 @@ def test_crn_small(golden_dir, tag):
 TWOSTAGE_CASES = [("twostage_small.npz", dict(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8, ndf2=8,
                                              GAN_losses_D2=("real_fake", "fake_fake"), GAN_losses_G2=("real_fake", "fake_fake"),
                                              weights=(2.0, 5.0))),
-                  ("twostage_full.npz", dict())]
+                  ("twostage_full.npz", dict()),
+                  ("twostage_nocycle_small.npz", dict(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8, ndf2=8,
+                                                      GAN_losses_D2=("real_fake", "fake_fake"), GAN_losses_G2=("real_fake", "fake_fake"),
+                                                      cycle=False, lambda_G1=0.7, lambda_G2=1.3))]     # --model twostage
 
 
 def twostage_noise(cfg):
@@ -340,11 +343,11 @@ def twostage_undet(cfg):
 
 
 def check_twostage_probe(cap, g, cfg, tol=TOL, robust=False, tally=None):
-    for key in ("fake_A", "fake_B_from_fake_A", "recon_fake_A"):
+    for key in ("fake_A", "fake_B_from_fake_A") + (("recon_fake_A",) if cfg.cycle else ()):
         assert rel(cap[key][:, :, :64, :64], g[f"probe/{key}_crop"]) < tol, key
     assert np.abs(np.asarray(list(cap["losses"].values())) - g["probe/losses"]).max() < tol * max(1.0, np.abs(g["probe/losses"]).max())
     u = twostage_undet(cfg)
-    for tag in ("G1", "G2", "F2"):
+    for tag in ("G1", "G2") + (("F2",) if cfg.cycle else ()):
         check_grads(cap["grad" + tag], g, f"probe/grad{tag}", u[tag], tol, robust, tally)
     for tag in ("D1", "D2"):
         for i, gd in enumerate(cap["grad" + tag]):

@@ -276,7 +276,7 @@ def main():
     ap.add_argument("--no_kernel_profile", action="store_true")
     ap.add_argument("--workload", default="fcgan", choices=["fcgan", "cgan", "twostage_cycle"],
                     help="fcgan = the headline metric (BASELINE configs[1]); cgan = BASELINE configs[2], twostage_cycle = configs[4], "
-                         "each reported under its own metric name (twostage_cycle runs eagerly, without the kernel profile)")
+                         "each reported under its own metric name (twostage_cycle without the kernel profile)")
     args = ap.parse_args()
 
     from supervised_gan_amd import dist as sdist
@@ -292,7 +292,7 @@ def main():
     cgan = args.workload == "cgan"
     two = args.workload == "twostage_cycle"
     if two:
-        args.eager, args.no_kernel_profile, args.no_cpu_baseline = True, True, True
+        args.no_kernel_profile, args.no_cpu_baseline = True, True
         model = build_twostage(args, rank)
         sdist.broadcast_parameters([model.netG1, model.netG2, model.netF2] + model.netD1 + model.netD2)
     else:
@@ -350,7 +350,7 @@ def main():
         if two:
             workload = ("twostage_cycle: G1 fcgan(ngf32) + bilinear x2 + G2 crn(ngf64, bilinear, 2-layer blocks) + F2 unet_128(nff32) + "
                         "D1 n_layers 3 3 (scale 1 2) + D2 n_layers 3 4 3 4 (scale 1 1 2 2) 512x512 bs=1, one D1, D2 and G update per "
-                        "step, Adam (BASELINE configs[4], fp32 compute, eager launches)")
+                        "step, Adam (BASELINE configs[4], fp32 compute)")
         out = {
             "metric": ("train-step images/sec, twostage_cycle 512x512 bs=1/GPU" if two else
                        "train-step images/sec, cgan unet_256 512x512 bs=1/GPU" if cgan else "train-step images/sec, fcgan 512x512 bs=1/GPU"),

@@ -19,12 +19,13 @@ from . import ops
 
 class GraphedStep:
     """Works on any trainer exposing optimizer_D/G, backward_D/G, forward, sample_noise, fake_pool, `_pool_source()`
-    (what the reference feeds ImagePool.query) and `_pool_override`."""
+    (what the reference feeds ImagePool.query) and `_pool_override`; or, for trainers with their own step structure
+    (the two-stage models), `graph_spec()` -> dict(pools, sources, set_overrides, program)."""
 
     def __init__(self, model, warmup_steps=2):
         self.m = model
         opt = model.opt
-        assert opt.n_update_D == 1, "graphed step supports n_update_D == 1 (every README recipe)"
+        assert hasattr(model, "graph_spec") or opt.n_update_D == 1, "graphed step supports n_update_D == 1 (every README recipe)"
         assert opt.batchSize == 1
         self._captured = False
         self._warmup_steps = warmup_steps
@@ -40,28 +41,42 @@ class GraphedStep:
                 prog[-1].append(m.sample_noise)
         return prog
 
+    def _spec(self):
+        m = self.m
+        if hasattr(m, "graph_spec"):
+            return m.graph_spec()
+        return dict(pools=[m.fake_pool], sources=lambda: [m._pool_source()],
+                    set_overrides=lambda views: setattr(m, "_pool_override", views[0]), program=self._program())
+
     def capture(self, example_input):
         m = self.m
         assert getattr(m, "noise_source", None) is None, "graphed step draws its latents on the device"
+        spec = self._spec()
         for _ in range(self._warmup_steps):   # lazy state (optimizer moments, caches) must exist before capture
             m.set_input(example_input)
             m.optimize_parameters()
-        m.optimizer_D.sync_lr()
-        m.optimizer_G.sync_lr()
+        for name in ("optimizer_D", "optimizer_D1", "optimizer_D2", "optimizer_G"):
+            if hasattr(m, name):
+                getattr(m, name).sync_lr()
         torch.cuda.synchronize()
-        H = W = m.opt.fineSize
-        nc = m._pool_source().shape[1]
-        self.fake_for_D = torch.zeros((H, W, ops.pad4(nc)), dtype=torch.float32, device=m.device)
-        m._pool_override = ops.logical_view(self.fake_for_D, nc)
+        self.pools = spec["pools"]
+        shapes = [tuple(t.shape) for t in spec["sources"]()]
+        self.fake_for_D = [torch.zeros((h, w, ops.pad4(nc)), dtype=torch.float32, device=m.device) for (_, nc, h, w) in shapes]
+        spec["set_overrides"]([ops.logical_view(buf, sh[1]) for buf, sh in zip(self.fake_for_D, shapes)])
         self.gA = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gA):
             m.forward()
-            self._fakeA = m._pool_source()
+            self._fakeA = spec["sources"]()
         pool = self.gA.pool()
         self.segs = []
         merged = []
-        for item in self._program():
-            if isinstance(item, str):
+        for item in spec["program"]:
+            if isinstance(item, tuple):          # ("sync", optimizer): data-parallel hand-off point
+                if m.grad_sync is not None:
+                    self.segs.append(("graph", self._capture(merged, pool)))
+                    self.segs.append(("sync", item[1]))
+                    merged = []
+            elif isinstance(item, str):
                 if m.grad_sync is not None:
                     self.segs.append(("graph", self._capture(merged, pool)))
                     self.segs.append(("sync", m.optimizer_D if item == "sync_D" else m.optimizer_G))
@@ -87,8 +102,8 @@ class GraphedStep:
         if data is not None:
             m.set_input(data)
         self.gA.replay()
-        q = m.fake_pool.query(self._fakeA)
-        self.fake_for_D.copy_(ops.as_nhwc(q))
+        for pool, src, buf in zip(self.pools, self._fakeA, self.fake_for_D):      # the reference's query order
+            buf.copy_(ops.as_nhwc(pool.query(src)))
         for kind, obj in self.segs:
             if kind == "graph":
                 obj.replay()

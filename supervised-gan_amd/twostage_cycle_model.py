@@ -134,6 +134,35 @@ class TwoStageCycleModel(BaseModel):
             self.optimizer_D1 = FusedAdam([p for d in self.netD1 for p in d.model.parameters()], lr=opt.lr1, betas=(opt.beta1, 0.999))
             self.optimizer_D2 = FusedAdam([p for d in self.netD2 for p in d.model.parameters()], lr=opt.lr2, betas=(opt.beta1, 0.999))
             self.grad_sync = None
+            self._pool_overrides = None     # graphed step: static buffers the host-side ImagePools fill
+
+    # ---- hipGraph hooks (graph_step.GraphedStep) --------------------------------------------------
+    def _pool_sources(self):
+        """What the step feeds to ImagePool.query, in the reference's order (backward_D1, then backward_D2_binary)."""
+        o = self.opt
+        srcs = [self.fake_A]
+        if 'real_fake' in o.GAN_losses_D2:
+            srcs.append(self._pair(self.real_A, self.fake_B_from_real_A))
+        if 'fake_fake' in o.GAN_losses_D2:
+            srcs.append(self._pair(self.transform(self.fake_A), self.fake_B_from_fake_A))
+        return srcs
+
+    def _query(self, idx, pool, src):
+        if self._pool_overrides is not None:
+            return self._pool_overrides[idx]
+        return pool.query(src())
+
+    def graph_spec(self):
+        o = self.opt
+        ups = (o.n_update_D1, o.n_update_D2, o.n_update_G) if self.cycle else (1, 1, 1)
+        assert ups == (1, 1, 1) and not o.use_fixed_noise1, "graphed two-stage step: one update each, device-drawn latents"
+        npool2 = ('real_fake' in o.GAN_losses_D2) + ('fake_fake' in o.GAN_losses_D2)
+        prog = [[self.optimizer_D1.zero_grad, self.backward_D1], ("sync", self.optimizer_D1),
+                [self.optimizer_D1.step, self.optimizer_D2.zero_grad, self.backward_D2], ("sync", self.optimizer_D2),
+                [self.optimizer_D2.step, self.optimizer_G.zero_grad, self.backward_G], ("sync", self.optimizer_G),
+                [self.optimizer_G.step]]
+        return dict(pools=[self.fake_pool1] + [self.fake_pool2] * npool2, sources=self._pool_sources,
+                    set_overrides=lambda views: setattr(self, "_pool_overrides", views), program=prog)
 
     # ---- data ---------------------------------------------------------------------------------
     def set_input(self, input):
@@ -201,7 +230,7 @@ class TwoStageCycleModel(BaseModel):
 
     def backward_D1(self):
         """(:245-262)"""
-        fake = self.fake_pool1.query(self.fake_A).detach()
+        fake = self._query(0, self.fake_pool1, lambda: self.fake_A).detach()
         real = self.transform_inverse(self.real_A)
         n = self.n_netD1
         self.loss_D1, each = self._gan(self.criterionGAN1, [(d, fake, False) for d in self.netD1] + [(d, real, True) for d in self.netD1],
@@ -218,9 +247,10 @@ class TwoStageCycleModel(BaseModel):
         jobs, n = [], self.n_netD2
         fakes = []
         if 'real_fake' in o.GAN_losses_D2:
-            fakes.append(self.fake_pool2.query(self._pair(self.real_A, self.fake_B_from_real_A)).detach())
+            fakes.append(self._query(1, self.fake_pool2, lambda: self._pair(self.real_A, self.fake_B_from_real_A)).detach())
         if 'fake_fake' in o.GAN_losses_D2:
-            fakes.append(self.fake_pool2.query(self._pair(self.transform(self.fake_A), self.fake_B_from_fake_A)).detach())
+            fakes.append(self._query(1 + len(fakes), self.fake_pool2,
+                                     lambda: self._pair(self.transform(self.fake_A), self.fake_B_from_fake_A)).detach())
         num_fake_pairs = len(fakes)
         for f in fakes:
             jobs += [(d, f, False) for d in self.netD2]

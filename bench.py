@@ -298,13 +298,15 @@ def main():
     else:
         model = build_cgan(args, rank) if cgan else build_model(args, rank)
         sdist.broadcast_parameters([model.netG] + model.netD)
-    if world > 1:
-        model.grad_sync = sdist.GradAverager()
     ring = synthetic_ring(64, rank, device)
 
     kern = None
-    if rank == 0 and not args.no_kernel_profile:
+    if rank == 0 and not args.no_kernel_profile:     # a few un-synchronised steps on rank 0 only (no collective inside) ...
         kern = profile_kernels(model, ring, workload=args.workload)
+    if world > 1:                                    # ... so every rank is handed rank 0's weights again before the timed run
+        nets = [model.netG1, model.netG2, model.netF2] + model.netD1 + model.netD2 if two else [model.netG] + model.netD
+        sdist.broadcast_parameters(nets)
+        model.grad_sync = sdist.GradAverager()
 
     if args.eager:
         def step(i):
@@ -382,7 +384,7 @@ def main():
                                            "step's conv calls (single stream), minus the median empty event pair",
                                "event_pair_overhead_us": ovh}
             out["kernels"] = {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kern.items())}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline_cgan(args.n_update_G) if cgan else cpu_baseline(args.n_update_G)
         print(json.dumps(out))
     if world > 1:

@@ -63,8 +63,15 @@ class GraphedStep:
         shapes = [tuple(t.shape) for t in spec["sources"]()]
         self.fake_for_D = [torch.zeros((h, w, ops.pad4(nc)), dtype=torch.float32, device=m.device) for (_, nc, h, w) in shapes]
         spec["set_overrides"]([ops.logical_view(buf, sh[1]) for buf, sh in zip(self.fake_for_D, shapes)])
+        # with a process group alive its watchdog thread polls CUDA events: only the capturing thread is held to the
+        # capture rules then (PyTorch's recipe for graphs next to NCCL)
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        self._mode = "thread_local" if dist_on else "global"
+        if dist_on:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
         self.gA = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.gA):
+        with torch.cuda.graph(self.gA, capture_error_mode=self._mode):
             m.forward()
             self._fakeA = spec["sources"]()
         pool = self.gA.pool()
@@ -73,25 +80,25 @@ class GraphedStep:
         for item in spec["program"]:
             if isinstance(item, tuple):          # ("sync", optimizer): data-parallel hand-off point
                 if m.grad_sync is not None:
-                    self.segs.append(("graph", self._capture(merged, pool)))
+                    self.segs.append(("graph", self._capture(merged, pool, self._mode)))
                     self.segs.append(("sync", item[1]))
                     merged = []
             elif isinstance(item, str):
                 if m.grad_sync is not None:
-                    self.segs.append(("graph", self._capture(merged, pool)))
+                    self.segs.append(("graph", self._capture(merged, pool, self._mode)))
                     self.segs.append(("sync", m.optimizer_D if item == "sync_D" else m.optimizer_G))
                     merged = []
             else:
                 merged += item
         if merged:
-            self.segs.append(("graph", self._capture(merged, pool)))
+            self.segs.append(("graph", self._capture(merged, pool, self._mode)))
         self._captured = True
         torch.cuda.synchronize()
 
     @staticmethod
-    def _capture(fns, pool):
+    def _capture(fns, pool, mode="global"):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool):
+        with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
             for f in fns:
                 f()
         return g

@@ -352,6 +352,23 @@ def golden_unet_small():
         save(f"unet_small_{tag}.npz", **arrs)
 
 
+def golden_autoencoder_small():
+    in_nc, out_nc, nl, ngf, hw = 2, 1, 3, 8, 128
+    sd = O.init_autoencoder(61, in_nc, out_nc, nl, ngf)
+    g = RN.define_G(in_nc, out_nc, ngf, "autoencoder", "instance", False, n_layers_G=nl, gpu_ids=[])
+    assert list(g.state_dict().keys()) == list(sd.keys()), (list(g.state_dict().keys()), list(sd.keys()))
+    load_sd(g, sd)
+    x = O.np_uniform(601, (1, in_nc, hw, hw)).requires_grad_(True)
+    r = O.np_normal(602, (1, out_nc, hw, hw))
+    y = g.forward(x)
+    loss = (y * r).sum()
+    loss.backward()
+    arrs = {"y": y.detach().numpy(), "dx": x.grad.numpy(), "loss": np.float64(loss.item())}
+    for k, p in g.named_parameters():
+        arrs["grad/" + k] = p.grad.numpy()
+    save("autoencoder_small.npz", **arrs)
+
+
 def golden_crn_small():
     """crn at 128x128 (label 2 ch, noise 8 x 2 x 2), ngf 8: ConvTranspose upsampling with 1-layer blocks, and the README's
     bilinear upsampling with 2-layer blocks; shared label block."""
@@ -596,6 +613,8 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
+    if not only or "autoencoder" in only:
+        golden_autoencoder_small()
     if not only or "crn" in only:
         golden_crn_small()
     if not only or "twostage" in only:

@@ -23,6 +23,7 @@ Reference map (paths relative to /root/reference):
   GANLoss                                     models/networks.py:152-185
   WeightedL1Loss                              models/networks.py:205-214
   UnetGenerator / UnetSkipConnectionBlock     models/networks.py:318-419
+  AutoEncoder                                 models/networks.py:421-490
   CascadedRefinementNetwork / Crn*Block       models/networks.py:642-794
   CGANModel step recipe                       models/cgan_model.py:134-226
   TwoStageCycleModel step recipe              models/twostage_cycle_model.py:193-438
@@ -514,6 +515,56 @@ def norm_cancelled_keys_unet(num_downs: int, ngf: int = 64, num_skips: int = -1)
         if lv["up_norm"]:
             keys.add(lv["up"][0] + ".bias")
     return keys
+
+
+# ----------------------------------------------------------------------------------
+# AutoEncoder generator (models/networks.py:421-490), no dropout
+# ----------------------------------------------------------------------------------
+def autoencoder_plan(input_nc: int, output_nc: int, n_layers: int, ngf: int):
+    """[(sequential index, kind, cin, cout, bias, normed)]"""
+    plan, idx, nf = [], 0, 1
+    plan.append((idx, "conv", input_nc, ngf, True, True))
+    idx += 3
+    for n in range(1, n_layers):
+        nf_prev, nf = nf, min(2 ** n, 8)
+        plan.append((idx, "conv", nf_prev * ngf, ngf * nf, True, True))
+        idx += 3
+    latent = min(2 ** n_layers, 8)
+    plan.append((idx, "conv", nf * ngf, latent, False, False))
+    idx += 1
+    nf = min(2 ** (n_layers - 1), 8)
+    plan.append((idx, "convt", latent, ngf * nf, False, True))
+    idx += 3
+    for n in range(1, n_layers):
+        nf_prev, nf = nf, min(2 ** (n_layers - n - 1), 8)
+        plan.append((idx, "convt", ngf * nf_prev, ngf * nf, True, True))
+        idx += 3
+    plan.append((idx, "convt", ngf, output_nc, False, False))
+    return plan
+
+
+def init_autoencoder(seed: int, input_nc: int, output_nc: int, n_layers: int = 3, ngf: int = 64):
+    sd = OrderedDict()
+    for k, (idx, kind, ci, co, bias, _n) in enumerate(autoencoder_plan(input_nc, output_nc, n_layers, ngf)):
+        shape = (co, ci, 4, 4) if kind == "conv" else (ci, co, 4, 4)
+        sd[f"model.{idx}.weight"] = np_normal(seed * 1000 + 2 * k, shape, 0.0, 0.02)
+        if bias:
+            b = 1.0 / math.sqrt((ci if kind == "conv" else co) * 16)
+            sd[f"model.{idx}.bias"] = np_uniform(seed * 1000 + 2 * k + 1, (co,), -b, b)
+    return sd
+
+
+def autoencoder_forward(sd, x, n_layers: int, ngf: int):
+    input_nc, output_nc = sd["model.0.weight"].shape[1], None
+    last = max(int(k.split(".")[1]) for k in sd)
+    output_nc = sd[f"model.{last}.weight"].shape[1]
+    h = x
+    for idx, kind, ci, co, bias, normed in autoencoder_plan(input_nc, output_nc, n_layers, ngf):
+        w, b = sd[f"model.{idx}.weight"], sd.get(f"model.{idx}.bias")
+        h = F.conv2d(h, w, b, stride=2, padding=1) if kind == "conv" else F.conv_transpose2d(h, w, b, stride=2, padding=1)
+        if normed:
+            h = F.relu(F.instance_norm(h, eps=IN_EPS))
+    return torch.tanh(h)
 
 
 # ----------------------------------------------------------------------------------

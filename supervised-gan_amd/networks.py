@@ -8,7 +8,7 @@ hand-written gfx950 kernels (include/sgan_hip.h); normalisation and activations 
 separate passes (they are applied while the consumer conv stages its input) and the whole net is
 one autograd node.
 
-Implemented: which_model_netG in {fcgan, deconv (README alias), unet_128, unet_256, crn}, which_model_netD in
+Implemented: which_model_netG in {fcgan, deconv (README alias), unet_128, unet_256, crn, autoencoder}, which_model_netD in
 {n_layers, basic}.  Other names raise NotImplementedError like the reference does for unknown
 names (models/networks.py:95,123)."""
 from __future__ import annotations
@@ -690,6 +690,53 @@ class FCGANGenerator(ChainNet):
             raise NotImplementedError("only the default Tanh output activation is implemented")
         params = list(self.model.parameters())
         return _ChainFn.apply(self, x, *params)
+
+    def _wrap_output(self, y):
+        return y
+
+
+class AutoEncoder(ChainNet):
+    """AutoEncoder (models/networks.py:421-490) without dropout: Conv(k4,s2,p1)+norm+ReLU x n_layers, a bias-free latent Conv
+    with nothing after it, then ConvT(k4,s2,p1)+norm+ReLU x n_layers and a bias-free ConvT -> Tanh."""
+    final_act = ACT_TANH
+
+    def __init__(self, input_nc, output_nc, n_layers=3, ngf=64, norm="batch", use_dropout=False, gpu_ids=[]):
+        if use_dropout:
+            raise NotImplementedError("AutoEncoder dropout (0.2 / 0.5 between norm and ReLU) is not on the MI355X path")
+        nrm = {"instance": "in", "batch": "bn"}[norm]
+        layers, idx = [], 0
+        nf = 1
+        layers.append(LayerSpec(str(idx), CONV, 4, 2, 1, input_nc, ngf, True, nrm, ACT_RELU))
+        idx += 3
+        for n in range(1, n_layers):
+            nf_prev, nf = nf, min(2 ** n, 8)
+            layers.append(LayerSpec(str(idx), CONV, 4, 2, 1, nf_prev * ngf, ngf * nf, True, nrm, ACT_RELU))
+            idx += 3
+        latent_nc = min(2 ** n_layers, 8)
+        layers.append(LayerSpec(str(idx), CONV, 4, 2, 1, nf * ngf, latent_nc, False, None, ACT_NONE))
+        idx += 1
+        nf = min(2 ** (n_layers - 1), 8)
+        layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, latent_nc, ngf * nf, False, nrm, ACT_RELU))
+        idx += 3
+        for n in range(1, n_layers):
+            nf_prev, nf = nf, min(2 ** (n_layers - n - 1), 8)
+            layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, ngf * nf_prev, ngf * nf, True, nrm, ACT_RELU))
+            idx += 3
+        layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, ngf, output_nc, False, None, ACT_NONE))
+        super().__init__(layers)
+        self.gpu_ids = gpu_ids
+        self.input_nc = input_nc
+
+    def _prepare_input(self, x, memo=None):
+        return {"chain_in": ops.as_nhwc(x)}
+
+    def _finish_input_grad(self, xb, dchain):
+        return ops.logical_view(dchain, self.input_nc)
+
+    def forward(self, x, noise=None, activation=None):
+        if activation is not None and not isinstance(activation, nn.Tanh):
+            raise NotImplementedError("only the default Tanh output activation is implemented")
+        return _ChainFn.apply(self, x, *list(self.model.parameters()))
 
     def _wrap_output(self, y):
         return y
@@ -1546,7 +1593,9 @@ def define_G(input_nc, output_nc, ngf, which_model_netG, norm='batch', use_dropo
                                          upsample_mode=upsample_mode, add_gaussian_noise=add_gaussian_noise,
                                          gaussian_sigma=gaussian_sigma, share_label_weights=share_label_weights,
                                          n_layers_block=n_layers_CRN_block, gpu_ids=gpu_ids)
-    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks', 'autoencoder', 'fcgan_star', 'dcgan'):
+    elif which_model_netG == 'autoencoder':
+        netG = AutoEncoder(input_nc, output_nc, n_layers_G, ngf, norm=norm, use_dropout=use_dropout, gpu_ids=gpu_ids)
+    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks', 'fcgan_star', 'dcgan'):
         raise NotImplementedError('Generator model name [%s] is not on the MI355X path yet' % which_model_netG)
     else:
         raise NotImplementedError('Generator model name [%s] is not recognized' % which_model_netG)

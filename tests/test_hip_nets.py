@@ -283,3 +283,22 @@ def test_crn_small(N, golden_dir, tag):
             assert np.abs(params[name].grad.cpu().numpy()).max() < TOL * scale, name
         else:
             assert rel(params[name].grad, g[k]) < TOL, name
+
+
+def test_autoencoder_small(N, golden_dir):
+    """`--which_model_netG autoencoder` (models/networks.py:421-490), a plain chain on the same kernels."""
+    g = load(golden_dir, "autoencoder_small.npz")
+    G = N.define_G(2, 1, 8, "autoencoder", "instance", False, n_layers_G=3, gpu_ids=[0])
+    sd = O.init_autoencoder(61, 2, 1, 3, 8)
+    assert list(G.state_dict().keys()) == list(sd.keys())
+    G.load_state_dict(sd)
+    x = O.np_uniform(601, (1, 2, 128, 128)).cuda().requires_grad_(True)
+    r = O.np_normal(602, (1, 1, 128, 128)).cuda()
+    y = G.forward(x)
+    (y * r).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, g["y"]) < TOL and rel(x.grad, g["dx"]) < TOL
+    params = dict(G.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith(".weight"):
+            assert rel(params[k[5:]].grad, g[k]) < TOL, k

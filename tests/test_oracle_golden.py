@@ -374,3 +374,20 @@ def test_twostage_cycle_step(golden_dir, name, kw):
         m.optimize_parameters()
         losses.append(list(m.losses().values()))
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+
+
+def test_autoencoder_small(golden_dir):
+    g = load(golden_dir, "autoencoder_small.npz")
+    sd = O.init_autoencoder(61, 2, 1, 3, 8)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = O.np_uniform(601, (1, 2, 128, 128)).requires_grad_(True)
+    r = O.np_normal(602, (1, 1, 128, 128))
+    y = O.autoencoder_forward(sd, x, 3, 8)
+    (y * r).sum().backward()
+    assert rel(y, g["y"]) < TIGHT * 5 and rel(x.grad, g["dx"]) < 1e-4
+    for k, v in sd.items():
+        if k.endswith(".bias"):     # every biased conv of this net feeds an InstanceNorm
+            assert float(v.grad.abs().max()) <= 1e-3 * float(sd[k.replace(".bias", ".weight")].grad.abs().max()), k
+        else:
+            assert rel(v.grad, g["grad/" + k]) < 1e-4, k

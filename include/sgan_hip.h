@@ -68,6 +68,11 @@ typedef struct sgan_conv_desc {
     int32_t k, stride, pad;
     int32_t Hin, Win, Cin;    /* forward input  (stored channels) */
     int32_t Hout, Wout, Cout; /* forward output (stored channels) */
+    /* Optional hint, 0 = unknown: how many of the stored channels carry data (the rest is the zero padding to a
+     * multiple of 4 -- a 1-channel logits map or a 2-channel image is stored with 4).  Kernels may skip arithmetic on
+     * channels beyond these counts: the padding channels of a result are then written as if their weights were zero
+     * (which they are in every buffer the host mirror builds). */
+    int32_t Cin_logical, Cout_logical;
 } sgan_conv_desc;
 
 const char* sgan_version(void);

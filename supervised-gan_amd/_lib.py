@@ -19,7 +19,8 @@ class NormDesc(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32),
-                ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cout", C.c_int32)]
+                ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cout", C.c_int32),
+                ("Cin_logical", C.c_int32), ("Cout_logical", C.c_int32)]
 
 
 class ConvFwdJob(C.Structure):

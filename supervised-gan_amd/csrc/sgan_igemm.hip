@@ -65,6 +65,7 @@ struct SgIgemmParams {   // the kernel argument (~2.3 KB)
     int32_t out_act;
     int32_t nphase, nprob;
     int32_t ksplit;       // > 1 (single problem only): split-K, raw partial tiles go to `slab`
+    int32_t n_real;       // result channels that carry data (<= N; the rest is zero padding), small-N kernel only
     int32_t pro_act, xn_act;
     float pro_slope, xn_slope, pro_eps, xn_eps;
     int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
@@ -266,14 +267,16 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
                 const int iy = a_iy[it] + t.x, ix = a_ix[it] + t.y;
-                const bool ok = a_rowok[it] && kok && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+                // bitwise on purpose: short-circuit evaluation turns into branches, and a branch ends the scheduling region
+                // this arithmetic is meant to share with the MFMA block
+                const bool ok = a_rowok[it] & kok & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
                 a_off_n[it] = ok ? (a_base[it] + toff) << 2 : OOB;
                 if constexpr (PRO) a_ok_n[it] = ok;
             }
             if constexpr (b_kcontig) {
                 const int woff = t.w + a_c;
 #pragma unroll
-                for (int it = 0; it < B_IT; ++it) b_off_n[it] = (b_rowok[it] && kok) ? (b_base[it] + woff) << 2 : OOB;
+                for (int it = 0; it < B_IT; ++it) b_off_n[it] = (b_rowok[it] & kok) ? (b_base[it] + woff) << 2 : OOB;
             }
             a_tap += adv_tap;
             a_c += adv_c;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
                 const int k = e / NQ, n4 = e % NQ;
                 const bool tok = b_tap[it] < ntaps;
                 const int wtap = ttab[tok ? b_tap[it] : 0].w;
-                const bool ok = (B_IT * 256 <= 32 * NQ || k < 32) && tok && n0 + n4 * 4 < N;
+                const bool ok = (B_IT * 256 <= 32 * NQ || k < 32) & tok & (n0 + n4 * 4 < N);
                 b_off_n[it] = ok ? (wtap + b_c[it] * P.w_ks + n0 + n4 * 4) << 2 : OOB;
                 b_tap[it] += adv_tap;
                 b_c[it] += adv_c;
@@ -316,17 +319,24 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
         float* Ab = As + (S & 1) * BM * 32;
         float* Bb = Bs + (S & 1) * BN * 32;
         if constexpr (PRO) {
+#if SG_ABLATE & 8
+            const f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f} * pro_neg, sh = (f32x4){0.f, 0.f, 0.f, 0.f} * pro_neg;
+#else
             const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + a_cs[S]);
             const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + a_cs[S]);
+#endif
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
-                f32x4 v = a_reg[S][it];
+                // act(y) = max(y, neg * y) for neg <= 1 (checked on the host); the conv zero padding applies AFTER norm +
+                // activation, so the validity flag rides along as a factor: okf * max(y, neg * y) = max(okf * y, okf * neg * y).
+                // Written on whole vectors so that it maps to packed fp32 math (2 pk_fma + 4 pk_mul + 4 max per 16 bytes).
+                const float okf = a_ok[S][it] ? 1.f : 0.f;
+                const float okn = okf * pro_neg;
+                const f32x4 y = a_reg[S][it] * sc + sh;
+                const f32x4 yp = y * okf, yn = y * okn;
+                f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y = v[j] * sc[j] + sh[j];
-                    v[j] = y > 0.f ? y : y * pro_neg;
-                }
-                if (!a_ok[S][it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // conv zero padding applies AFTER norm + activation
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(yp[j], yn[j]);
                 *reinterpret_cast<f32x4*>(Ab + a_dst[it]) = v;
             }
         } else {
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
 // which stay L1/L2 resident), keeps 4 accumulators, and a shuffle tree combines the lanes.
 // Same prologue (norm + activation on load) and bias / tanh epilogue as the MFMA kernel.
 // ------------------------------------------------------------------------------------------
-template <int LPP, bool BKC>
+template <int LPP, int R, int U, int NR, bool BKC>
 __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParams G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* tdy = reinterpret_cast<int*>(smem);
@@ -565,95 +575,133 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
         }
     }
     __syncthreads();
-    constexpr int PPB = 256 / LPP;  // pixels per workgroup
+    // LPP lanes share a pixel; every lane works on R pixels at once (PPB apart), so one set of weight chunks and one
+    // scale/shift chunk serve R gathered chunks, and a workgroup's setup is spread over PPB * R pixels.  The loop is
+    // load-latency bound: the loads of U chunks (U * (R + NW) 16-byte loads per lane) are issued before any of them is
+    // consumed.
+    constexpr int PPB = 256 / LPP;
+    constexpr int NW = BKC ? NR : 4;   // weight chunks per k chunk
     const int sub = tid % LPP;
-    const int m = mtile * PPB + tid / LPP;
-    const bool mok = m < M;
-    const int py = mok ? m / Wp : 0, px = mok ? m - py * Wp : 0;
-    const int iy0 = py * P.is, ix0 = px * P.is;
+    const int mbase = mtile * (PPB * R) + tid / LPP;
+    int iy0[R], ix0[R], pyv[R], pxv[R];
+    bool mok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int m = mbase + r * PPB;
+        mok[r] = m < M;
+        pyv[r] = mok[r] ? m / Wp : 0;
+        pxv[r] = mok[r] ? m - pyv[r] * Wp : 0;
+        iy0[r] = pyv[r] * P.is;
+        ix0[r] = pxv[r] * P.is;
+    }
     // (tap, channel) walk of this lane: chunk q = sub, sub + LPP, ...  (4 k per chunk)
     const int adv_tap = (4 * LPP) / Ck, adv_c = 4 * LPP - adv_tap * Ck;
     int tap = (4 * sub) / Ck;
     int c = 4 * sub - tap * Ck;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nq = (G.ktot[phz] + 4 * LPP - 1) / (4 * LPP);
-    for (int q = 0; q < nq; ++q) {
-        const bool kok = tap < ntaps;
-        const int t = kok ? tap : 0;
-        const int iy = iy0 + tdy[t], ix = ix0 + tdx[t];
-        const bool ok = mok && kok && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-        const int cc = kok ? c : 0;
-        const int off = ok ? (iy * P.Win + ix) * P.in_ld + cc : 0;
-        f32x4 a = *reinterpret_cast<const f32x4*>(P.in + off);
-        const float* wb = P.w + two[t];
-        f32x4 w0, w1, w2, w3;
-        if constexpr (BKC) {  // forward: W[tap][n][k] -> one 16-byte chunk of k per output channel n
-            w0 = *reinterpret_cast<const f32x4*>(wb + 0 * P.w_ns + cc);
-            w1 = *reinterpret_cast<const f32x4*>(wb + 1 * P.w_ns + cc);
-            w2 = *reinterpret_cast<const f32x4*>(wb + 2 * P.w_ns + cc);
-            w3 = *reinterpret_cast<const f32x4*>(wb + 3 * P.w_ns + cc);
-        } else {              // backward-data: W[tap][k][n], n = 0..3 contiguous -> one chunk per k
-            w0 = *reinterpret_cast<const f32x4*>(wb + (int64_t)(cc + 0) * P.w_ks);
-            w1 = *reinterpret_cast<const f32x4*>(wb + (int64_t)(cc + 1) * P.w_ks);
-            w2 = *reinterpret_cast<const f32x4*>(wb + (int64_t)(cc + 2) * P.w_ks);
-            w3 = *reinterpret_cast<const f32x4*>(wb + (int64_t)(cc + 3) * P.w_ks);
-        }
-        if (has_pro) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + cc);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + cc);
+    float acc[R][NR];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float y = a[j] * sc[j] + sh[j];
-                a[j] = y > 0.f ? y : y * pro_neg;
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int n = 0; n < NR; ++n) acc[r][n] = 0.f;
+    const int nq = (G.ktot[phz] + 4 * LPP - 1) / (4 * LPP);
+    for (int q0 = 0; q0 < nq; q0 += U) {
+        f32x4 a[U][R], w[U][NW];
+        bool ok[U][R];
+        int ccs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool kok = tap < ntaps;     // chunks past the end of K (q0 + u >= nq included) load offset 0 and are masked
+            const int t = kok ? tap : 0;
+            const int dy = tdy[t], dx = tdx[t];
+            const int cc = kok ? c : 0;
+            ccs[u] = cc;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int iy = iy0[r] + dy, ix = ix0[r] + dx;
+                ok[u][r] = mok[r] && kok && (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
+                const int off = ok[u][r] ? (iy * P.Win + ix) * P.in_ld + cc : 0;
+                a[u][r] = *reinterpret_cast<const f32x4*>(P.in + off);
+            }
+            const float* wb = P.w + two[t];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                if constexpr (BKC) w[u][j] = *reinterpret_cast<const f32x4*>(wb + j * P.w_ns + cc);   // W[tap][n = j][k chunk]
+                else w[u][j] = *reinterpret_cast<const f32x4*>(wb + (int64_t)(cc + j) * P.w_ks);      // W[tap][k = cc + j][n 0..3]
+            }
+            tap += adv_tap;
+            c += adv_c;
+            if (c >= Ck) { c -= Ck; ++tap; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 sc = (f32x4){1.f, 1.f, 1.f, 1.f}, sh = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (has_pro) {
+                sc = *reinterpret_cast<const f32x4*>(pscale + ccs[u]);
+                sh = *reinterpret_cast<const f32x4*>(pshift + ccs[u]);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                f32x4 v = a[u][r];
+                if (has_pro) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float y = v[j] * sc[j] + sh[j];
+                        v[j] = y > 0.f ? y : y * pro_neg;
+                    }
+                }
+                if (!ok[u][r]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int n = 0; n < NR; ++n) {
+                    if constexpr (BKC) acc[r][n] += v[0] * w[u][n][0] + v[1] * w[u][n][1] + v[2] * w[u][n][2] + v[3] * w[u][n][3];
+                    else acc[r][n] += v[0] * w[u][0][n] + v[1] * w[u][1][n] + v[2] * w[u][2][n] + v[3] * w[u][3][n];
+                }
             }
         }
-        if (!ok) a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if constexpr (BKC) {
-            acc[0] += a[0] * w0[0] + a[1] * w0[1] + a[2] * w0[2] + a[3] * w0[3];
-            acc[1] += a[0] * w1[0] + a[1] * w1[1] + a[2] * w1[2] + a[3] * w1[3];
-            acc[2] += a[0] * w2[0] + a[1] * w2[1] + a[2] * w2[2] + a[3] * w2[3];
-            acc[3] += a[0] * w3[0] + a[1] * w3[1] + a[2] * w3[2] + a[3] * w3[3];
-        } else {
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[n] += a[0] * w0[n] + a[1] * w1[n] + a[2] * w2[n] + a[3] * w3[n];
-        }
-        tap += adv_tap;
-        c += adv_c;
-        if (c >= Ck) { c -= Ck; ++tap; }
     }
 #pragma unroll
-    for (int o = LPP / 2; o > 0; o >>= 1) {
+    for (int r = 0; r < R; ++r) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n] += __shfl_xor(acc[n], o);
-    }
-    if (sub == 0 && mok) {
-        const int64_t pix = (int64_t)(py * P.os + G.oa[phz]) * P.Wout + (px * P.os + G.ob[phz]);
+        for (int o = LPP / 2; o > 0; o >>= 1) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            float v = acc[n] + (P.bias ? P.bias[n] : 0.f);
-            if (P.out_act == SGAN_ACT_TANH) v = tanhf(v);
-            acc[n] = v;
+            for (int n = 0; n < NR; ++n) acc[r][n] += __shfl_xor(acc[r][n], o);
         }
-        *reinterpret_cast<f32x4*>(P.out + pix * P.out_ld) = acc;
+        if (sub == 0 && mok[r]) {
+            const int64_t pix = (int64_t)(pyv[r] * P.os + G.oa[phz]) * P.Wout + (pxv[r] * P.os + G.ob[phz]);
+            f32x4 o4;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float v = (n < NR ? acc[r][n < NR ? n : 0] : 0.f) + (P.bias ? P.bias[n] : 0.f);
+                if (P.out_act == SGAN_ACT_TANH) v = tanhf(v);
+                o4[n] = v;
+            }
+            *reinterpret_cast<f32x4*>(P.out + pix * P.out_ld) = o4;
+        }
     }
 }
 
 static int sg_fill_tiles(SgIgemmParams& P, int rows_per_tile);   // prefix table; returns total tiles
 
-template <int LPP>
-static int sg_launch_small_n(SgIgemmParams& P, hipStream_t st) {
+template <int LPP, int R, int U, int NR>
+static int sg_launch_small_n_nr(SgIgemmParams& P, hipStream_t st) {
     constexpr int PPB = 256 / LPP;
-    const int tiles = sg_fill_tiles(P, PPB);
+    const int tiles = sg_fill_tiles(P, PPB * R);
     if (tiles == 0) return SGAN_OK;
     dim3 grid(tiles, 1, 1);
     const size_t lds = 3 * SGAN_MAX_TAPS * 4 + (size_t)2 * P.Ck * 4;
     sg_prof_begin(st);
-    if (P.w_ks == 1) hipLaunchKernelGGL((sg_conv_small_n_kernel<LPP, true>), grid, dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((sg_conv_small_n_kernel<LPP, false>), grid, dim3(256), lds, st, P);
+    if (P.w_ks == 1) hipLaunchKernelGGL((sg_conv_small_n_kernel<LPP, R, U, NR, true>), grid, dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((sg_conv_small_n_kernel<LPP, R, U, NR, false>), grid, dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = LPP == 64 ? "sg_conv_small_n_kernel<64>" : LPP == 16 ? "sg_conv_small_n_kernel<16>" : "sg_conv_small_n_kernel<8>";
     sg_prof_end(st, g_sgan_last_kernel);
     return SGAN_OK;
+}
+
+template <int LPP, int R, int U>
+static int sg_launch_small_n(SgIgemmParams& P, hipStream_t st) {
+    if (P.n_real <= 1) return sg_launch_small_n_nr<LPP, R, U, 1>(P, st);
+    if (P.n_real == 2) return sg_launch_small_n_nr<LPP, R, U, 2>(P, st);
+    return sg_launch_small_n_nr<LPP, R, U, 4>(P, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -926,9 +974,9 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
     P.slab_stride = 0;
     if (sg_use_small_n(P)) {   // skinny result: direct kernel
         const int ktot = sg_max_k(P);
-        if (ktot >= 2048) return sg_launch_small_n<64>(P, st);
-        if (ktot >= 256) return sg_launch_small_n<16>(P, st);
-        return sg_launch_small_n<8>(P, st);
+        if (ktot >= 2048) return sg_launch_small_n<64, 1, 8>(P, st);
+        if (ktot >= 256) return sg_launch_small_n<16, 2, 4>(P, st);
+        return sg_launch_small_n<8, 4, 4>(P, st);
     }
     int BM, BN;
     sg_pick_tile(P, &BM, &BN);
@@ -942,7 +990,12 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
         const long blocks = sg_total_tiles(P, 64) * sg_cdiv(P.N, 64);
         const int nkt = sg_cdiv(sg_max_k(P), 32);
         static const int half_nkt = getenv("SGAN_HALF_NKT") ? atoi(getenv("SGAN_HALF_NKT")) : 128;
-        if (blocks <= half && nkt <= half_nkt && sg_plan_ksplit(P, 64, 64) == 1) return sg_launch_igemm<64, 32, 2, 2>(P, st, ws, ws_bytes);
+        // ... unless the full-width tiles happen to fill the chip in one go: 3 workgroups of 64x64 fit a CU (768 slots); a
+        // grid of 80..100 % of that runs as one balanced wave (measured on the grouped 128->256 discriminator layer:
+        // 157 -> 137 us), where 2x as many half tiles would need one and a half waves of their 1024 slots
+        static const int full_lo = getenv("SGAN_FULL_LO") ? atoi(getenv("SGAN_FULL_LO")) : 620;
+        const bool one_wave = blocks >= full_lo && blocks <= 768;
+        if (!one_wave && blocks <= half && nkt <= half_nkt && sg_plan_ksplit(P, 64, 64) == 1) return sg_launch_igemm<64, 32, 2, 2>(P, st, ws, ws_bytes);
     }
     return sg_launch_igemm<64, 64, 2, 2>(P, st, ws, ws_bytes);
 }
@@ -966,7 +1019,8 @@ static int sg_check_common(const sgan_conv_desc* d) {
 }
 
 static bool sg_same_layer(const sgan_conv_desc* a, const sgan_conv_desc* b) {
-    return a->kind == b->kind && a->k == b->k && a->stride == b->stride && a->pad == b->pad && a->Cin == b->Cin && a->Cout == b->Cout;
+    return a->kind == b->kind && a->k == b->k && a->stride == b->stride && a->pad == b->pad && a->Cin == b->Cin && a->Cout == b->Cout &&
+           a->Cin_logical == b->Cin_logical && a->Cout_logical == b->Cout_logical;
 }
 
 // common part of a group from its first descriptor; per-problem phase sizes from each descriptor
@@ -974,6 +1028,10 @@ static int sg_group_geometry(SgIgemmParams& P, const sgan_conv_desc* const* desc
     if (n < 1 || n > SG_MAX_PROB) return sgan_fail(SGAN_ERR_INVALID, "1..%d problems per grouped launch", SG_MAX_PROB);
     memset(&P, 0, sizeof(P));
     P.nprob = n;
+    {
+        const int nl = dgrad ? descs[0]->Cin_logical : descs[0]->Cout_logical, ns = dgrad ? descs[0]->Cin : descs[0]->Cout;
+        P.n_real = (nl > 0 && nl <= ns) ? nl : ns;
+    }
     for (int g = 0; g < n; ++g) {
         int rc = sg_check_common(descs[g]);
         if (rc) return rc;
@@ -1018,6 +1076,7 @@ extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, i
     P.out_act = out_act;
     const sgan_norm_desc* n0 = jobs[0].in_norm;
     P.pro_act = n0 ? n0->act : SGAN_ACT_NONE; P.pro_slope = n0 ? n0->slope : 0.f; P.pro_eps = n0 ? n0->eps : 0.f;
+    SGAN_CHECK(P.pro_act != SGAN_ACT_LRELU || P.pro_slope <= 1.f, "LeakyReLU slope must be <= 1 (the kernels evaluate max(y, slope * y))");
     P.xn_act = SGAN_ACT_NONE;
     for (int g = 0; g < n; ++g) {
         const sgan_conv_fwd_job& J = jobs[g];

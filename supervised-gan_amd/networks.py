@@ -296,7 +296,7 @@ class ChainNet(nn.Module):
                 ho, wo = L.out_hw(h, w)
                 if ho <= 0 or wo <= 0:
                     raise SganError(f"input {H}x{W} too small for layer {L.key}")
-                geo.append((ops.conv_desc(L.kind, L.k, L.stride, L.pad, h, w, L.cin_s, ho, wo, L.cout_s), h, w, ho, wo))
+                geo.append((ops.conv_desc(L.kind, L.k, L.stride, L.pad, h, w, L.cin_s, ho, wo, L.cout_s, L.cin, L.cout), h, w, ho, wo))
                 h, w = ho, wo
             self._geom_cache[key] = geo
         return self._geom_cache[key]
@@ -812,8 +812,8 @@ class UnetGenerator(ChainNet):
                 hi, wi = (H, W) if l == 0 else hw[l - 1]
                 ho, wo = hw[l]
                 d, u = self.down[l], self.up[l]
-                dn.append(ops.conv_desc(CONV, 4, 2, 1, hi, wi, d.cin_s, ho, wo, d.cout_s))
-                upd.append(ops.conv_desc(CONVT, 4, 2, 1, ho, wo, u.cin_s, hi, wi, u.cout_s))
+                dn.append(ops.conv_desc(CONV, 4, 2, 1, hi, wi, d.cin_s, ho, wo, d.cout_s, d.cin, d.cout))
+                upd.append(ops.conv_desc(CONVT, 4, 2, 1, ho, wo, u.cin_s, hi, wi, u.cout_s, u.cin, u.cout))
             self._geom_cache[key] = (hw, dn, upd)
         return self._geom_cache[key]
 
@@ -1107,7 +1107,7 @@ class CascadedRefinementNetwork(ChainNet):
         key = ("crn", L.key, h, w)
         if key not in self._geom_cache:
             ho, wo = L.out_hw(h, w)
-            self._geom_cache[key] = ops.conv_desc(L.kind, L.k, L.stride, L.pad, h, w, L.cin_s, ho, wo, L.cout_s)
+            self._geom_cache[key] = ops.conv_desc(L.kind, L.k, L.stride, L.pad, h, w, L.cin_s, ho, wo, L.cout_s, L.cin, L.cout)
         return self._geom_cache[key]
 
     def run_forward(self, x, update_running=True):

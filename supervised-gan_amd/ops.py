@@ -35,8 +35,9 @@ def _act(t):
     return t
 
 
-def conv_desc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s):
-    return L.ConvDesc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s)
+def conv_desc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin=0, Cout=0):
+    """Cin / Cout: logical channel counts (0 = unknown), a hint that lets kernels skip the zero padding channels."""
+    return L.ConvDesc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin, Cout)
 
 
 def norm_desc(stats=None, gamma=None, beta=None, count=1, eps=1e-5, act=ACT_NONE, slope=0.0, sq_stride=0):

@@ -78,7 +78,8 @@ def test_conv_layer_fwd_bwd(hip, case):
     (out * R).sum().backward()
     Ho, Wo = out.shape[2:]
 
-    desc = ops.conv_desc(1 if tr else 0, k, s, p, H, W, pad4(cin), Ho, Wo, pad4(cout))
+    desc = ops.conv_desc(1 if tr else 0, k, s, p, H, W, pad4(cin), Ho, Wo, pad4(cout), cin, cout)   # with the logical-channel hint
+    desc_plain = ops.conv_desc(1 if tr else 0, k, s, p, H, W, pad4(cin), Ho, Wo, pad4(cout))
     xb = to_buf(x.detach())
     wm = master_weight(w.detach(), tr)
     bb = pad_vec(b.detach())
@@ -100,6 +101,9 @@ def test_conv_layer_fwd_bwd(hip, case):
     assert rel(ost, ref_st) < 1e-4
     if pad4(cout) != cout:
         assert float(ob[..., cout:].abs().max()) == 0.0     # padded channels stay exactly zero
+        ob2 = torch.full_like(ob, float("nan"))
+        ops.conv_fwd(desc_plain, xb, in_norm, wm, bb, ob2, 0, None)      # same result without the hint
+        assert rel(ob2, ob) < 1e-6
 
     # ---- backward data (+ act', norm sums) then norm backward ----
     Rb = to_buf(R)
@@ -127,6 +131,11 @@ def test_conv_layer_fwd_bwd(hip, case):
         ops.norm_bwd_apply(din2, xb, in_norm, sums2)
     torch.cuda.synchronize()
     assert rel(from_buf(din2, cin), x.grad) < TOL
+    if pad4(cin) != cin and not norm:
+        din3 = torch.full((H, W, pad4(cin)), float("nan"), device="cuda")
+        ops.conv_dgrad(desc_plain, Rb, wm, din3, xb, in_norm, None)
+        torch.cuda.synchronize()
+        assert rel(din3, din) < 1e-6 and float(din[..., cin:].abs().max()) == 0.0
 
     # ---- backward weight / bias (accumulating) ----
     dw = torch.zeros_like(wm)

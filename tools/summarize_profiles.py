@@ -18,7 +18,7 @@ def short(name):
     m = re.match(r"(sg_igemm_kernel|sg_wgrad_kernel)<(.*),(true|false)>$", n)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    m = re.match(r"sg_conv_small_n_kernel<(\d+),(true|false)>$", n)
+    m = re.match(r"sg_conv_small_n_kernel<(\d+),(?:\d+,)*(true|false)>$", n)
     if m:
         return f"sg_conv_small_n_kernel<{m.group(1)}>"
     m = re.match(r"sg_wgrad_thin_kernel<(\d+),(true|false),(true|false)>$", n)

@@ -136,27 +136,34 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     int a_off_n[A_IT], d_off_n[D_IT];
     bool a_ok_n[A_IT];
     const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
-    const int oa = ph_oa, ob = ph_ob;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.dout), 0, 0x7FFFFFFF, 0x00020000);
     constexpr int OOB = (int)0x80000000u;
 
     // pixel walk: row r of chunk ch is pixel m = ch*32 + r; (py, px) advance by 32 pixels per chunk with one
-    // conditional wrap (32 = adv_y * Wp + adv_x) -- no division inside the loop
+    // conditional wrap (32 = adv_y * Wp + adv_x).  Input coordinates and the two linear element offsets advance with
+    // them by constants (a second constant on the wrap) -- no division and no multiply inside the loop.
     const int adv_y = BP / Wp, adv_x = BP - adv_y * Wp;
-    int a_py[A_IT], a_px[A_IT], d_py[D_IT], d_px[D_IT];
+    int a_py[A_IT], a_px[A_IT], a_iy[A_IT], a_ix[A_IT], a_lin[A_IT], d_py[D_IT], d_px[D_IT], d_lin[D_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int m = ch_begin * BP + a_row0 + it * A_ROWS_PER_IT;
         a_py[it] = m / Wp;
         a_px[it] = m - a_py[it] * Wp;
+        a_iy[it] = a_py[it] * P.is + a_dy;
+        a_ix[it] = a_px[it] * P.is + a_dx;
+        a_lin[it] = (a_iy[it] * P.Win + a_ix[it]) * P.in_ld + a_c;
     }
 #pragma unroll
     for (int it = 0; it < D_IT; ++it) {
         const int m = ch_begin * BP + d_row0 + it * D_ROWS_PER_IT;
         d_py[it] = m / Wp;
         d_px[it] = m - d_py[it] * Wp;
+        d_lin[it] = ((d_py[it] * P.os + ph_oa) * P.Wout + (d_px[it] * P.os + ph_ob)) * P.dout_ld + co0 + d_c4 * 4;
     }
+    const int a_iy_step = adv_y * P.is, a_ix_step = adv_x * P.is, a_ix_wrap = -Wp * P.is;
+    const int a_lin_step = (a_iy_step * P.Win + a_ix_step) * P.in_ld, a_lin_wrap = (P.is * P.Win + a_ix_wrap) * P.in_ld;
+    const int d_lin_step = (adv_y * P.os * P.Wout + adv_x * P.os) * P.dout_ld, d_lin_wrap = (P.os * P.Wout - Wp * P.os) * P.dout_ld;
     int ch_next = ch_begin;   // chunk whose offsets next_addrs computes next
 
     auto next_addrs = [&]() {
@@ -164,24 +171,29 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int prow = a_row0 + it * A_ROWS_PER_IT;
-            const int iy = a_py[it] * P.is + a_dy, ix = a_px[it] * P.is + a_dx;
-            const bool ok = chok && (A_IT * A_ROWS_PER_IT == BP || prow < BP) && a_py[it] < Hp && a_kok &&
-                            (unsigned)iy < (unsigned)P.Hin && (unsigned)ix < (unsigned)P.Win;
-            a_off_n[it] = ok ? ((iy * P.Win + ix) * P.in_ld + a_c) << 2 : OOB;
+            // bitwise on purpose (see sgan_igemm.hip): no branches inside the region shared with the MFMA block
+            const bool ok = chok & (A_IT * A_ROWS_PER_IT == BP || prow < BP) & (a_py[it] < Hp) & a_kok &
+                            ((unsigned)a_iy[it] < (unsigned)P.Hin) & ((unsigned)a_ix[it] < (unsigned)P.Win);
+            a_off_n[it] = ok ? a_lin[it] << 2 : OOB;
             if constexpr (PRO) a_ok_n[it] = ok;
-            a_py[it] += adv_y;
             a_px[it] += adv_x;
-            if (a_px[it] >= Wp) { a_px[it] -= Wp; ++a_py[it]; }
+            const bool wrap = a_px[it] >= Wp;
+            a_px[it] -= wrap ? Wp : 0;
+            a_py[it] += adv_y + (wrap ? 1 : 0);
+            a_iy[it] += a_iy_step + (wrap ? P.is : 0);
+            a_ix[it] += a_ix_step + (wrap ? a_ix_wrap : 0);
+            a_lin[it] += a_lin_step + (wrap ? a_lin_wrap : 0);
         }
 #pragma unroll
         for (int it = 0; it < D_IT; ++it) {
             const int prow = d_row0 + it * D_ROWS_PER_IT;
-            const bool ok = chok && (D_IT * D_ROWS_PER_IT == BP || prow < BP) && d_py[it] < Hp && d_cok;
-            const int pix = (d_py[it] * P.os + oa) * P.Wout + (d_px[it] * P.os + ob);
-            d_off_n[it] = ok ? (pix * P.dout_ld + co0 + d_c4 * 4) << 2 : OOB;
-            d_py[it] += adv_y;
+            const bool ok = chok & (D_IT * D_ROWS_PER_IT == BP || prow < BP) & (d_py[it] < Hp) & d_cok;
+            d_off_n[it] = ok ? d_lin[it] << 2 : OOB;
             d_px[it] += adv_x;
-            if (d_px[it] >= Wp) { d_px[it] -= Wp; ++d_py[it]; }
+            const bool wrap = d_px[it] >= Wp;
+            d_px[it] -= wrap ? Wp : 0;
+            d_py[it] += adv_y + (wrap ? 1 : 0);
+            d_lin[it] += d_lin_step + (wrap ? d_lin_wrap : 0);
         }
         ++ch_next;
     };
@@ -198,6 +210,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
             d_reg[S][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, d_off_n[it], 0, 0));
     };
 
+    f32x4 bacc = (f32x4){0.f, 0.f, 0.f, 0.f};   // this thread's channel quad d_c4 summed over the pixel rows it stages
     auto store_chunk = [&](auto S_, int buf) {
         constexpr int S = decltype(S_)::value;
         float* Ab = As + buf * BP * LDA;
@@ -208,13 +221,14 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
 #pragma unroll
             for (int it = 0; it < A_IT; ++it) {
                 const int prow = a_row0 + it * A_ROWS_PER_IT;
-                f32x4 v = a_reg[S][it];
+                // okf * act(y) = max(okf * y, okf * neg * y), neg <= 1: packed fp32 math (see sgan_igemm.hip)
+                const float okf = a_val[S][it] ? 1.f : 0.f;
+                const float okn = okf * pro_neg;
+                const f32x4 y = a_reg[S][it] * sc + sh;
+                const f32x4 yp = y * okf, yn = y * okn;
+                f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y = v[j] * sc[j] + sh[j];
-                    v[j] = y > 0.f ? y : y * pro_neg;
-                }
-                if (!a_val[S][it]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(yp[j], yn[j]);
                 if (A_IT * A_ROWS_PER_IT == BP || prow < BP) *reinterpret_cast<f32x4*>(Ab + prow * LDA + a_c4 * 4) = v;
             }
         } else {
@@ -227,7 +241,10 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
 #pragma unroll
         for (int it = 0; it < D_IT; ++it) {
             const int prow = d_row0 + it * D_ROWS_PER_IT;
-            if (D_IT * D_ROWS_PER_IT == BP || prow < BP) *reinterpret_cast<f32x4*>(Db + prow * LDD + d_c4 * 4) = d_reg[S][it];
+            if (D_IT * D_ROWS_PER_IT == BP || prow < BP) {
+                *reinterpret_cast<f32x4*>(Db + prow * LDD + d_c4 * 4) = d_reg[S][it];
+                bacc += d_reg[S][it];   // bias gradient = column sums of dOut: every chunk passes through here exactly once
+            }
         }
     };
 
@@ -236,7 +253,6 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
     const bool do_bias = (P.dbias != nullptr) && (blockIdx.x == 0);
 
     __syncthreads();  // pscale/pshift visible
@@ -251,25 +267,35 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
         const int buf = it_no & 1;
         const float* Ab = As + buf * BP * LDA;
         const float* Db = Ds + buf * BP * LDD;
+        // Fragment reads run half a chunk ahead of the MFMAs that consume them (a read issued right before its MFMA
+        // leaves the matrix pipe idle for the LDS latency, 8 times per chunk); the second half of the MFMAs shares its
+        // scheduling region with the transform + LDS store of the next chunk and the address arithmetic.
+        constexpr int KH = BP / 8;
+        float af[2 * KH][MB], bf[2 * KH][NB];
+        auto read_frags = [&](int k0) {
 #pragma unroll
-        for (int k4 = 0; k4 < BP / 4; ++k4) {
-            float af[MB], bf[NB];
+            for (int k4 = k0; k4 < k0 + KH; ++k4) {
 #pragma unroll
-            for (int i = 0; i < MB; ++i) af[i] = Db[(k4 * 4 + fq) * LDD + wc * WTC + i * 16 + fr];
+                for (int i = 0; i < MB; ++i) af[k4][i] = Db[(k4 * 4 + fq) * LDD + wc * WTC + i * 16 + fr];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) bf[j] = Ab[(k4 * 4 + fq) * LDA + wk * WTK + j * 16 + fr];
+                for (int j = 0; j < NB; ++j) bf[k4][j] = Ab[(k4 * 4 + fq) * LDA + wk * WTK + j * 16 + fr];
+            }
+        };
+        auto mfmas = [&](int k0) {
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
+            for (int k4 = k0; k4 < k0 + KH; ++k4)
 #pragma unroll
-                for (int j = 0; j < NB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (do_bias && tid < BCO) {
-            float sb = 0.f;
-#pragma unroll 8
-            for (int p = 0; p < BP; ++p) sb += Db[p * LDD + tid];
-            bsum += sb;
-        }
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[k4][i], bf[k4][j], acc[i][j], 0, 0, 0);
+        };
+        read_frags(0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(KH);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(KH);
         store_chunk(std::integral_constant<int, (S + 1) % NS>{}, buf ^ 1);   // chunk it_no + 1
         next_addrs();
         ++it_no;
@@ -312,7 +338,17 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
             }
         }
     }
-    if (do_bias && tid < BCO && co0 + tid < Cout) atomicAdd(P.dbias + co0 + tid, bsum);
+    if (do_bias) {   // (uniform) combine the per-thread column sums: threads tid = d_c4 + DQ * row share a channel quad
+        f32x4* red = reinterpret_cast<f32x4*>(smem);   // the staging buffers are dead: every wave is past the last barrier
+        red[tid] = bacc;
+        __syncthreads();
+        if (tid < BCO && co0 + tid < Cout) {
+            float sb = 0.f;
+#pragma unroll
+            for (int r = 0; r < 256 / DQ; ++r) sb += reinterpret_cast<const float*>(red + (tid >> 2) + DQ * r)[tid & 3];
+            atomicAdd(P.dbias + co0 + tid, sb);
+        }
+    }
 }
 
 static inline int sgw_cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -730,6 +766,7 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
     if (!d0) return sgan_fail(SGAN_ERR_INVALID, "null desc");
     const sgan_norm_desc* n0 = jobs[0].in_norm;
     P.pro_act = n0 ? n0->act : SGAN_ACT_NONE; P.pro_slope = n0 ? n0->slope : 0.f; P.pro_eps = n0 ? n0->eps : 0.f;
+    SGAN_CHECK(P.pro_act != SGAN_ACT_LRELU || P.pro_slope <= 1.f, "LeakyReLU slope must be <= 1 (the kernels evaluate max(y, slope * y))");
     for (int g = 0; g < n; ++g) {
         const sgan_conv_wgrad_job& J = jobs[g];
         const sgan_conv_desc* d = J.d;

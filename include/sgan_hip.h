@@ -218,7 +218,8 @@ int sgan_gauss_down_fwd(const float* in, int32_t in_ld, int32_t H, int32_t W, in
                         float* out, int32_t out_ld, int32_t Ho, int32_t Wo, void* stream);
 int sgan_gauss_down_bwd(const float* dout, int32_t dout_ld, int32_t Ho, int32_t Wo, int32_t C, int32_t Creal,
                         const float* g, int32_t g_chan_stride, int32_t k, int32_t pad, int32_t s,
-                        float* din, int32_t din_ld, int32_t H, int32_t W, void* stream);
+                        float* din, int32_t din_ld, int32_t H, int32_t W, int32_t accumulate /* din += instead of = */,
+                        void* stream);
 
 /* ---- GAN loss on a logits map (channel 0 of an NHWC-4 tensor) --------------------------------
  * mode 0: BCE(sigmoid(x), t) with torch's log clamp at -100 (GANLoss, --no_lsgan);
@@ -241,8 +242,11 @@ typedef struct sgan_gan_loss_job {
     float target; float weight;
     float* dlogits; int32_t dld;   /* backward only */
 } sgan_gan_loss_job;
+/* `workspace`: SGAN_GAN_LOSS_WS_BYTES of 8-byte aligned device scratch (uninitialised is fine): the terms are reduced by
+ * several workgroups each and finished by a second kernel. */
+#define SGAN_GAN_LOSS_WS_BYTES 1024
 int sgan_gan_loss_multi_fwd(const sgan_gan_loss_job* jobs, int32_t n, int32_t mode, float* each_out, float* total_out,
-                            void* stream);
+                            void* workspace, int64_t workspace_bytes, void* stream);
 int sgan_gan_loss_multi_bwd(const sgan_gan_loss_job* jobs, int32_t n, int32_t mode, const float* gout, void* stream);
 
 /* ---- standalone nn.Sigmoid on channel 0 of a logits map (models/networks.py:836-837) --------

@@ -89,10 +89,10 @@ SIGNATURES = {
     "sgan_scale": [_P, _P, _P, _L, _P],
     "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],
     "sgan_gauss_down_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
-    "sgan_gauss_down_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    "sgan_gauss_down_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P],
     "sgan_gan_loss_fwd": [_P, _I, _I, _F, _I, _P, _P, _P],
     "sgan_gan_loss_bwd": [_P, _I, _I, _F, _I, _P, _P, _I, _P],
-    "sgan_gan_loss_multi_fwd": [C.POINTER(GanLossJob), _I, _I, _P, _P, _P],
+    "sgan_gan_loss_multi_fwd": [C.POINTER(GanLossJob), _I, _I, _P, _P, _P, C.c_int64, _P],
     "sgan_gan_loss_multi_bwd": [C.POINTER(GanLossJob), _I, _I, _P, _P],
     "sgan_sigmoid_fwd": [_P, _I, _I, _P, _I, _P],
     "sgan_sigmoid_bwd": [_P, _I, _P, _I, _I, _P, _I, _P],

@@ -24,6 +24,13 @@ class BaseModel:
     def Tensor(self, *size):
         return torch.empty(*size, dtype=torch.float32, device=self.device)
 
+    def _backward(self, loss):
+        """loss.backward() with a cached unit gradient (autograd would launch a fill kernel for it on every call)."""
+        one = getattr(self, '_grad_one', None)
+        if one is None or one.device != loss.device or one.shape != loss.shape:
+            one = self._grad_one = torch.ones_like(loss)
+        loss.backward(one)
+
     def set_input(self, input):
         self.input = input
 

@@ -143,7 +143,7 @@ class CGANModel(BaseModel):
         n = self.n_netD
         self.loss_D, self._each_D = self._d_losses([(d, fake, False) for d in self.netD] + [(d, real, True) for d in self.netD],
                                                    [0.5] * (2 * n))
-        self.loss_D.backward()
+        self._backward(self.loss_D)
 
     def backward_G(self):
         """loss_G = sum_i lambda_i * GAN(D_i(cat(A, fake_B)), 1) + lambda_A * L1_w(fake_B, real_B)  (cgan_model.py:184-210)"""
@@ -158,7 +158,7 @@ class CGANModel(BaseModel):
             netD.compute_param_grads = True
         self.loss_G_L1 = self.criterionL1.from_labels(self.fake_B, self.real_B, self.real_A, self.opt.weights, self.opt.lambda_A)
         self.loss_G = gan + self.loss_G_L1
-        self.loss_G.backward()
+        self._backward(self.loss_G)
 
     @property
     def loss_D_fake(self):

@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void sg_gauss_fwd_kernel(const float* in, int 
 // transpose of the above: only the taps with (iy + pad - ky) % s == 0 reach an output row (ceil(k/s) per axis)
 __global__ __launch_bounds__(256) void sg_gauss_bwd_kernel(const float* dout, int dout_ld, int Ho, int Wo, int C, int Creal,
                                                            const float* g, int gcs, int k, int pad, int s, float* din,
-                                                           int din_ld, int H, int W) {
+                                                           int din_ld, int H, int W, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gs = reinterpret_cast<float*>(smem);
     for (int i = threadIdx.x; i < k * k * C; i += 256) {
@@ -498,7 +498,8 @@ __global__ __launch_bounds__(256) void sg_gauss_bwd_kernel(const float* dout, in
                        *reinterpret_cast<const f32x4*>(dout + ((int64_t)oy * Wo + ox) * dout_ld + c);
             }
         }
-        *reinterpret_cast<f32x4*>(din + pix * din_ld + c) = acc;
+        f32x4* o = reinterpret_cast<f32x4*>(din + pix * din_ld + c);
+        *o = accumulate ? *o + acc : acc;
     }
 }
 
@@ -519,7 +520,7 @@ extern "C" int sgan_gauss_down_fwd(const float* in, int32_t in_ld, int32_t H, in
 
 extern "C" int sgan_gauss_down_bwd(const float* dout, int32_t dout_ld, int32_t Ho, int32_t Wo, int32_t C, int32_t Creal,
                                    const float* g, int32_t g_chan_stride, int32_t k, int32_t pad, int32_t s, float* din,
-                                   int32_t din_ld, int32_t H, int32_t W, void* stream) {
+                                   int32_t din_ld, int32_t H, int32_t W, int32_t accumulate, void* stream) {
     SGAN_CHECK(dout && g && din && k > 0 && s > 0 && Creal <= C, "bad argument");
     SGAN_CHECK((C & 3) == 0 && (din_ld & 3) == 0 && (dout_ld & 3) == 0 && din_ld >= C && dout_ld >= C && k * k * C * 4 <= 60000, "bad channel layout");
     SGAN_CHECK(Ho == (H + 2 * pad - k) / s + 1 && Wo == (W + 2 * pad - k) / s + 1, "gauss geometry mismatch");
@@ -527,7 +528,7 @@ extern "C" int sgan_gauss_down_bwd(const float* dout, int32_t dout_ld, int32_t H
     int blocks = ew_cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(sg_gauss_bwd_kernel, dim3(blocks), dim3(256), (size_t)k * k * C * 4, (hipStream_t)stream, dout, dout_ld, Ho, Wo, C, Creal,
-                       g, g_chan_stride, k, pad, s, din, din_ld, H, W);
+                       g, g_chan_stride, k, pad, s, din, din_ld, H, W, accumulate);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
 }
@@ -805,54 +806,60 @@ struct SgLossMulti {
     int32_t n, mode;
 };
 
-// 1024 threads = 8 groups of two waves; group j reduces term j, so all terms are in flight together
-__global__ __launch_bounds__(1024) void sg_gan_loss_multi_fwd_kernel(SgLossMulti J, float* each, float* total) {
-    __shared__ double wsum[8][2];
-    const int j = threadIdx.x >> 7, lt = threadIdx.x & 127;
+// The log / exp arithmetic of a few 67x67 maps keeps a single CU busy for ~20 us, so the terms are spread over
+// SG_LOSS_BLOCKS workgroups each: block (b, j) leaves the fp64 partial sum of its slice of term j in `part`, and a second,
+// one-wave kernel turns the partials into each[] and the weighted total (a kernel boundary is the cheapest device-wide
+// release/acquire there is; no atomics, no zero-initialised scratch).
+#define SG_LOSS_BLOCKS 16
+__global__ __launch_bounds__(256) void sg_gan_loss_multi_fwd_kernel(SgLossMulti J, double* part) {
+    __shared__ double wsum[4];
+    const int j = blockIdx.y, b = blockIdx.x;
+    const float tg = J.target[j];
+    const int np = J.npix[j], ld = J.ld[j];
+    const float* lg = J.logits[j];
     double acc = 0.0;
-    if (j < J.n) {
-        const float tg = J.target[j];
-        // eight independent strided loads in flight per lane: the loop is load-latency bound otherwise (a 67x67 map is
-        // 35 dependent round trips per lane)
-        const int np = J.npix[j], ld = J.ld[j];
-        const float* lg = J.logits[j];
-        for (int i0 = lt; i0 < np; i0 += 128 * 8) {
-            float xs[8];
+    for (int i0 = b * 256 + threadIdx.x; i0 < np; i0 += SG_LOSS_BLOCKS * 256 * 4) {
+        float xs[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u * 128;
-                xs[u] = i < np ? lg[(int64_t)i * ld] : 0.f;
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * SG_LOSS_BLOCKS * 256;
+            xs[u] = i < np ? lg[(int64_t)i * ld] : 0.f;
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (i0 + u * 128 >= np) break;
-                const float x = xs[u];
-                float l;
-                if (J.mode == 0) {
-                    const float p = sg_sigmoid(x);
-                    const float lp = fmaxf(logf(p), -100.f);
-                    const float lq = fmaxf(log1pf(-p), -100.f);
-                    l = -(tg * lp + (1.f - tg) * lq);
-                } else {
-                    const float d = x - tg;
-                    l = d * d;
-                }
-                acc += (double)l;
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * SG_LOSS_BLOCKS * 256 >= np) break;
+            const float x = xs[u];
+            float l;
+            if (J.mode == 0) {
+                const float p = sg_sigmoid(x);
+                const float lp = fmaxf(logf(p), -100.f);
+                const float lq = fmaxf(log1pf(-p), -100.f);
+                l = -(tg * lp + (1.f - tg) * lq);
+            } else {
+                const float d = x - tg;
+                l = d * d;
             }
+            acc += (double)l;
         }
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if ((threadIdx.x & 63) == 0) wsum[j][(threadIdx.x >> 6) & 1] = acc;
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int t = 0; t < J.n; ++t) {
-            const float m = (float)((wsum[t][0] + wsum[t][1]) / (double)J.npix[t]);
-            each[t] = m;
-            tot += (double)J.weight[t] * (double)m;
-        }
-        total[0] = (float)tot;
+    if (threadIdx.x == 0) part[j * SG_LOSS_BLOCKS + b] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(64) void sg_gan_loss_multi_fin_kernel(SgLossMulti J, const double* part, float* each, float* total) {
+    const int t = threadIdx.x;
+    double w = 0.0;
+    if (t < J.n) {
+        double sum = 0.0;
+        for (int b = 0; b < SG_LOSS_BLOCKS; ++b) sum += part[t * SG_LOSS_BLOCKS + b];
+        const float m = (float)(sum / (double)J.npix[t]);
+        each[t] = m;
+        w = (double)J.weight[t] * (double)m;
     }
+    for (int off = 4; off > 0; off >>= 1) w += __shfl_xor(w, off);   // n <= 8 terms sit in lanes 0..7
+    if (t == 0) total[0] = (float)w;
 }
 
 __global__ __launch_bounds__(256) void sg_gan_loss_multi_bwd_kernel(SgLossMulti J, const float* gout) {
@@ -889,12 +896,18 @@ static int sg_fill_loss(SgLossMulti& J, const sgan_gan_loss_job* jobs, int n, in
 }
 
 extern "C" int sgan_gan_loss_multi_fwd(const sgan_gan_loss_job* jobs, int32_t n, int32_t mode, float* each_out,
-                                       float* total_out, void* stream) {
+                                       float* total_out, void* workspace, int64_t workspace_bytes, void* stream) {
     SgLossMulti J;
     int rc = sg_fill_loss(J, jobs, n, mode, false);
     if (rc) return rc;
     SGAN_CHECK(each_out && total_out, "null output");
-    hipLaunchKernelGGL(sg_gan_loss_multi_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, J, each_out, total_out);
+    SGAN_CHECK(workspace && workspace_bytes >= SGAN_GAN_LOSS_WS_BYTES && ((uintptr_t)workspace & 7) == 0,
+               "workspace of SGAN_GAN_LOSS_WS_BYTES (8-byte aligned) required");
+    static_assert(8 * SG_LOSS_BLOCKS * sizeof(double) <= SGAN_GAN_LOSS_WS_BYTES, "workspace size");
+    double* part = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(sg_gan_loss_multi_fwd_kernel, dim3(SG_LOSS_BLOCKS, n), dim3(256), 0, (hipStream_t)stream, J, part);
+    SGAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sg_gan_loss_multi_fin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, J, part, each_out, total_out);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
 }
@@ -1089,8 +1102,13 @@ __device__ __forceinline__ void sg_philox(uint32_t c0, uint32_t c1, uint32_t c2,
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__global__ __launch_bounds__(256) void sg_normal_fill_kernel(float* dst, int64_t n, uint64_t seed, const uint64_t* offset) {
+// advance_by != 0 (single-block launches only): the block moves the stream offset itself once every thread has read it
+__global__ __launch_bounds__(256) void sg_normal_fill_kernel(float* dst, int64_t n, uint64_t seed, uint64_t* offset, uint64_t advance_by) {
     const uint64_t off = offset ? offset[0] : 0;
+    if (advance_by) {
+        __syncthreads();
+        if (threadIdx.x == 0) offset[0] = off + advance_by;
+    }
     const int64_t nq = (n + 3) >> 2;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
         const uint64_t ctr = off + (uint64_t)q;
@@ -1148,9 +1166,10 @@ extern "C" int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* 
     int blocks = ew_cdiv(nq, 256);
     if (blocks > 1024) blocks = 1024;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sg_normal_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, n, seed, offset_dev);
+    const bool self_advance = offset_dev && blocks == 1;
+    hipLaunchKernelGGL(sg_normal_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, n, seed, offset_dev, self_advance ? (uint64_t)nq : 0);
     SGAN_LAUNCH_CHECK();
-    if (offset_dev) {
+    if (offset_dev && !self_advance) {
         hipLaunchKernelGGL(sg_rng_advance_kernel, dim3(1), dim3(1), 0, st, offset_dev, (uint64_t)nq);
         SGAN_LAUNCH_CHECK();
     }

@@ -168,7 +168,7 @@ class FCGANModel(BaseModel):
         n = self.n_netD
         self.loss_D, self._each_D = self._d_losses([(d, fake, False) for d in self.netD] + [(d, self.real, True) for d in self.netD],
                                                    [0.5] * (2 * n))
-        self.loss_D.backward()
+        self._backward(self.loss_D)
         self._join_streams()
 
     def backward_G(self):
@@ -182,7 +182,7 @@ class FCGANModel(BaseModel):
                                                    [l if trick else -l for l in self.opt.lambda_D])
         for netD in self.netD:
             netD.compute_param_grads = True
-        self.loss_G.backward()
+        self._backward(self.loss_G)
         self._join_streams()
 
     @property

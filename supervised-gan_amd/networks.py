@@ -606,6 +606,7 @@ class _MultiChainFn(torch.autograd.Function):
         xbs = [net._prepare_input(x, memo) for net, x in zip(nets, xlog)]
         outs, stats = _grouped_forward(nets, [xb["chain_in"] for xb in xbs])
         ctx.nets, ctx.xbs, ctx.outs, ctx.stats = nets, xbs, outs, stats
+        ctx.in_keys = [(x.data_ptr(), tuple(x.shape), tuple(x.stride())) for x in xlog]
         ctx.need_dx = [bool(ctx.needs_input_grad[1 + j]) for j in range(J)]
         any_param = any(ctx.needs_input_grad[1 + J:])
         ctx.want_wgrad = [net.compute_param_grads and any_param for net in nets]
@@ -622,8 +623,24 @@ class _MultiChainFn(torch.autograd.Function):
                 g = torch.zeros_like(ops.logical_view(ctx.outs[j][-1], nets[j].layers[-1].cout))
             douts.append(ops.as_nhwc(g))
         dch = _grouped_backward(nets, [xb["chain_in"] for xb in ctx.xbs], ctx.outs, ctx.stats, douts, ctx.need_dx, ctx.want_wgrad)
-        dxs = tuple(nets[j]._finish_input_grad(ctx.xbs[j], dch[j]) if ctx.need_dx[j] else None for j in range(J))
-        return (None,) + dxs + (None,) * (len(ctx.needs_input_grad) - 1 - J)
+        # discriminators fed with the same image (the multi-scale set on `fake`) share one image-gradient buffer: the
+        # first writes it, the others add into it and hand autograd None -- no gradient-accumulation kernels afterwards
+        dxs, shared = [], {}
+        for j in range(J):
+            if not ctx.need_dx[j]:
+                dxs.append(None)
+                continue
+            buf = shared.get(ctx.in_keys[j])
+            if buf is not None and hasattr(nets[j], "scale_factor"):
+                dxs.append(nets[j]._finish_input_grad(ctx.xbs[j], dch[j], into=buf))
+                continue
+            dx = nets[j]._finish_input_grad(ctx.xbs[j], dch[j])
+            if hasattr(nets[j], "scale_factor"):
+                buf = ops.buffer_of(dx)
+                if buf is not None:
+                    shared[ctx.in_keys[j]] = buf
+            dxs.append(dx)
+        return (None,) + tuple(dxs) + (None,) * (len(ctx.needs_input_grad) - 1 - J)
 
 
 def multi_forward(jobs):
@@ -1372,13 +1389,17 @@ class NLayerDiscriminator(ChainNet):
             xb["chain_in"] = xb["img"]
         return xb
 
-    def _finish_input_grad(self, xb, dchain):
+    def _finish_input_grad(self, xb, dchain, into=None):
+        """Gradient w.r.t. the image.  `into`: an NHWC image-gradient buffer another discriminator fed with the same image
+        already produced -- this one's contribution is added to it and None is returned."""
         if self.scale_factor > 1:
             wg, gcs, kg, padg = self._gauss_args()
-            dimg = torch.empty_like(xb["img"])
-            ops.gauss_down_bwd(dchain, self.input_nc, wg, gcs, kg, padg, self.scale_factor, dimg)
+            dimg = into if into is not None else torch.empty_like(xb["img"])
+            ops.gauss_down_bwd(dchain, self.input_nc, wg, gcs, kg, padg, self.scale_factor, dimg, accumulate=into is not None)
             dchain = dimg
-        return ops.logical_view(dchain, self.input_nc)
+        elif into is not None:
+            into.add_(dchain)
+        return None if into is not None else ops.logical_view(dchain, self.input_nc)
 
     def forward(self, x):
         params = list(self.model.parameters())

@@ -241,11 +241,11 @@ def gauss_down_fwd(x, Creal, g, g_chan_stride, k, pad, s, out):
                                         _ptr(_act(out)), out.stride(1), Ho, Wo, _stream()), "sgan_gauss_down_fwd")
 
 
-def gauss_down_bwd(dout, Creal, g, g_chan_stride, k, pad, s, din):
+def gauss_down_bwd(dout, Creal, g, g_chan_stride, k, pad, s, din, accumulate=False):
     Ho, Wo, Cs = dout.shape
     H, W, _ = din.shape
     L.check(L.lib().sgan_gauss_down_bwd(_ptr(_act(dout)), dout.stride(1), Ho, Wo, Cs, Creal, _ptr(g), g_chan_stride, k, pad, s,
-                                        _ptr(_act(din)), din.stride(1), H, W, _stream()), "sgan_gauss_down_bwd")
+                                        _ptr(_act(din)), din.stride(1), H, W, int(bool(accumulate)), _stream()), "sgan_gauss_down_bwd")
 
 
 def gan_loss_fwd(logits, target, mode, loss_out, p_out=None):
@@ -260,11 +260,16 @@ def gan_loss_bwd(logits, target, mode, gout, dlogits):
                                       _ptr(_act(dlogits)), dlogits.stride(1), _stream()), "sgan_gan_loss_bwd")
 
 
+GAN_LOSS_WS_BYTES = 1024   # SGAN_GAN_LOSS_WS_BYTES
+
+
 def gan_loss_multi_fwd(logits, targets, weights, mode, each_out, total_out):
     arr = (L.GanLossJob * len(logits))()
     for i, (lb, t, w) in enumerate(zip(logits, targets, weights)):
         arr[i] = L.GanLossJob(_ptr(_act(lb)).value, lb.stride(1), lb.shape[0] * lb.shape[1], float(t), float(w), None, 0)
-    L.check(L.lib().sgan_gan_loss_multi_fwd(arr, len(logits), mode, _ptr(each_out), _ptr(total_out), _stream()), "sgan_gan_loss_multi_fwd")
+    ws = torch.empty(GAN_LOSS_WS_BYTES // 8, dtype=torch.float64, device=each_out.device)
+    L.check(L.lib().sgan_gan_loss_multi_fwd(arr, len(logits), mode, _ptr(each_out), _ptr(total_out), _ptr(ws), GAN_LOSS_WS_BYTES,
+                                            _stream()), "sgan_gan_loss_multi_fwd")
 
 
 def gan_loss_multi_bwd(logits, targets, weights, mode, gout, dlogits):
@@ -321,6 +326,19 @@ def logical_view(buf: torch.Tensor, C_real: int) -> torch.Tensor:
         for k in [k for k, (r, _) in _VIEW_REGISTRY.items() if r() is None]:
             del _VIEW_REGISTRY[k]
     return v
+
+
+def buffer_of(t: torch.Tensor):
+    """The padded NHWC buffer a logical_view() tensor was made from (same memory), or None."""
+    ent = _VIEW_REGISTRY.get(t.data_ptr())
+    if ent is None or t.dim() != 4:
+        return None
+    buf = ent[0]()
+    _, Cr, H, W = t.shape
+    if (buf is not None and ent[1] == Cr and buf.shape[:2] == (H, W) and buf.data_ptr() == t.data_ptr()
+            and t.stride(1) == 1 and t.stride(2) == buf.stride(0) and t.stride(3) == buf.stride(1)):
+        return buf
+    return None
 
 
 def as_nhwc(t: torch.Tensor) -> torch.Tensor:

@@ -236,7 +236,7 @@ class TwoStageCycleModel(BaseModel):
         self.loss_D1, each = self._gan(self.criterionGAN1, [(d, fake, False) for d in self.netD1] + [(d, real, True) for d in self.netD1],
                                        [0.5] * (2 * n))
         self.loss_D1_fake, self.loss_D1_real = each[:n].sum(), each[n:].sum()
-        self.loss_D1.backward()
+        self._backward(self.loss_D1)
 
     def _pair(self, a, b):
         return b if self.opt.no_cgan else torch.cat([a, b], 1)
@@ -266,7 +266,7 @@ class TwoStageCycleModel(BaseModel):
         self.loss_D2_fake = each[:n * num_fake_pairs].sum() / num_fake_pairs
         self.loss_D2_real = each[n * num_fake_pairs:].sum()
         self.loss_D2 = total
-        self.loss_D2.backward()
+        self._backward(self.loss_D2)
 
     def backward_G(self):
         """(:337-410)"""
@@ -297,7 +297,7 @@ class TwoStageCycleModel(BaseModel):
         if not self.cycle:      # TwoStageModel.backward_G (twostage_model.py:369-377): plain L1Loss, lambda_G1 / lambda_G2
             self.loss_G = self.loss_G1_GAN * o.lambda_G1 + self.loss_G2_GAN / num_fake_pairs * o.lambda_G2 \
                 + self.loss_G2_L1 * o.lambda_G2 * o.lambda_A
-            self.loss_G.backward()
+            self._backward(self.loss_G)
             return
         self.loss_F2_CE = networks.bce_on_rescaled(self.fake_A_from_real_B, self.real_A)
         self.loss_G2_real_cycle = networks.bce_on_rescaled(self.recon_real_A, self.real_A)
@@ -305,7 +305,7 @@ class TwoStageCycleModel(BaseModel):
         self.loss_G = self.loss_G1_GAN + self.loss_G2_GAN / num_fake_pairs + self.loss_G2_L1 * o.lambda_A \
             + self.loss_F2_CE * o.lambda_B + self.loss_G2_real_cycle * o.lambda_A_cycle \
             + self.loss_G2_fake_cycle * o.lambda_A_cycle * o.lambda_fake_cycle
-        self.loss_G.backward()
+        self._backward(self.loss_G)
 
     def optimize_parameters(self):
         o = self.opt

@@ -196,7 +196,10 @@ def test_gauss_down(hip, s, nc):
     ops.gauss_down_fwd(xb, nc, wgd, (nc + 1) * kg * kg, kg, padg, s, out)
     din = torch.empty(H, W, 4, device="cuda")
     ops.gauss_down_bwd(to_buf(R), nc, wgd, (nc + 1) * kg * kg, kg, padg, s, din)
+    din2 = din.clone()
+    ops.gauss_down_bwd(to_buf(R), nc, wgd, (nc + 1) * kg * kg, kg, padg, s, din2, accumulate=True)   # din2 += ...
     torch.cuda.synchronize()
+    assert rel(din2, 2 * din) < 1e-6
     assert rel(from_buf(out, nc), y) < 1e-5
     assert rel(from_buf(din, nc), x.grad) < 1e-5
     assert float(out[..., nc:].abs().max()) == 0.0

@@ -124,8 +124,13 @@ __device__ __forceinline__ int sg_swz(int row, int kslot) { return (kslot ^ ((ro
 
 // BKC: B operand is k-contiguous in memory (forward: W[tap][n][k]); otherwise n-contiguous (backward-data)
 // PRO: the gathered tensor gets the producer's norm + activation applied while it is staged
-template <int BM, int BN, int WGM, int WGN, bool BKC, bool PRO>
-__global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
+// KW:  wave groups per workgroup.  KW = 2 (512 threads): the two groups of four waves take one half each of the
+//      workgroup's k-tiles through their own LDS buffers, in step (shared barriers), and group 1 hands its accumulators
+//      to group 0 through LDS before the epilogue.  A grid of fewer than ~2 tiles per CU is latency bound -- one wave
+//      per SIMD waits out every barrier and LDS round trip alone -- and this doubles the waves without the slab round
+//      trip and second kernel of the global split-K.
+template <int BM, int BN, int WGM, int WGN, bool BKC, bool PRO, int KW = 1>
+__global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams G) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MB = WTM / 16, NB = WTN / 16;
     constexpr int A_IT = BM * 8 / 256;
     constexpr int B_IT = (BN * 8 + 255) / 256;
@@ -133,16 +138,18 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
     static_assert(BM * 8 % 256 == 0, "A tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* As = reinterpret_cast<float*>(smem);  // [2][BM*32]
-    float* Bs = As + 2 * BM * 32;                // [2][BN*32]
+    constexpr int GROUP_FLOATS = 2 * BM * 32 + 2 * BN * 32;
+    const int kg = KW == 1 ? 0 : (int)(threadIdx.x >> 8);   // wave group
+    float* As = reinterpret_cast<float*>(smem) + kg * GROUP_FLOATS;  // [2][BM*32]
+    float* Bs = As + 2 * BM * 32;                                    // [2][BN*32]
     // statistics are accumulated in fp64 from the first add on: var = E[x^2] - mean^2 cancels catastrophically in fp32
     // partial sums as soon as |mean| >> std (conv of a near-constant map plus its bias, e.g. the CRN label branch)
-    double* red = reinterpret_cast<double*>(Bs + 2 * BN * 32);   // [2*BN]
+    double* red = reinterpret_cast<double*>(reinterpret_cast<float*>(smem) + KW * GROUP_FLOATS);   // [2*BN]
     int4* ttab = reinterpret_cast<int4*>(red + 2 * BN);  // [16] {dy, dx, gather offset, weight slab offset}
     float* pscale = reinterpret_cast<float*>(ttab + SGAN_MAX_TAPS);  // [Ck]
     float* pshift = pscale + G.Ck;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
     // grid.x enumerates (M tile, N tile) pairs, N fastest, in XCD-contiguous order; grid.z = K split
     const int ntn = (G.N + BN - 1) / BN;
@@ -166,18 +173,22 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
     // this workgroup's k-tile range (split-K)
     const int nkt_total = (ktot + 31) >> 5;
     const int kt_per = (nkt_total + P.ksplit - 1) / P.ksplit;
-    const int kt0 = split * kt_per;
-    const int nkt = min(nkt_total, kt0 + kt_per) - kt0;   // may be <= 0 for a trailing split: writes zeros
+    const int wg_kt0 = split * kt_per;
+    const int wg_nkt = max(min(nkt_total, wg_kt0 + kt_per) - wg_kt0, 0);   // may be 0 for a trailing split: writes zeros
+    // this wave group's share; every group runs `nkt` iterations (shared barriers), tiles past `my_nkt` load as zeros
+    const int nkt = (wg_nkt + KW - 1) / KW;
+    const int kt0 = wg_kt0 + kg * nkt;
+    const int my_nkt = min(max(wg_nkt - kg * nkt, 0), nkt);
 
     // ---- one-time setup: tap table, prologue scale/shift, reduction scratch ----
-    if (tid < SGAN_MAX_TAPS) {
+    if (threadIdx.x < SGAN_MAX_TAPS) {
         const bool v = tid < G.ntaps[phz];
         const int dy = v ? (int)G.taps[phz][tid].dy : 0, dx = v ? (int)G.taps[phz][tid].dx : 0;
         ttab[tid] = make_int4(dy, dx, (dy * P.Win + dx) * P.in_ld, v ? G.taps[phz][tid].w_off : 0);
     }
-    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * BN; i += 256 * KW) red[i] = 0.0;
     {   // always present (identity when there is no prologue) so the main loop is branch-free
-        for (int c = tid; c < Ck; c += 256) {
+        for (int c = threadIdx.x; c < Ck; c += 256 * KW) {
             float sc = 1.f, sh = 0.f;
             if (P.pro.stats) {
                 float mean, rstd;
@@ -258,9 +269,12 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
     // Pure address arithmetic for the next tile (no memory traffic except the LDS tap table): scheduled
     // inside the MFMA block of the previous tile.  Invalid elements get offset 0 and are zeroed when the
     // registers are written to LDS, so the loads themselves are unconditional.
+    int ld_left = my_nkt;   // tiles of this group's range not yet addressed
     auto next_addrs = [&]() {
+        const bool in_range = ld_left > 0;
+        --ld_left;
         {
-            const bool kok = a_tap < ntaps;
+            const bool kok = (a_tap < ntaps) & in_range;
             const int4 t = ttab[kok ? a_tap : 0];
             a_cs_n = kok ? a_c : 0;
             const int toff = t.z + a_c;
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
             for (int it = 0; it < B_IT; ++it) {
                 const int e = tid + it * 256;
                 const int k = e / NQ, n4 = e % NQ;
-                const bool tok = b_tap[it] < ntaps;
+                const bool tok = (b_tap[it] < ntaps) & in_range;
                 const int wtap = ttab[tok ? b_tap[it] : 0].w;
                 const bool ok = (B_IT * 256 <= 32 * NQ || k < 32) & tok & (n0 + n4 * 4 < N);
                 b_off_n[it] = ok ? (wtap + b_c[it] * P.w_ks + n0 + n4 * 4) << 2 : OOB;
@@ -444,6 +458,26 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
         if (kt + 2 < nkt) iteration(I2{});
     }
 
+    const bool want_stats = P.stats != nullptr;
+    if constexpr (KW == 2) {   // group 1 -> group 0 (the tile buffers are dead: every wave is past the loop's last barrier)
+        f32x4* xch = reinterpret_cast<f32x4*>(smem);
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) xch[(i * NB + j) * 256 + tid] = acc[i][j];
+        }
+        __syncthreads();
+        if (kg == 1) {
+            if (P.ksplit <= 1 && want_stats) __syncthreads();   // keep the barrier count of group 0's epilogue
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] += xch[(i * NB + j) * 256 + tid];
+    }
+
     // ---- epilogue ----
     if (P.ksplit > 1) {   // split-K: raw partial tile to this split's slab; sg_splitk_epilogue_kernel finishes
         float* sl = P.slab + (int64_t)split * P.slab_stride;
@@ -466,7 +500,6 @@ __global__ __launch_bounds__(256) void sg_igemm_kernel(const SgIgemmParams G) {
         return;
     }
     const bool dact = P.xref != nullptr;
-    const bool want_stats = P.stats != nullptr;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int nl = wn * WTN + j * 16 + fr;
@@ -921,13 +954,24 @@ static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t 
     P.slab = ks > 1 ? ws : nullptr;
     P.slab_stride = slab;
     dim3 grid(tiles * sg_cdiv(P.N, BN), 1, ks);
-    const size_t lds = (size_t)(2 * BM * 32 + 2 * BN * 32 + 4 * BN) * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
+    // two wave groups per workgroup when the grid leaves most SIMDs with a single wave (see the kernel header)
+    static const long kw2_max = getenv("SGAN_KW2_MAX") ? atol(getenv("SGAN_KW2_MAX")) : 512;
+    const long wgs = (long)grid.x * ks;
+    const int nkt_wg = sg_cdiv(sg_cdiv(sg_max_k(P), 32), ks);
+    const bool kw2 = BM == 64 && bkc && wgs <= kw2_max && nkt_wg >= 8;
+    const int kw = kw2 ? 2 : 1;
+    const size_t lds = (size_t)(kw * (2 * BM * 32 + 2 * BN * 32) + 4 * BN) * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
     if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
     sg_prof_begin(st);
     bool pro = P.pro_act != SGAN_ACT_NONE;
     for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
     if (!bkc && pro) return sgan_fail(SGAN_ERR_UNSUPPORTED, "backward-data has no prologue");
-    if (!bkc) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(256), lds, st, P);
+    if constexpr (BM == 64) {
+        if (kw2 && pro) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true, true, 2>), grid, dim3(512), lds, st, P);
+        else if (kw2) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true, false, 2>), grid, dim3(512), lds, st, P);
+    }
+    if (kw2) { /* launched above */ }
+    else if (!bkc) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(256), lds, st, P);
     else if (pro) hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true, true>), grid, dim3(256), lds, st, P);
     else hipLaunchKernelGGL((sg_igemm_kernel<BM, BN, WGM, WGN, true, false>), grid, dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();

@@ -15,7 +15,10 @@ def short(name):
     """rocprofv3 kernel name -> the name libsgan_hip reports through sgan_last_kernel() (template variants of one kernel
     merged: the prologue flag of sg_igemm / sg_wgrad, the layout flag of sg_conv_small_n)."""
     n = name.split("(")[0].replace("void ", "").replace(" ", "")
-    m = re.match(r"(sg_igemm_kernel|sg_wgrad_kernel)<(.*),(true|false)>$", n)
+    m = re.match(r"(sg_igemm_kernel)<(\d+,\d+,\d+,\d+,(?:true|false)),(?:true|false)(?:,\d+)?>$", n)   # prologue flag, wave groups
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"(sg_wgrad_kernel)<(.*),(true|false)>$", n)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
     m = re.match(r"sg_conv_small_n_kernel<(\d+),(?:\d+,)*(true|false)>$", n)

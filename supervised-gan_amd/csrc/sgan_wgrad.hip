@@ -360,7 +360,7 @@ static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
     int maxK = 0;
     for (int i = 0; i < P.nphase; ++i) maxK = max(maxK, P.ktot[i]);
     const int tiles = sgw_cdiv(maxK, BKC) * sgw_cdiv(P.Cout, BCO);
-    // pixel-range split per problem: ~1024 workgroups over the whole launch with the SAME number of 32-pixel chunks each
+    // pixel-range split per problem: ~512 workgroups over the whole launch with the SAME number of 32-pixel chunks each
     // (the longest workgroup is the critical path), >= 4 chunks per workgroup
     long chunks_total = 0;
     for (int g = 0; g < P.nprob; ++g) {
@@ -369,7 +369,8 @@ static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
         chunks_total += (long)sgw_cdiv(maxM, 32) * P.nphase;
     }
     if (chunks_total == 0) return SGAN_OK;
-    const double want = getenv("SGAN_WGRAD_WANT") ? atof(getenv("SGAN_WGRAD_WANT")) : 1024.0;
+    // 512 workgroups (two per CU): with the fragment-prefetching main loop more splits only add atomics (sweep on the fcgan step)
+    const double want = getenv("SGAN_WGRAD_WANT") ? atof(getenv("SGAN_WGRAD_WANT")) : 512.0;
     int per = (int)((double)chunks_total * tiles / want + 0.999);
     if (per < 4) per = 4;
     int z = 0;

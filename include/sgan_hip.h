@@ -221,6 +221,18 @@ int sgan_gauss_down_bwd(const float* dout, int32_t dout_ld, int32_t Ho, int32_t 
                         float* din, int32_t din_ld, int32_t H, int32_t W, int32_t accumulate /* din += instead of = */,
                         void* stream);
 
+/* Several pre-filters in one launch (the multi-scale discriminators filter one image at scale 2 and at scale 4;
+ * models/fcgan_model.py:86-93 builds one NLayerDiscriminator per --scale_factor entry).  Forward: n <= 4 independent jobs.
+ * Backward: the jobs must share `image` (the image gradient): it receives the SUM of their contributions
+ * (accumulate != 0: added to what it holds). */
+typedef struct sgan_gauss_job {
+    float* image; int32_t image_ld, H, W;    /* full-resolution side: read by fwd, written by bwd */
+    float* down; int32_t down_ld, Ho, Wo;    /* filtered + strided side: written by fwd, read by bwd */
+    const float* g; int32_t g_chan_stride, k, pad, s;
+} sgan_gauss_job;
+int sgan_gauss_down_multi_fwd(const sgan_gauss_job* jobs, int32_t n, int32_t C, int32_t Creal, void* stream);
+int sgan_gauss_down_multi_bwd(const sgan_gauss_job* jobs, int32_t n, int32_t C, int32_t Creal, int32_t accumulate, void* stream);
+
 /* ---- GAN loss on a logits map (channel 0 of an NHWC-4 tensor) --------------------------------
  * mode 0: BCE(sigmoid(x), t) with torch's log clamp at -100 (GANLoss, --no_lsgan);
  * mode 1: MSE(x, t) (lsgan, no sigmoid).  loss_out[0] = mean loss; p_out (optional) = sigmoid(x).

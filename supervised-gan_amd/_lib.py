@@ -23,6 +23,12 @@ class ConvDesc(C.Structure):
                 ("Cin_logical", C.c_int32), ("Cout_logical", C.c_int32)]
 
 
+class GaussJob(C.Structure):
+    _fields_ = [("image", C.c_void_p), ("image_ld", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("down", C.c_void_p), ("down_ld", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("g", C.c_void_p), ("g_chan_stride", C.c_int32), ("k", C.c_int32), ("pad", C.c_int32), ("s", C.c_int32)]
+
+
 class ConvFwdJob(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("inp", C.c_void_p), ("in_ld", C.c_int32), ("in_norm", C.POINTER(NormDesc)),
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_stats", C.c_void_p),
@@ -89,6 +95,8 @@ SIGNATURES = {
     "sgan_scale": [_P, _P, _P, _L, _P],
     "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],
     "sgan_gauss_down_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    "sgan_gauss_down_multi_fwd": [C.POINTER(GaussJob), _I, _I, _I, _P],
+    "sgan_gauss_down_multi_bwd": [C.POINTER(GaussJob), _I, _I, _I, _I, _P],
     "sgan_gauss_down_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P],
     "sgan_gan_loss_fwd": [_P, _I, _I, _F, _I, _P, _P, _P],
     "sgan_gan_loss_bwd": [_P, _I, _I, _F, _I, _P, _P, _I, _P],

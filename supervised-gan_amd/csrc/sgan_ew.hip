@@ -503,6 +503,141 @@ __global__ __launch_bounds__(256) void sg_gauss_bwd_kernel(const float* dout, in
     }
 }
 
+// ---- several pre-filters in one launch: the multi-scale discriminators filter the same image at scale 2 and 4 --------
+struct SgGaussJob {
+    const float* src; float* dst; const float* g;
+    int32_t src_ld, dst_ld, Hs, Ws, Hd, Wd, gcs, k, pad, s;   // src/dst: fwd = (image, downsampled), bwd = (d downsampled, d image)
+};
+struct SgGaussTable { SgGaussJob j[4]; int32_t n, C, Creal, accumulate; };
+
+__global__ __launch_bounds__(256) void sg_gauss_multi_fwd_kernel(const SgGaussTable T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gs = reinterpret_cast<float*>(smem);   // [k*k][C] (zero for padding channels)
+    const SgGaussJob& J = T.j[blockIdx.y];
+    const int C = T.C, k = J.k, pad = J.pad, s = J.s, H = J.Hs, W = J.Ws, Ho = J.Hd, Wo = J.Wd;
+    for (int i = threadIdx.x; i < k * k * C; i += 256) {
+        const int c = i % C, t = i / C;
+        gs[i] = c < T.Creal ? J.g[(int64_t)c * J.gcs + t] : 0.f;
+    }
+    __syncthreads();
+    const int CQ = C >> 2;
+    const int64_t total = (int64_t)Ho * Wo * CQ;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % CQ) * 4;
+        const int64_t pix = e / CQ;
+        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ky0 = max(0, pad - oy * s), ky1 = min(k, H + pad - oy * s);
+        const int kx0 = max(0, pad - ox * s), kx1 = min(k, W + pad - ox * s);
+        for (int ky = ky0; ky < ky1; ++ky) {
+            const float* row = J.src + ((int64_t)(oy * s + ky - pad) * W + (ox * s - pad)) * J.src_ld + c;
+            for (int kx = kx0; kx < kx1; ++kx)
+                acc += *reinterpret_cast<const f32x4*>(gs + (ky * k + kx) * C + c) * *reinterpret_cast<const f32x4*>(row + (int64_t)kx * J.src_ld);
+        }
+        *reinterpret_cast<f32x4*>(J.dst + pix * J.dst_ld + c) = acc;
+    }
+}
+
+// backward of several pre-filters of ONE image: every thread owns an image (pixel, channel quad) and sums the jobs
+__global__ __launch_bounds__(256) void sg_gauss_multi_bwd_kernel(const SgGaussTable T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gs = reinterpret_cast<float*>(smem);   // job after job: [k*k][C]
+    const int C = T.C;
+    int goff[4];
+    {
+        int o = 0;
+        for (int j = 0; j < T.n; ++j) {
+            goff[j] = o;
+            const int kk = T.j[j].k * T.j[j].k;
+            for (int i = threadIdx.x; i < kk * C; i += 256) {
+                const int c = i % C, t = i / C;
+                gs[o + i] = c < T.Creal ? T.j[j].g[(int64_t)c * T.j[j].gcs + t] : 0.f;
+            }
+            o += kk * C;
+        }
+    }
+    __syncthreads();
+    const int H = T.j[0].Hd, W = T.j[0].Wd, CQ = C >> 2;
+    const int64_t total = (int64_t)H * W * CQ;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % CQ) * 4;
+        const int64_t pix = e / CQ;
+        const int ix = (int)(pix % W), iy = (int)(pix / W);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < T.n; ++j) {
+            const SgGaussJob& J = T.j[j];
+            const int k = J.k, pad = J.pad, s = J.s, Ho = J.Hs, Wo = J.Ws;
+            const float* gj = gs + goff[j];
+            for (int ky = (iy + pad) % s; ky < k; ky += s) {
+                const int oy = (iy + pad - ky) / s;          // exact; decreasing in ky
+                if (iy + pad - ky < 0) break;
+                if (oy >= Ho) continue;
+                for (int kx = (ix + pad) % s; kx < k; kx += s) {
+                    const int ox = (ix + pad - kx) / s;
+                    if (ix + pad - kx < 0) break;
+                    if (ox >= Wo) continue;
+                    acc += *reinterpret_cast<const f32x4*>(gj + (ky * k + kx) * C + c) *
+                           *reinterpret_cast<const f32x4*>(J.src + ((int64_t)oy * Wo + ox) * J.src_ld + c);
+                }
+            }
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(T.j[0].dst + pix * T.j[0].dst_ld + c);
+        *o = T.accumulate ? *o + acc : acc;
+    }
+}
+
+static int sg_fill_gauss(SgGaussTable& T, const sgan_gauss_job* jobs, int n, int C, int Creal, bool bwd) {
+    if (!jobs || n < 1 || n > 4 || (C & 3) || Creal > C || C <= 0) return sgan_fail(SGAN_ERR_INVALID, "1..4 gauss jobs, C % 4 == 0");
+    memset(&T, 0, sizeof(T));
+    T.n = n; T.C = C; T.Creal = Creal;
+    int lds = 0;
+    for (int i = 0; i < n; ++i) {
+        const sgan_gauss_job& J = jobs[i];
+        if (!J.image || !J.down || !J.g || J.k <= 0 || J.s <= 0 || (J.image_ld & 3) || (J.down_ld & 3) || J.image_ld < C || J.down_ld < C)
+            return sgan_fail(SGAN_ERR_INVALID, "bad gauss job %d", i);
+        if (J.Ho != (J.H + 2 * J.pad - J.k) / J.s + 1 || J.Wo != (J.W + 2 * J.pad - J.k) / J.s + 1)
+            return sgan_fail(SGAN_ERR_INVALID, "gauss geometry mismatch in job %d", i);
+        SgGaussJob& D = T.j[i];
+        D.g = J.g; D.gcs = J.g_chan_stride; D.k = J.k; D.pad = J.pad; D.s = J.s;
+        if (!bwd) { D.src = J.image; D.src_ld = J.image_ld; D.Hs = J.H; D.Ws = J.W; D.dst = J.down; D.dst_ld = J.down_ld; D.Hd = J.Ho; D.Wd = J.Wo; }
+        else { D.src = J.down; D.src_ld = J.down_ld; D.Hs = J.Ho; D.Ws = J.Wo; D.dst = J.image; D.dst_ld = J.image_ld; D.Hd = J.H; D.Wd = J.W; }
+        lds += J.k * J.k * C * 4;
+        if (bwd && (J.image != jobs[0].image || J.H != jobs[0].H || J.W != jobs[0].W || J.image_ld != jobs[0].image_ld))
+            return sgan_fail(SGAN_ERR_INVALID, "backward jobs must share the image gradient");
+    }
+    if (lds > 60000) return sgan_fail(SGAN_ERR_UNSUPPORTED, "gauss taps do not fit LDS");
+    return SGAN_OK;
+}
+
+extern "C" int sgan_gauss_down_multi_fwd(const sgan_gauss_job* jobs, int32_t n, int32_t C, int32_t Creal, void* stream) {
+    SgGaussTable T;
+    int rc = sg_fill_gauss(T, jobs, n, C, Creal, false);
+    if (rc) return rc;
+    int64_t maxt = 0;
+    int maxk = 0;
+    for (int i = 0; i < n; ++i) { maxt = max(maxt, (int64_t)jobs[i].Ho * jobs[i].Wo * (C >> 2)); maxk = max(maxk, jobs[i].k); }
+    int blocks = ew_cdiv(maxt, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sg_gauss_multi_fwd_kernel, dim3(blocks, n), dim3(256), (size_t)maxk * maxk * C * 4, (hipStream_t)stream, T);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_gauss_down_multi_bwd(const sgan_gauss_job* jobs, int32_t n, int32_t C, int32_t Creal, int32_t accumulate, void* stream) {
+    SgGaussTable T;
+    int rc = sg_fill_gauss(T, jobs, n, C, Creal, true);
+    if (rc) return rc;
+    T.accumulate = accumulate;
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) lds += (size_t)jobs[i].k * jobs[i].k * C * 4;
+    const int64_t total = (int64_t)jobs[0].H * jobs[0].W * (C >> 2);
+    int blocks = ew_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sg_gauss_multi_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, T);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
 extern "C" int sgan_gauss_down_fwd(const float* in, int32_t in_ld, int32_t H, int32_t W, int32_t C, int32_t Creal,
                                    const float* g, int32_t g_chan_stride, int32_t k, int32_t pad, int32_t s, float* out,
                                    int32_t out_ld, int32_t Ho, int32_t Wo, void* stream) {

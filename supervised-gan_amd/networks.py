@@ -602,8 +602,12 @@ class _MultiChainFn(torch.autograd.Function):
     def forward(ctx, nets, *tensors):
         J = len(nets)
         xlog = tensors[:J]
-        memo = {}       # the same image goes to several discriminators: one layout conversion
-        xbs = [net._prepare_input(x, memo) for net, x in zip(nets, xlog)]
+        memo = {}       # the same image goes to several discriminators: one layout conversion ...
+        gauss = []      # ... and one launch for all their Gaussian pre-filters
+        xbs = [net._prepare_input(x, memo, gauss) if hasattr(net, "scale_factor") else net._prepare_input(x, memo)
+               for net, x in zip(nets, xlog)]
+        for creal in sorted({c for c, _ in gauss}):
+            ops.gauss_down_multi_fwd([job for c, job in gauss if c == creal], creal)
         outs, stats = _grouped_forward(nets, [xb["chain_in"] for xb in xbs])
         ctx.nets, ctx.xbs, ctx.outs, ctx.stats = nets, xbs, outs, stats
         ctx.in_keys = [(x.data_ptr(), tuple(x.shape), tuple(x.stride())) for x in xlog]
@@ -624,22 +628,33 @@ class _MultiChainFn(torch.autograd.Function):
             douts.append(ops.as_nhwc(g))
         dch = _grouped_backward(nets, [xb["chain_in"] for xb in ctx.xbs], ctx.outs, ctx.stats, douts, ctx.need_dx, ctx.want_wgrad)
         # discriminators fed with the same image (the multi-scale set on `fake`) share one image-gradient buffer: the
-        # first writes it, the others add into it and hand autograd None -- no gradient-accumulation kernels afterwards
-        dxs, shared = [], {}
+        # scale-1 chain's backward-data wrote it, the pre-filter backward of all the others adds into it in one launch,
+        # and autograd is handed one gradient and Nones -- no gradient-accumulation kernels afterwards
+        dxs, groups = [None] * J, {}
         for j in range(J):
             if not ctx.need_dx[j]:
-                dxs.append(None)
                 continue
-            buf = shared.get(ctx.in_keys[j])
-            if buf is not None and hasattr(nets[j], "scale_factor"):
-                dxs.append(nets[j]._finish_input_grad(ctx.xbs[j], dch[j], into=buf))
-                continue
-            dx = nets[j]._finish_input_grad(ctx.xbs[j], dch[j])
             if hasattr(nets[j], "scale_factor"):
-                buf = ops.buffer_of(dx)
-                if buf is not None:
-                    shared[ctx.in_keys[j]] = buf
-            dxs.append(dx)
+                groups.setdefault(ctx.in_keys[j], []).append(j)
+            else:
+                dxs[j] = nets[j]._finish_input_grad(ctx.xbs[j], dch[j])
+        for js in groups.values():
+            ones = [j for j in js if nets[j].scale_factor == 1]
+            downs = [j for j in js if nets[j].scale_factor > 1]
+            nc = nets[js[0]].input_nc
+            if ones:
+                buf = dch[ones[0]]
+                for j in ones[1:]:
+                    buf.add_(dch[j])
+            else:
+                buf = torch.empty_like(ctx.xbs[js[0]]["img"])
+            if downs:
+                jobs = []
+                for j in downs:
+                    wg, gcs, kg, padg = nets[j]._gauss_args()
+                    jobs.append((buf, dch[j], wg, gcs, kg, padg, nets[j].scale_factor))
+                ops.gauss_down_multi_bwd(jobs, nc, accumulate=bool(ones))
+            dxs[js[0]] = ops.logical_view(buf, nc)
         return (None,) + tuple(dxs) + (None,) * (len(ctx.needs_input_grad) - 1 - J)
 
 
@@ -1367,7 +1382,9 @@ class NLayerDiscriminator(ChainNet):
         kg, padg = self._gauss
         return wg, (self.input_nc + 1) * kg * kg, kg, padg
 
-    def _prepare_input(self, x, memo=None):
+    def _prepare_input(self, x, memo=None, defer=None):
+        """`defer`: a list that collects the pre-filter jobs instead of launching them (the caller flushes the list with
+        ops.gauss_down_multi_fwd: one launch for the scale-2 and scale-4 discriminators of a multi-scale set)."""
         key = (x.data_ptr(), tuple(x.shape), x.stride())
         img = memo.get(key) if memo is not None else None
         if img is None:
@@ -1383,7 +1400,10 @@ class NLayerDiscriminator(ChainNet):
             Ho, Wo = (Ho - 1) // s + 1, (Wo - 1) // s + 1                              # AvgPool2d(1, stride s)
             out = torch.empty((Ho, Wo, Cs), dtype=torch.float32, device=x.device)
             # conv(pad) then pick every s-th pixel == strided conv with the same pad
-            ops.gauss_down_fwd(xb["img"], self.input_nc, wg, gcs, kg, padg, s, out)
+            if defer is not None:
+                defer.append((self.input_nc, (xb["img"], out, wg, gcs, kg, padg, s)))
+            else:
+                ops.gauss_down_fwd(xb["img"], self.input_nc, wg, gcs, kg, padg, s, out)
             xb["chain_in"] = out
         else:
             xb["chain_in"] = xb["img"]

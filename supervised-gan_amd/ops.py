@@ -248,6 +248,32 @@ def gauss_down_bwd(dout, Creal, g, g_chan_stride, k, pad, s, din, accumulate=Fal
                                         _ptr(_act(din)), din.stride(1), H, W, int(bool(accumulate)), _stream()), "sgan_gauss_down_bwd")
 
 
+def _gauss_jobs(jobs):
+    """jobs: [(image, down, g, g_chan_stride, k, pad, s)] NHWC buffers of one channel count."""
+    arr = (L.GaussJob * len(jobs))()
+    for i, (img, down, g, gcs, k, pad, s) in enumerate(jobs):
+        H, W, _ = img.shape
+        Ho, Wo, _ = down.shape
+        arr[i] = L.GaussJob(_ptr(_act(img)).value, img.stride(1), H, W, _ptr(_act(down)).value, down.stride(1), Ho, Wo,
+                            _ptr(g).value, int(gcs), int(k), int(pad), int(s))
+    return arr
+
+
+def gauss_down_multi_fwd(jobs, Creal):
+    for i0 in range(0, len(jobs), 4):
+        part = jobs[i0: i0 + 4]
+        L.check(L.lib().sgan_gauss_down_multi_fwd(_gauss_jobs(part), len(part), part[0][0].shape[2], Creal, _stream()),
+                "sgan_gauss_down_multi_fwd")
+
+
+def gauss_down_multi_bwd(jobs, Creal, accumulate=False):
+    """All jobs share jobs[i][0], the image gradient, which receives the sum of their contributions."""
+    for i0 in range(0, len(jobs), 4):
+        part = jobs[i0: i0 + 4]
+        L.check(L.lib().sgan_gauss_down_multi_bwd(_gauss_jobs(part), len(part), part[0][0].shape[2], Creal,
+                                                  int(bool(accumulate or i0 > 0)), _stream()), "sgan_gauss_down_multi_bwd")
+
+
 def gan_loss_fwd(logits, target, mode, loss_out, p_out=None):
     H, W, _ = logits.shape
     L.check(L.lib().sgan_gan_loss_fwd(_ptr(_act(logits)), logits.stride(1), H * W, float(target), mode, _ptr(loss_out),

@@ -205,6 +205,42 @@ def test_gauss_down(hip, s, nc):
     assert float(out[..., nc:].abs().max()) == 0.0
 
 
+def test_gauss_down_multi(hip):
+    """Scale-2 and scale-4 pre-filters of one image in one launch each way == the single-job entry points."""
+    import sgan_oracle as O
+    ops = hip
+    nc, H, W = 2, 37, 41
+    g = torch.Generator().manual_seed(77)
+    xb = torch.randn(H, W, 4, generator=g).cuda()
+    xb[..., nc:] = 0
+    jobs, outs, refs, douts = [], [], [], []
+    for s in (2, 4):
+        kg, padg = 4 * (s // 2) + 1, 2 * (s // 2)
+        wg = O.gauss_filter_weight(nc, s).cuda()
+        Ho, Wo = (H + 2 * padg - kg) // s + 1, (W + 2 * padg - kg) // s + 1
+        out, ref = torch.empty(Ho, Wo, 4, device="cuda"), torch.empty(Ho, Wo, 4, device="cuda")
+        ops.gauss_down_fwd(xb, nc, wg, (nc + 1) * kg * kg, kg, padg, s, ref)
+        jobs.append((xb, out, wg, (nc + 1) * kg * kg, kg, padg, s))
+        outs.append(out)
+        refs.append(ref)
+        douts.append(torch.randn(Ho, Wo, 4, generator=g).cuda())
+    ops.gauss_down_multi_fwd(jobs, nc)
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)
+    din_ref = torch.zeros(H, W, 4, device="cuda")
+    for (x_, o_, wg, gcs, kg, padg, s), d in zip(jobs, douts):
+        ops.gauss_down_bwd(d, nc, wg, gcs, kg, padg, s, din_ref, accumulate=True)
+    base = torch.randn(H, W, 4, generator=g).cuda()
+    din = base.clone()
+    ops.gauss_down_multi_bwd([(din, d, wg, gcs, kg, padg, s) for (x_, o_, wg, gcs, kg, padg, s), d in zip(jobs, douts)], nc, accumulate=True)
+    din2 = torch.full((H, W, 4), float("nan"), device="cuda")
+    ops.gauss_down_multi_bwd([(din2, d, wg, gcs, kg, padg, s) for (x_, o_, wg, gcs, kg, padg, s), d in zip(jobs, douts)], nc)
+    torch.cuda.synchronize()
+    assert float((din2 - din_ref).abs().max()) <= 1e-6 * float(din_ref.abs().max())
+    assert float((din - base - din_ref).abs().max()) <= 1e-5 * float(din_ref.abs().max())
+
+
 @pytest.mark.parametrize("mode,target", [(0, 1.0), (0, 0.0), (1, 1.0), (1, 0.0)])
 def test_gan_loss(hip, mode, target):
     from hip_utils import from_buf, rel, to_buf

@@ -393,10 +393,13 @@ def golden_crn_small():
 
 def build_ref_cgan(cfg: "O.CGANConfig", seed: int, tmpdir: str):
     from options.train_options import TrainOptions
-    from models.cgan_model import CGANModel
+    if cfg.variant == "cgan2":
+        from models.cgan2_model import CGANModel
+    else:
+        from models.cgan_model import CGANModel
     netG = {7: "unet_128", 8: "unet_256"}[cfg.num_downs]
-    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "cgan", "--which_direction", "AtoB",
-            "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize), "--batchSize", "1",
+    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", cfg.variant, "--which_direction", "AtoB",
+            "--dataset_mode", "unaligned" if cfg.variant == "cgan2" else "aligned", "--fineSize", str(cfg.fineSize), "--batchSize", "1",
             "--which_model_netG", netG, "--ngf", str(cfg.ngf), "--which_model_netD", "n_layers",
             "--n_layers_D", *map(str, cfg.n_layers_D), "--ndf", str(cfg.ndf), "--scale_factor", *map(str, cfg.scale_factor),
             "--lambda_D", *map(str, cfg.lambda_D), "--lambda_A", str(cfg.lambda_A), "--norm", "instance",
@@ -411,6 +414,10 @@ def build_ref_cgan(cfg: "O.CGANConfig", seed: int, tmpdir: str):
         argv += ["--add_gaussian_noise", "--gaussian_sigma", str(cfg.gaussian_sigma)]
     if cfg.weights is not None:
         argv += ["--weights", *map(str, cfg.weights)]
+    if cfg.train_D_on_fake_fake_pair:
+        argv.append("--train_D_on_fake_fake_pair")
+    if cfg.train_G_on_fake_fake_pair:
+        argv.append("--train_G_on_fake_fake_pair")
     old = sys.argv
     sys.argv = argv
     try:
@@ -448,9 +455,13 @@ def golden_cgan_step(name, cfg: "O.CGANConfig", seed: int, nsteps: int):
                     model.optimize_parameters()
                 else:
                     model.forward()
-                    fake1 = model.fake_B.detach()
+                    fake1 = (model.fake_B_from_real_A if cfg.variant == "cgan2" else model.fake_B).detach()
                     arrs["step1/fake_summary"] = np.asarray(O.tensor_summary(fake1))
                     arrs["step1/fake_crop"] = fake1[:, :, :64, :64].numpy().copy()
+                    if cfg.variant == "cgan2":
+                        fake2 = model.fake_B_from_fake_A.detach()
+                        arrs["step1/fake2_summary"] = np.asarray(O.tensor_summary(fake2))
+                        arrs["step1/fake2_crop"] = fake2[:, :, :64, :64].numpy().copy()
                     model.optimizer_D.zero_grad()
                     model.backward_D()
                     for i, d in enumerate(model.netD):
@@ -467,7 +478,8 @@ def golden_cgan_step(name, cfg: "O.CGANConfig", seed: int, nsteps: int):
         arrs["losses"] = np.asarray(losses, dtype=np.float64)
         probe = build_ref_cgan(cfg, seed, tmp)
         probe.set_input(cgan_batch(cfg, 0))
-        with UnetRandomInjector(9000, 9500):
+        with UnetRandomInjector(9000, 9500) as pinj:
+            pinj.count_forwards(probe.netG)      # cgan2 runs the generator twice per forward(): seeds advance per call
             probe.forward()
             probe.optimizer_G.zero_grad()
             probe.optimizer_D.zero_grad()
@@ -615,6 +627,12 @@ def main():
     only = sys.argv[1:]
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
+    if not only or "cgan2" in only:
+        small = dict(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0), variant="cgan2", n_layers_D=(3, 3), scale_factor=(1, 2),
+                     no_lsgan=True, n_update_G=2)
+        golden_cgan_step("cgan2_step_small.npz", O.CGANConfig(**small), 0, 2)
+        golden_cgan_step("cgan2_step_small_fakefake.npz",
+                         O.CGANConfig(**dict(small, train_D_on_fake_fake_pair=True, train_G_on_fake_fake_pair=True)), 0, 2)
     if not only or "crn" in only:
         golden_crn_small()
     if not only or "twostage" in only:

@@ -23,6 +23,7 @@ Reference map (paths relative to /root/reference):
   GANLoss                                     models/networks.py:152-185
   WeightedL1Loss                              models/networks.py:205-214
   UnetGenerator / UnetSkipConnectionBlock     models/networks.py:318-419
+  CGANModel of cgan2 (two label images)       models/cgan2_model.py:129-233
   AutoEncoder                                 models/networks.py:421-490
   CascadedRefinementNetwork / Crn*Block       models/networks.py:642-794
   CGANModel step recipe                       models/cgan_model.py:134-226
@@ -655,7 +656,10 @@ class CGANConfig:
     def __init__(self, num_downs=8, input_nc=2, output_nc=1, ngf=64, ndf=64, n_layers_D=(3, 4), scale_factor=(1, 2),
                  lambda_D=(1.0, 1.0), lambda_A=10.0, weights=None, use_dropout=True, n_layers_G_skip=-1,
                  add_gaussian_noise=False, gaussian_sigma=0.1, fineSize=512, lr=2e-4, beta1=0.5, pool_size=50,
-                 no_lsgan=False, no_logD_trick=False, no_cgan=False, n_update_G=1):
+                 no_lsgan=False, no_logD_trick=False, no_cgan=False, n_update_G=1, variant="cgan",
+                 train_D_on_fake_fake_pair=False, train_G_on_fake_fake_pair=False):
+        # variant "cgan2" (models/cgan2_model.py): a second label image fake_A (channels of input['B']) goes through G as
+        # well, and the two flags pick which (label, generated) pair the discriminator step / the generator step uses
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -690,12 +694,24 @@ class CGANOracle:
         self.pool = ImagePool(c.pool_size)
         self.nfwd = 0
 
-    def forward(self):
+    def _g(self, a):
         c = self.cfg
-        self.fake_B = unet_forward(self.G, self.real_A, c.num_downs, c.ngf, c.n_layers_G_skip, c.use_dropout,
-                                   mask_seed=9000 + 100 * self.nfwd, add_gaussian_noise=c.add_gaussian_noise,
-                                   gaussian_sigma=c.gaussian_sigma, noise_seed=9500 + 100 * self.nfwd)
+        y = unet_forward(self.G, a, c.num_downs, c.ngf, c.n_layers_G_skip, c.use_dropout,
+                         mask_seed=9000 + 100 * self.nfwd, add_gaussian_noise=c.add_gaussian_noise,
+                         gaussian_sigma=c.gaussian_sigma, noise_seed=9500 + 100 * self.nfwd)
         self.nfwd += 1
+        return y
+
+    def forward(self):
+        self.fake_B = self._g(self.real_A)
+        if self.cfg.variant == "cgan2":            # cgan2_model.py:137-138: real_A first, then fake_A
+            self.fake_B_from_fake_A = self._g(self.fake_A)
+
+    def _pair(self, fake_fake):
+        """(label, generated) the reference feeds a discriminator (cgan2_model.py:169-178, :200-210)."""
+        if self.cfg.variant == "cgan2" and fake_fake:
+            return self.fake_A, self.fake_B_from_fake_A
+        return self.real_A, self.fake_B
 
     def _d(self, i, x):
         c = self.cfg
@@ -703,7 +719,8 @@ class CGANOracle:
 
     def backward_D(self):
         c = self.cfg
-        fake = self.fake_B if c.no_cgan else torch.cat((self.real_A, self.fake_B), 1)
+        a, b = self._pair(c.train_D_on_fake_fake_pair)
+        fake = b if c.no_cgan else torch.cat((a, b), 1)
         fake = self.pool.query(fake)
         self.loss_D_fake = sum(gan_loss(self._d(i, fake.detach()), False, not c.no_lsgan) for i in range(len(self.D)))
         real = self.real_B if c.no_cgan else torch.cat((self.real_A, self.real_B), 1)
@@ -713,7 +730,8 @@ class CGANOracle:
 
     def backward_G(self):
         c = self.cfg
-        fake = self.fake_B if c.no_cgan else torch.cat((self.real_A, self.fake_B), 1)
+        a, b = self._pair(c.train_G_on_fake_fake_pair)
+        fake = b if c.no_cgan else torch.cat((a, b), 1)
         loss = 0
         for i, lam in enumerate(c.lambda_D):
             pred = self._d(i, fake)
@@ -727,12 +745,16 @@ class CGANOracle:
             a01 = (self.real_A.detach() + 1) / 2
             for i, wv in enumerate(c.weights):
                 weight = weight + a01.narrow(1, i, 1) * (wv - 1.0)
-        self.loss_G_L1 = weighted_l1(self.fake_B, self.real_B, weight) * c.lambda_A
-        self.loss_G = loss + self.loss_G_L1
+        if c.variant == "cgan2":      # cgan2_model.py:219-232: loss_G_L1 is kept UNscaled, and there is none on the unpaired label
+            self.loss_G_L1 = torch.zeros(()) if c.train_G_on_fake_fake_pair else weighted_l1(self.fake_B, self.real_B, weight)
+            self.loss_G = loss + self.loss_G_L1 * c.lambda_A
+        else:
+            self.loss_G_L1 = weighted_l1(self.fake_B, self.real_B, weight) * c.lambda_A
+            self.loss_G = loss + self.loss_G_L1
         self.loss_G.backward()
 
-    def set_input(self, real_A, real_B):
-        self.real_A, self.real_B = real_A, real_B
+    def set_input(self, real_A, real_B, fake_A=None):
+        self.real_A, self.real_B, self.fake_A = real_A, real_B, fake_A
 
     def _g_steps(self):
         for _ in range(self.cfg.n_update_G):
@@ -756,6 +778,8 @@ class CGANOracle:
         cap = {}
         self.forward()
         cap["fake"] = self.fake_B.detach().clone()
+        if self.cfg.variant == "cgan2":
+            cap["fake2"] = self.fake_B_from_fake_A.detach().clone()
         self.opt_D.zero_grad()
         self.backward_D()
         cap["gradD"] = self._gradD()

@@ -14,9 +14,12 @@ def create_model(opt):
     elif opt.model == 'twostage':
         from .twostage_cycle_model import TwoStageModel
         model = TwoStageModel()
-    elif opt.model in ('cgan2', 'cgan_cycle', 'cgan2_cycle', 'twostage_factd',
+    elif opt.model == 'cgan2':
+        from .cgan2_model import CGAN2Model
+        model = CGAN2Model()
+    elif opt.model in ('cgan_cycle', 'cgan2_cycle', 'twostage_factd',
                        'test', 'segmentation', 'segmentation_cycle'):
-        raise NotImplementedError("model [%s] is not on the MI355X path yet (fcgan, cgan, twostage and twostage_cycle are; see DESIGN.md scope)" % opt.model)
+        raise NotImplementedError("model [%s] is not on the MI355X path yet (fcgan, cgan, cgan2, twostage and twostage_cycle are; see DESIGN.md scope)" % opt.model)
     else:
         raise ValueError("Model [%s] not recognized." % opt.model)
     model.initialize(opt)

@@ -163,6 +163,8 @@ class TrainOptions(BaseOptions):
         a('--noise_pool_size', type=int, default=100)
         a('--optimizer', type=str, default='adam')
         a('--pool_reject_prob', type=float, default=0.5)
+        a('--train_D_on_fake_fake_pair', action='store_true')   # cgan2 (options/train_options.py:33-34)
+        a('--train_G_on_fake_fake_pair', action='store_true')
         a('--no_logD_trick', action='store_true')
         a('--lambda_fake_cycle', type=float, default=1.0)
         a('--which_model_to_load', nargs='+', default=[''])

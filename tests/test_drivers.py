@@ -49,3 +49,18 @@ def test_train_then_test_cgan(tmp_path):
     assert all(np.isfinite(v) for v in m.get_current_errors().values())
     out = test_driver.main(net + ["--results_dir", str(tmp_path / "res"), "--how_many", "2"])
     assert len(out) == 4 and all(os.path.exists(p) for p in out)            # real_A + fake_B per image
+
+
+def test_train_cgan2(tmp_path):
+    """`--model cgan2` (two label images per sample, unaligned feeder) through train.py, with either pair choice."""
+    _need_gpu()
+    import train as train_driver
+    net = ["--name", "drv_cgan2", "--model", "cgan2", "--dataset_mode", "unaligned", "--fineSize", "256",
+           "--which_model_netG", "unet_128", "--ngf", "8", "--norm", "instance", "--which_channel", "rg_b", "--gpu_ids", "0",
+           "--checkpoints_dir", str(tmp_path / "ckpt"), "--dataroot", "synthetic", "--manualSeed", "4",
+           "--which_model_netD", "n_layers", "--n_layers_D", "3", "3", "--ndf", "8", "--scale_factor", "1", "2",
+           "--lambda_D", "0.5", "0.5", "--weights", "2", "4", "--no_lsgan", "--max_steps", "3", "--print_freq", "1"]
+    for extra in ([], ["--train_D_on_fake_fake_pair", "--train_G_on_fake_fake_pair"]):
+        m = train_driver.main(net + extra)
+        assert all(np.isfinite(v) for v in m.get_current_errors().values())
+        assert m.fake_B_from_fake_A.shape == (1, 1, 256, 256)

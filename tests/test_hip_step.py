@@ -167,7 +167,7 @@ def build_cgan(cfg, extra=()):
         pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")
     from supervised_gan_amd.models import create_model
     from supervised_gan_amd.options import TrainOptions
-    argv = ["--name", "t", "--model", "cgan", "--which_direction", "AtoB", "--dataset_mode", "aligned",
+    argv = ["--name", "t", "--model", cfg.variant, "--which_direction", "AtoB", "--dataset_mode", "unaligned" if cfg.variant == "cgan2" else "aligned",
             "--fineSize", str(cfg.fineSize), "--which_model_netG", {7: "unet_128", 8: "unet_256"}[cfg.num_downs],
             "--ngf", str(cfg.ngf), "--which_model_netD", "n_layers", "--n_layers_D", *map(str, cfg.n_layers_D),
             "--ndf", str(cfg.ndf), "--scale_factor", *map(str, cfg.scale_factor), "--lambda_D", *map(str, cfg.lambda_D),
@@ -179,6 +179,10 @@ def build_cgan(cfg, extra=()):
         argv += ["--add_gaussian_noise", "--gaussian_sigma", str(cfg.gaussian_sigma)]
     if cfg.no_lsgan:
         argv.append("--no_lsgan")
+    if cfg.train_D_on_fake_fake_pair:
+        argv.append("--train_D_on_fake_fake_pair")
+    if cfg.train_G_on_fake_fake_pair:
+        argv.append("--train_G_on_fake_fake_pair")
     argv += ["--n_update_G", str(cfg.n_update_G)]
     opt = TrainOptions().parse(argv, save=False, verbose=False)
     m = create_model(opt)
@@ -228,6 +232,8 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
     m.set_input(cgan_input(cfg, 0))
     m.forward()
     cap = {"fake": m.fake_B.detach().cpu().clone()}
+    if cfg.variant == "cgan2":
+        cap["fake2"] = m.fake_B_from_fake_A.detach().cpu().clone()
     m.optimizer_D.zero_grad()
     m.backward_D()
     cap["gradD"] = [_grads(d) for d in m.netD]
@@ -245,11 +251,13 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
     print(f"{name}: {strict}/{len(tally)} gradient tensors within 1e-3 (max-abs/max|g|); worst rel-L2 {worst[3]:.2e} at {worst[0]}/{worst[1]}")
     assert float(np.median([t[3] for t in tally])) <= 5e-3, tally
     # (3) trajectory through the losses
-    losses = [list(m.get_current_errors().values())]
+    def errs():     # the golden rows are (loss_G, loss_G_L1, D_real, D_fake); cgan2's get_current_errors has no G_L1 entry
+        return [float(m.loss_G), float(m.loss_G_L1), float(m.loss_D_real), float(m.loss_D_fake)]
+    losses = [errs()]
     for step in range(1, g["losses"].shape[0]):
         m.set_input(cgan_input(cfg, step))
         m.optimize_parameters()
-        losses.append(list(m.get_current_errors().values()))
+        losses.append(errs())
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
 
 

@@ -239,6 +239,8 @@ def test_unet_small(golden_dir, tag):
 def cgan_batch(cfg, step):
     A = O.np_uniform(7100 + step, (1, 3, cfg.fineSize, cfg.fineSize))
     B = O.np_uniform(7200 + step, (1, 3, cfg.fineSize, cfg.fineSize))
+    if getattr(cfg, "variant", "cgan") == "cgan2":       # cgan2_model.py:122-124: (label, image) from input['A'], the second label from input['B']
+        return A[:, :2].contiguous(), A[:, 2:3].contiguous(), B[:, :2].contiguous()
     return A[:, :2].contiguous(), B[:, 2:3].contiguous()       # --which_channel rg_b
 
 
@@ -248,6 +250,9 @@ def cgan_undet_D(cfg, i):
 
 def check_cgan_step1(cap, g, cfg, tol=TOL, robust=False, tally=None):
     check_forward(cap, g, tol)
+    if "fake2" in cap:
+        check_forward({"fake": cap["fake2"], "loss_D": cap["loss_D"]}, {"step1/fake_summary": g["step1/fake2_summary"],
+                      "step1/fake_crop": g["step1/fake2_crop"], "step1/loss_D": g["step1/loss_D"]}, tol)
     for i, gd in enumerate(cap["gradD"]):
         check_grads(gd, g, f"step1/gradD_{i}", cgan_undet_D(cfg, i), tol, robust, tally)
 
@@ -260,8 +265,12 @@ def check_cgan_probe(pr, g, cfg, tol=TOL, robust=False, tally=None):
         check_grads(gd, g, f"probeG/gradD_{i}", cgan_undet_D(cfg, i), tol, robust, tally)
 
 
+CGAN2_SMALL = dict(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0), variant="cgan2", n_layers_D=(3, 3), scale_factor=(1, 2),
+                   no_lsgan=True, n_update_G=2)
 CGAN_CASES = [("cgan_step_small.npz", dict(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0))),
-              ("cgan_step_full.npz", O.CGAN_README)]            # BASELINE configs[2]: unet_256 + D 3 4 @512x512
+              ("cgan_step_full.npz", O.CGAN_README),            # BASELINE configs[2]: unet_256 + D 3 4 @512x512
+              ("cgan2_step_small.npz", CGAN2_SMALL),            # --model cgan2 (models/cgan2_model.py)
+              ("cgan2_step_small_fakefake.npz", dict(CGAN2_SMALL, train_D_on_fake_fake_pair=True, train_G_on_fake_fake_pair=True))]
 
 
 @pytest.mark.parametrize("name,kw", CGAN_CASES)

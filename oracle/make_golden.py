@@ -496,6 +496,80 @@ def golden_cgan_step(name, cfg: "O.CGANConfig", seed: int, nsteps: int):
 
 
 # ---------------------------------------------------------------------------------------
+# cgan_cycle
+# ---------------------------------------------------------------------------------------
+def build_ref_cgan_cycle(cfg: "O.CGANCycleConfig", seed: int, tmpdir: str):
+    from options.train_options import TrainOptions
+    from models.cgan_cycle_model import CGANCycleModel
+    L = lambda xs: [str(x) for x in xs]
+    unet = {7: "unet_128", 8: "unet_256"}
+    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "cgan_cycle", "--which_direction", "AtoB",
+            "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize), "--batchSize", "1", "--which_channel", "rg_b",
+            "--which_model_netG1", unet[cfg.num_downs1], "--ngf1", str(cfg.ngf1), "--which_model_netG2", unet[cfg.num_downs2],
+            "--ngf2", str(cfg.ngf2), "--which_model_netD1", "n_layers", "--n_layers_D1", *L(cfg.n_layers_D1), "--ndf1", str(cfg.ndf1),
+            "--scale_factor1", *L(cfg.scale_factor1), "--lambda_D1", *L(cfg.lambda_D1), "--lambda_A", str(cfg.lambda_A),
+            "--lambda_B", str(cfg.lambda_B), "--lambda_A_cycle", str(cfg.lambda_A_cycle), "--lr1", str(cfg.lr1), "--lr2", str(cfg.lr2),
+            "--norm", "instance", "--no_dropout1", "--no_dropout2", "--n_update_G", str(cfg.n_update_G), "--pool_size", str(cfg.pool_size),
+            "--gpu_ids", "-1", "--display_id", "0", "--checkpoints_dir", tmpdir]
+    if cfg.no_lsgan1:
+        argv.append("--no_lsgan1")
+    if cfg.weights is not None:
+        argv += ["--weights", *L(cfg.weights)]
+    old = sys.argv
+    sys.argv = argv
+    try:
+        opt = TrainOptions().parse()
+    finally:
+        sys.argv = old
+    opt.scale_factor1 = [Py2Int(s) if s > 1 else s for s in opt.scale_factor1]
+    model = CGANCycleModel()
+    model.initialize(opt)
+    load_sd(model.netG1, O.init_unet(seed + 1, cfg.num_downs1, cfg.input_nc, cfg.output_nc, cfg.ngf1, -1))
+    load_sd(model.netG2, O.init_unet(seed + 2, cfg.num_downs2, cfg.output_nc, cfg.input_nc, cfg.ngf2, -1))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D1, cfg.scale_factor1)):
+        load_sd(model.netD1[i], O.init_nlayer_d(seed + 3 + i, cfg.input_nc + cfg.output_nc, cfg.ndf1, nl, sf))
+    return model
+
+
+def golden_cgan_cycle(name, cfg: "O.CGANCycleConfig", seed: int, nsteps: int):
+    import random
+    import tempfile
+    from collections import namedtuple
+    with tempfile.TemporaryDirectory() as tmp:
+        arrs = {}
+        C = namedtuple("C", "fineSize")(cfg.fineSize)
+        probe = build_ref_cgan_cycle(cfg, seed, tmp)
+        random.seed(1234)
+        probe.set_input(cgan_batch(C, 0))
+        probe.forward()
+        for key in ("fake_B", "fake_A", "recon_A"):
+            t = getattr(probe, key).detach()
+            arrs[f"probe/{key}_summary"] = np.asarray(O.tensor_summary(t))
+            arrs[f"probe/{key}_crop"] = t[:, :, :64, :64].numpy().copy()
+        probe.optimizer_D1.zero_grad()
+        probe.backward_D1()
+        for i, d in enumerate(probe.netD1):
+            capture_grads(arrs, f"probe/gradD_{i}", d)
+        arrs["probe/loss_D"] = np.asarray([float(probe.loss_D_real), float(probe.loss_D_fake)])
+        probe.optimizer_D1.zero_grad()
+        probe.optimizer_G.zero_grad()
+        probe.backward_G()
+        capture_grads(arrs, "probe/gradG1", probe.netG1)
+        capture_grads(arrs, "probe/gradG2", probe.netG2)
+        arrs["probe/loss_G"] = np.asarray([float(probe.loss_G), float(probe.loss_G_GAN), float(probe.loss_G_L1), float(probe.loss_G_CE),
+                                           float(probe.loss_G_cycle)])
+        random.seed(1234)
+        model = build_ref_cgan_cycle(cfg, seed, tmp)
+        losses = []
+        for step in range(nsteps):
+            model.set_input(cgan_batch(C, step))
+            model.optimize_parameters()
+            losses.append([float(model.loss_G), float(model.loss_G_cycle), float(model.loss_D)])
+        arrs["losses"] = np.asarray(losses, dtype=np.float64)
+        save(name, **arrs)
+
+
+# ---------------------------------------------------------------------------------------
 # twostage_cycle (DSGAN)
 # ---------------------------------------------------------------------------------------
 class TwoNoiseInjector:
@@ -627,6 +701,11 @@ def main():
     only = sys.argv[1:]
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
+    if not only or "cgan_cycle" in only:
+        golden_cgan_cycle("cgan_cycle_small.npz", O.CGANCycleConfig(), 0, 3)
+        # (n_update_G > 1 is not a case: the reference's sample_noise does not regenerate fake_A, so its second backward_G walks a
+        # freed graph and raises)
+        golden_cgan_cycle("cgan_cycle_small_d34.npz", O.CGANCycleConfig(scale_factor1=(1, 1), n_layers_D1=(3, 4), weights=None, no_lsgan1=False), 0, 2)
     if not only or "cgan2" in only:
         small = dict(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0), variant="cgan2", n_layers_D=(3, 3), scale_factor=(1, 2),
                      no_lsgan=True, n_update_G=2)

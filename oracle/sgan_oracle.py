@@ -24,6 +24,7 @@ Reference map (paths relative to /root/reference):
   WeightedL1Loss                              models/networks.py:205-214
   UnetGenerator / UnetSkipConnectionBlock     models/networks.py:318-419
   CGANModel of cgan2 (two label images)       models/cgan2_model.py:129-233
+  CGANCycleModel                              models/cgan_cycle_model.py:129-240
   AutoEncoder                                 models/networks.py:421-490
   CascadedRefinementNetwork / Crn*Block       models/networks.py:642-794
   CGANModel step recipe                       models/cgan_model.py:134-226
@@ -805,6 +806,127 @@ class CGANOracle:
 # ----------------------------------------------------------------------------------
 # the twostage_cycle (DSGAN) training step (models/twostage_cycle_model.py:193-438)
 # ----------------------------------------------------------------------------------
+class CGANCycleConfig:
+    """cgan_cycle flags with unet generators both ways (dropout off, no Gaussian noise: the step is deterministic)."""
+    def __init__(self, num_downs1=7, num_downs2=7, input_nc=2, output_nc=1, ngf1=8, ngf2=8, ndf1=8, n_layers_D1=(3, 3), scale_factor1=(1, 2),
+                 lambda_D1=(0.6, 0.4), lambda_A=10.0, lambda_B=10.0, lambda_A_cycle=10.0, weights=(2.0, 5.0), fineSize=256,
+                 lr1=2e-4, lr2=1e-4, beta1=0.5, pool_size=50, no_lsgan1=True, no_logD_trick=False, n_update_G=1):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+class CGANCycleOracle:
+    """CGANCycleModel restated (models/cgan_cycle_model.py: forward :129-138, sample_noise :140-146, backward_D1 :162-186,
+    backward_G :188-225, optimize_parameters :227-240 with n_update_D1 = 1; Adam groups G1 @ lr1, G2 @ lr2 :99-102)."""
+
+    def __init__(self, cfg: CGANCycleConfig, seed: int = 0):
+        self.cfg = c = cfg
+        self.G1 = init_unet(seed + 1, c.num_downs1, c.input_nc, c.output_nc, c.ngf1, -1)
+        self.G2 = init_unet(seed + 2, c.num_downs2, c.output_nc, c.input_nc, c.ngf2, -1)
+        self.D = [init_nlayer_d(seed + 3 + i, c.input_nc + c.output_nc, c.ndf1, nl, sf) for i, (nl, sf) in enumerate(zip(c.n_layers_D1, c.scale_factor1))]
+        for sd in [self.G1, self.G2] + self.D:
+            for v in sd.values():
+                if v.is_floating_point():
+                    v.requires_grad_(True)
+        self.opt_G1 = Adam(list(self.G1.values()), c.lr1, c.beta1)
+        self.opt_G2 = Adam(list(self.G2.values()), c.lr2, c.beta1)
+        self.opt_D = Adam([v for d in self.D for k, v in d.items() if k.startswith("model.")], c.lr1, c.beta1)
+        self.pool = ImagePool(c.pool_size)
+
+    def set_input(self, real_A, real_B):
+        self.real_A, self.real_B = real_A, real_B
+
+    def _g1(self, a):
+        return unet_forward(self.G1, a, self.cfg.num_downs1, self.cfg.ngf1, -1, False)
+
+    def _g2(self, b):
+        return unet_forward(self.G2, b, self.cfg.num_downs2, self.cfg.ngf2, -1, False)
+
+    def forward(self):
+        self.fake_B = self._g1(self.real_A)
+        self.fake_A = self._g2(self.real_B)
+        self.recon_A = self._g2(self.fake_B)
+
+    def sample_noise(self):
+        self.fake_B = self._g1(self.real_A)
+        self.recon_A = self._g2(self.fake_B)
+
+    def _d(self, i, x):
+        c = self.cfg
+        return nlayer_d_forward(self.D[i], x, c.n_layers_D1[i], c.scale_factor1[i], use_sigmoid=c.no_lsgan1)
+
+    def backward_D1(self):
+        c = self.cfg
+        fake = self.pool.query(torch.cat((self.real_A, self.fake_B), 1))
+        self.loss_D_fake = sum(gan_loss(self._d(i, fake.detach()), False, not c.no_lsgan1) for i in range(len(self.D)))
+        real = torch.cat((self.real_A, self.real_B), 1)
+        self.loss_D_real = sum(gan_loss(self._d(i, real), True, not c.no_lsgan1) for i in range(len(self.D)))
+        self.loss_D = (self.loss_D_fake + self.loss_D_real) * 0.5
+        self.loss_D.backward()
+
+    def backward_G(self):
+        c = self.cfg
+        fake = torch.cat((self.real_A, self.fake_B), 1)
+        gan = 0
+        for i, lam in enumerate(c.lambda_D1):
+            pred = self._d(i, fake)
+            gan = gan + (gan_loss(pred, True, not c.no_lsgan1) * lam if not c.no_logD_trick else -gan_loss(pred, False, not c.no_lsgan1) * lam)
+        weight = None
+        if c.weights is not None:
+            weight = torch.ones(1, 1, c.fineSize, c.fineSize)
+            a01 = (self.real_A.detach() + 1) / 2
+            for i, wv in enumerate(c.weights):
+                weight = weight + a01.narrow(1, i, 1) * (wv - 1.0)
+        self.loss_G_GAN = gan
+        self.loss_G_L1 = weighted_l1(self.fake_B, self.real_B, weight)
+        self.loss_G_CE = F.binary_cross_entropy((self.fake_A + 1) / 2, (self.real_A + 1) / 2)
+        self.loss_G_cycle = F.binary_cross_entropy((self.recon_A + 1) / 2, (self.real_A + 1) / 2)
+        self.loss_G = gan + self.loss_G_L1 * c.lambda_A + self.loss_G_CE * c.lambda_B + self.loss_G_cycle * c.lambda_A_cycle
+        self.loss_G.backward()
+
+    def _zero_G(self):
+        self.opt_G1.zero_grad()
+        self.opt_G2.zero_grad()
+
+    def _g_steps(self):
+        for _ in range(self.cfg.n_update_G):
+            self._zero_G()
+            self.backward_G()
+            self.opt_G1.step()
+            self.opt_G2.step()
+            if self.cfg.n_update_G > 1:
+                self.sample_noise()
+
+    def optimize_parameters(self):
+        self.forward()
+        self.opt_D.zero_grad()
+        self.backward_D1()
+        self.opt_D.step()
+        self._g_steps()
+
+    def _gradD(self):
+        return [{k: v.grad.detach().clone() for k, v in d.items() if k.startswith("model.") and v.grad is not None} for d in self.D]
+
+    def probe(self):
+        """forward() + backward_D1() (before any update) + backward_G() through the initial discriminators."""
+        self.forward()
+        self.opt_D.zero_grad()
+        self.backward_D1()
+        out = {"fake_B": self.fake_B.detach().clone(), "fake_A": self.fake_A.detach().clone(), "recon_A": self.recon_A.detach().clone(),
+               "gradD_Dstep": self._gradD(), "loss_D": [float(self.loss_D_real.detach()), float(self.loss_D_fake.detach())]}
+        self.opt_D.zero_grad()
+        self._zero_G()
+        self.backward_G()
+        out["gradG1"] = {k: v.grad.detach().clone() for k, v in self.G1.items()}
+        out["gradG2"] = {k: v.grad.detach().clone() for k, v in self.G2.items()}
+        out["loss_G"] = [float(self.loss_G.detach()), float(self.loss_G_GAN.detach()), float(self.loss_G_L1.detach()),
+                         float(self.loss_G_CE.detach()), float(self.loss_G_cycle.detach())]
+        return out
+
+    def losses(self):
+        return [float(self.loss_G.detach()), float(self.loss_G_cycle.detach()), float(self.loss_D.detach())]
+
+
 class TwoStageConfig:
     """README.md:18 flags (BASELINE configs[4]) by default; binary GAN objective, no dropout."""
     def __init__(self, input_nc=2, output_nc=1, fineSize=512, ngf1=32, n_layers_G1=5, noise_nc1=8, noiseSize1=4,

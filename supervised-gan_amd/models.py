@@ -17,9 +17,12 @@ def create_model(opt):
     elif opt.model == 'cgan2':
         from .cgan2_model import CGAN2Model
         model = CGAN2Model()
-    elif opt.model in ('cgan_cycle', 'cgan2_cycle', 'twostage_factd',
+    elif opt.model == 'cgan_cycle':
+        from .cgan_cycle_model import CGANCycleModel
+        model = CGANCycleModel()
+    elif opt.model in ('cgan2_cycle', 'twostage_factd',
                        'test', 'segmentation', 'segmentation_cycle'):
-        raise NotImplementedError("model [%s] is not on the MI355X path yet (fcgan, cgan, cgan2, twostage and twostage_cycle are; see DESIGN.md scope)" % opt.model)
+        raise NotImplementedError("model [%s] is not on the MI355X path yet (fcgan, cgan, cgan2, cgan_cycle, twostage and twostage_cycle are; see DESIGN.md scope)" % opt.model)
     else:
         raise ValueError("Model [%s] not recognized." % opt.model)
     model.initialize(opt)

@@ -29,6 +29,12 @@ TWOSTAGE = ["--model", "twostage_cycle", "--which_direction", "AtoB", "--dataset
             "--GAN_losses_D2", "real_fake", "fake_fake", "--GAN_losses_G2", "real_fake", "fake_fake"]
 
 
+CGAN_CYCLE = ["--model", "cgan_cycle", "--which_direction", "AtoB", "--dataset_mode", "single", "--fineSize", "256", "--which_channel", "rg_b",
+              "--which_model_netG1", "unet_128", "--ngf1", "8", "--which_model_netG2", "unet_128", "--ngf2", "8", "--n_layers_D1", "3", "3",
+              "--ndf1", "8", "--scale_factor1", "1", "2", "--lambda_D1", "0.6", "0.4", "--no_dropout1", "--no_dropout2", "--no_lsgan1",
+              "--weights", "2", "4"]
+
+
 def _build(argv):
     from supervised_gan_amd.models import create_model
     from supervised_gan_amd.options import TrainOptions
@@ -44,8 +50,9 @@ def _ring(hw, n=4):
              "A_paths": ["s"], "B_paths": ["s"]} for _ in range(n)]
 
 
-@pytest.mark.parametrize("argv,hw,out", [(FCGAN, 128, "fake"), (CGAN, 256, "fake_B"), (TWOSTAGE, 256, "fake_B_from_fake_A")],
-                         ids=["fcgan", "cgan", "twostage_cycle"])
+@pytest.mark.parametrize("argv,hw,out", [(FCGAN, 128, "fake"), (CGAN, 256, "fake_B"), (TWOSTAGE, 256, "fake_B_from_fake_A"),
+                                         (CGAN_CYCLE, 256, "recon_A")],
+                         ids=["fcgan", "cgan", "twostage_cycle", "cgan_cycle"])
 def test_graphed_step_equals_eager(argv, hw, out):
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")

@@ -400,3 +400,49 @@ def test_autoencoder_small(golden_dir):
             assert float(v.grad.abs().max()) <= 1e-3 * float(sd[k.replace(".bias", ".weight")].grad.abs().max()), k
         else:
             assert rel(v.grad, g["grad/" + k]) < 1e-4, k
+
+
+# ------------------------------------------------------------------------------------------------
+# cgan_cycle ((f) rank 2: G1 label -> image, G2 image -> label, BCE cycle terms)
+# ------------------------------------------------------------------------------------------------
+CGAN_CYCLE_CASES = [("cgan_cycle_small.npz", dict()),
+                    ("cgan_cycle_small_d34.npz", dict(scale_factor1=(1, 1), n_layers_D1=(3, 4), weights=None, no_lsgan1=False))]
+
+
+def cgan_cycle_batch(cfg, step):
+    A = O.np_uniform(7100 + step, (1, 3, cfg.fineSize, cfg.fineSize))
+    B = O.np_uniform(7200 + step, (1, 3, cfg.fineSize, cfg.fineSize))
+    return A[:, :2].contiguous(), B[:, 2:3].contiguous()
+
+
+def check_cgan_cycle_probe(pr, g, cfg, tol=TOL, robust=False, tally=None):
+    for key in ("fake_B", "fake_A", "recon_A"):
+        assert rel(pr[key][:, :, :64, :64], g[f"probe/{key}_crop"]) < tol, key
+        assert abs(O.tensor_summary(pr[key])[2] - g[f"probe/{key}_summary"][2]) <= tol * g[f"probe/{key}_summary"][2], key
+    assert np.abs(np.asarray(pr["loss_D"]) - g["probe/loss_D"]).max() < tol
+    assert np.abs(np.asarray(pr["loss_G"]) - g["probe/loss_G"]).max() < tol * max(1.0, float(np.abs(g["probe/loss_G"]).max()))
+    for i, gd in enumerate(pr["gradD_Dstep"]):
+        check_grads(gd, g, f"probe/gradD_{i}", O.norm_cancelled_keys_d(cfg.input_nc + cfg.output_nc, cfg.ndf1, cfg.n_layers_D1[i]),
+                    tol, robust, tally)
+    check_grads(pr["gradG1"], g, "probe/gradG1", O.norm_cancelled_keys_unet(cfg.num_downs1, cfg.ngf1, -1), tol, robust, tally)
+    check_grads(pr["gradG2"], g, "probe/gradG2", O.norm_cancelled_keys_unet(cfg.num_downs2, cfg.ngf2, -1), tol, robust, tally)
+
+
+@pytest.mark.parametrize("name,kw", CGAN_CYCLE_CASES)
+def test_cgan_cycle_step(golden_dir, name, kw):
+    import random
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    g = load(golden_dir, name)
+    cfg = O.CGANCycleConfig(**kw)
+    random.seed(1234)
+    pr = O.CGANCycleOracle(cfg, seed=0)
+    pr.set_input(*cgan_cycle_batch(cfg, 0))
+    check_cgan_cycle_probe(pr.probe(), g, cfg, tol=1e-4)
+    random.seed(1234)
+    m = O.CGANCycleOracle(cfg, seed=0)
+    losses = []
+    for step in range(g["losses"].shape[0]):
+        m.set_input(*cgan_cycle_batch(cfg, step))
+        m.optimize_parameters()
+        losses.append(m.losses())
+    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])

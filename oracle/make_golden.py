@@ -500,11 +500,15 @@ def golden_cgan_step(name, cfg: "O.CGANConfig", seed: int, nsteps: int):
 # ---------------------------------------------------------------------------------------
 def build_ref_cgan_cycle(cfg: "O.CGANCycleConfig", seed: int, tmpdir: str):
     from options.train_options import TrainOptions
-    from models.cgan_cycle_model import CGANCycleModel
+    if cfg.variant == "cgan2_cycle":
+        from models.cgan2_cycle_model import CGANCycleModel
+    else:
+        from models.cgan_cycle_model import CGANCycleModel
     L = lambda xs: [str(x) for x in xs]
     unet = {7: "unet_128", 8: "unet_256"}
-    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "cgan_cycle", "--which_direction", "AtoB",
-            "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize), "--batchSize", "1", "--which_channel", "rg_b",
+    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", cfg.variant, "--which_direction", "AtoB",
+            "--dataset_mode", "unaligned" if cfg.variant == "cgan2_cycle" else "aligned", "--fineSize", str(cfg.fineSize), "--batchSize", "1", "--which_channel", "rg_b",
+            "--lambda_fake_cycle", str(cfg.lambda_fake_cycle),
             "--which_model_netG1", unet[cfg.num_downs1], "--ngf1", str(cfg.ngf1), "--which_model_netG2", unet[cfg.num_downs2],
             "--ngf2", str(cfg.ngf2), "--which_model_netD1", "n_layers", "--n_layers_D1", *L(cfg.n_layers_D1), "--ndf1", str(cfg.ndf1),
             "--scale_factor1", *L(cfg.scale_factor1), "--lambda_D1", *L(cfg.lambda_D1), "--lambda_A", str(cfg.lambda_A),
@@ -515,6 +519,10 @@ def build_ref_cgan_cycle(cfg: "O.CGANCycleConfig", seed: int, tmpdir: str):
         argv.append("--no_lsgan1")
     if cfg.weights is not None:
         argv += ["--weights", *L(cfg.weights)]
+    if cfg.train_D_on_fake_fake_pair:
+        argv.append("--train_D_on_fake_fake_pair")
+    if cfg.train_G_on_fake_fake_pair:
+        argv.append("--train_G_on_fake_fake_pair")
     old = sys.argv
     sys.argv = argv
     try:
@@ -542,8 +550,11 @@ def golden_cgan_cycle(name, cfg: "O.CGANCycleConfig", seed: int, nsteps: int):
         random.seed(1234)
         probe.set_input(cgan_batch(C, 0))
         probe.forward()
-        for key in ("fake_B", "fake_A", "recon_A"):
-            t = getattr(probe, key).detach()
+        two = cfg.variant == "cgan2_cycle"
+        names = {"fake_B": "fake_B_from_real_A", "fake_A": "fake_A_from_real_B", "recon_A": "recon_real_A", "recon_fake_A": "recon_fake_A"} if two \
+            else {"fake_B": "fake_B", "fake_A": "fake_A", "recon_A": "recon_A"}
+        for key, attr in names.items():
+            t = getattr(probe, attr).detach()
             arrs[f"probe/{key}_summary"] = np.asarray(O.tensor_summary(t))
             arrs[f"probe/{key}_crop"] = t[:, :, :64, :64].numpy().copy()
         probe.optimizer_D1.zero_grad()
@@ -557,14 +568,14 @@ def golden_cgan_cycle(name, cfg: "O.CGANCycleConfig", seed: int, nsteps: int):
         capture_grads(arrs, "probe/gradG1", probe.netG1)
         capture_grads(arrs, "probe/gradG2", probe.netG2)
         arrs["probe/loss_G"] = np.asarray([float(probe.loss_G), float(probe.loss_G_GAN), float(probe.loss_G_L1), float(probe.loss_G_CE),
-                                           float(probe.loss_G_cycle)])
+                                           float(probe.loss_G_real_cycle if two else probe.loss_G_cycle)])
         random.seed(1234)
         model = build_ref_cgan_cycle(cfg, seed, tmp)
         losses = []
         for step in range(nsteps):
             model.set_input(cgan_batch(C, step))
             model.optimize_parameters()
-            losses.append([float(model.loss_G), float(model.loss_G_cycle), float(model.loss_D)])
+            losses.append([float(model.loss_G), float(model.loss_G_real_cycle if two else model.loss_G_cycle), float(model.loss_D)])
         arrs["losses"] = np.asarray(losses, dtype=np.float64)
         save(name, **arrs)
 
@@ -701,6 +712,11 @@ def main():
     only = sys.argv[1:]
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
+    if not only or "cgan2_cycle" in only:
+        two = dict(variant="cgan2_cycle", lambda_fake_cycle=0.5)
+        golden_cgan_cycle("cgan2_cycle_small.npz", O.CGANCycleConfig(**two), 0, 2)
+        golden_cgan_cycle("cgan2_cycle_small_fakefake.npz",
+                          O.CGANCycleConfig(**dict(two, train_D_on_fake_fake_pair=True, train_G_on_fake_fake_pair=True, n_update_G=2)), 0, 2)
     if not only or "cgan_cycle" in only:
         golden_cgan_cycle("cgan_cycle_small.npz", O.CGANCycleConfig(), 0, 3)
         # (n_update_G > 1 is not a case: the reference's sample_noise does not regenerate fake_A, so its second backward_G walks a

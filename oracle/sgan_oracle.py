@@ -25,6 +25,7 @@ Reference map (paths relative to /root/reference):
   UnetGenerator / UnetSkipConnectionBlock     models/networks.py:318-419
   CGANModel of cgan2 (two label images)       models/cgan2_model.py:129-233
   CGANCycleModel                              models/cgan_cycle_model.py:129-240
+  CGANCycleModel of cgan2_cycle               models/cgan2_cycle_model.py:114-262
   AutoEncoder                                 models/networks.py:421-490
   CascadedRefinementNetwork / Crn*Block       models/networks.py:642-794
   CGANModel step recipe                       models/cgan_model.py:134-226
@@ -810,7 +811,9 @@ class CGANCycleConfig:
     """cgan_cycle flags with unet generators both ways (dropout off, no Gaussian noise: the step is deterministic)."""
     def __init__(self, num_downs1=7, num_downs2=7, input_nc=2, output_nc=1, ngf1=8, ngf2=8, ndf1=8, n_layers_D1=(3, 3), scale_factor1=(1, 2),
                  lambda_D1=(0.6, 0.4), lambda_A=10.0, lambda_B=10.0, lambda_A_cycle=10.0, weights=(2.0, 5.0), fineSize=256,
-                 lr1=2e-4, lr2=1e-4, beta1=0.5, pool_size=50, no_lsgan1=True, no_logD_trick=False, n_update_G=1):
+                 lr1=2e-4, lr2=1e-4, beta1=0.5, pool_size=50, no_lsgan1=True, no_logD_trick=False, n_update_G=1, variant="cgan_cycle",
+                 train_D_on_fake_fake_pair=False, train_G_on_fake_fake_pair=False, lambda_fake_cycle=1.0):
+        # variant "cgan2_cycle" (models/cgan2_cycle_model.py): second label image fake_A, five generator calls, pair-choice flags
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -833,8 +836,8 @@ class CGANCycleOracle:
         self.opt_D = Adam([v for d in self.D for k, v in d.items() if k.startswith("model.")], c.lr1, c.beta1)
         self.pool = ImagePool(c.pool_size)
 
-    def set_input(self, real_A, real_B):
-        self.real_A, self.real_B = real_A, real_B
+    def set_input(self, real_A, real_B, fake_A=None):
+        self.real_A, self.real_B, self.fake_A_in = real_A, real_B, fake_A
 
     def _g1(self, a):
         return unet_forward(self.G1, a, self.cfg.num_downs1, self.cfg.ngf1, -1, False)
@@ -843,13 +846,27 @@ class CGANCycleOracle:
         return unet_forward(self.G2, b, self.cfg.num_downs2, self.cfg.ngf2, -1, False)
 
     def forward(self):
+        if self.cfg.variant == "cgan2_cycle":      # cgan2_cycle_model.py:123-137 (sample_noise :139-149 is the same five calls)
+            self.fake_B = self._g1(self.real_A)
+            self.fake_B_from_fake_A = self._g1(self.fake_A_in)
+            self.fake_A = self._g2(self.real_B)                 # fake_A_from_real_B
+            self.recon_A = self._g2(self.fake_B)                # recon_real_A
+            self.recon_fake_A = self._g2(self.fake_B_from_fake_A)
+            return
         self.fake_B = self._g1(self.real_A)
         self.fake_A = self._g2(self.real_B)
         self.recon_A = self._g2(self.fake_B)
 
     def sample_noise(self):
+        if self.cfg.variant == "cgan2_cycle":
+            return self.forward()
         self.fake_B = self._g1(self.real_A)
         self.recon_A = self._g2(self.fake_B)
+
+    def _fake_pair(self, fake_fake):
+        if self.cfg.variant == "cgan2_cycle" and fake_fake:
+            return torch.cat((self.fake_A_in, self.fake_B_from_fake_A), 1)
+        return torch.cat((self.real_A, self.fake_B), 1)
 
     def _d(self, i, x):
         c = self.cfg
@@ -857,7 +874,7 @@ class CGANCycleOracle:
 
     def backward_D1(self):
         c = self.cfg
-        fake = self.pool.query(torch.cat((self.real_A, self.fake_B), 1))
+        fake = self.pool.query(self._fake_pair(c.train_D_on_fake_fake_pair))
         self.loss_D_fake = sum(gan_loss(self._d(i, fake.detach()), False, not c.no_lsgan1) for i in range(len(self.D)))
         real = torch.cat((self.real_A, self.real_B), 1)
         self.loss_D_real = sum(gan_loss(self._d(i, real), True, not c.no_lsgan1) for i in range(len(self.D)))
@@ -866,7 +883,7 @@ class CGANCycleOracle:
 
     def backward_G(self):
         c = self.cfg
-        fake = torch.cat((self.real_A, self.fake_B), 1)
+        fake = self._fake_pair(c.train_G_on_fake_fake_pair)
         gan = 0
         for i, lam in enumerate(c.lambda_D1):
             pred = self._d(i, fake)
@@ -878,10 +895,14 @@ class CGANCycleOracle:
             for i, wv in enumerate(c.weights):
                 weight = weight + a01.narrow(1, i, 1) * (wv - 1.0)
         self.loss_G_GAN = gan
-        self.loss_G_L1 = weighted_l1(self.fake_B, self.real_B, weight)
+        two = c.variant == "cgan2_cycle"
+        self.loss_G_L1 = torch.zeros(()) if (two and c.train_G_on_fake_fake_pair) else weighted_l1(self.fake_B, self.real_B, weight)
         self.loss_G_CE = F.binary_cross_entropy((self.fake_A + 1) / 2, (self.real_A + 1) / 2)
         self.loss_G_cycle = F.binary_cross_entropy((self.recon_A + 1) / 2, (self.real_A + 1) / 2)
         self.loss_G = gan + self.loss_G_L1 * c.lambda_A + self.loss_G_CE * c.lambda_B + self.loss_G_cycle * c.lambda_A_cycle
+        if two:     # cgan2_cycle_model.py:239-246
+            self.loss_G_fake_cycle = F.binary_cross_entropy((self.recon_fake_A + 1) / 2, (self.fake_A_in + 1) / 2)
+            self.loss_G = self.loss_G + self.loss_G_fake_cycle * c.lambda_A_cycle * c.lambda_fake_cycle
         self.loss_G.backward()
 
     def _zero_G(self):
@@ -913,6 +934,7 @@ class CGANCycleOracle:
         self.opt_D.zero_grad()
         self.backward_D1()
         out = {"fake_B": self.fake_B.detach().clone(), "fake_A": self.fake_A.detach().clone(), "recon_A": self.recon_A.detach().clone(),
+               **({"recon_fake_A": self.recon_fake_A.detach().clone()} if self.cfg.variant == "cgan2_cycle" else {}),
                "gradD_Dstep": self._gradD(), "loss_D": [float(self.loss_D_real.detach()), float(self.loss_D_fake.detach())]}
         self.opt_D.zero_grad()
         self._zero_G()

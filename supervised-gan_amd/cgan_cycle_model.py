@@ -14,6 +14,8 @@ from .optim import AdamGroups, FusedAdam
 
 
 class CGANCycleModel(BaseModel):
+    allow_multi_G_updates = False
+
     def name(self):
         return 'CGANCycleModel'
 
@@ -53,7 +55,8 @@ class CGANCycleModel(BaseModel):
             assert (len(opt.scale_factor1) == len(opt.lambda_D1) == len(opt.n_layers_D1))
             # the reference's sample_noise (:140-146) does not regenerate fake_A: its second backward_G of a step walks a freed
             # autograd graph and raises
-            assert opt.n_update_G == 1, "cgan_cycle: --n_update_G > 1 fails in the reference as well (stale fake_A graph)"
+            assert opt.n_update_G == 1 or self.allow_multi_G_updates, \
+                "cgan_cycle: --n_update_G > 1 fails in the reference as well (stale fake_A graph)"
             self.n_netD1 = len(opt.scale_factor1)
             self.netD1 = []
             d_nc = opt.output_nc if opt.no_cgan else opt.output_nc + opt.input_nc
@@ -99,7 +102,7 @@ class CGANCycleModel(BaseModel):
         prog = [[self.optimizer_D1.zero_grad, self.backward_D1], ("sync", self.optimizer_D1),
                 [self.optimizer_D1.step, self.optimizer_G.zero_grad, self.backward_G], ("sync", self.optimizer_G),
                 [self.optimizer_G.step]]
-        return dict(pools=[self.fake_pool1], sources=lambda: [self._pair(self.real_A, self.fake_B)],
+        return dict(pools=[self.fake_pool1], sources=lambda: [self._d_fake_source()],
                     set_overrides=lambda views: setattr(self, "_pool_overrides", views), program=prog)
 
     # ---- data ---------------------------------------------------------------------------------
@@ -149,6 +152,10 @@ class CGANCycleModel(BaseModel):
         return self.image_paths
 
     # ---- losses ---------------------------------------------------------------------------------
+    def _d_fake_source(self):
+        """What backward_D1 hands to ImagePool.query."""
+        return self._pair(self.real_A, self.fake_B)
+
     def _gan(self, jobs, weights):
         preds = networks.multi_forward([(d, x) for d, x, _ in jobs])
         return self.criterionGAN1.weighted_sum(preds, [r for _, _, r in jobs], weights)
@@ -158,7 +165,7 @@ class CGANCycleModel(BaseModel):
         if self._pool_overrides is not None:
             fake = self._pool_overrides[0]
         else:
-            fake = self.fake_pool1.query(self._pair(self.real_A, self.fake_B))
+            fake = self.fake_pool1.query(self._d_fake_source())
         fake = fake.detach()
         real = self._pair(self.real_A, self.real_B)
         n = self.n_netD1

@@ -20,9 +20,12 @@ def create_model(opt):
     elif opt.model == 'cgan_cycle':
         from .cgan_cycle_model import CGANCycleModel
         model = CGANCycleModel()
-    elif opt.model in ('cgan2_cycle', 'twostage_factd',
+    elif opt.model == 'cgan2_cycle':
+        from .cgan2_cycle_model import CGAN2CycleModel
+        model = CGAN2CycleModel()
+    elif opt.model in ('twostage_factd',
                        'test', 'segmentation', 'segmentation_cycle'):
-        raise NotImplementedError("model [%s] is not on the MI355X path yet (fcgan, cgan, cgan2, cgan_cycle, twostage and twostage_cycle are; see DESIGN.md scope)" % opt.model)
+        raise NotImplementedError("model [%s] is not on the MI355X path yet (fcgan, cgan, cgan2, cgan_cycle, cgan2_cycle, twostage and twostage_cycle are; see DESIGN.md scope)" % opt.model)
     else:
         raise ValueError("Model [%s] not recognized." % opt.model)
     model.initialize(opt)

@@ -446,7 +446,8 @@ def build_cgan_cycle(cfg):
     from supervised_gan_amd.options import TrainOptions
     L = lambda xs: [str(x) for x in xs]
     unet = {7: "unet_128", 8: "unet_256"}
-    argv = ["--name", "t", "--model", "cgan_cycle", "--which_direction", "AtoB", "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize),
+    argv = ["--name", "t", "--model", cfg.variant, "--which_direction", "AtoB", "--dataset_mode", "unaligned" if cfg.variant == "cgan2_cycle" else "aligned",
+            "--fineSize", str(cfg.fineSize), "--lambda_fake_cycle", str(cfg.lambda_fake_cycle), "--n_update_G", str(cfg.n_update_G),
             "--which_channel", "rg_b", "--which_model_netG1", unet[cfg.num_downs1], "--ngf1", str(cfg.ngf1),
             "--which_model_netG2", unet[cfg.num_downs2], "--ngf2", str(cfg.ngf2), "--which_model_netD1", "n_layers",
             "--n_layers_D1", *L(cfg.n_layers_D1), "--ndf1", str(cfg.ndf1), "--scale_factor1", *L(cfg.scale_factor1),
@@ -457,6 +458,10 @@ def build_cgan_cycle(cfg):
         argv.append("--no_lsgan1")
     if cfg.weights is not None:
         argv += ["--weights", *L(cfg.weights)]
+    if cfg.train_D_on_fake_fake_pair:
+        argv.append("--train_D_on_fake_fake_pair")
+    if cfg.train_G_on_fake_fake_pair:
+        argv.append("--train_G_on_fake_fake_pair")
     m = create_model(TrainOptions().parse(argv, save=False, verbose=False))
     m.netG1.load_state_dict(O.init_unet(1, cfg.num_downs1, cfg.input_nc, cfg.output_nc, cfg.ngf1, -1))
     m.netG2.load_state_dict(O.init_unet(2, cfg.num_downs2, cfg.output_nc, cfg.input_nc, cfg.ngf2, -1))
@@ -476,7 +481,10 @@ def test_cgan_cycle_step_vs_reference_golden(golden_dir, name, kw):
     p = build_cgan_cycle(cfg)
     p.set_input(cgan_input(cfg, 0))
     p.forward()
-    pr = {k: getattr(p, k).detach().cpu().clone() for k in ("fake_B", "fake_A", "recon_A")}
+    two = cfg.variant == "cgan2_cycle"
+    names = {"fake_B": "fake_B_from_real_A", "fake_A": "fake_A_from_real_B", "recon_A": "recon_real_A", "recon_fake_A": "recon_fake_A"} if two \
+        else {"fake_B": "fake_B", "fake_A": "fake_A", "recon_A": "recon_A"}
+    pr = {k: getattr(p, a).detach().cpu().clone() for k, a in names.items()}
     p.optimizer_D1.zero_grad()
     p.backward_D1()
     pr["gradD_Dstep"] = [_grads(d) for d in p.netD1]
@@ -486,7 +494,8 @@ def test_cgan_cycle_step_vs_reference_golden(golden_dir, name, kw):
     p.backward_G()
     torch.cuda.synchronize()
     pr["gradG1"], pr["gradG2"] = _grads(p.netG1), _grads(p.netG2)
-    pr["loss_G"] = [float(p.loss_G), float(p.loss_G_GAN), float(p.loss_G_L1), float(p.loss_G_CE), float(p.loss_G_cycle)]
+    pr["loss_G"] = [float(p.loss_G), float(p.loss_G_GAN), float(p.loss_G_L1), float(p.loss_G_CE),
+                    float(p.loss_G_real_cycle if two else p.loss_G_cycle)]
     # the inner U-Net blocks normalise 2x2 - 4x4 maps: robust per-tensor criterion + median, strict count reported
     tally = []
     check_cgan_cycle_probe(pr, g, cfg, tol=1e-3, robust=True, tally=tally)
@@ -500,5 +509,5 @@ def test_cgan_cycle_step_vs_reference_golden(golden_dir, name, kw):
     for step in range(g["losses"].shape[0]):
         m.set_input(cgan_input(cfg, step))
         m.optimize_parameters()
-        losses.append(list(m.get_current_errors().values()))
+        losses.append([float(m.loss_G), float(m.loss_G_real_cycle if two else m.loss_G_cycle), float(m.loss_D)])
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])

@@ -405,18 +405,24 @@ def test_autoencoder_small(golden_dir):
 # ------------------------------------------------------------------------------------------------
 # cgan_cycle ((f) rank 2: G1 label -> image, G2 image -> label, BCE cycle terms)
 # ------------------------------------------------------------------------------------------------
+CGAN2_CYCLE = dict(variant="cgan2_cycle", lambda_fake_cycle=0.5)
 CGAN_CYCLE_CASES = [("cgan_cycle_small.npz", dict()),
-                    ("cgan_cycle_small_d34.npz", dict(scale_factor1=(1, 1), n_layers_D1=(3, 4), weights=None, no_lsgan1=False))]
+                    ("cgan_cycle_small_d34.npz", dict(scale_factor1=(1, 1), n_layers_D1=(3, 4), weights=None, no_lsgan1=False)),
+                    ("cgan2_cycle_small.npz", CGAN2_CYCLE),             # --model cgan2_cycle (models/cgan2_cycle_model.py)
+                    ("cgan2_cycle_small_fakefake.npz", dict(CGAN2_CYCLE, train_D_on_fake_fake_pair=True, train_G_on_fake_fake_pair=True,
+                                                            n_update_G=2))]
 
 
 def cgan_cycle_batch(cfg, step):
     A = O.np_uniform(7100 + step, (1, 3, cfg.fineSize, cfg.fineSize))
     B = O.np_uniform(7200 + step, (1, 3, cfg.fineSize, cfg.fineSize))
+    if cfg.variant == "cgan2_cycle":     # cgan2_cycle_model.py:114-121
+        return A[:, :2].contiguous(), A[:, 2:3].contiguous(), B[:, :2].contiguous()
     return A[:, :2].contiguous(), B[:, 2:3].contiguous()
 
 
 def check_cgan_cycle_probe(pr, g, cfg, tol=TOL, robust=False, tally=None):
-    for key in ("fake_B", "fake_A", "recon_A"):
+    for key in ("fake_B", "fake_A", "recon_A") + (("recon_fake_A",) if "recon_fake_A" in pr else ()):
         assert rel(pr[key][:, :, :64, :64], g[f"probe/{key}_crop"]) < tol, key
         assert abs(O.tensor_summary(pr[key])[2] - g[f"probe/{key}_summary"][2]) <= tol * g[f"probe/{key}_summary"][2], key
     assert np.abs(np.asarray(pr["loss_D"]) - g["probe/loss_D"]).max() < tol

@@ -284,8 +284,11 @@ int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* 
 /* ---- BCELoss on rescaled tanh outputs (two-stage trainers): loss = mean BCE((x + 1) / 2, (t + 1) / 2) over npix * C
  * with torch's -100 log clamp; g = dloss/dx for a unit upstream gradient (backward: dx = gout * g, sgan_scale).
  * Replaces: torch.nn.BCELoss()((x + 1) / 2, (t + 1) / 2) at models/twostage_cycle_model.py:398-403. */
+/* `workspace` (this function and sgan_l1w_fwd): SGAN_IMAGE_LOSS_WS_BYTES of 8-byte aligned device scratch (uninitialised is
+ * fine) for the per-workgroup partial sums a second kernel finishes. */
+#define SGAN_IMAGE_LOSS_WS_BYTES 2048
 int sgan_bce01_fwd(const float* x, int32_t x_ld, const float* t, int32_t t_ld, int32_t npix, int32_t C, float* loss_out,
-                   float* g, int32_t g_ld, void* stream);
+                   float* g, int32_t g_ld, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- CRN building blocks (models/networks.py:642-794) --------------------------------------------
  * sgan_bilinear_up2_fwd: nn.Upsample(scale_factor=2, mode='bilinear') (align_corners = False) of an [H, W, C] tensor
@@ -310,7 +313,7 @@ int sgan_avgpool_pyramid_bwd(const float* const* dlevels, const int32_t* level_l
  * and the weight-map construction in CGANModel.backward_G (models/cgan_model.py:196-207). */
 int sgan_l1w_fwd(const float* x, int32_t x_ld, const float* y, int32_t y_ld, int32_t npix, int32_t C,
                  const float* a, int32_t a_ld, const float* weights_dev, int32_t nweights, float lambda,
-                 float* loss_out, float* g, int32_t g_ld, void* stream);
+                 float* loss_out, float* g, int32_t g_ld, void* workspace, int64_t workspace_bytes, void* stream);
 int sgan_scale(const float* gout, const float* g, float* dx, int64_t n, void* stream);   /* dx = gout[0] * g */
 
 /* ---- elementwise helpers ---------------------------------------------------------------------

@@ -83,7 +83,7 @@ SIGNATURES = {
     "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
     "sgan_norm_bwd_apply_multi": [C.POINTER(NormBwdJob), _I, _P],
     "sgan_transpose_weights": [_P, _P, C.POINTER(WtSeg), _I, _P],
-    "sgan_bce01_fwd": [_P, _I, _P, _I, _I, _I, _P, _P, _I, _P],
+    "sgan_bce01_fwd": [_P, _I, _P, _I, _I, _I, _P, _P, _I, _P, C.c_int64, _P],
     "sgan_bilinear_up2_fwd": [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "sgan_bilinear_up2_bwd": [_P, _I, _I, _I, _I, _P, _I, _P],
     "sgan_avgpool_pyramid_fwd": [_P, _I, _I, _I, _P, _P, _P],
@@ -91,7 +91,7 @@ SIGNATURES = {
     "sgan_norm_apply_fwd": [_P, _I, C.POINTER(NormDesc), _P, _P, _F, _P, _I, _I, _I, _P],
     "sgan_norm_apply_bwd_sums": [_P, _I, _P, _P, _I, C.POINTER(NormDesc), _P, _I, _I, _P],
     "sgan_dropout_mask": [_P, _L, _F, C.c_uint64, _P, _P],
-    "sgan_l1w_fwd": [_P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _F, _P, _P, _I, _P],
+    "sgan_l1w_fwd": [_P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _F, _P, _P, _I, _P, C.c_int64, _P],
     "sgan_scale": [_P, _P, _P, _L, _P],
     "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],
     "sgan_gauss_down_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],

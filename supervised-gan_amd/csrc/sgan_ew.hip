@@ -256,15 +256,32 @@ extern "C" int sgan_norm_apply_bwd_sums(float* dt, int32_t dt_ld, const float* m
 }
 
 // ------------------------------------------------------------------------------------------
-// weighted L1, scalar scale
+// weighted L1 / BCE on rescaled maps: image-sized losses.  One pixel per thread over up to SG_IMGLOSS_BLOCKS workgroups
+// (a single workgroup walking 512x512 pixels took 400 us); block partial sums (fp64) go to the caller's scratch and a
+// one-wave kernel finishes the mean -- a kernel boundary instead of atomics or a zero-initialised accumulator.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void sg_l1w_fwd_kernel(const float* x, int x_ld, const float* y, int y_ld, int npix, int C,
-                                                          const float* a, int a_ld, const float* wts, int nw, float lambda,
-                                                          float* loss_out, float* g, int g_ld) {
-    __shared__ double wsum[16];
+#define SG_IMGLOSS_BLOCKS 256
+__device__ __forceinline__ void sg_block_partial(double acc, double* part) {
+    __shared__ double wsum[4];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(64) void sg_imgloss_fin_kernel(const double* part, int nparts, double scale, float* loss_out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) acc += part[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (threadIdx.x == 0) loss_out[0] = (float)(acc * scale);
+}
+
+__global__ __launch_bounds__(256) void sg_l1w_fwd_kernel(const float* x, int x_ld, const float* y, int y_ld, int npix, int C,
+                                                         const float* a, int a_ld, const float* wts, int nw, float lambda,
+                                                         double* part, float* g, int g_ld) {
     const double inv = 1.0 / ((double)npix * (double)C);
     double acc = 0.0;
-    for (int p = threadIdx.x; p < npix; p += 1024) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
         float w = 1.f;
         if (a) {
             if (nw == 0) w = a[(int64_t)p * a_ld];   // explicit per-pixel weight map
@@ -280,14 +297,7 @@ __global__ __launch_bounds__(1024) void sg_l1w_fwd_kernel(const float* x, int x_
             g[(int64_t)p * g_ld + c] = gv;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < 16; ++i) t += wsum[i];
-        loss_out[0] = (float)(t * inv * (double)lambda);
-    }
+    sg_block_partial(acc, part);
 }
 
 __global__ __launch_bounds__(256) void sg_scale_kernel(const float* gout, const float* g, float* dx, int64_t n4) {
@@ -301,12 +311,11 @@ __global__ __launch_bounds__(256) void sg_scale_kernel(const float* gout, const 
 
 // BCELoss((x + 1) / 2, (t + 1) / 2), mean over npix * C (torch's -100 log clamp); g = dloss/dx for a unit upstream
 // gradient (torch: dL/dp = (p - t) / max(p (1 - p), 1e-12), then dp/dx = 1/2)
-__global__ __launch_bounds__(1024) void sg_bce01_fwd_kernel(const float* x, int x_ld, const float* t, int t_ld, int npix, int C,
-                                                            float* loss_out, float* g, int g_ld) {
-    __shared__ double wsum[16];
+__global__ __launch_bounds__(256) void sg_bce01_fwd_kernel(const float* x, int x_ld, const float* t, int t_ld, int npix, int C,
+                                                           double* part, float* g, int g_ld) {
     const double inv = 1.0 / ((double)npix * (double)C);
     double acc = 0.0;
-    for (int p = threadIdx.x; p < npix; p += 1024) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
         for (int c = 0; c < g_ld; ++c) {
             float gv = 0.f;
             if (c < C) {
@@ -318,31 +327,43 @@ __global__ __launch_bounds__(1024) void sg_bce01_fwd_kernel(const float* x, int 
             g[(int64_t)p * g_ld + c] = gv;
         }
     }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < 16; ++i) s += wsum[i];
-        loss_out[0] = (float)(s * inv);
-    }
+    sg_block_partial(acc, part);
+}
+
+static int sg_imgloss_blocks(int npix) {
+    int b = ew_cdiv(npix, 256);
+    return b > SG_IMGLOSS_BLOCKS ? SG_IMGLOSS_BLOCKS : b;
 }
 
 extern "C" int sgan_bce01_fwd(const float* x, int32_t x_ld, const float* t, int32_t t_ld, int32_t npix, int32_t C, float* loss_out,
-                              float* g, int32_t g_ld, void* stream) {
+                              float* g, int32_t g_ld, void* workspace, int64_t workspace_bytes, void* stream) {
     SGAN_CHECK(x && t && loss_out && g && npix > 0 && C > 0 && g_ld >= C && x_ld >= C && t_ld >= C, "bad argument");
-    hipLaunchKernelGGL(sg_bce01_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, x_ld, t, t_ld, npix, C, loss_out, g, g_ld);
+    SGAN_CHECK(workspace && workspace_bytes >= SGAN_IMAGE_LOSS_WS_BYTES && ((uintptr_t)workspace & 7) == 0,
+               "workspace of SGAN_IMAGE_LOSS_WS_BYTES (8-byte aligned) required");
+    static_assert(SG_IMGLOSS_BLOCKS * sizeof(double) <= SGAN_IMAGE_LOSS_WS_BYTES, "workspace size");
+    const int blocks = sg_imgloss_blocks(npix);
+    double* part = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(sg_bce01_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, t, t_ld, npix, C, part, g, g_ld);
+    SGAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sg_imgloss_fin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, blocks, 1.0 / ((double)npix * (double)C), loss_out);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
 }
 
 extern "C" int sgan_l1w_fwd(const float* x, int32_t x_ld, const float* y, int32_t y_ld, int32_t npix, int32_t C, const float* a,
                             int32_t a_ld, const float* weights_dev, int32_t nweights, float lambda, float* loss_out, float* g,
-                            int32_t g_ld, void* stream) {
+                            int32_t g_ld, void* workspace, int64_t workspace_bytes, void* stream) {
     SGAN_CHECK(x && y && loss_out && g && npix > 0 && C > 0 && g_ld >= C && x_ld >= C && y_ld >= C, "bad argument");
     SGAN_CHECK(!a || nweights == 0 || (weights_dev && nweights > 0 && a_ld >= nweights), "weights need the label image");
-    hipLaunchKernelGGL(sg_l1w_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, x_ld, y, y_ld, npix, C, a, a_ld,
-                       weights_dev, nweights, lambda, loss_out, g, g_ld);
+    SGAN_CHECK(workspace && workspace_bytes >= SGAN_IMAGE_LOSS_WS_BYTES && ((uintptr_t)workspace & 7) == 0,
+               "workspace of SGAN_IMAGE_LOSS_WS_BYTES (8-byte aligned) required");
+    const int blocks = sg_imgloss_blocks(npix);
+    double* part = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(sg_l1w_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, x_ld, y, y_ld, npix, C, a, a_ld,
+                       weights_dev, nweights, lambda, part, g, g_ld);
+    SGAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sg_imgloss_fin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, blocks,
+                       (double)lambda / ((double)npix * (double)C), loss_out);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
 }

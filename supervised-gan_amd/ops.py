@@ -208,17 +208,22 @@ def dropout_mask(mask, p, seed, offset_dev=None):
                                       _stream()), "sgan_dropout_mask")
 
 
+IMAGE_LOSS_WS_BYTES = 2048   # SGAN_IMAGE_LOSS_WS_BYTES
+
+
 def l1w_fwd(x, y, Creal, a, weights_dev, nweights, lam, loss_out, g):
     H, W, _ = x.shape
+    ws = torch.empty(IMAGE_LOSS_WS_BYTES // 8, dtype=torch.float64, device=x.device)
     L.check(L.lib().sgan_l1w_fwd(_ptr(_act(x)), x.stride(1), _ptr(_act(y)), y.stride(1), H * W, Creal,
                                  _ptr(a), a.stride(1) if a is not None else 0, _ptr(weights_dev), nweights, float(lam),
-                                 _ptr(loss_out), _ptr(_act(g)), g.stride(1), _stream()), "sgan_l1w_fwd")
+                                 _ptr(loss_out), _ptr(_act(g)), g.stride(1), _ptr(ws), IMAGE_LOSS_WS_BYTES, _stream()), "sgan_l1w_fwd")
 
 
 def bce01_fwd(x, t, Creal, loss_out, g):
     H, W, _ = x.shape
+    ws = torch.empty(IMAGE_LOSS_WS_BYTES // 8, dtype=torch.float64, device=x.device)
     L.check(L.lib().sgan_bce01_fwd(_ptr(_act(x)), x.stride(1), _ptr(_act(t)), t.stride(1), H * W, Creal, _ptr(loss_out),
-                                   _ptr(_act(g)), g.stride(1), _stream()), "sgan_bce01_fwd")
+                                   _ptr(_act(g)), g.stride(1), _ptr(ws), IMAGE_LOSS_WS_BYTES, _stream()), "sgan_bce01_fwd")
 
 
 def scale(gout, g, dx):

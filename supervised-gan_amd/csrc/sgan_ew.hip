@@ -206,20 +206,44 @@ __global__ __launch_bounds__(256) void sg_norm_apply_bwd_sums_kernel(float* dt, 
     __syncthreads();
     const int CQ = C >> 2;
     const int64_t total = (int64_t)npix * CQ;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int p = (int)(e / CQ), c = (int)(e - (int64_t)p * CQ) * 4;
-        f32x4 d = *reinterpret_cast<const f32x4*>(dt + (int64_t)p * dt_ld + c);
-        const f32x4 x = *reinterpret_cast<const f32x4*>(u + (int64_t)p * u_ld + c);
-        if (mask) {
-            const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (int64_t)p * C + c);
-            d *= m;
-            *reinterpret_cast<f32x4*>(dt + (int64_t)p * dt_ld + c) = d;
+    if (256 % CQ == 0) {
+        // the element stride (gridDim.x * 256) is a multiple of CQ: this thread always sees channel group tid % CQ, so the
+        // two sums live in registers and reach LDS once per thread (an LDS atomic per element was the whole cost of this kernel)
+        const int c = (threadIdx.x % CQ) * 4;
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(cMean + c), rstd = *reinterpret_cast<const f32x4*>(cRstd + c);
+        f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+            const int64_t p = e / CQ;
+            f32x4 d = *reinterpret_cast<const f32x4*>(dt + p * dt_ld + c);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(u + p * u_ld + c);
+            if (mask) {
+                d *= *reinterpret_cast<const f32x4*>(mask + p * C + c);
+                *reinterpret_cast<f32x4*>(dt + p * dt_ld + c) = d;
+            }
+            s1 += d;
+            s2 += d * ((x - mean) * rstd);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float xhat = (x[j] - cMean[c + j]) * cRstd[c + j];
-            atomicAdd(&red[c + j], d[j]);
-            atomicAdd(&red[C + c + j], d[j] * xhat);
+            atomicAdd(&red[c + j], s1[j]);
+            atomicAdd(&red[C + c + j], s2[j]);
+        }
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+            const int p = (int)(e / CQ), c = (int)(e - (int64_t)p * CQ) * 4;
+            f32x4 d = *reinterpret_cast<const f32x4*>(dt + (int64_t)p * dt_ld + c);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(u + (int64_t)p * u_ld + c);
+            if (mask) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (int64_t)p * C + c);
+                d *= m;
+                *reinterpret_cast<f32x4*>(dt + (int64_t)p * dt_ld + c) = d;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xhat = (x[j] - cMean[c + j]) * cRstd[c + j];
+                atomicAdd(&red[c + j], d[j]);
+                atomicAdd(&red[C + c + j], d[j] * xhat);
+            }
         }
     }
     __syncthreads();

@@ -279,7 +279,7 @@ int sgan_norm_apply_fwd(const float* u, int32_t u_ld, const sgan_norm_desc* u_no
 int sgan_norm_apply_bwd_sums(float* dt, int32_t dt_ld, const float* mask, const float* u, int32_t u_ld,
                              const sgan_norm_desc* u_norm, double* bwd_sums, int32_t npix, int32_t C, void* stream);
 /* mask[i] = uniform(Philox(seed, *offset_dev + i)) < p ? 0 : 1/(1-p); advances *offset_dev (nn.Dropout). */
-int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* offset_dev, void* stream);
+int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* offset_dev, int32_t advance, void* stream);
 
 /* ---- BCELoss on rescaled tanh outputs (two-stage trainers): loss = mean BCE((x + 1) / 2, (t + 1) / 2) over npix * C
  * with torch's -100 log clamp; g = dloss/dx for a unit upstream gradient (backward: dx = gout * g, sgan_scale).
@@ -342,8 +342,11 @@ int sgan_adam_multi(const sgan_adam_seg* segs, int32_t nseg, const float* lr_dev
 
 /* ---- N(0,1) fill (Philox4x32-10 + Box-Muller), counter-based -----------------------------------
  * Replaces: noise_.normal_(0, 1) (models/fcgan_model.py:126-127).  `offset_dev` is a device uint64
- * the kernel reads and block 0 advances by n (graph-replay safe). */
-int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, void* stream);
+ * the kernels read; with advance != 0 it is moved on by ceil(n / 4) afterwards (graph-replay safe).  Fills with different
+ * seeds are independent streams, so a net that draws several tensors per forward pass reads one offset (advance = 0) and
+ * moves it once with sgan_rng_advance. */
+int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, int32_t advance, void* stream);
+int sgan_rng_advance(uint64_t* offset_dev, uint64_t by, void* stream);
 
 #ifdef __cplusplus
 }

@@ -90,7 +90,8 @@ SIGNATURES = {
     "sgan_avgpool_pyramid_bwd": [_P, _P, _I, _I, _P, _I, _I, _P],
     "sgan_norm_apply_fwd": [_P, _I, C.POINTER(NormDesc), _P, _P, _F, _P, _I, _I, _I, _P],
     "sgan_norm_apply_bwd_sums": [_P, _I, _P, _P, _I, C.POINTER(NormDesc), _P, _I, _I, _P],
-    "sgan_dropout_mask": [_P, _L, _F, C.c_uint64, _P, _P],
+    "sgan_dropout_mask": [_P, _L, _F, C.c_uint64, _P, _I, _P],
+    "sgan_rng_advance": [_P, C.c_uint64, _P],
     "sgan_l1w_fwd": [_P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _F, _P, _P, _I, _P, C.c_int64, _P],
     "sgan_scale": [_P, _P, _P, _L, _P],
     "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],
@@ -107,7 +108,7 @@ SIGNATURES = {
     "sgan_tanh_bwd": [_P, _P, _P, _L, _P],
     "sgan_to_nhwc": [_P, _L, _L, _L, _I, _I, _I, _P, _I, _I, _P],
     "sgan_adam_multi": [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _P, _P],
-    "sgan_normal_fill": [_P, _L, C.c_uint64, _P, _P],
+    "sgan_normal_fill": [_P, _L, C.c_uint64, _P, _I, _P],
     "sgan_profile_enable": [_I],
     "sgan_profile_count": [],
     "sgan_profile_mark": [_P],

@@ -1325,7 +1325,14 @@ __global__ __launch_bounds__(256) void sg_dropout_mask_kernel(float* mask, int64
     }
 }
 
-extern "C" int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* offset_dev, void* stream) {
+extern "C" int sgan_rng_advance(uint64_t* offset_dev, uint64_t by, void* stream) {
+    SGAN_CHECK(offset_dev, "null offset");
+    hipLaunchKernelGGL(sg_rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, offset_dev, by);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* offset_dev, int32_t advance, void* stream) {
     SGAN_CHECK(mask && n > 0 && p >= 0.f && p < 1.f, "bad argument");
     const int64_t nq = (n + 3) >> 2;
     int blocks = ew_cdiv(nq, 256);
@@ -1333,19 +1340,24 @@ extern "C" int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed,
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sg_dropout_mask_kernel, dim3(blocks), dim3(256), 0, st, mask, n, p, 1.f / (1.f - p), seed, offset_dev);
     SGAN_LAUNCH_CHECK();
-    if (offset_dev) {
+    if (offset_dev && advance) {
         hipLaunchKernelGGL(sg_rng_advance_kernel, dim3(1), dim3(1), 0, st, offset_dev, (uint64_t)nq);
         SGAN_LAUNCH_CHECK();
     }
     return SGAN_OK;
 }
 
-extern "C" int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, void* stream) {
+extern "C" int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, int32_t advance, void* stream) {
     SGAN_CHECK(dst && n > 0, "bad argument");
     const int64_t nq = (n + 3) >> 2;
     int blocks = ew_cdiv(nq, 256);
     if (blocks > 1024) blocks = 1024;
     hipStream_t st = (hipStream_t)stream;
+    if (!advance) {
+        hipLaunchKernelGGL(sg_normal_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, n, seed, offset_dev, (uint64_t)0);
+        SGAN_LAUNCH_CHECK();
+        return SGAN_OK;
+    }
     const bool self_advance = offset_dev && blocks == 1;
     hipLaunchKernelGGL(sg_normal_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, n, seed, offset_dev, self_advance ? (uint64_t)nq : 0);
     SGAN_LAUNCH_CHECK();

@@ -899,19 +899,23 @@ class UnetGenerator(ChainNet):
         return ops.norm_desc(catstat[l], None, None, hw[l - 1][0] * hw[l - 1][1], IN_EPS, ACT_RELU, 0.0, 0)
 
     def _random(self, l, shape, dev):
+        """Dropout mask / Gaussian noise of level l.  Every (level, kind) is its own Philox stream (seed), all read the same
+        offset; run_forward moves the offset once per pass (one launch instead of one per tensor)."""
         mask = noise = None
         if self.drop[l]:
             if self.mask_override is not None:
                 mask = self.mask_override[l]
             else:
                 mask = torch.empty(shape, dtype=torch.float32, device=dev)
-                ops.dropout_mask(mask, 0.5, self._rng_seed + 2 * l, self._rng_offset)
+                ops.dropout_mask(mask, 0.5, self._rng_seed + 2 * l, self._rng_offset, advance=False)
+                self._rng_drawn = max(self._rng_drawn, (mask.numel() + 3) // 4)
         if self.add_gauss:
             if self.noise_override is not None:
                 noise = self.noise_override[l]
             else:
                 noise = torch.empty(shape, dtype=torch.float32, device=dev)
-                ops.normal_fill(noise, self._rng_seed + 2 * l + 1, self._rng_offset)
+                ops.normal_fill(noise, self._rng_seed + 2 * l + 1, self._rng_offset, advance=False)
+                self._rng_drawn = max(self._rng_drawn, (noise.numel() + 3) // 4)
         return mask, noise
 
     # ---- programs -------------------------------------------------------------------------------
@@ -926,6 +930,7 @@ class UnetGenerator(ChainNet):
         hw, dn, upd = self._unet_geometry(H, W)
         if self._rng_offset is None or self._rng_offset.device != dev:
             self._rng_offset = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._rng_drawn = 0     # longest stream drawn in this pass (in Philox blocks of 4 values)
         lay, total, tmpl = self._stat_template(hw, dev)
         arena = tmpl.clone()
         catw = [0] * (n + 1)
@@ -977,6 +982,8 @@ class UnetGenerator(ChainNet):
         wt, b = self._wb(L)
         out = torch.empty((H, W, L.cout_s), dtype=torch.float32, device=dev)
         ops.conv_fwd(upd[0], cat[1], self._cat_norm(1, hw, catstat), wt, b, out, self.final_act, None)
+        if self._rng_drawn:
+            ops.rng_advance(self._rng_offset, self._rng_drawn)
         saved = dict(x=x, hw=hw, cat=cat, catw=catw, catstat=catstat, ustat=ustat, xr=xr, xstat=xstat, u=u, masks=masks,
                      out=out, lay=lay, total=total, bwd=_BwdArena(arena[total:]))
         return [out], saved

@@ -203,9 +203,13 @@ def avgpool_pyramid_bwd(dlevels, dlabel, accumulate=False):
             "sgan_avgpool_pyramid_bwd")
 
 
-def dropout_mask(mask, p, seed, offset_dev=None):
+def dropout_mask(mask, p, seed, offset_dev=None, advance=True):
     L.check(L.lib().sgan_dropout_mask(_ptr(mask), mask.numel(), float(p), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(offset_dev),
-                                      _stream()), "sgan_dropout_mask")
+                                      int(bool(advance)), _stream()), "sgan_dropout_mask")
+
+
+def rng_advance(offset_dev, by):
+    L.check(L.lib().sgan_rng_advance(_ptr(offset_dev), C.c_uint64(int(by)), _stream()), "sgan_rng_advance")
 
 
 IMAGE_LOSS_WS_BYTES = 2048   # SGAN_IMAGE_LOSS_WS_BYTES
@@ -335,10 +339,10 @@ def adam_multi(segs, lr_dev, beta1, beta2, eps, state_dev):
     L.check(L.lib().sgan_adam_multi(arr, len(segs), _ptr(lr_dev), beta1, beta2, eps, _ptr(state_dev), _stream()), "sgan_adam_multi")
 
 
-def normal_fill(dst, seed, offset_dev=None):
+def normal_fill(dst, seed, offset_dev=None, advance=True):
     assert dst.is_contiguous() and dst.dtype == torch.float32
-    L.check(L.lib().sgan_normal_fill(_ptr(dst), dst.numel(), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(offset_dev), _stream()),
-            "sgan_normal_fill")
+    L.check(L.lib().sgan_normal_fill(_ptr(dst), dst.numel(), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(offset_dev), int(bool(advance)),
+                                     _stream()), "sgan_normal_fill")
 
 
 # ------------------------------------------------------------------------------------------------

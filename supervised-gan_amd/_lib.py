@@ -130,6 +130,10 @@ def lib():
             raise SganError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C supervised-gan_amd/csrc`.  There is no CPU/PyTorch fallback for this path.")
+        # libsgan_hip.so needs libamdhip64.so.N.  PyTorch-ROCm ships its own copy (and its own HSA runtime); whichever copy is
+        # mapped first serves the whole process.  If the system copy came first, torch's HSA runtime and the system HIP runtime
+        # would be mixed and the first kernel launch fails with "no ROCm-capable device is detected" -- so torch goes first.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)

@@ -633,6 +633,8 @@ def build_ref_twostage(cfg: "O.TwoStageConfig", seed: int, tmpdir: str):
         argv += ["--weights", *L(cfg.weights)]
     if not cfg.cycle:
         argv += ["--lambda_G1", str(cfg.lambda_G1), "--lambda_G2", str(cfg.lambda_G2)]
+    if cfg.use_multi_class_GAN:
+        argv.append("--use_multi_class_GAN")
     old = sys.argv
     sys.argv = argv
     try:
@@ -651,7 +653,8 @@ def build_ref_twostage(cfg: "O.TwoStageConfig", seed: int, tmpdir: str):
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D1, cfg.scale_factor1)):
         load_sd(model.netD1[i], O.init_nlayer_d(seed + 10 + i, cfg.input_nc, cfg.ndf1, nl, sf))
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D2, cfg.scale_factor2)):
-        load_sd(model.netD2[i], O.init_nlayer_d(seed + 20 + i, cfg.input_nc + cfg.output_nc, cfg.ndf2, nl, sf))
+        load_sd(model.netD2[i], O.init_nlayer_d(seed + 20 + i, cfg.input_nc + cfg.output_nc, cfg.ndf2, nl, sf,
+                                                3 if cfg.use_multi_class_GAN else 1))
     return model
 
 
@@ -730,6 +733,12 @@ def main():
                          O.CGANConfig(**dict(small, train_D_on_fake_fake_pair=True, train_G_on_fake_fake_pair=True)), 0, 2)
     if not only or "crn" in only:
         golden_crn_small()
+    if not only or "multiclass" in only:
+        golden_twostage("twostage_multiclass_small.npz",
+                        O.TwoStageConfig(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8, ndf2=8,
+                                         GAN_losses_D2=("real_fake", "fake_fake"), GAN_losses_G2=("real_fake", "fake_fake"),
+                                         weights=(2.0, 5.0), use_multi_class_GAN=True, no_lsgan2=True, n_layers_D2=(3, 4),
+                                         scale_factor2=(1, 2), lambda_D2=(0.6, 0.4)), seed=0, nsteps=3)
     if not only or "twostage" in only:
         golden_twostage("twostage_small.npz", O.TwoStageConfig(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8,
                                                                ndf2=8, GAN_losses_D2=("real_fake", "fake_fake"),

@@ -126,9 +126,9 @@ def init_fcgan_g(seed: int, noise_nc: int, out_nc: int, ngf: int = 32, n_layers:
     return sd
 
 
-def nlayer_d_plan(input_nc: int, ndf: int, n_layers: int):
+def nlayer_d_plan(input_nc: int, ndf: int, n_layers: int, logit_nc: int = 1):
     """[(idx, cin, cout, stride, has_norm)] of NLayerDiscriminator.model convs
-    (models/networks.py:814-835); final logits conv last."""
+    (models/networks.py:814-835); final logits conv last (logit_nc = num_classes when num_classes > 2, :806)."""
     plan = [(0, input_nc, ndf, 2, False)]
     nf = 1
     idx = 2
@@ -137,16 +137,17 @@ def nlayer_d_plan(input_nc: int, ndf: int, n_layers: int):
         plan.append((idx, ndf * nf_prev, ndf * nf, 2, True)); idx += 3
     nf_prev, nf = nf, min(2 ** n_layers, 8)
     plan.append((idx, ndf * nf_prev, ndf * nf, 1, True)); idx += 3
-    plan.append((idx, ndf * nf, 1, 1, False))
+    plan.append((idx, ndf * nf, logit_nc, 1, False))
     return plan
 
 
-def init_nlayer_d(seed: int, input_nc: int, ndf: int = 32, n_layers: int = 3, scale_factor: int = 1) -> "OrderedDict[str, torch.Tensor]":
+def init_nlayer_d(seed: int, input_nc: int, ndf: int = 32, n_layers: int = 3, scale_factor: int = 1,
+                  logit_nc: int = 1) -> "OrderedDict[str, torch.Tensor]":
     sd = OrderedDict()
     s = seed * 1000
     if scale_factor > 1:
         sd["gauss_filter.0.weight"] = gauss_filter_weight(input_nc, scale_factor)
-    for idx, cin, cout, _stride, _norm in nlayer_d_plan(input_nc, ndf, n_layers):
+    for idx, cin, cout, _stride, _norm in nlayer_d_plan(input_nc, ndf, n_layers, logit_nc):
         sd[f"model.{idx}.weight"] = np_normal(s, (cout, cin, 4, 4), 0.0, 0.02); s += 1
         bound = 1.0 / math.sqrt(cin * 16)
         sd[f"model.{idx}.bias"] = np_uniform(s, (cout,), -bound, bound); s += 1
@@ -195,7 +196,8 @@ def nlayer_d_forward(sd, x, n_layers: int = 3, scale_factor: int = 1, use_sigmoi
         x = gauss_down(x, sd["gauss_filter.0.weight"], scale_factor)
     input_nc = x.shape[1]
     ndf = sd["model.0.weight"].shape[0]
-    for li, (idx, _cin, _cout, stride, has_norm) in enumerate(nlayer_d_plan(input_nc, ndf, n_layers)):
+    logit_nc = sd[f"model.{nlayer_d_plan(input_nc, ndf, n_layers)[-1][0]}.weight"].shape[0]
+    for li, (idx, _cin, _cout, stride, has_norm) in enumerate(nlayer_d_plan(input_nc, ndf, n_layers, logit_nc)):
         x = F.conv2d(x, sd[f"model.{idx}.weight"], sd[f"model.{idx}.bias"], stride=stride, padding=2)
         if taps is not None:
             taps[f"conv{li}"] = x
@@ -211,6 +213,13 @@ def gan_loss(pred, target_is_real: bool, use_lsgan: bool = False):
     """GANLoss.__call__ (models/networks.py:183-185): BCELoss / MSELoss vs a constant map."""
     t = torch.full_like(pred, 1.0 if target_is_real else 0.0)
     return F.mse_loss(pred, t) if use_lsgan else F.binary_cross_entropy(pred, t)
+
+
+def gan_loss_multiclass(pred, label: int):
+    """GANLossMultiClass.__call__ (models/networks.py:188-202): CrossEntropyLoss over the class channel of every pixel."""
+    nc = pred.shape[1]
+    flat = pred.permute(0, 2, 3, 1).contiguous().view(-1, nc)
+    return F.cross_entropy(flat, torch.full((flat.shape[0],), int(label), dtype=torch.long))
 
 
 def weighted_l1(x, y, w=None):
@@ -957,7 +966,10 @@ class TwoStageConfig:
                  scale_factor2=(1, 1, 2, 2), lambda_D2=(0.3, 0.3, 0.2, 0.2), lambda_A=10.0, lambda_B=10.0, lambda_A_cycle=5.0,
                  lambda_fake_cycle=1.0, weights=None, no_lsgan1=True, no_lsgan2=False, GAN_losses_D2=("real_fake",),
                  GAN_losses_G2=("real_fake",), lr=2e-4, lr1=2e-4, lr2=2e-4, beta1=0.5, pool_size=50, transform_1to2="bilinear_2",
-                 detach_G1_from_G2_x=False, detach_G1_from_G2_y=False, no_logD_trick=False, cycle=True, lambda_G1=1.0, lambda_G2=1.0):
+                 detach_G1_from_G2_x=False, detach_G1_from_G2_y=False, no_logD_trick=False, cycle=True, lambda_G1=1.0, lambda_G2=1.0,
+                 use_multi_class_GAN=False):
+        # use_multi_class_GAN (twostage_cycle_model.py:86,120-146,302-335,352): D2 ends in 3 logits per pixel, classes
+        # 0 = (real_A, real_B), 1 = (real_A, fake_B), 2 = (fake_A, fake_B), cross-entropy, one ImagePool per fake class
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -977,7 +989,7 @@ class TwoStageCycleOracle:
         self.G2 = init_crn(seed + 2, c.input_nc, c.output_nc, c.noise_nc2, c.ngf2, c.upsample_mode2, c.n_layers_CRN_block2, True)
         self.F2 = init_unet(seed + 3, 7, c.output_nc, c.input_nc, c.nff2, -1)
         self.D1 = [init_nlayer_d(seed + 10 + i, c.input_nc, c.ndf1, nl, sf) for i, (nl, sf) in enumerate(zip(c.n_layers_D1, c.scale_factor1))]
-        self.D2 = [init_nlayer_d(seed + 20 + i, c.input_nc + c.output_nc, c.ndf2, nl, sf)
+        self.D2 = [init_nlayer_d(seed + 20 + i, c.input_nc + c.output_nc, c.ndf2, nl, sf, 3 if c.use_multi_class_GAN else 1)
                    for i, (nl, sf) in enumerate(zip(c.n_layers_D2, c.scale_factor2))]
         for net in [self.G1, self.G2, self.F2] + self.D1 + self.D2:
             for k, v in net.items():
@@ -990,6 +1002,7 @@ class TwoStageCycleOracle:
         self.opt_D1 = Adam([v for d in self.D1 for k, v in d.items() if k.startswith("model.")], c.lr1, c.beta1)
         self.opt_D2 = Adam([v for d in self.D2 for k, v in d.items() if k.startswith("model.")], c.lr2, c.beta1)
         self.pool1, self.pool2 = ImagePool(c.pool_size), ImagePool(c.pool_size)
+        self.pool2_1, self.pool2_2 = ImagePool(c.pool_size), ImagePool(c.pool_size)      # multi-class: one per fake class
         self.noise_iter = None      # iterator yielding (z1, z2) per forward()
 
     def transform(self, x):
@@ -1033,8 +1046,25 @@ class TwoStageCycleOracle:
         self.loss_D1 = (self.loss_D1_fake + self.loss_D1_real) * 0.5
         self.loss_D1.backward()
 
+    def backward_D2_multiclass(self):
+        """(:302-335)"""
+        c = self.cfg
+        n = len(self.D2)
+        d2 = lambda i, x: self._d(self.D2, c.n_layers_D2, c.scale_factor2, i, x, c.no_lsgan2)
+        real = torch.cat([self.real_A, self.real_B], 1)
+        self.loss_D2_0 = sum(gan_loss_multiclass(d2(i, real), 0) for i in range(n))
+        fake = self.pool2_1.query(torch.cat([self.real_A, self.fake_B_from_real_A], 1))
+        self.loss_D2_1 = sum(gan_loss_multiclass(d2(i, fake.detach()), 1) for i in range(n))
+        fake = self.pool2_2.query(torch.cat([self.transform(self.fake_A), self.fake_B_from_fake_A], 1))
+        self.loss_D2_2 = sum(gan_loss_multiclass(d2(i, fake.detach()), 2) for i in range(n))
+        self.loss_D2 = (self.loss_D2_0 + self.loss_D2_1 + self.loss_D2_2) / 3
+        self.loss_D2_real, self.loss_D2_fake = self.loss_D2_0, (self.loss_D2_1 + self.loss_D2_2) / 2     # for the shared reporting
+        self.loss_D2.backward()
+
     def backward_D2(self):
         c = self.cfg
+        if c.use_multi_class_GAN:
+            return self.backward_D2_multiclass()
         n = len(self.D2)
         d2 = lambda i, x: self._d(self.D2, c.n_layers_D2, c.scale_factor2, i, x, c.no_lsgan2)
         self.loss_D2_fake, pairs = 0, 0
@@ -1071,6 +1101,9 @@ class TwoStageCycleOracle:
             pairs += 1
             for i, lam in enumerate(c.lambda_D2):
                 pred = self._d(self.D2, c.n_layers_D2, c.scale_factor2, i, fake, c.no_lsgan2)
+                if c.use_multi_class_GAN:      # flipped_label = 0 (:352); criterionGAN2(pred, False) is class 0 as well
+                    g2 = g2 + (gan_loss_multiclass(pred, 0) * lam if not c.no_logD_trick else -gan_loss_multiclass(pred, 0) * lam)
+                    continue
                 g2 = g2 + (gan_loss(pred, True, not c.no_lsgan2) * lam if not c.no_logD_trick else -gan_loss(pred, False, not c.no_lsgan2) * lam)
         self.loss_G2_GAN = g2
         if "real_fake" in c.GAN_losses_G2:

@@ -20,6 +20,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, CONV, CONVT, SganError
@@ -1349,8 +1350,7 @@ class NLayerDiscriminator(ChainNet):
 
     def __init__(self, input_nc, ndf=64, n_layers=3, norm="instance", use_sigmoid=False, scale_factor=1,
                  num_classes=2, gpu_ids=[]):
-        if num_classes != 2:
-            raise NotImplementedError("multi-class logits are not on the MI355X path")
+        logit_nc = 1 if num_classes == 2 else int(num_classes)      # models/networks.py:806
         nrm = {"instance": "in", "batch": "bn"}[norm]
         kw, padw = 4, int(np.ceil((4 - 1) / 2))
         layers = [LayerSpec("0", CONV, kw, 2, padw, input_nc, ndf, True, None, ACT_LRELU, 0.2)]
@@ -1362,9 +1362,10 @@ class NLayerDiscriminator(ChainNet):
         nf_prev, nf = nf, min(2 ** n_layers, 8)
         layers.append(LayerSpec(str(idx), CONV, kw, 1, padw, ndf * nf_prev, ndf * nf, True, nrm, ACT_LRELU, 0.2))
         idx += 3
-        layers.append(LayerSpec(str(idx), CONV, kw, 1, padw, ndf * nf, 1, True, None, ACT_NONE))
+        layers.append(LayerSpec(str(idx), CONV, kw, 1, padw, ndf * nf, logit_nc, True, None, ACT_NONE))
         super().__init__(layers)
         self.gpu_ids = gpu_ids
+        self.logit_nc = logit_nc
         self.use_sigmoid = use_sigmoid
         self.scale_factor = int(scale_factor)
         self.input_nc = input_nc
@@ -1435,6 +1436,8 @@ class NLayerDiscriminator(ChainNet):
     def _wrap_output(self, logits):
         if not self.use_sigmoid:
             return logits
+        if self.logit_nc > 1:      # class scores (--use_multi_class_GAN): a 3 x 67 x 67 map, plain elementwise sigmoid
+            return torch.sigmoid(logits)
         if self.fuse_sigmoid_into_loss:
             logits._sgan_pending_sigmoid = True
             return logits
@@ -1532,6 +1535,23 @@ class GANLoss(nn.Module):
         ts = [self.real_label if r else self.fake_label for r in targets_are_real]
         return _GanLossMultiFn.apply(ts, [float(w) for w in weights], 1 if self.use_lsgan else 0,
                                      *[self._logits_of(i) for i in inputs])
+
+
+class GANLossMultiClass(nn.Module):
+    """GANLossMultiClass (models/networks.py:188-202): CrossEntropyLoss over the class channel of every pixel of a
+    discriminator map.  The maps are 3 x 67 x 67: the loss runs on PyTorch's own kernels."""
+
+    def __init__(self, use_lsgan=False, num_classes=3, use_gpu=False):
+        super().__init__()
+        assert use_lsgan is False
+        self.num_classes = num_classes
+
+    def __call__(self, input, target_label):
+        flat = input.permute(0, 2, 3, 1).reshape(-1, self.num_classes)
+        tgt = getattr(self, "_tgt", None)
+        if tgt is None or tgt.device != flat.device or tgt.shape[1] != flat.shape[0]:
+            tgt = self._tgt = torch.arange(self.num_classes, device=flat.device).view(-1, 1).expand(-1, flat.shape[0]).contiguous()
+        return F.cross_entropy(flat, tgt[int(target_label)])
 
 
 class _L1Fn(torch.autograd.Function):

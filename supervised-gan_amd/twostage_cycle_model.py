@@ -3,8 +3,8 @@ image), F2 (image -> label), discriminators D1 on labels and D2 on (label, image
 one joint G update with  G1_GAN + G2_GAN / num_pairs + lambda_A L1 + lambda_B BCE(F2(real_B)) + lambda_A_cycle BCE(recon_real_A)
 + lambda_A_cycle lambda_fake_cycle BCE(recon_fake_A)  (:405-409), driving the MI355X kernels.
 
-Same method names, loss definitions and update order as the reference.  Implemented: the binary GAN objective (the
-`--use_multi_class_GAN` 3-way head is not on the MI355X path), `--transform_1to2 None | bilinear_2`."""
+Same method names, loss definitions and update order as the reference.  Implemented: the binary GAN objective and the
+`--use_multi_class_GAN` 3-way head (cross-entropy on PyTorch's kernels: 3 x 67 x 67 maps), `--transform_1to2 None | bilinear_2`."""
 from collections import OrderedDict
 
 import torch
@@ -25,8 +25,7 @@ class TwoStageCycleModel(BaseModel):
     def initialize(self, opt):
         BaseModel.initialize(self, opt)
         self.isTrain = opt.isTrain
-        if getattr(opt, 'use_multi_class_GAN', False):
-            raise NotImplementedError("--use_multi_class_GAN (GANLossMultiClass) is not on the MI355X path")
+        self.multi_class = bool(getattr(opt, 'use_multi_class_GAN', False)) and self.cycle
         idx_dict = {'r': 0, 'g': 1, 'b': 2}
         self.chnl_idx_input = [[idx_dict[c] for c in s] for s in opt.which_channel.split('_')]
         assert len(self.chnl_idx_input) == 2
@@ -91,8 +90,9 @@ class TwoStageCycleModel(BaseModel):
             d2_nc = opt.output_nc if opt.no_cgan else opt.output_nc + opt.input_nc
             for scale, n_layers in zip(opt.scale_factor2, opt.n_layers_D2):
                 d = networks.define_D(d2_nc, opt.ndf2, opt.which_model_netD2, n_layers_D=n_layers, norm=opt.norm,
-                                      use_sigmoid=opt.no_lsgan2, scale_factor=scale, num_classes=2, gpu_ids=self.gpu_ids)
-                d.fuse_sigmoid_into_loss = True
+                                      use_sigmoid=opt.no_lsgan2, scale_factor=scale, num_classes=3 if self.multi_class else 2,
+                                      gpu_ids=self.gpu_ids)
+                d.fuse_sigmoid_into_loss = not self.multi_class
                 self.netD2.append(d)
             if self.gpu_ids:
                 networks.pack_flat(self.netD1)
@@ -118,14 +118,16 @@ class TwoStageCycleModel(BaseModel):
         if self.isTrain:
             self.fake_pool1 = ImagePool(opt.pool_size)
             self.fake_pool2 = ImagePool(opt.pool_size)
+            self.fake_pool2_1, self.fake_pool2_2 = ImagePool(opt.pool_size), ImagePool(opt.pool_size)     # multi-class (:122-124)
             if opt.use_fixed_noise1:
                 self.noise_pool1 = ImagePool(opt.noise_pool_size)
                 self.noise_pool1.query(self.fixed_noise1)
             self.old_lr, self.old_lr1, self.old_lr2 = opt.lr, opt.lr1, opt.lr2
             self.criterionGAN1 = networks.GANLoss(use_lsgan=not opt.no_lsgan1)
-            self.criterionGAN2 = networks.GANLoss(use_lsgan=not opt.no_lsgan2)
+            self.criterionGAN2 = (networks.GANLossMultiClass(use_lsgan=not opt.no_lsgan2, num_classes=3) if self.multi_class
+                                  else networks.GANLoss(use_lsgan=not opt.no_lsgan2))
             self.criterionL1 = networks.WeightedL1Loss()
-            self.backward_D2 = self.backward_D2_binary
+            self.backward_D2 = self.backward_D2_multiclass if self.multi_class else self.backward_D2_binary
             groups = [{'name': 'G1', 'params': self.netG1.parameters(), 'lr': opt.lr1},
                       {'name': 'G2', 'params': self.netG2.parameters(), 'lr': opt.lr2}]
             if self.cycle:
@@ -141,6 +143,8 @@ class TwoStageCycleModel(BaseModel):
         """What the step feeds to ImagePool.query, in the reference's order (backward_D1, then backward_D2_binary)."""
         o = self.opt
         srcs = [self.fake_A]
+        if self.multi_class:
+            return srcs + [self._pair(self.real_A, self.fake_B_from_real_A), self._pair(self.transform(self.fake_A), self.fake_B_from_fake_A)]
         if 'real_fake' in o.GAN_losses_D2:
             srcs.append(self._pair(self.real_A, self.fake_B_from_real_A))
         if 'fake_fake' in o.GAN_losses_D2:
@@ -157,11 +161,12 @@ class TwoStageCycleModel(BaseModel):
         ups = (o.n_update_D1, o.n_update_D2, o.n_update_G) if self.cycle else (1, 1, 1)
         assert ups == (1, 1, 1) and not o.use_fixed_noise1, "graphed two-stage step: one update each, device-drawn latents"
         npool2 = ('real_fake' in o.GAN_losses_D2) + ('fake_fake' in o.GAN_losses_D2)
+        pools2 = [self.fake_pool2_1, self.fake_pool2_2] if self.multi_class else [self.fake_pool2] * npool2
         prog = [[self.optimizer_D1.zero_grad, self.backward_D1], ("sync", self.optimizer_D1),
                 [self.optimizer_D1.step, self.optimizer_D2.zero_grad, self.backward_D2], ("sync", self.optimizer_D2),
                 [self.optimizer_D2.step, self.optimizer_G.zero_grad, self.backward_G], ("sync", self.optimizer_G),
                 [self.optimizer_G.step]]
-        return dict(pools=[self.fake_pool1] + [self.fake_pool2] * npool2, sources=self._pool_sources,
+        return dict(pools=[self.fake_pool1] + pools2, sources=self._pool_sources,
                     set_overrides=lambda views: setattr(self, "_pool_overrides", views), program=prog)
 
     # ---- data ---------------------------------------------------------------------------------
@@ -268,6 +273,19 @@ class TwoStageCycleModel(BaseModel):
         self.loss_D2 = total
         self._backward(self.loss_D2)
 
+    def backward_D2_multiclass(self):
+        """(:302-335): classes 0 = (real_A, real_B), 1 = (real_A, fake_B), 2 = (fake_A, fake_B); cross-entropy; one pool per fake class."""
+        real = self._pair(self.real_A, self.real_B)
+        f1 = self._query(1, self.fake_pool2_1, lambda: self._pair(self.real_A, self.fake_B_from_real_A)).detach()
+        f2 = self._query(2, self.fake_pool2_2, lambda: self._pair(self.transform(self.fake_A), self.fake_B_from_fake_A)).detach()
+        n = self.n_netD2
+        preds = networks.multi_forward([(d, real) for d in self.netD2] + [(d, f1) for d in self.netD2] + [(d, f2) for d in self.netD2])
+        ce = [sum(self.criterionGAN2(p, k) for p in preds[k * n:(k + 1) * n]) for k in range(3)]
+        self.loss_D2_0, self.loss_D2_1, self.loss_D2_2 = ce
+        self.loss_D2 = (ce[0] + ce[1] + ce[2]) / 3
+        self.loss_D2_real, self.loss_D2_fake = ce[0], (ce[1] + ce[2]) / 2
+        self._backward(self.loss_D2)
+
     def backward_G(self):
         """(:337-410)"""
         o = self.opt
@@ -285,6 +303,11 @@ class TwoStageCycleModel(BaseModel):
         num_fake_pairs = len(pairs)
         self.loss_G2_GAN = 0
         for fake in pairs:
+            if self.multi_class:       # flipped_label = 0 (:352); criterionGAN2(pred, False) addresses class 0 as well
+                preds = networks.multi_forward([(d, fake) for d in self.netD2])
+                for p, lam in zip(preds, o.lambda_D2):
+                    self.loss_G2_GAN = self.loss_G2_GAN + self.criterionGAN2(p, 0) * (lam if trick else -lam)
+                continue
             t, _ = self._gan(self.criterionGAN2, [(d, fake, trick) for d in self.netD2], [l if trick else -l for l in o.lambda_D2])
             self.loss_G2_GAN = self.loss_G2_GAN + t
         for netD in self.netD1 + self.netD2:

@@ -327,6 +327,8 @@ def build_twostage(cfg):
         argv += ["--weights", *L(cfg.weights)]
     if not cfg.cycle:
         argv += ["--lambda_G1", str(cfg.lambda_G1), "--lambda_G2", str(cfg.lambda_G2)]
+    if cfg.use_multi_class_GAN:
+        argv.append("--use_multi_class_GAN")
     m = create_model(TrainOptions().parse(argv, save=False, verbose=False))
     m.netG1.load_state_dict(O.init_fcgan_g(1, cfg.noise_nc1, cfg.input_nc, cfg.ngf1, cfg.n_layers_G1))
     m.netG2.load_state_dict(O.init_crn(2, cfg.input_nc, cfg.output_nc, cfg.noise_nc2, cfg.ngf2, cfg.upsample_mode2, cfg.n_layers_CRN_block2, True))
@@ -335,7 +337,8 @@ def build_twostage(cfg):
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D1, cfg.scale_factor1)):
         m.netD1[i].load_state_dict(O.init_nlayer_d(10 + i, cfg.input_nc, cfg.ndf1, nl, sf))
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D2, cfg.scale_factor2)):
-        m.netD2[i].load_state_dict(O.init_nlayer_d(20 + i, cfg.input_nc + cfg.output_nc, cfg.ndf2, nl, sf))
+        m.netD2[i].load_state_dict(O.init_nlayer_d(20 + i, cfg.input_nc + cfg.output_nc, cfg.ndf2, nl, sf,
+                                                   3 if cfg.use_multi_class_GAN else 1))
     ctr = {1: 0, 2: 0}
 
     def src(which):

@@ -369,6 +369,53 @@ def golden_autoencoder_small():
     save("autoencoder_small.npz", **arrs)
 
 
+def golden_g_nofcn_small():
+    """FCGANGenerator with --noiseSize 1 (use_fcn False): first ConvT k4 s1 p0, 1x1 latent -> 4x4 (models/networks.py:503-504)."""
+    ngf, nl, nz, out_nc = 8, 5, 8, 2
+    sd = O.init_fcgan_g(12, nz, out_nc, ngf, nl)
+    g = RN.define_G(out_nc, 0, ngf, "fcgan", "instance", False, n_layers_G=nl, use_fcn=False, noise_nc=nz, gpu_ids=[])
+    load_sd(g, sd)
+    z = O.np_normal(111, (1, nz, 1, 1)).requires_grad_(True)
+    y = g.forward(z)
+    r = O.np_normal(112, tuple(y.shape))
+    (y * r).sum().backward()
+    arrs = {"y": y.detach().numpy(), "dz": z.grad.numpy()}
+    for k, p in g.named_parameters():
+        arrs["grad/" + k] = p.grad.numpy()
+    save("fcgan_g_nofcn_small.npz", **arrs)
+
+
+def golden_dcgan_small():
+    """`--which_model_netG dcgan` / `--which_model_netD dcgan` (128x128): G(z) and D(x) with all gradients and BN running stats."""
+    nz, nc, ngf, ndf = 8, 2, 8, 8
+    g = RN.define_G(nc, 0, ngf, "dcgan", "batch", False, noise_nc=nz, gpu_ids=[])
+    sd = O.init_dcgan_g(71, nz, nc, ngf)
+    assert list(g.state_dict().keys()) == list(sd.keys()), (list(g.state_dict().keys()), list(sd.keys()))
+    load_sd(g, sd)
+    z = O.np_normal(701, (1, nz, 1, 1)).requires_grad_(True)
+    y = g.forward(z)
+    r = O.np_normal(702, tuple(y.shape))
+    (y * r).sum().backward()
+    arrs = {"G/y": y.detach().numpy(), "G/dz": z.grad.numpy()}
+    for k, p in g.named_parameters():
+        arrs["G/grad/" + k] = p.grad.numpy()
+    for k, v in g.state_dict().items():
+        if "running" in k:
+            arrs["G/buf/" + k] = v.numpy().copy()
+    d = RN.define_D(nc, ndf, "dcgan", gpu_ids=[])
+    sdd = O.init_dcgan_d(72, nc, ndf)
+    assert list(d.state_dict().keys()) == list(sdd.keys()), (list(d.state_dict().keys()), list(sdd.keys()))
+    load_sd(d, sdd)
+    x = O.np_uniform(703, (1, nc, 128, 128)).requires_grad_(True)
+    p = d.forward(x)
+    loss = torch.nn.functional.binary_cross_entropy(p, torch.ones_like(p))
+    loss.backward()
+    arrs.update({"D/p": p.detach().numpy(), "D/dx": x.grad.numpy(), "D/loss": np.float64(loss.item())})
+    for k, q in d.named_parameters():
+        arrs["D/grad/" + k] = q.grad.numpy()
+    save("dcgan_small.npz", **arrs)
+
+
 def golden_crn_small():
     """crn at 128x128 (label 2 ch, noise 8 x 2 x 2), ngf 8: ConvTranspose upsampling with 1-layer blocks, and the README's
     bilinear upsampling with 2-layer blocks; shared label block."""
@@ -715,6 +762,9 @@ def main():
     only = sys.argv[1:]
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
+    if not only or "dcgan" in only:
+        golden_dcgan_small()
+        golden_g_nofcn_small()
     if not only or "cgan2_cycle" in only:
         two = dict(variant="cgan2_cycle", lambda_fake_cycle=0.5)
         golden_cgan_cycle("cgan2_cycle_small.npz", O.CGANCycleConfig(**two), 0, 2)

@@ -27,6 +27,7 @@ Reference map (paths relative to /root/reference):
   CGANCycleModel                              models/cgan_cycle_model.py:129-240
   CGANCycleModel of cgan2_cycle               models/cgan2_cycle_model.py:114-262
   AutoEncoder                                 models/networks.py:421-490
+  DCGANGenerator / DCGANDiscriminator         models/networks.py:1015-1129
   CascadedRefinementNetwork / Crn*Block       models/networks.py:642-794
   CGANModel step recipe                       models/cgan_model.py:134-226
   TwoStageCycleModel step recipe              models/twostage_cycle_model.py:193-438
@@ -158,13 +159,15 @@ def init_nlayer_d(seed: int, input_nc: int, ndf: int = 32, n_layers: int = 3, sc
 # network forwards (functional; autograd gives the backward)
 # ----------------------------------------------------------------------------------
 def fcgan_g_forward(sd, z, n_layers: int = 5, update_running: bool = True, tanh: bool = True,
-                    taps: dict | None = None):
+                    taps: dict | None = None, use_fcn: bool = True):
     """FCGANGenerator.forward (models/networks.py:535-540), BatchNorm always in train mode
     (the reference never calls .eval()).  `taps` (optional dict) receives raw conv outputs."""
     x = z
     idx = 0
     for li in range(n_layers):
-        x = F.conv_transpose2d(x, sd[f"model.{idx}.weight"], sd.get(f"model.{idx}.bias"), stride=2, padding=1)
+        first_1x1 = li == 0 and not use_fcn     # --noiseSize 1: ConvT k4 s1 p0 on the 1x1 latent (models/networks.py:503-504)
+        x = F.conv_transpose2d(x, sd[f"model.{idx}.weight"], sd.get(f"model.{idx}.bias"), stride=1 if first_1x1 else 2,
+                               padding=0 if first_1x1 else 1)
         if taps is not None:
             taps[f"conv{li}"] = x
         rm = sd[f"model.{idx + 1}.running_mean"] if update_running else None
@@ -577,6 +580,75 @@ def autoencoder_forward(sd, x, n_layers: int, ngf: int):
         if normed:
             h = F.relu(F.instance_norm(h, eps=IN_EPS))
     return torch.tanh(h)
+
+
+# ----------------------------------------------------------------------------------
+# DCGAN generator / discriminator (models/networks.py:1015-1129): bias-free chains with BatchNorm
+# ----------------------------------------------------------------------------------
+def dcgan_g_plan(nz: int, nc: int, ngf: int):
+    """[(sequential index, cin, cout, stride, pad, has_bn)]"""
+    ch = [ngf * 8, ngf * 4, ngf * 2, ngf, int(ngf / 2)]
+    plan = [(0, nz, ch[0], 1, 0, True)]
+    for i in range(1, 5):
+        plan.append((3 * i, ch[i - 1], ch[i], 2, 1, True))
+    plan.append((15, ch[4], nc, 2, 1, False))
+    return plan
+
+
+def dcgan_d_plan(nc: int, ndf: int):
+    ch = [int(ndf / 2), ndf, ndf * 2, ndf * 4, ndf * 8]
+    plan = [(0, nc, ch[0], 2, 1, False)]
+    for i in range(1, 5):
+        plan.append((3 * i - 1, ch[i - 1], ch[i], 2, 1, True))
+    plan.append((14, ch[4], 1, 1, 0, False))
+    return plan
+
+
+def _init_dcgan(seed, plan, transposed):
+    sd = OrderedDict()
+    for k, (idx, ci, co, _s, _p, bn) in enumerate(plan):
+        sd[f"model.{idx}.weight"] = np_normal(seed * 1000 + 3 * k, (ci, co, 4, 4) if transposed else (co, ci, 4, 4), 0.0, 0.02)
+        if bn:
+            sd[f"model.{idx + 1}.weight"] = np_normal(seed * 1000 + 3 * k + 1, (co,), 1.0, 0.02)
+            sd[f"model.{idx + 1}.bias"] = torch.zeros(co)
+            sd[f"model.{idx + 1}.running_mean"] = torch.zeros(co)
+            sd[f"model.{idx + 1}.running_var"] = torch.ones(co)
+            sd[f"model.{idx + 1}.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+    return sd
+
+
+def init_dcgan_g(seed: int, nz: int, nc: int, ngf: int):
+    return _init_dcgan(seed, dcgan_g_plan(nz, nc, ngf), True)
+
+
+def init_dcgan_d(seed: int, nc: int, ndf: int):
+    return _init_dcgan(seed, dcgan_d_plan(nc, ndf), False)
+
+
+def _bn_train(x, sd, idx):
+    return F.batch_norm(x, sd[f"model.{idx}.running_mean"], sd[f"model.{idx}.running_var"], sd[f"model.{idx}.weight"],
+                        sd[f"model.{idx}.bias"], training=True, momentum=0.1, eps=BN_EPS)
+
+
+def dcgan_g_forward(sd, z, nz: int, nc: int, ngf: int):
+    h = z
+    for idx, _ci, _co, s_, p_, bn in dcgan_g_plan(nz, nc, ngf):
+        h = F.conv_transpose2d(h, sd[f"model.{idx}.weight"], None, stride=s_, padding=p_)
+        if bn:
+            h = F.relu(_bn_train(h, sd, idx + 1))
+    return torch.tanh(h)
+
+
+def dcgan_d_forward(sd, x, nc: int, ndf: int):
+    h = x
+    plan = dcgan_d_plan(nc, ndf)
+    for li, (idx, _ci, _co, s_, p_, bn) in enumerate(plan):
+        h = F.conv2d(h, sd[f"model.{idx}.weight"], None, stride=s_, padding=p_)
+        if bn:
+            h = _bn_train(h, sd, idx + 1)
+        if li < len(plan) - 1:
+            h = F.leaky_relu(h, 0.2)
+    return torch.sigmoid(h).view(-1, 1).squeeze(1)
 
 
 # ----------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ hand-written gfx950 kernels (include/sgan_hip.h); normalisation and activations 
 separate passes (they are applied while the consumer conv stages its input) and the whole net is
 one autograd node.
 
-Implemented: which_model_netG in {fcgan, deconv (README alias), unet_128, unet_256, crn, autoencoder}, which_model_netD in
+Implemented: which_model_netG in {fcgan, deconv (README alias), unet_128, unet_256, crn, autoencoder, dcgan}, which_model_netD in
 {n_layers, basic}.  Other names raise NotImplementedError like the reference does for unknown
 names (models/networks.py:95,123)."""
 from __future__ import annotations
@@ -696,13 +696,12 @@ class FCGANGenerator(ChainNet):
     final_act = ACT_TANH
 
     def __init__(self, noise_nc, input_nc, ngf=64, n_layers=3, use_dropout=False, use_fcn=False, gpu_ids=[]):
-        if not use_fcn:
-            raise NotImplementedError("FCGANGenerator with noiseSize==1 (k4 s1 p0 first layer) is not on the MI355X path")
         if use_dropout:
             raise NotImplementedError("FCGANGenerator dropout is not on the MI355X path (README uses --no_dropout)")
         layers = []
         nf = min(2 ** (n_layers - 1), 8)
-        layers.append(LayerSpec("0", CONVT, 4, 2, 1, noise_nc, ngf * nf, False, "bn", ACT_RELU))
+        # --noiseSize 1 (use_fcn False): the first ConvT is k4 s1 p0 and turns the 1x1 latent into a 4x4 map (:503-504)
+        layers.append(LayerSpec("0", CONVT, 4, 2 if use_fcn else 1, 1 if use_fcn else 0, noise_nc, ngf * nf, False, "bn", ACT_RELU))
         idx = 3
         for n in range(1, n_layers):
             nf_prev, nf = nf, min(2 ** (n_layers - n - 1), 8)
@@ -726,6 +725,76 @@ class FCGANGenerator(ChainNet):
 
     def _wrap_output(self, y):
         return y
+
+
+class DCGANGenerator(ChainNet):
+    """DCGANGenerator (models/networks.py:1015-1071): ConvT(nz -> 8 ngf, k4, s1, p0) on a 1x1 latent, four ConvT(k4,s2,p1)
+    halving the channels down to ngf/2, each followed by BatchNorm + ReLU, then ConvT(ngf/2 -> nc) -> Tanh (128x128 output);
+    no biases.  The Tanh is part of `model` in the reference; here it is the last conv's epilogue."""
+    final_act = ACT_TANH
+
+    def __init__(self, gpu_ids=[], nz=100, nc=3, ngf=64):
+        chans = [ngf * 8, ngf * 4, ngf * 2, ngf, int(ngf / 2)]
+        layers = [LayerSpec("0", CONVT, 4, 1, 0, nz, chans[0], False, "bn", ACT_RELU)]
+        for i in range(1, 5):
+            layers.append(LayerSpec(str(3 * i), CONVT, 4, 2, 1, chans[i - 1], chans[i], False, "bn", ACT_RELU))
+        layers.append(LayerSpec("15", CONVT, 4, 2, 1, chans[4], nc, False, None, ACT_NONE))
+        super().__init__(layers)
+        self.gpu_ids = gpu_ids
+
+    def _prepare_input(self, x, memo=None):
+        return {"chain_in": ops.as_nhwc(x)}
+
+    def _finish_input_grad(self, xb, dchain):
+        return ops.logical_view(dchain, self.layers[0].cin)
+
+    def forward(self, input):
+        return _ChainFn.apply(self, input, *list(self.model.parameters()))
+
+    def _wrap_output(self, y):
+        return y
+
+
+class DCGANDiscriminator(ChainNet):
+    """DCGANDiscriminator (models/networks.py:1074-1129) for 128x128 inputs: Conv(nc -> ndf/2, k4,s2,p1) + LeakyReLU(0.2),
+    four Conv(k4,s2,p1) + BatchNorm + LeakyReLU doubling the channels to 8 ndf, Conv(8 ndf -> 1, k4, s1, p0) -> Sigmoid,
+    output flattened to [N]; no biases."""
+
+    def __init__(self, gpu_ids=[], nc=3, ndf=64):
+        chans = [int(ndf / 2), ndf, ndf * 2, ndf * 4, ndf * 8]
+        layers = [LayerSpec("0", CONV, 4, 2, 1, nc, chans[0], False, None, ACT_LRELU, 0.2)]
+        for i in range(1, 5):
+            layers.append(LayerSpec(str(3 * i - 1), CONV, 4, 2, 1, chans[i - 1], chans[i], False, "bn", ACT_LRELU, 0.2))
+        layers.append(LayerSpec("14", CONV, 4, 1, 0, chans[4], 1, False, None, ACT_NONE))
+        super().__init__(layers)
+        self.gpu_ids = gpu_ids
+        self.input_nc = nc
+        self.use_sigmoid = True
+        self.gauss_filter = None
+        self.fuse_sigmoid_into_loss = False     # trainers feeding GANLoss set it: forward then returns the tagged logits
+
+    def _prepare_input(self, x, memo=None):
+        key = (x.data_ptr(), tuple(x.shape), x.stride())
+        img = memo.get(key) if memo is not None else None
+        if img is None:
+            img = ops.as_nhwc(x)
+            if memo is not None:
+                memo[key] = img
+        return {"img": img, "chain_in": img}
+
+    def _finish_input_grad(self, xb, dchain, into=None):
+        return ops.logical_view(dchain, self.input_nc)
+
+    def forward(self, input):
+        return self._wrap_output(_ChainFn.apply(self, input, *list(self.model.parameters())))
+
+    def _wrap_output(self, logits):
+        if self.fuse_sigmoid_into_loss:
+            logits._sgan_pending_sigmoid = True
+            return logits
+        p = _SigmoidFn.apply(logits)
+        p._sgan_logits = logits
+        return p.view(-1, 1).squeeze(1)
 
 
 class AutoEncoder(ChainNet):
@@ -1663,7 +1732,9 @@ def define_G(input_nc, output_nc, ngf, which_model_netG, norm='batch', use_dropo
                                          n_layers_block=n_layers_CRN_block, gpu_ids=gpu_ids)
     elif which_model_netG == 'autoencoder':
         netG = AutoEncoder(input_nc, output_nc, n_layers_G, ngf, norm=norm, use_dropout=use_dropout, gpu_ids=gpu_ids)
-    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks', 'fcgan_star', 'dcgan'):
+    elif which_model_netG == 'dcgan':
+        netG = DCGANGenerator(gpu_ids=gpu_ids, nz=noise_nc, nc=input_nc, ngf=ngf)
+    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks', 'fcgan_star'):
         raise NotImplementedError('Generator model name [%s] is not on the MI355X path yet' % which_model_netG)
     else:
         raise NotImplementedError('Generator model name [%s] is not recognized' % which_model_netG)
@@ -1681,7 +1752,11 @@ def define_D(input_nc, ndf, which_model_netD, n_layers_D=3, norm='batch', use_si
     elif which_model_netD == 'n_layers':
         netD = NLayerDiscriminator(input_nc, ndf, n_layers=n_layers_D, norm=norm, use_sigmoid=use_sigmoid,
                                    scale_factor=scale_factor, num_classes=num_classes, gpu_ids=gpu_ids)
-    elif which_model_netD in ('n_layers_sep', 'dcgan'):
+    elif which_model_netD == 'dcgan':
+        if scale_factor > 1:
+            raise NotImplementedError("the dcgan discriminator has no Gaussian pre-filter (the reference fails on scale_factor > 1 too)")
+        netD = DCGANDiscriminator(gpu_ids=gpu_ids, nc=input_nc, ndf=ndf)
+    elif which_model_netD == 'n_layers_sep':
         raise NotImplementedError('Discriminator model name [%s] is not on the MI355X path yet' % which_model_netD)
     else:
         raise NotImplementedError('Discriminator model name [%s] is not recognized' % which_model_netD)

@@ -302,3 +302,58 @@ def test_autoencoder_small(N, golden_dir):
     for k in g.files:
         if k.startswith("grad/") and k.endswith(".weight"):
             assert rel(params[k[5:]].grad, g[k]) < TOL, k
+
+
+def test_dcgan_small(N, golden_dir):
+    """`--which_model_netG dcgan` / `--which_model_netD dcgan` (models/networks.py:1015-1129): k4 s1 p0 ConvT on a 1x1 latent, BatchNorm
+    chains without biases, a k4 s1 p0 logits conv on a 4x4 map."""
+    g = load(golden_dir, "dcgan_small.npz")
+    nz, nc, ngf, ndf = 8, 2, 8, 8
+    G = N.define_G(nc, 0, ngf, "dcgan", "batch", False, noise_nc=nz, gpu_ids=[0])
+    sd = O.init_dcgan_g(71, nz, nc, ngf)
+    assert list(G.state_dict().keys()) == list(sd.keys())
+    G.load_state_dict(sd)
+    z = O.np_normal(701, (1, nz, 1, 1)).cuda().requires_grad_(True)
+    y = G.forward(z)
+    (y * O.np_normal(702, tuple(y.shape)).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (1, nc, 128, 128)
+    assert rel(y, g["G/y"]) < TOL and rel(z.grad, g["G/dz"]) < TOL
+    params, bufs = dict(G.named_parameters()), G.state_dict()
+    for k in g.files:
+        if k.startswith("G/grad/") and k.endswith(".weight"):
+            assert rel(params[k[7:]].grad, g[k]) < TOL, k
+        if k.startswith("G/buf/"):
+            assert rel(bufs[k[6:]], g[k]) < 1e-4, k
+    D = N.define_D(nc, ndf, "dcgan", gpu_ids=[0])
+    sdd = O.init_dcgan_d(72, nc, ndf)
+    assert list(D.state_dict().keys()) == list(sdd.keys())
+    D.load_state_dict(sdd)
+    x = O.np_uniform(703, (1, nc, 128, 128)).cuda().requires_grad_(True)
+    p = D.forward(x)
+    assert tuple(p.shape) == (1,)
+    loss = torch.nn.functional.binary_cross_entropy(p, torch.ones_like(p))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(p, g["D/p"]) < TOL and abs(float(loss) - float(g["D/loss"])) < 1e-4 and rel(x.grad, g["D/dx"]) < TOL
+    dparams = dict(D.named_parameters())
+    for k in g.files:
+        if k.startswith("D/grad/") and k.endswith(".weight"):
+            assert rel(dparams[k[7:]].grad, g[k]) < TOL, k
+
+
+def test_fcgan_g_noisesize1(N, golden_dir):
+    """FCGANGenerator with --noiseSize 1 (use_fcn False, models/networks.py:503-504): first ConvT k4 s1 p0 on a 1x1 latent."""
+    g = load(golden_dir, "fcgan_g_nofcn_small.npz")
+    G = N.define_G(2, 0, 8, "fcgan", "instance", False, n_layers_G=5, use_fcn=False, noise_nc=8, gpu_ids=[0])
+    G.load_state_dict(O.init_fcgan_g(12, 8, 2, 8, 5))
+    z = O.np_normal(111, (1, 8, 1, 1)).cuda().requires_grad_(True)
+    y = G.forward(z)
+    assert y.shape == (1, 2, 128, 128)
+    (y * O.np_normal(112, tuple(y.shape)).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, g["y"]) < TOL and rel(z.grad, g["dz"]) < TOL
+    params = dict(G.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith(".weight") and params[k[5:]].dim() == 4:
+            assert rel(params[k[5:]].grad, g[k]) < TOL, k

@@ -456,3 +456,53 @@ def test_cgan_cycle_step(golden_dir, name, kw):
         m.optimize_parameters()
         losses.append(m.losses())
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+
+
+# ------------------------------------------------------------------------------------------------
+# DCGAN generator / discriminator ((f) rank 3 nets)
+# ------------------------------------------------------------------------------------------------
+def test_dcgan_small(golden_dir):
+    g = load(golden_dir, "dcgan_small.npz")
+    nz, nc, ngf, ndf = 8, 2, 8, 8
+    sd = O.init_dcgan_g(71, nz, nc, ngf)
+    for k, v in sd.items():
+        if k.endswith((".weight", ".bias")):
+            v.requires_grad_(True)
+    z = O.np_normal(701, (1, nz, 1, 1)).requires_grad_(True)
+    y = O.dcgan_g_forward(sd, z, nz, nc, ngf)
+    (y * O.np_normal(702, tuple(y.shape))).sum().backward()
+    assert rel(y, g["G/y"]) < 1e-4 and rel(z.grad, g["G/dz"]) < 1e-4
+    for k in g.files:
+        if k.startswith("G/grad/"):
+            assert rel(sd[k[7:]].grad, g[k]) < 1e-4, k
+        if k.startswith("G/buf/"):
+            assert rel(sd[k[6:]], g[k]) < 1e-5, k
+    sdd = O.init_dcgan_d(72, nc, ndf)
+    for k, v in sdd.items():
+        if k.endswith((".weight", ".bias")):
+            v.requires_grad_(True)
+    x = O.np_uniform(703, (1, nc, 128, 128)).requires_grad_(True)
+    p = O.dcgan_d_forward(sdd, x, nc, ndf)
+    loss = torch.nn.functional.binary_cross_entropy(p, torch.ones_like(p))
+    loss.backward()
+    assert rel(p, g["D/p"]) < 1e-4 and abs(float(loss) - float(g["D/loss"])) < 1e-5 and rel(x.grad, g["D/dx"]) < 1e-4
+    for k in g.files:
+        if k.startswith("D/grad/"):
+            assert rel(sdd[k[7:]].grad, g[k]) < 1e-4, k
+
+
+def test_fcgan_g_noisesize1(golden_dir):
+    """FCGANGenerator with a 1x1 latent (use_fcn False): first ConvT k4 s1 p0."""
+    g = load(golden_dir, "fcgan_g_nofcn_small.npz")
+    sd = O.init_fcgan_g(12, 8, 2, 8, 5)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    z = O.np_normal(111, (1, 8, 1, 1)).requires_grad_(True)
+    y = O.fcgan_g_forward(sd, z, 5, use_fcn=False)
+    assert tuple(y.shape) == (1, 2, 128, 128)
+    (y * O.np_normal(112, tuple(y.shape))).sum().backward()
+    assert rel(y, g["y"]) < TIGHT and rel(z.grad, g["dz"]) < TIGHT
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith(".weight") and sd[k[5:]].dim() == 4:
+            assert rel(sd[k[5:]].grad, g[k]) < 1e-4, k

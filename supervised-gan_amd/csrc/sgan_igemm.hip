@@ -738,6 +738,163 @@ static int sg_launch_small_n(SgIgemmParams& P, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Scatter form for 4-channel results of stride-2 transposed layers (generator output ConvT 32 -> 2, image gradient of the
+// first discriminator conv): every input pixel feeds 16 (phase, tap) outputs, so the gather kernel above reads each
+// activation 4 times through L1 and is bound by exactly that.  Here a workgroup takes an 8 x 32 tile of INPUT pixels,
+// computes Z[pixel][(phase, tap, co)] = sum_c x[pixel][c] * W[(phase, tap)][co][c] as a dense 256 x 64 x Ck MFMA GEMM (A read
+// from global memory once, normalise-on-load applied in registers, B = the whole weight tensor), parks Z in LDS, and
+// then every output pixel of the 6 x 30 interior adds its 4 (neighbour, tap) entries: out = bias + sum_t Z[p + d_t][t].
+// Requires 4 phases x 4 taps with |dy|, |dx| <= 1 (k4 s2), Ck % 16 == 0, Ck <= 64.
+// ------------------------------------------------------------------------------------------
+#define SG_SC_TH 8
+#define SG_SC_TW 32
+#define SG_SC_LDZ 68
+__global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmParams G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Zs = reinterpret_cast<float*>(smem);                    // [256][SG_SC_LDZ]
+    float* pscale = Zs + 256 * SG_SC_LDZ;                          // [Ck]
+    float* pshift = pscale + G.Ck;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    int g = 0;
+    for (int gi = 1; gi < G.nprob; ++gi)
+        if ((int)blockIdx.x >= G.q[gi].tile0[0]) g = gi;
+    const SgLocal P = sg_local(G, g);
+    const int tloc = blockIdx.x - G.q[g].tile0[0];
+    const int tiles_x = G.q[g].tile0[1];
+    const int ty = tloc / tiles_x, tx = tloc - ty * tiles_x;
+    const int y0 = ty * (SG_SC_TH - 2), x0 = tx * (SG_SC_TW - 2);     // first interior (phase-grid) pixel of this tile
+    const int Ck = P.Ck;
+    const bool has_pro = (P.pro.stats != nullptr) || (P.pro.act != SGAN_ACT_NONE);
+    const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
+    for (int c = tid; c < Ck; c += 256) {
+        float sc = 1.f, sh = 0.f;
+        if (P.pro.stats) {
+            float mean, rstd;
+            sg_mean_rstd(P.pro, Ck, c, mean, rstd);
+            const float gm = P.pro.gamma ? P.pro.gamma[c] : 1.f;
+            const float bt = P.pro.beta ? P.pro.beta[c] : 0.f;
+            sc = gm * rstd;
+            sh = bt - mean * sc;
+        }
+        pscale[c] = sc;
+        pshift[c] = sh;
+    }
+    __syncthreads();
+
+    // ---- Z = X W^T: wave w owns tile rows 2w, 2w+1 (64 pixels = 4 MFMA row blocks), all 64 columns ----
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.w), 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int OOB = (int)0x80000000u;
+    int a_off[4], b_off[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = wid * 64 + i * 16 + fr;
+        const int iy = y0 - 1 + m / SG_SC_TW, ix = x0 - 1 + m % SG_SC_TW;
+        a_ok[i] = ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
+        a_off[i] = a_ok[i] ? ((iy * P.Win + ix) * P.in_ld + fq * 4) << 2 : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {      // column n = j*16 + fr = (phase j, tap fr >> 2, co fr & 3)
+        const int t = fr >> 2, co = fr & 3;
+        b_off[j] = (G.taps[j][t].w_off + co * P.w_ns + fq * 4) << 2;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < Ck; kk += 16) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off[i] + kk * 4, 0, 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[j] + kk * 4, 0, 0));
+        if (has_pro) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + kk + fq * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(pshift + kk + fq * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float okf = a_ok[i] ? 1.f : 0.f, okn = okf * pro_neg;     // zero padding applies after norm + activation
+                const f32x4 y = a[i] * sc + sh;
+                const f32x4 yp = y * okf, yn = y * okn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[i][e] = fmaxf(yp[e], yn[e]);
+            }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s4], b[j][s4], acc[i][j], 0, 0, 0);
+    }
+    // acc[i][j][r] = Z[m = wid*64 + i*16 + fq*4 + r][n = j*16 + fr]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Zs[(wid * 64 + i * 16 + fq * 4 + r) * SG_SC_LDZ + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+
+    // ---- overlap-add: the (TH-2) x (TW-2) interior in all 4 phases, row-major over output pixels (coalesced 16-byte stores) ----
+    constexpr int OH = 2 * (SG_SC_TH - 2), OW = 2 * (SG_SC_TW - 2);
+    f32x4 bias = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (P.bias) bias = *reinterpret_cast<const f32x4*>(P.bias);
+    for (int idx = tid; idx < OH * OW; idx += 256) {
+        const int ry = idx / OW, rx = idx - ry * OW;
+        const int a_ = ry & 1, b_ = rx & 1, ph = a_ * 2 + b_;        // os = 2: output (2 py + a, 2 px + b)
+        const int py = y0 + (ry >> 1), px = x0 + (rx >> 1);
+        if (py >= G.q[g].Hp[ph] || px >= G.q[g].Wp[ph]) continue;
+        f32x4 v = bias;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int my = py + G.taps[ph][t].dy - (y0 - 1), mx = px + G.taps[ph][t].dx - (x0 - 1);
+            v += *reinterpret_cast<const f32x4*>(Zs + (my * SG_SC_TW + mx) * SG_SC_LDZ + ph * 16 + t * 4);
+        }
+        if (P.out_act == SGAN_ACT_TANH) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        }
+        const int64_t pix = (int64_t)(py * 2 + a_) * P.Wout + (px * 2 + b_);
+        *reinterpret_cast<f32x4*>(P.out + pix * P.out_ld) = v;
+    }
+}
+
+static bool sg_use_scatter4(const SgIgemmParams& P) {
+    static const int off = getenv("SGAN_NO_SCATTER4") ? 1 : 0;
+    if (off || P.N != 4 || P.nphase != 4 || P.os != 2 || P.is != 1 || P.w_ks != 1 || (P.Ck & 15) || P.Ck > 64 || P.Ck < 16) return false;
+    for (int ph = 0; ph < 4; ++ph) {
+        if (P.ntaps[ph] != 4 || P.oa[ph] != (ph >> 1) || P.ob[ph] != (ph & 1)) return false;
+        for (int t = 0; t < 4; ++t)
+            if (P.taps[ph][t].dy < -1 || P.taps[ph][t].dy > 1 || P.taps[ph][t].dx < -1 || P.taps[ph][t].dx > 1) return false;
+    }
+    return true;
+}
+
+static int sg_launch_scatter4(SgIgemmParams& P, hipStream_t st) {
+    int t = 0;
+    for (int g = 0; g < P.nprob; ++g) {
+        int hp = 0, wp = 0;
+        for (int ph = 0; ph < 4; ++ph) { hp = max(hp, P.q[g].Hp[ph]); wp = max(wp, P.q[g].Wp[ph]); }
+        const int tx = (wp + SG_SC_TW - 3) / (SG_SC_TW - 2), ty = (hp + SG_SC_TH - 3) / (SG_SC_TH - 2);
+        P.q[g].tile0[0] = t;
+        P.q[g].tile0[1] = tx;
+        t += tx * ty;
+    }
+    if (t == 0) return SGAN_OK;
+    const size_t lds = (size_t)256 * SG_SC_LDZ * 4 + (size_t)2 * P.Ck * 4;
+    sg_prof_begin(st);
+    hipLaunchKernelGGL(sg_conv_scatter4_kernel, dim3(t), dim3(256), lds, st, P);
+    SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = "sg_conv_scatter4_kernel";
+    sg_prof_end(st, g_sgan_last_kernel);
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Split-K finish: out = epilogue( sum_s slab[s] ) -- the same epilogue as the unsplit kernel (bias,
 // per-channel statistics, tanh; or act'(norm(x)) and the two norm-backward sums), as one 16-byte-
 // per-lane streaming pass.  Thread t always works on channel group t % (N/4), so the statistics are
@@ -1016,7 +1173,8 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
     P.ksplit = 1;
     P.slab = nullptr;
     P.slab_stride = 0;
-    if (sg_use_small_n(P)) {   // skinny result: direct kernel
+    if (sg_use_small_n(P)) {   // skinny result: direct kernels
+        if (sg_use_scatter4(P)) return sg_launch_scatter4(P, st);
         const int ktot = sg_max_k(P);
         if (ktot >= 2048) return sg_launch_small_n<64, 1, 8>(P, st);
         if (ktot >= 256) return sg_launch_small_n<16, 2, 4>(P, st);

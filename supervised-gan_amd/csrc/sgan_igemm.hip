@@ -744,7 +744,7 @@ static int sg_launch_small_n(SgIgemmParams& P, hipStream_t st) {
 // computes Z[pixel][(phase, tap, co)] = sum_c x[pixel][c] * W[(phase, tap)][co][c] as a dense 256 x 64 x Ck MFMA GEMM (A read
 // from global memory once, normalise-on-load applied in registers, B = the whole weight tensor), parks Z in LDS, and
 // then every output pixel of the 6 x 30 interior adds its 4 (neighbour, tap) entries: out = bias + sum_t Z[p + d_t][t].
-// Requires 4 phases x 4 taps with |dy|, |dx| <= 1 (k4 s2), Ck % 16 == 0, Ck <= 64.
+// Requires 4 phases x 4 taps with |dy|, |dx| <= 1 (k4 s2), Ck % 16 == 0, Ck <= 512.
 // ------------------------------------------------------------------------------------------
 #define SG_SC_TH 8
 #define SG_SC_TW 32
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmPara
 
 static bool sg_use_scatter4(const SgIgemmParams& P) {
     static const int off = getenv("SGAN_NO_SCATTER4") ? 1 : 0;
-    if (off || P.N != 4 || P.nphase != 4 || P.os != 2 || P.is != 1 || P.w_ks != 1 || (P.Ck & 15) || P.Ck > 64 || P.Ck < 16) return false;
+    if (off || P.N != 4 || P.nphase != 4 || P.os != 2 || P.is != 1 || P.w_ks != 1 || (P.Ck & 15) || P.Ck > 512 || P.Ck < 16) return false;
     for (int ph = 0; ph < 4; ++ph) {
         if (P.ntaps[ph] != 4 || P.oa[ph] != (ph >> 1) || P.ob[ph] != (ph & 1)) return false;
         for (int t = 0; t < 4; ++t)

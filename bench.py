@@ -303,7 +303,11 @@ def main():
     kern = None
     if rank == 0 and not args.no_kernel_profile:     # a few un-synchronised steps on rank 0 only (no collective inside) ...
         kern = profile_kernels(model, ring, workload=args.workload)
-    if world > 1:                                    # ... so every rank is handed rank 0's weights again before the timed run
+    if kern is not None:                             # ... whose optimizer moments must not leak into the measured run
+        for name in ("optimizer_D", "optimizer_D1", "optimizer_D2", "optimizer_G"):
+            if hasattr(model, name):
+                getattr(model, name).reset_state()
+    if world > 1:                                    # ... and every rank is handed rank 0's weights again before the timed run
         nets = [model.netG1, model.netG2, model.netF2] + model.netD1 + model.netD2 if two else [model.netG] + model.netD
         sdist.broadcast_parameters(nets)
         model.grad_sync = sdist.GradAverager()

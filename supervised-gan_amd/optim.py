@@ -53,6 +53,11 @@ class FusedAdam:
         self._state = torch.zeros(4, dtype=torch.int32, device=dev)
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
 
+    def reset_state(self):
+        """Forget the moments and the step counter (as a freshly constructed optimizer)."""
+        self._state = None
+        self._lr_host = None
+
     def sync_lr(self):
         """Push param_groups[0]['lr'] to the device scalar (call outside graph capture)."""
         self._lazy_state()
@@ -110,6 +115,10 @@ class AdamGroups:
     def sync_lr(self):
         for o in self.optimizers:
             o.sync_lr()
+
+    def reset_state(self):
+        for o in self.optimizers:
+            o.reset_state()
 
     def segments(self):
         return [s for o in self.optimizers for s in o.segments()]

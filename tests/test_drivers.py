@@ -64,3 +64,23 @@ def test_train_cgan2(tmp_path):
         m = train_driver.main(net + extra)
         assert all(np.isfinite(v) for v in m.get_current_errors().values())
         assert m.fake_B_from_fake_A.shape == (1, 1, 256, 256)
+
+
+@pytest.mark.parametrize("model,mode", [("cgan_cycle", "single"), ("cgan2_cycle", "unaligned")])
+def test_train_then_test_cgan_cycle(tmp_path, model, mode):
+    """`--model cgan_cycle` / `cgan2_cycle` through train.py (checkpoints G1, G2, D1_n) and test.py (sampling from them)."""
+    _need_gpu()
+    import test as test_driver
+    import train as train_driver
+    name = "drv_" + model
+    net = ["--name", name, "--model", model, "--which_direction", "AtoB", "--dataset_mode", mode, "--fineSize", "256",
+           "--which_model_netG1", "unet_128", "--ngf1", "8", "--which_model_netG2", "unet_128", "--ngf2", "8", "--norm", "instance",
+           "--which_channel", "rg_b", "--gpu_ids", "0", "--checkpoints_dir", str(tmp_path / "ckpt"), "--dataroot", "synthetic",
+           "--manualSeed", "4", "--no_dropout1", "--no_dropout2"]
+    m = train_driver.main(net + ["--which_model_netD1", "n_layers", "--n_layers_D1", "3", "3", "--ndf1", "8", "--scale_factor1", "1", "2",
+                                 "--lambda_D1", "0.6", "0.4", "--weights", "2", "4", "--no_lsgan1", "--max_steps", "2", "--print_freq", "1"])
+    assert all(np.isfinite(v) for v in m.get_current_errors().values())
+    files = sorted(f for f in os.listdir(tmp_path / "ckpt" / name) if f.endswith(".pth"))
+    assert files == ["latest_net_D1_0.pth", "latest_net_D1_1.pth", "latest_net_G1.pth", "latest_net_G2.pth"]
+    out = test_driver.main(net + ["--results_dir", str(tmp_path / "res"), "--how_many", "2"])
+    assert len(out) == 4 and all(os.path.exists(p) for p in out)            # real_A + fake_B per image

@@ -84,3 +84,20 @@ def test_train_then_test_cgan_cycle(tmp_path, model, mode):
     assert files == ["latest_net_D1_0.pth", "latest_net_D1_1.pth", "latest_net_G1.pth", "latest_net_G2.pth"]
     out = test_driver.main(net + ["--results_dir", str(tmp_path / "res"), "--how_many", "2"])
     assert len(out) == 4 and all(os.path.exists(p) for p in out)            # real_A + fake_B per image
+
+
+def test_train_graphed(tmp_path):
+    """train.py --graph: the driver loop on hipGraph replays (capture on the first batch, then replays)."""
+    _need_gpu()
+    import train as train_driver
+    net = ["--name", "drv_graph", "--model", "fcgan", "--which_direction", "A", "--dataset_mode", "single", "--fineSize", "128",
+           "--input_nc", "2", "--which_model_netG", "deconv", "--n_layers_G", "5", "--ngf", "8", "--noise_nc", "8", "--noiseSize", "2",
+           "--norm", "instance", "--no_dropout", "--which_channel", "rg", "--gpu_ids", "0", "--checkpoints_dir", str(tmp_path / "ckpt"),
+           "--dataroot", "synthetic", "--manualSeed", "3", "--which_model_netD", "n_layers", "--n_layers_D", "3", "3", "--ndf", "8",
+           "--scale_factor", "1", "2", "--lambda_D", "0.6", "0.4", "--n_update_G", "2", "--no_lsgan", "--max_steps", "6", "--print_freq", "1",
+           "--graph"]
+    m = train_driver.main(net)
+    torch.cuda.synchronize()
+    assert all(np.isfinite(v) for v in m.get_current_errors().values())
+    assert m.optimizer_D.step_count == 2 + 5            # two capture steps on the first batch, then five replays
+    assert os.path.exists(tmp_path / "ckpt" / "drv_graph" / "latest_net_G.pth")

@@ -53,6 +53,8 @@ CASES = [
     ("conv", 3, 1, 1, 16, 8, 12, 12, "in", 0),      # CRN stage conv: norm without activation on load
     ("conv", 3, 1, 1, 2, 8, 16, 16, None, 0),       # CRN label conv
     ("convT", 4, 2, 1, 16, 8, 6, 6, "in", 0),       # CRN ConvT upsampling, norm without activation on load
+    ("conv", 4, 2, 1, 512, 512, 8, 8, "in", 2),     # U-Net inner down conv: 8 tiles x 256 k-tiles -> split-K 32 AND two wave groups
+    ("convT", 4, 2, 1, 512, 256, 4, 4, "in", 1),    # U-Net inner up conv (4 phases, deep reduction on a 4x4 map)
 ]
 
 

@@ -1093,7 +1093,8 @@ static int sg_plan_ksplit(const SgIgemmParams& P, int BM, int BN) {
     if (nkt < min_nkt) return 1;
     int ks = (int)sg_cdiv(512, (int)blocks);
     ks = min(ks, nkt / 4);
-    ks = min(ks, 32);
+    static const int ks_max = getenv("SGAN_KS_MAX") ? atoi(getenv("SGAN_KS_MAX")) : 32;      // tuning / test knob
+    ks = min(ks, ks_max);
     if (ks < 2) return 1;
     const int per = sg_cdiv(nkt, ks);
     return sg_cdiv(nkt, per);   // every split non-empty

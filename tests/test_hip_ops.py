@@ -105,7 +105,7 @@ def test_conv_layer_fwd_bwd(hip, case):
         assert float(ob[..., cout:].abs().max()) == 0.0     # padded channels stay exactly zero
         ob2 = torch.full_like(ob, float("nan"))
         ops.conv_fwd(desc_plain, xb, in_norm, wm, bb, ob2, 0, None)      # same result without the hint
-        assert rel(ob2, ob) < 1e-6
+        assert rel(ob2, ob) < 1e-5
 
     # ---- backward data (+ act', norm sums) then norm backward ----
     Rb = to_buf(R)

@@ -122,7 +122,9 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
 
     def flops(desc):   # stored 4 channels <- logical channels: fcgan 2-channel image / 1-channel logits; cgan 2-channel label
         # (U-Net, pad 1), 3-channel pair (discriminators, pad 2), 1-channel image and logits
-        if workload == "fcgan":
+        if desc.Cin_logical and desc.Cout_logical:      # the networks fill the logical-channel hint of every descriptor
+            cin, cout = desc.Cin_logical, desc.Cout_logical
+        elif workload == "fcgan":
             cin = desc.Cin if desc.Cin > 4 else 2
             cout = desc.Cout if desc.Cout > 4 else (2 if desc.kind == 1 else 1)
         else:
@@ -276,7 +278,7 @@ def main():
     ap.add_argument("--no_kernel_profile", action="store_true")
     ap.add_argument("--workload", default="fcgan", choices=["fcgan", "cgan", "twostage_cycle"],
                     help="fcgan = the headline metric (BASELINE configs[1]); cgan = BASELINE configs[2], twostage_cycle = configs[4], "
-                         "each reported under its own metric name (twostage_cycle without the kernel profile)")
+                         "each reported under its own metric name")
     args = ap.parse_args()
 
     from supervised_gan_amd import dist as sdist
@@ -292,7 +294,7 @@ def main():
     cgan = args.workload == "cgan"
     two = args.workload == "twostage_cycle"
     if two:
-        args.no_kernel_profile, args.no_cpu_baseline = True, True
+        args.no_cpu_baseline = True
         model = build_twostage(args, rank)
         sdist.broadcast_parameters([model.netG1, model.netG2, model.netF2] + model.netD1 + model.netD2)
     else:
@@ -375,9 +377,9 @@ def main():
             dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
             peak = 157.3   # fp32 matrix peak, MI355X_MICROARCH.md "Peak FP32 (matrix)"
             traffic = None     # HBM bytes per launch from the committed PMC passes (profiles/), same kernel
-            try:
+            try:      # the committed counter passes were taken on the fcgan step: only that workload's launch mix matches them
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                traffic = pm[dom]["hbm_bytes_per_launch"] if dom in pm else None
+                traffic = pm[dom]["hbm_bytes_per_launch"] if (dom in pm and args.workload == "fcgan") else None
             except Exception:
                 traffic = None
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": peak,

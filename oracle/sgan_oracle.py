@@ -21,6 +21,7 @@ Reference map (paths relative to /root/reference):
   NLayerDiscriminator                         models/networks.py:798-847
   define_D gaussian init (py2 int division)   models/networks.py:124-129
   GANLoss                                     models/networks.py:152-185
+  GANLossMultiClass (+ backward_D2_multiclass) models/networks.py:188-202, models/twostage_cycle_model.py:302-335
   WeightedL1Loss                              models/networks.py:205-214
   UnetGenerator / UnetSkipConnectionBlock     models/networks.py:318-419
   CGANModel of cgan2 (two label images)       models/cgan2_model.py:129-233

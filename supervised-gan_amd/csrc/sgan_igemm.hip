@@ -1076,6 +1076,14 @@ static long sg_total_tiles(const SgIgemmParams& P, int BM) {
     return t;
 }
 
+// Rough duration (us) of `wgs` 64x64 workgroups walking `nkt_wg` k-tiles each, fitted to the per-call timings of the
+// cgan step: a workgroup alone on its CU needs ~1.1 us per k-tile (latency bound, ~40 % of the CU's MFMA rate); from two
+// co-resident workgroups on the CU is saturated at ~0.69 us per k-tile per workgroup, and the chip waits for the fullest CU.
+static double sg_time_model(long wgs, int nkt_wg) {
+    const double per_cu = (double)((wgs + 255) / 256);
+    return nkt_wg * fmax(1.1, per_cu * 0.69);
+}
+
 // Split-K plan (single problem only): deep reductions on small grids (a 17x17 layer is 24 workgroups walking
 // 64-128 k-tiles one after the other) are cut so that ~2 workgroups land on every CU.  Needs N % 4 == 0 channels
 // with 256 % (N/4) == 0 for the epilogue.
@@ -1090,6 +1098,27 @@ static int sg_plan_ksplit(const SgIgemmParams& P, int BM, int BN) {
     // measured on MI355X (tools/bench_layers.py): the slab round trip only pays when the grid is well under
     // one workgroup per CU, and the deeper the reduction the larger the grid it still pays for
     const int min_nkt = blocks <= 32 ? 16 : blocks <= 96 ? 32 : blocks <= 192 ? 64 : 1 << 30;
+    // Grids a little over one workgroup per CU with a deep reduction (discriminator 256 -> 512 @65x65: 268 tiles x 256
+    // k-tiles): twelve CUs get two tiles and the chip waits for them while the rest run one workgroup each, well under a CU's
+    // MFMA rate.  A split both fills the CUs and evens them out; pick it with sg_time_model().
+    static const int mid = getenv("SGAN_NO_MID_SPLIT") ? 0 : 1;
+    static const int mid_force = getenv("SGAN_MID_KS") ? atoi(getenv("SGAN_MID_KS")) : 0;    // tuning knob
+    if (mid && blocks > 192 && blocks <= 768 && nkt >= 128) {
+        const double slab_us = (double)Q.Hout * Q.Wout * P.N * 8.0 / 4e6;     // write + read of one slab at ~4 TB/s
+        int best = 1;
+        double best_cost = sg_time_model(blocks, nkt);
+        for (int c : {2, 3, 4, 6, 8}) {
+            if (nkt / c < 16) break;
+            const double cost = sg_time_model(blocks * c, sg_cdiv(nkt, c)) + c * slab_us + 12.0;
+            if (cost < 0.95 * best_cost) { best = c; best_cost = cost; }
+        }
+        if (mid_force) best = mid_force;
+        if (best > 1) {
+            const int per = sg_cdiv(nkt, best);
+            return sg_cdiv(nkt, per);
+        }
+        return 1;
+    }
     if (nkt < min_nkt) return 1;
     int ks = (int)sg_cdiv(512, (int)blocks);
     ks = min(ks, nkt / 4);

@@ -179,6 +179,47 @@ def test_conv_plain_dgrad_and_tanh(hip):
     assert float(dx[..., 2:].abs().max()) == 0.0
 
 
+def test_grouped_deep_reduction(hip):
+    """Two deep 512 -> 512 problems of different size (@33x33, @33x31) in one grouped call -- 256 k-tiles per workgroup, two wave
+    groups, no split along K (each alone would be split).  Forward (+ statistics) and backward-data against torch."""
+    from hip_utils import from_buf, master_weight, pad_vec, rel, stats_of, to_buf
+    ops = hip
+    g = torch.Generator().manual_seed(77)
+    sizes = [(33, 33), (33, 31)]
+    cin = cout = 512
+    w = torch.randn(cout, cin, 4, 4, generator=g) * 0.02
+    b = torch.randn(cout, generator=g) * 0.1
+    wm, bb = master_weight(w, False), pad_vec(b)
+    fjobs, djobs, refs, keep = [], [], [], []
+    for H, W in sizes:
+        x = (torch.randn(1, cin, H, W, generator=g) * 1.5 + 0.3).requires_grad_(True)
+        a = F.leaky_relu(F.instance_norm(x, eps=1e-5), 0.2)
+        out = F.conv2d(a, w, b, stride=1, padding=1)
+        R = torch.randn(out.shape, generator=g)
+        (out * R).sum().backward()
+        Ho, Wo = out.shape[2:]
+        desc = ops.conv_desc(0, 4, 1, 1, H, W, cin, Ho, Wo, cout)
+        xb = to_buf(x.detach())
+        nd = ops.norm_desc(stats_of(x.detach()), None, None, H * W, 1e-5, 2, 0.2)
+        ob = torch.full((Ho, Wo, cout), float("nan"), device="cuda")
+        ost = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+        din = torch.full((H, W, cin), float("nan"), device="cuda")
+        sums = torch.zeros(2 * cin, dtype=torch.float64, device="cuda")
+        fjobs.append((desc, xb, nd, wm, bb, ob, ost))
+        djobs.append((desc, to_buf(R), wm, din, xb, nd, sums))
+        refs.append((out.detach(), x.grad, ob, ost, din, sums, nd, xb, cin))
+        keep.append((desc, nd))
+    ops.conv_fwd_grouped(fjobs)
+    ops.conv_dgrad_grouped(djobs)
+    for out, xg, ob, ost, din, sums, nd, xb, c in refs:
+        ops.norm_bwd_apply(din, xb, nd, sums, None, None)
+    torch.cuda.synchronize()
+    for out, xg, ob, ost, din, sums, nd, xb, c in refs:
+        assert rel(from_buf(ob, cout), out) < 10 * EXPECT
+        assert rel(ost, stats_of(out, "cpu")) < 1e-4
+        assert rel(from_buf(din, c), xg) < TOL
+
+
 @pytest.mark.parametrize("s,nc", [(2, 2), (4, 2), (2, 3)])
 def test_gauss_down(hip, s, nc):
     import sgan_oracle as O

@@ -18,6 +18,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between the ranks of this host
+
 import torch  # noqa: E402
 
 # SURVEY 8(d) / BASELINE.md section 3: conv MACs per forward pass of the reference nets
@@ -207,6 +209,17 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
                 "tflops": v[2] / (v[1] * 1e-3) / 1e12, "gflop_per_launch": v[2] / v[0] / 1e9} for k, v in agg.items()}
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline_cgan(n_update_G, budget_s=25.0):
     """The CPU oracle's cgan step (same README config) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -256,9 +269,18 @@ def cpu_baseline(n_update_G, budget_s=20.0):
         if time.perf_counter() - t0 > budget_s or n >= 40:
             break
     dt = time.perf_counter() - t0
+    # a 1-thread figure beside the all-cores one (two steps, ~1.5 s each)
+    torch.set_num_threads(1)
+    o.optimize_parameters(real[0])
+    t1 = time.perf_counter()
+    for i in range(2):
+        o.optimize_parameters(real[i])
+    dt1 = (time.perf_counter() - t1) / 2
+    torch.set_num_threads(cores)
     return {"value": n / dt, "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"{n} steps of the same fcgan 512x512 bs=1 n_update_G={n_update_G} workload after 2 warm-up steps, "
-                      f"torch {torch.__version__} fp32 CPU oracle, {cores} threads"}
+                      f"torch {torch.__version__} fp32 CPU oracle, {cores} threads",
+            "cpu_model": _cpu_model(), "value_1thread": 1.0 / dt1}
 
 
 def main():

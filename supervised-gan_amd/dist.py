@@ -15,6 +15,7 @@ import torch.distributed as dist
 
 def init_from_env(backend=None):
     """(rank, world, local_rank); initialises torch.distributed when WORLD_SIZE > 1."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC between the ranks of a host (read when HSA starts)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -203,7 +203,9 @@ typedef struct sgan_bn_running_desc {
     float* running_var;
     int64_t* num_batches_tracked; /* device int64 incremented by one, or NULL */
     int32_t C;
-    int32_t count; /* H*W */
+    int32_t count;     /* H*W */
+    int32_t sq_stride; /* distance from a channel's sum to its sum of squares inside `stats`; 0 = C (wider when `stats`
+                          is a slice of a concatenated tensor's statistics, or C is not a multiple of 4) */
 } sgan_bn_running_desc;
 int sgan_bn_running_update(const sgan_bn_running_desc* layers, int32_t n, float momentum, void* stream);
 

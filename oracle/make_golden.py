@@ -416,6 +416,27 @@ def golden_dcgan_small():
     save("dcgan_small.npz", **arrs)
 
 
+def golden_fcgan_star_small():
+    """`--which_model_netG fcgan_star` at 2x128x128 (z 8 x 2 x 2, ngf 4): output, latent gradient, all parameter gradients,
+    BN running statistics after one forward."""
+    nz, ngf = 8, 4
+    g = RN.define_G(2, 0, ngf, "fcgan_star", "batch", False, n_layers_G=5, use_fcn=True, noise_nc=nz, gpu_ids=[])
+    sd = O.init_fcgan_star(81, nz, ngf)
+    assert list(g.state_dict().keys()) == list(sd.keys()), (list(g.state_dict().keys()), list(sd.keys()))
+    load_sd(g, sd)
+    z = O.np_normal(801, (1, nz, 2, 2)).requires_grad_(True)
+    y = g.forward(z)
+    r = O.np_normal(802, tuple(y.shape))
+    (y * r).sum().backward()
+    arrs = {"y": y.detach().numpy(), "dz": z.grad.numpy()}
+    for k, p in g.named_parameters():
+        arrs["grad/" + k] = p.grad.numpy()
+    for k, v in g.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            arrs["buf/" + k] = v.numpy().copy()
+    save("fcgan_star_small.npz", **arrs)
+
+
 def golden_crn_small():
     """crn at 128x128 (label 2 ch, noise 8 x 2 x 2), ngf 8: ConvTranspose upsampling with 1-layer blocks, and the README's
     bilinear upsampling with 2-layer blocks; shared label block."""
@@ -760,6 +781,8 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
+    if not only or "fcgan_star" in only:
+        golden_fcgan_star_small()
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
     if not only or "dcgan" in only:

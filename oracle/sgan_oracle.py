@@ -29,6 +29,7 @@ Reference map (paths relative to /root/reference):
   CGANCycleModel of cgan2_cycle               models/cgan2_cycle_model.py:114-262
   AutoEncoder                                 models/networks.py:421-490
   DCGANGenerator / DCGANDiscriminator         models/networks.py:1015-1129
+  FCGANGeneratorStar                          models/networks.py:543-640
   CascadedRefinementNetwork / Crn*Block       models/networks.py:642-794
   CGANModel step recipe                       models/cgan_model.py:134-226
   TwoStageCycleModel step recipe              models/twostage_cycle_model.py:193-438
@@ -650,6 +651,59 @@ def dcgan_d_forward(sd, x, nc: int, ndf: int):
         if li < len(plan) - 1:
             h = F.leaky_relu(h, 0.2)
     return torch.sigmoid(h).view(-1, 1).squeeze(1)
+
+
+# ----------------------------------------------------------------------------------
+# FCGANGeneratorStar (models/networks.py:543-640): two bias-free deconv chains; chain b reads cat(a, b) of the level below
+# ----------------------------------------------------------------------------------
+def fcgan_star_plan(noise_nc: int, ngf: int):
+    """[(module name, cin, cout, has_bn)] in the reference's module order: conv0a..conv5a, then conv0b..conv5b (:556-623)."""
+    half = int(noise_nc / 2)
+    ch = [ngf * 8, ngf * 8, ngf * 4, ngf * 2, ngf]
+    plan = [("conv0a", half, ch[0], True)]
+    for i in range(1, 5):
+        plan.append((f"conv{i}a", ch[i - 1], ch[i], True))
+    plan.append(("conv5a", ch[4], 1, False))
+    plan.append(("conv0b", half, ch[0], True))
+    for i in range(1, 5):
+        plan.append((f"conv{i}b", 2 * ch[i - 1], ch[i], True))
+    plan.append(("conv5b", 2 * ch[4], 1, False))
+    return plan
+
+
+def init_fcgan_star(seed: int, noise_nc: int, ngf: int):
+    sd = OrderedDict()
+    for k, (name, ci, co, bn) in enumerate(fcgan_star_plan(noise_nc, ngf)):
+        sd[f"{name}.0.weight"] = np_normal(seed * 1000 + 2 * k, (ci, co, 4, 4), 0.0, 0.02)
+        if bn:
+            sd[f"{name}.1.weight"] = np_normal(seed * 1000 + 2 * k + 1, (co,), 1.0, 0.02)
+            sd[f"{name}.1.bias"] = torch.zeros(co)
+            sd[f"{name}.1.running_mean"] = torch.zeros(co)
+            sd[f"{name}.1.running_var"] = torch.ones(co)
+            sd[f"{name}.1.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+    return sd
+
+
+def fcgan_star_forward(sd, z, noise_nc: int):
+    """FCGANGeneratorStar.forward (:625-640): noise1 = first half of z feeds chain b, noise2 = second half chain a; every
+    b layer above the first reads cat([ha, hb]); output tanh(cat([ha, hb]))."""
+    half = int(noise_nc / 2)
+
+    def layer(name, h, bn=True):
+        h = F.conv_transpose2d(h, sd[f"{name}.0.weight"], None, stride=2, padding=1)
+        if not bn:
+            return h
+        h = F.batch_norm(h, sd[f"{name}.1.running_mean"], sd[f"{name}.1.running_var"], sd[f"{name}.1.weight"], sd[f"{name}.1.bias"],
+                         training=True, momentum=BN_MOMENTUM, eps=BN_EPS)
+        sd[f"{name}.1.num_batches_tracked"] += 1
+        return F.relu(h)
+
+    hb = layer("conv0b", z.narrow(1, 0, half))
+    ha = layer("conv0a", z.narrow(1, half, half))
+    for i in range(1, 6):
+        hb = layer(f"conv{i}b", torch.cat([ha, hb], 1), bn=i < 5)
+        ha = layer(f"conv{i}a", ha, bn=i < 5)
+    return torch.tanh(torch.cat([ha, hb], 1))
 
 
 # ----------------------------------------------------------------------------------

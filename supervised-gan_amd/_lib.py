@@ -64,7 +64,7 @@ class GanLossJob(C.Structure):
 
 class BnRunningDesc(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
-                ("num_batches_tracked", C.c_void_p), ("C", C.c_int32), ("count", C.c_int32)]
+                ("num_batches_tracked", C.c_void_p), ("C", C.c_int32), ("count", C.c_int32), ("sq_stride", C.c_int32)]
 
 
 class AdamSeg(C.Structure):

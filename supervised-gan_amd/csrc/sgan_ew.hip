@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void sg_bn_running_kernel(SgBnRunTable T) {
     if (threadIdx.x == 0 && L.num_batches_tracked) L.num_batches_tracked[0] += 1;
     for (int c = threadIdx.x; c < L.C; c += 256) {
         const double m = L.stats[c] * inv;
-        double var = L.stats[L.C + c] * inv - m * m;
+        double var = L.stats[(L.sq_stride ? L.sq_stride : L.C) + c] * inv - m * m;
         if (var < 0.0) var = 0.0;
         L.running_mean[c] = (1.f - T.momentum) * L.running_mean[c] + T.momentum * (float)m;
         L.running_var[c] = (1.f - T.momentum) * L.running_var[c] + T.momentum * (float)(var * unb);

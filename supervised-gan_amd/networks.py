@@ -145,18 +145,7 @@ class ChainNet(nn.Module):
     def __init__(self, layers: List[LayerSpec]):
         super().__init__()
         self.layers = layers
-        off = 0
-        for L in layers:
-            L.w_off = off
-            off += L.k * L.k * L.cout_s * L.cin_s
-            if L.bias:
-                L.b_off = off
-                off += L.cout_s
-            if L.norm == "bn":
-                L.g_off = off
-                off += L.cout_s
-                L.be_off = off
-                off += L.cout_s
+        off = self._assign_offsets(layers)
         self._nflat = off
         self._flat = torch.zeros(off, dtype=torch.float32)
         self._gflat = torch.zeros(off, dtype=torch.float32)
@@ -175,12 +164,29 @@ class ChainNet(nn.Module):
                 nb.register_buffer("running_mean", torch.zeros(L.cout))
                 nb.register_buffer("running_var", torch.ones(L.cout))
                 nb.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
-                self.model.add_module(str(int(L.key) + 1), nb)
+                parts = L.key.split(".")      # the norm is the next numbered child of the same nn.Sequential
+                self._add_box(".".join(parts[:-1] + [str(int(parts[-1]) + 1)]), nb)
                 self._bn_boxes[L.key] = nb
         self._rebind()
         self._default_bias_init()
         self.compute_param_grads = True   # trainers may clear this while only dX is wanted (G step)
         self._geom_cache = {}
+
+    def _assign_offsets(self, layers):
+        """Place every layer's weight / bias / BN affine in the flat storage; returns the total length."""
+        off = 0
+        for L in layers:
+            L.w_off = off
+            off += L.k * L.k * L.cout_s * L.cin_s
+            if L.bias:
+                L.b_off = off
+                off += L.cout_s
+            if L.norm == "bn":
+                L.g_off = off
+                off += L.cout_s
+                L.be_off = off
+                off += L.cout_s
+        return off
 
     # ---- module tree ---------------------------------------------------------------------------
     def _add_box(self, key, box):
@@ -377,7 +383,7 @@ class ChainNet(nn.Module):
                 if L.norm == "bn":
                     nb = self._bn_boxes[L.key]
                     _, _, _, ho, wo = geo[li]
-                    rl.append((stats[li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo))
+                    rl.append((stats[li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo, L.cout_s))
             ops.bn_running_update(rl, BN_MOMENTUM)
         return outs, stats
 
@@ -524,7 +530,7 @@ def _grouped_forward(nets, xs):
                 if L.norm == "bn":
                     nb = net._bn_boxes[L.key]
                     _, _, _, ho, wo = geos[j][li]
-                    rl.append((stats[j][li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo))
+                    rl.append((stats[j][li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo, L.cout_s))
             ops.bn_running_update(rl, BN_MOMENTUM)
     return outs, stats
 
@@ -725,6 +731,180 @@ class FCGANGenerator(ChainNet):
 
     def _wrap_output(self, y):
         return y
+
+
+class FCGANGeneratorStar(ChainNet):
+    """FCGANGeneratorStar (models/networks.py:543-640): two bias-free ConvT(k4,s2,p1) -> BatchNorm -> ReLU chains of six layers.
+    Chain a runs on the second half of the latent; every layer of chain b above the first reads cat([ha, hb]) of the level below;
+    the image is tanh(cat([ha, hb])).
+
+    Layout: both chains of a level write their raw outputs side by side into ONE [H, W, 2C] buffer (chain a the first C channels)
+    with one [sum(2C) | sumsq(2C)] statistics array, and the level's BN affine parameters sit side by side in the flat storage --
+    so the concatenation is never materialised: chain a's next layer reads the first half through a leading dimension, chain b's
+    the whole buffer.  Backward-data of the b layer writes all 2C channels, the a layer's accumulates into the first C."""
+
+    def __init__(self, noise_nc, input_nc, ngf=64, n_layers=3, use_dropout=False, use_fcn=False, gpu_ids=[]):
+        assert n_layers == 5 and use_fcn is True and input_nc == 2        # models/networks.py:550-552
+        half = int(noise_nc / 2)
+        ch = [ngf * 8, ngf * 8, ngf * 4, ngf * 2, ngf]
+        if ngf % 4:
+            raise NotImplementedError("FCGANGeneratorStar on the MI355X path needs ngf % 4 == 0 (channel slices are read in 16-byte chunks)")
+        self.ch, self.la, self.lb = ch, [], []
+        for i in range(6):
+            cout = ch[i] if i < 5 else 1
+            nrm, act = ("bn", ACT_RELU) if i < 5 else (None, ACT_NONE)
+            self.la.append(LayerSpec(f"conv{i}a.0", CONVT, 4, 2, 1, half if i == 0 else ch[i - 1], cout, False, nrm, act))
+            self.lb.append(LayerSpec(f"conv{i}b.0", CONVT, 4, 2, 1, half if i == 0 else 2 * ch[i - 1], cout, False, nrm, act))
+        super().__init__(self.la + self.lb)        # the reference's module order: chain a, then chain b
+        del self.model                              # layers are direct attributes there: no `model.` prefix in state_dict keys
+        self.noise_nc = half
+        self.gpu_ids = gpu_ids
+
+    def _param_root(self):
+        return self
+
+    def _assign_offsets(self, layers):
+        off = 0
+        for A, B in zip(self.la, self.lb):
+            for L in (A, B):
+                L.w_off = off
+                off += L.k * L.k * L.cout_s * L.cin_s
+            if A.norm == "bn":          # [gamma_a | gamma_b][beta_a | beta_b]: the affine of the concatenated tensor, contiguous
+                A.g_off, B.g_off = off, off + A.cout_s
+                off += 2 * A.cout_s
+                A.be_off, B.be_off = off, off + A.cout_s
+                off += 2 * A.cout_s
+        return off
+
+    def _desc(self, L, h, w):
+        key = ("star", L.key, h, w)
+        if key not in self._geom_cache:
+            ho, wo = L.out_hw(h, w)
+            self._geom_cache[key] = ops.conv_desc(L.kind, L.k, L.stride, L.pad, h, w, L.cin_s, ho, wo, L.cout_s, L.cin, L.cout)
+        return self._geom_cache[key]
+
+    def _level_norms(self, i, stats, count):
+        """How the next layers read level i: (chain a's half, the whole concatenation)."""
+        A, C = self.la[i], self.ch[i]
+        f = self._flat
+        na = ops.norm_desc(stats[i], f[A.g_off: A.g_off + C], f[A.be_off: A.be_off + C], count, BN_EPS, ACT_RELU, 0.0, sq_stride=2 * C)
+        nb = ops.norm_desc(stats[i], f[A.g_off: A.g_off + 2 * C], f[A.be_off: A.be_off + 2 * C], count, BN_EPS, ACT_RELU, 0.0)
+        return na, nb
+
+    def run_forward(self, x, update_running=True):
+        xa, xb = x["a"], x["b"]
+        ops.require_gpu(xa, type(self).__name__)
+        if self._flat.device != xa.device:
+            raise SganError(f"module parameters are on {self._flat.device}, input on {xa.device}")
+        dev, ch = xa.device, self.ch
+        n_stats = sum(4 * c for c in ch)
+        arena = torch.zeros(2 * n_stats, dtype=torch.float64, device=dev)      # forward statistics | backward sums
+        stats, o = [], 0
+        for c in ch:
+            stats.append(arena[o: o + 4 * c])
+            o += 4 * c
+        h, w = xa.shape[0], xa.shape[1]
+        cats, rl = [], []
+        src_a, src_b, na, nb = xa, xb, None, None
+        for i in range(5):
+            A, B, C = self.la[i], self.lb[i], ch[i]
+            ho, wo = A.out_hw(h, w)
+            cat = torch.empty((ho, wo, 2 * C), dtype=torch.float32, device=dev)
+            ops.conv_fwd(self._desc(B, h, w), src_b, nb, self._wb(B)[0], None, cat[..., C:], ACT_NONE, stats[i][C:], 2 * C)
+            ops.conv_fwd(self._desc(A, h, w), src_a, na, self._wb(A)[0], None, cat[..., :C], ACT_NONE, stats[i], 2 * C)
+            for L, st in ((A, stats[i]), (B, stats[i][C:])):
+                nbx = self._bn_boxes[L.key]
+                rl.append((st, nbx.running_mean, nbx.running_var, nbx.num_batches_tracked, C, ho * wo, 2 * C))
+            cats.append(cat)
+            h, w = ho, wo
+            na, nb = self._level_norms(i, stats, h * w)
+            src_a, src_b = cat[..., :C], cat
+        A, B = self.la[5], self.lb[5]
+        ho, wo = A.out_hw(h, w)
+        out_a = torch.empty((ho, wo, A.cout_s), dtype=torch.float32, device=dev)
+        out_b = torch.empty((ho, wo, B.cout_s), dtype=torch.float32, device=dev)
+        ops.conv_fwd(self._desc(B, h, w), src_b, nb, self._wb(B)[0], None, out_b, ACT_NONE, None)
+        ops.conv_fwd(self._desc(A, h, w), src_a, na, self._wb(A)[0], None, out_a, ACT_NONE, None)
+        if update_running:
+            ops.bn_running_update(rl, BN_MOMENTUM)
+        return (out_a, out_b), {"x": x, "cats": cats, "stats": stats, "bwd": _BwdArena(arena[n_stats:])}
+
+    def run_backward(self, x, outs, saved, douts, need_dx, want_wgrad):
+        """douts: gradients of the two raw last-layer outputs ([H, W, 4] each).  Returns (dxa, dxb) or (None, None)."""
+        xa, xb = saved["x"]["a"], saved["x"]["b"]
+        cats, stats, ch = saved["cats"], saved["stats"], self.ch
+        dev = xa.device
+        if want_wgrad:
+            self._ensure_grads()
+        n_stats = sum(4 * c for c in ch)
+        arena = saved["bwd"].take(n_stats)
+        sums, o = [], 0
+        for c in ch:
+            sums.append(arena[o: o + 4 * c])
+            o += 4 * c
+        d_a, d_b = douts
+        for i in range(5, 0, -1):               # layer i of both chains reads level i - 1
+            A, B, C, cat = self.la[i], self.lb[i], ch[i - 1], cats[i - 1]
+            h, w = cat.shape[0], cat.shape[1]
+            na, nb = self._level_norms(i - 1, stats, h * w)
+            da, db = self._desc(A, h, w), self._desc(B, h, w)
+            if want_wgrad:
+                ops.conv_wgrad(db, cat, nb, d_b, self._gwb(B)[0], None)
+                ops.conv_wgrad(da, cat[..., :C], na, d_a, self._gwb(A)[0], None)
+            dcat = torch.empty_like(cat)
+            ops.conv_dgrad(db, d_b, self._wt(B), dcat, cat, nb, sums[i - 1], w_transposed=True)
+            ops.conv_dgrad(da, d_a, self._wt(A), dcat[..., :C], cat[..., :C], na, sums[i - 1], sums_sq=2 * C, accumulate=True,
+                           w_transposed=True)
+            P = self.la[i - 1]
+            dg = self._gflat[P.g_off: P.g_off + 2 * C] if want_wgrad else None
+            dbe = self._gflat[P.be_off: P.be_off + 2 * C] if want_wgrad else None
+            ops.norm_bwd_apply(dcat, cat, nb, sums[i - 1], dg, dbe)
+            d_a, d_b = dcat[..., :C], dcat[..., C:]
+        A, B = self.la[0], self.lb[0]
+        h, w = xa.shape[0], xa.shape[1]
+        if want_wgrad:
+            ops.conv_wgrad(self._desc(B, h, w), xb, None, d_b, self._gwb(B)[0], None)
+            ops.conv_wgrad(self._desc(A, h, w), xa, None, d_a, self._gwb(A)[0], None)
+        if not need_dx:
+            return None, None
+        dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+        ops.conv_dgrad(self._desc(A, h, w), d_a, self._wt(A), dxa, None, None, None, w_transposed=True)
+        ops.conv_dgrad(self._desc(B, h, w), d_b, self._wt(B), dxb, None, None, None, w_transposed=True)
+        return dxa, dxb
+
+    def forward(self, noise, activation=None):
+        if activation is not None and not isinstance(activation, nn.Tanh):
+            raise NotImplementedError("only the default Tanh output activation is implemented")
+        ha, hb = _StarFn.apply(self, noise, *list(self.parameters()))
+        return torch.tanh(torch.cat([ha, hb], 1))
+
+    def _wrap_output(self, y):
+        return y
+
+
+class _StarFn(torch.autograd.Function):
+    """One autograd node for both chains of FCGANGeneratorStar; returns the two raw single-channel images."""
+
+    @staticmethod
+    def forward(ctx, net, noise, *params):
+        half = net.noise_nc
+        x = {"b": ops.as_nhwc(noise.narrow(1, 0, half)), "a": ops.as_nhwc(noise.narrow(1, half, half))}   # :626-629
+        (out_a, out_b), saved = net.run_forward(x)
+        ctx.net, ctx.saved = net, saved
+        ctx.need_dx = ctx.needs_input_grad[1]
+        ctx.want_wgrad = net.compute_param_grads and any(ctx.needs_input_grad[2:])
+        return ops.logical_view(out_a, 1), ops.logical_view(out_b, 1)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        net = ctx.net
+        dxa, dxb = net.run_backward(None, None, ctx.saved, (ops.as_nhwc(ga.contiguous()), ops.as_nhwc(gb.contiguous())), ctx.need_dx,
+                                    ctx.want_wgrad)
+        dz = None
+        if ctx.need_dx:
+            half = net.noise_nc
+            dz = torch.cat([ops.logical_view(dxb, half), ops.logical_view(dxa, half)], 1)
+        return (None, dz) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
 class DCGANGenerator(ChainNet):
@@ -1734,7 +1914,10 @@ def define_G(input_nc, output_nc, ngf, which_model_netG, norm='batch', use_dropo
         netG = AutoEncoder(input_nc, output_nc, n_layers_G, ngf, norm=norm, use_dropout=use_dropout, gpu_ids=gpu_ids)
     elif which_model_netG == 'dcgan':
         netG = DCGANGenerator(gpu_ids=gpu_ids, nz=noise_nc, nc=input_nc, ngf=ngf)
-    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks', 'fcgan_star'):
+    elif which_model_netG == 'fcgan_star':
+        netG = FCGANGeneratorStar(noise_nc, input_nc, ngf, n_layers=n_layers_G, use_dropout=use_dropout, use_fcn=use_fcn,
+                                  gpu_ids=gpu_ids)
+    elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks'):
         raise NotImplementedError('Generator model name [%s] is not on the MI355X path yet' % which_model_netG)
     else:
         raise NotImplementedError('Generator model name [%s] is not recognized' % which_model_netG)

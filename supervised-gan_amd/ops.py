@@ -236,10 +236,12 @@ def scale(gout, g, dx):
 
 
 def bn_running_update(layers, momentum=0.1):
-    """layers: list of (stats, running_mean, running_var, num_batches_tracked, C, count)."""
+    """layers: list of (stats, running_mean, running_var, num_batches_tracked, C, count[, sq_stride])."""
     arr = (L.BnRunningDesc * len(layers))()
-    for i, (st, rm, rv, nbt, c, cnt) in enumerate(layers):
-        arr[i] = L.BnRunningDesc(st.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr() if nbt is not None else 0, c, cnt)
+    for i, job in enumerate(layers):
+        st, rm, rv, nbt, c, cnt = job[:6]
+        arr[i] = L.BnRunningDesc(st.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr() if nbt is not None else 0, c, cnt,
+                                 int(job[6]) if len(job) > 6 else 0)
     L.check(L.lib().sgan_bn_running_update(arr, len(layers), momentum, _stream()), "sgan_bn_running_update")
 
 

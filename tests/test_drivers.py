@@ -37,6 +37,28 @@ def test_train_then_test_fcgan(tmp_path):
     assert im.shape == (128, 128, 3) and im[..., 2].max() == 0          # 2-channel label image: blue plane is zero
 
 
+def test_train_then_test_fcgan_star(tmp_path):
+    """`--which_model_netG fcgan_star` (models/networks.py:89-91) through the fcgan trainer, eager and as hipGraphs, then test.py."""
+    _need_gpu()
+    import test as test_driver
+    import train as train_driver
+    net = ["--name", "drv_star", "--model", "fcgan", "--which_direction", "A", "--dataset_mode", "single", "--fineSize", "128",
+           "--input_nc", "2", "--which_model_netG", "fcgan_star", "--n_layers_G", "5", "--ngf", "8", "--noise_nc", "8", "--noiseSize", "2",
+           "--norm", "instance", "--no_dropout", "--which_channel", "rg", "--gpu_ids", "0", "--checkpoints_dir", str(tmp_path / "ckpt"),
+           "--dataroot", "synthetic", "--manualSeed", "3"]
+    d = ["--which_model_netD", "n_layers", "--n_layers_D", "3", "3", "--ndf", "8", "--scale_factor", "1", "2", "--lambda_D", "0.6", "0.4",
+         "--n_update_G", "2", "--no_lsgan", "--max_steps", "3", "--print_freq", "1"]
+    for extra in ([], ["--graph"]):
+        m = train_driver.main(net + d + extra)
+        torch.cuda.synchronize()
+        n = 4 if extra else 3            # --graph: two capture steps on the first batch, then replays
+        assert m.optimizer_D.step_count == n and m.optimizer_G.step_count == 2 * n
+        assert all(np.isfinite(v) for v in m.get_current_errors().values())
+        assert int(m.netG.state_dict()["conv3b.1.num_batches_tracked"]) >= 6
+    out = test_driver.main(net + ["--results_dir", str(tmp_path / "res"), "--how_many", "2"])
+    assert len(out) == 2 and all(os.path.exists(p) for p in out)
+
+
 def test_train_then_test_cgan(tmp_path):
     _need_gpu()
     import test as test_driver

@@ -342,6 +342,40 @@ def test_dcgan_small(N, golden_dir):
             assert rel(dparams[k[7:]].grad, g[k]) < TOL, k
 
 
+def test_fcgan_star_small(N, golden_dir):
+    """`--which_model_netG fcgan_star` (models/networks.py:543-640): two deconv chains, chain b fed the concatenation of both
+    (written side by side, never concatenated here); output, latent gradient, every weight / BN gradient, running statistics."""
+    g = load(golden_dir, "fcgan_star_small.npz")
+    nz, ngf = 8, 4
+    G = N.define_G(2, 0, ngf, "fcgan_star", "batch", False, n_layers_G=5, use_fcn=True, noise_nc=nz, gpu_ids=[0])
+    sd = O.init_fcgan_star(81, nz, ngf)
+    assert list(G.state_dict().keys()) == list(sd.keys())
+    G.load_state_dict(sd)
+    z = O.np_normal(801, (1, nz, 2, 2)).cuda().requires_grad_(True)
+    y = G.forward(z)
+    (y * O.np_normal(802, tuple(y.shape)).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (1, 2, 128, 128)
+    assert rel(y, g["y"]) < TOL and rel(z.grad, g["dz"]) < TOL
+    params, bufs = dict(G.named_parameters()), G.state_dict()
+    n = 0
+    for k in g.files:
+        if k.startswith("grad/"):
+            # BN beta / gamma gradients of the deepest levels are sums of a few hundred terms that nearly cancel
+            assert rel(params[k[5:]].grad, g[k]) < (TOL if k.endswith(".0.weight") else 5 * TOL), k
+            n += 1
+        if k.startswith("buf/"):
+            assert rel(bufs[k[4:]].double(), g[k]) < 1e-4, k
+    assert n == 32
+    # G-step use inside a trainer: no parameter gradients wanted, second forward advances the running statistics again
+    G.zero_grad_flat()
+    G.compute_param_grads = False
+    y2 = G.forward(z.detach().requires_grad_(True))
+    y2.sum().backward()
+    assert float(G._gflat.abs().max()) == 0.0
+    assert int(bufs["conv0a.1.num_batches_tracked"]) == 2
+
+
 def test_fcgan_g_noisesize1(N, golden_dir):
     """FCGANGenerator with --noiseSize 1 (use_fcn False, models/networks.py:503-504): first ConvT k4 s1 p0 on a 1x1 latent."""
     g = load(golden_dir, "fcgan_g_nofcn_small.npz")

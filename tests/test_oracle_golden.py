@@ -491,6 +491,29 @@ def test_dcgan_small(golden_dir):
             assert rel(sdd[k[7:]].grad, g[k]) < 1e-4, k
 
 
+def test_fcgan_star_small(golden_dir):
+    """FCGANGeneratorStar (models/networks.py:543-640): two deconv chains, chain b fed cat(a, b)."""
+    g = load(golden_dir, "fcgan_star_small.npz")
+    nz, ngf = 8, 4
+    sd = O.init_fcgan_star(81, nz, ngf)
+    for k, v in sd.items():
+        if k.endswith((".weight", ".bias")):
+            v.requires_grad_(True)
+    z = O.np_normal(801, (1, nz, 2, 2)).requires_grad_(True)
+    y = O.fcgan_star_forward(sd, z, nz)
+    assert tuple(y.shape) == (1, 2, 128, 128)
+    (y * O.np_normal(802, tuple(y.shape))).sum().backward()
+    assert rel(y, g["y"]) < 1e-4 and rel(z.grad, g["dz"]) < 1e-4
+    n = 0
+    for k in g.files:
+        if k.startswith("grad/"):
+            assert rel(sd[k[5:]].grad, g[k]) < 1e-4, k
+            n += 1
+        if k.startswith("buf/"):
+            assert rel(sd[k[4:]].double(), g[k]) < 1e-5, k
+    assert n == 12 + 2 * 10
+
+
 def test_fcgan_g_noisesize1(golden_dir):
     """FCGANGenerator with a 1x1 latent (use_fcn False): first ConvT k4 s1 p0."""
     g = load(golden_dir, "fcgan_g_nofcn_small.npz")

@@ -1103,7 +1103,8 @@ static int sg_plan_ksplit(const SgIgemmParams& P, int BM, int BN) {
     // MFMA rate.  A split both fills the CUs and evens them out; pick it with sg_time_model().
     static const int mid = getenv("SGAN_NO_MID_SPLIT") ? 0 : 1;
     static const int mid_force = getenv("SGAN_MID_KS") ? atoi(getenv("SGAN_MID_KS")) : 0;    // tuning knob
-    if (mid && blocks > 192 && blocks <= 768 && nkt >= 128) {
+    static const int mid_nkt = getenv("SGAN_MID_NKT") ? atoi(getenv("SGAN_MID_NKT")) : 128;          // tuning knob
+    if (mid && blocks > 192 && blocks <= 768 && nkt >= mid_nkt) {
         const double slab_us = (double)Q.Hout * Q.Wout * P.N * 8.0 / 4e6;     // write + read of one slab at ~4 TB/s
         int best = 1;
         double best_cost = sg_time_model(blocks, nkt);

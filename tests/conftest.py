@@ -18,3 +18,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """Path of libsgan_hip.so; built first (hipcc cross-compiles gfx950 without a GPU) when a fresh checkout lacks it."""
+    from supervised_gan_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    assert os.path.exists(_lib.LIB_PATH), _lib.LIB_PATH
+    return _lib.LIB_PATH

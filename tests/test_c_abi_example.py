@@ -20,13 +20,13 @@ def _build(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not found")
-def test_c_abi_example_compiles(tmp_path):
+def test_c_abi_example_compiles(tmp_path, built_lib):
     """Header and library are self-contained for a C++ caller (no GPU needed to compile and link)."""
     assert os.path.exists(_build(tmp_path))
 
 
 @pytest.mark.gpu
-def test_c_abi_example_runs(tmp_path):
+def test_c_abi_example_runs(tmp_path, built_lib):
     exe = _build(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(out.stdout, out.stderr)

@@ -14,7 +14,7 @@ import sgan_oracle as O
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_c_abi_library_exports_every_declared_symbol():
+def test_c_abi_library_exports_every_declared_symbol(built_lib):
     """libsgan_hip.so loads without a GPU and exports exactly what include/sgan_hip.h declares."""
     from supervised_gan_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "sgan_hip.h")).read()

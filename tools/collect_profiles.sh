@@ -15,6 +15,9 @@ echo "== rocprofv3 kernel trace + stats of the bench command (hipGraph replay)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --steps 50 --warmup 10 --no_cpu_baseline > $OUT/rocprof_stats.log 2>&1; echo "exit $?"
 echo "== rocprofv3 kernel trace + stats, eager single stream (the regime of bench.py's live per-kernel measurement)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_eager -- python bench.py --eager --no_d_streams --steps 20 --warmup 5 --no_cpu_baseline > $OUT/rocprof_eager.log 2>&1; echo "exit $?"
+echo "== same for the secondary workloads (their roofline objects quote the 64x64 kernel)"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cgan_eager -- python bench.py --workload cgan --eager --no_d_streams --steps 10 --warmup 3 --no_cpu_baseline > $OUT/rocprof_cgan_eager.log 2>&1; echo "exit $?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_twostage_eager -- python bench.py --workload twostage_cycle --eager --no_d_streams --steps 10 --warmup 3 --no_cpu_baseline > $OUT/rocprof_twostage_eager.log 2>&1; echo "exit $?"
 echo "== rocprofv3 PMC passes (separate runs, eager, few steps)"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_FETCH_SIZE -- python tools/prof_step.py --steps 2 --no_d_streams > $OUT/pmc_fetch.log 2>&1; echo "exit $?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_WRITE_SIZE -- python tools/prof_step.py --steps 2 --no_d_streams > $OUT/pmc_write.log 2>&1; echo "exit $?"

@@ -30,7 +30,8 @@ def short(name):
     return n
 
 
-for tag, sub in (("bench", "stats"), ("bench_eager_1stream", "stats_eager")):
+for tag, sub in (("bench", "stats"), ("bench_eager_1stream", "stats_eager"), ("bench_cgan_eager_1stream", "stats_cgan_eager"),
+                 ("bench_twostage_eager_1stream", "stats_twostage_eager")):
     f = newest(f"{sub}/*/*_kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(dst, f"{R}_{tag}_kernel_stats.csv"))

@@ -582,3 +582,43 @@ def test_bilinear_up2_and_pyramid(hip):
     for s in range(6):
         assert rel(from_buf(bufs[s], 2), lvl[s]) < 5e-6, s    # hierarchical vs flat summation order
     assert rel(from_buf(dl, 2), lab.grad) < 1e-6
+
+
+def test_c_abi_error_paths(hip):
+    """Bad arguments come back as a negative status with a message (no exception across the ABI, nothing launched): geometry that
+    does not match the conv arithmetic, channel counts that are not multiples of 4, tensors beyond the 31-bit offsets, null tensors,
+    a grouped call mixing layer types, a LeakyReLU slope above 1, a net input smaller than its receptive field."""
+    from supervised_gan_amd import networks as N
+    from supervised_gan_amd._lib import SganError
+    ops = hip
+    x = torch.zeros(16, 16, 8, device="cuda")
+    w = torch.zeros(16 * 8 * 8, device="cuda")
+    y = torch.zeros(9, 9, 8, device="cuda")
+    good = ops.conv_desc(0, 4, 2, 2, 16, 16, 8, 9, 9, 8)
+    ops.conv_fwd(good, x, None, w, None, y)                                           # the baseline call is fine
+    with pytest.raises(SganError, match="geometry"):
+        ops.conv_fwd(ops.conv_desc(0, 4, 2, 2, 16, 16, 8, 8, 8, 8), x, None, w, None, y)
+    with pytest.raises(SganError, match="multiples of 4"):
+        ops.conv_fwd(ops.conv_desc(0, 4, 2, 2, 16, 16, 6, 9, 9, 8), x, None, w, None, y)
+    with pytest.raises(SganError, match="too large"):
+        ops.conv_fwd(ops.conv_desc(0, 4, 1, 2, 16384, 16384, 4, 16385, 16385, 4), x, None, w, None, y)
+    with pytest.raises(SganError, match="kernel size"):
+        ops.conv_fwd(ops.conv_desc(0, 7, 1, 3, 16, 16, 8, 16, 16, 8), x, None, w, None, y)
+    with pytest.raises(SganError, match="bad conv kind"):
+        ops.conv_fwd(ops.conv_desc(5, 4, 2, 2, 16, 16, 8, 9, 9, 8), x, None, w, None, y)
+    with pytest.raises(SganError, match="same layer type"):
+        other = ops.conv_desc(0, 4, 1, 2, 16, 16, 8, 17, 17, 8)
+        ops.conv_fwd_grouped([(good, x, None, w, None, y, None), (other, x, None, w, None, torch.zeros(17, 17, 8, device="cuda"), None)])
+    with pytest.raises(SganError, match="slope"):
+        ops.conv_fwd(good, x, ops.norm_desc(None, None, None, 256, 0.0, 2, 1.5), w, None, y)
+    rc = L_raw().sgan_conv_fwd(None, None, 0, None, None, None, None, 0, 0, None, None, 0, None)
+    assert rc < 0 and L_raw().sgan_last_error()
+    D = N.define_D(2, 8, "dcgan", gpu_ids=[0])             # five k4 s2 p1 convs, then k4 s1 p0 on what must be a 4x4 map
+    with pytest.raises(SganError, match="too small"):
+        D.forward(torch.rand(1, 2, 32, 32, device="cuda"))
+    torch.cuda.synchronize()
+
+
+def L_raw():
+    from supervised_gan_amd import _lib
+    return _lib.lib()

@@ -325,6 +325,14 @@ int sgan_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* s
 int sgan_to_nhwc(const float* src, int64_t sc, int64_t sh, int64_t sw, int32_t H, int32_t W, int32_t Creal,
                  float* dst, int32_t dst_ld, int32_t Cstore, void* stream);
 
+/* ---- input pipeline tail (data/base_dataset.py:17-55, data/aligned_dataset.py:31-42) ------------
+ * From a decoded (and, if asked, host-resized) RGB image `img` [H0][W0][3] uint8 already in device memory: crop the n x n window at
+ * (x0, y0) (transforms.RandomCrop / the aligned dataset's offsets) -> horizontal flip (RandomHorizontalFlip) -> rotate by
+ * 90 deg * rot counter-clockwise (__rotate: PIL's exact transpose path for square images) -> ToTensor (/255) -> Normalize(0.5, 0.5),
+ * written as an NHWC fp32 buffer [n][n][Cstore >= 3] (extra channels zero).  The random draws stay with the caller. */
+int sgan_image_prep(const unsigned char* img, int32_t H0, int32_t W0, int32_t x0, int32_t y0, int32_t n, int32_t flip, int32_t rot,
+                    float* dst, int32_t dst_ld, int32_t Cstore, void* stream);
+
 /* ---- Adam over up to 64 contiguous fp32 segments in one launch --------------------------------
  * torch.optim.Adam default form (models/fcgan_model.py:98-109):
  *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)

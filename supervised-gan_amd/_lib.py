@@ -95,6 +95,7 @@ SIGNATURES = {
     "sgan_l1w_fwd": [_P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _F, _P, _P, _I, _P, C.c_int64, _P],
     "sgan_scale": [_P, _P, _P, _L, _P],
     "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],
+    "sgan_image_prep": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "sgan_gauss_down_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "sgan_gauss_down_multi_fwd": [C.POINTER(GaussJob), _I, _I, _I, _P],
     "sgan_gauss_down_multi_bwd": [C.POINTER(GaussJob), _I, _I, _I, _I, _P],

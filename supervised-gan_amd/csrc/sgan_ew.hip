@@ -482,6 +482,47 @@ extern "C" int sgan_bn_running_update(const sgan_bn_running_desc* layers, int32_
 }
 
 // ------------------------------------------------------------------------------------------
+// Input pipeline tail: crop -> horizontal flip -> rotate by 90 deg * rot -> ToTensor -> Normalize(0.5, 0.5), one thread per
+// output pixel: a 4-byte store per selected channel, the decoded RGB bytes gathered from the crop window.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_image_prep_kernel(const unsigned char* img, int H0, int W0, int x0, int y0, int n, int flip,
+                                                            int rot, float* dst, int dst_ld, int Cstore) {
+    const int64_t total = (int64_t)n * n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int j = (int)(e % n), i = (int)(e / n);
+        // PIL's transpose(ROTATE_90 * rot) is counter-clockwise: R[i][j] = F[j][n-1-i] (rot 1), F[n-1-i][n-1-j] (2), F[n-1-j][i] (3)
+        int a = i, b = j;
+        if (rot == 1) { a = j; b = n - 1 - i; }
+        else if (rot == 2) { a = n - 1 - i; b = n - 1 - j; }
+        else if (rot == 3) { a = n - 1 - j; b = i; }
+        if (flip) b = n - 1 - b;
+        const unsigned char* px = img + ((int64_t)(y0 + a) * W0 + (x0 + b)) * 3;
+        float* o = dst + e * dst_ld;
+        for (int c = 0; c < Cstore; ++c) {
+            float v = 0.f;
+            if (c < 3) {
+                v = (float)px[c] / 255.f;         // ToTensor
+                v = (v - 0.5f) / 0.5f;            // Normalize((.5,.5,.5), (.5,.5,.5)), same operation order: bit-exact
+            }
+            o[c] = v;
+        }
+    }
+}
+
+extern "C" int sgan_image_prep(const unsigned char* img, int32_t H0, int32_t W0, int32_t x0, int32_t y0, int32_t n, int32_t flip,
+                               int32_t rot, float* dst, int32_t dst_ld, int32_t Cstore, void* stream) {
+    SGAN_CHECK(img && dst && H0 > 0 && W0 > 0 && n > 0, "bad argument");
+    SGAN_CHECK(x0 >= 0 && y0 >= 0 && x0 + n <= W0 && y0 + n <= H0, "crop window %d+%d x %d+%d outside the %d x %d image", x0, n, y0, n, W0, H0);
+    SGAN_CHECK(rot >= 0 && rot <= 3 && Cstore >= 3 && dst_ld >= Cstore, "bad rot / channel count");
+    int blocks = ew_cdiv((int64_t)n * n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sg_image_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, H0, W0, x0, y0, n, flip != 0, rot, dst,
+                       dst_ld, Cstore);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Gaussian pre-filter: depthwise (diagonal of the dense reference weight), strided outputs only
 // ------------------------------------------------------------------------------------------
 // one thread per (pixel, channel quad): 16-byte loads, the k x k taps of the channel's Gaussian from LDS

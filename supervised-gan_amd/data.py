@@ -1,0 +1,146 @@
+"""Image-folder feeders with the reference's transforms (data/single_dataset.py, data/aligned_dataset.py, data/base_dataset.py:17-55,
+data/image_folder.py): file listing and PIL decode / resize on the host, then ONE kernel per image on the device for
+crop -> flip -> rot90 -> ToTensor -> Normalize (`sgan_image_prep`), so the float image never exists in host memory and the
+trainers' set_input reads a device tensor.
+
+Yields what the reference's DataLoader yields at batchSize 1: {'A': [1, 3, H, W] in [-1, 1], 'A_paths': [path]} (single) or
+{'A', 'B', 'A_paths', 'B_paths'} (aligned, unaligned).  Random draws use Python's `random` like the reference; the aligned feeder makes them
+in the reference's order (aligned_dataset.py:31-38), the single feeder's crop offsets are torchvision-internal there and drawn
+here as x then y."""
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import ops
+
+IMG_EXTENSIONS = ['.jpg', '.JPG', '.jpeg', '.JPEG', '.png', '.PNG', '.ppm', '.PPM', '.bmp', '.BMP']      # image_folder.py:14-17
+
+
+def make_dataset(dir):
+    """All image files under `dir`, subdirectories included (data/image_folder.py:24-35)."""
+    assert os.path.isdir(dir), '%s is not a valid directory' % dir
+    images = []
+    for root, _, fnames in sorted(os.walk(dir)):
+        for fname in fnames:
+            if any(fname.endswith(e) for e in IMG_EXTENSIONS):
+                images.append(os.path.join(root, fname))
+    return images
+
+
+def _scale_width(img, target_width):
+    from PIL import Image
+    ow, oh = img.size
+    if ow == target_width:
+        return img
+    return img.resize((target_width, int(target_width * oh / ow)), Image.BILINEAR)      # base_dataset.py:43-50
+
+
+class _FolderDataset:
+    def __init__(self, opt, device=None):
+        self.opt = opt
+        self.device = device if device is not None else torch.device('cuda', opt.gpu_ids[0])
+        self.paths = sorted(make_dataset(os.path.join(opt.dataroot, opt.phase)))
+        if not self.paths:
+            raise RuntimeError('no images under %s' % os.path.join(opt.dataroot, opt.phase))
+        self.order = list(range(len(self.paths)))
+
+    def __len__(self):
+        return min(len(self.paths), self.opt.max_dataset_size) if getattr(self.opt, 'max_dataset_size', None) else len(self.paths)
+
+    def _to_device(self, img):
+        return torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device, non_blocking=True)      # [H, W, 3], a writable copy
+
+    def __iter__(self):
+        if not self.opt.serial_batches:
+            random.shuffle(self.order)
+        for i in self.order[:len(self)]:
+            yield self[i]
+
+
+class SingleFolderDataset(_FolderDataset):
+    """SingleDataset (data/single_dataset.py:8-31) + get_transform (data/base_dataset.py:17-41)."""
+
+    def __getitem__(self, index):
+        path = self.paths[index]
+        return {'A': ops.logical_view(self._transform(path), 3), 'A_paths': [path]}
+
+    def _transform(self, path):
+        from PIL import Image
+        opt = self.opt
+        img = Image.open(path).convert('RGB')
+        n = opt.fineSize
+        crop = True
+        if opt.resize_or_crop == 'resize_and_crop':
+            img = img.resize((opt.loadSize, opt.loadSize), Image.BILINEAR)      # transforms.Scale([loadSize, loadSize], BILINEAR)
+        elif opt.resize_or_crop == 'scale_width':
+            img, crop = _scale_width(img, opt.fineSize), False
+        elif opt.resize_or_crop == 'scale_width_and_crop':
+            img = _scale_width(img, opt.loadSize)
+        elif opt.resize_or_crop != 'crop':
+            raise ValueError('--resize_or_crop %s' % opt.resize_or_crop)
+        w, h = img.size
+        if crop:
+            if w < n or h < n:
+                raise ValueError('image %s is %dx%d after resizing, smaller than --fineSize %d' % (path, w, h, n))
+            x0, y0 = random.randint(0, w - n), random.randint(0, h - n)
+        else:
+            if w != h:
+                raise NotImplementedError('scale_width of a non-square image gives a non-square tensor; the MI355X feeder crops squares')
+            x0 = y0 = 0
+        flip = opt.isTrain and not opt.no_flip and random.random() < 0.5
+        rot = random.randint(0, 3) if (opt.isTrain and not opt.no_rotate) else 0
+        return ops.image_prep(self._to_device(img), x0, y0, n, flip, rot)
+
+
+class UnalignedFolderDataset(SingleFolderDataset):
+    """UnalignedDataset (data/unaligned_dataset.py:10-41): <root>/<phase>A and <root>/<phase>B, the i-th file of each (modulo its
+    length), each through its own draw of the single-image transform."""
+
+    def __init__(self, opt, device=None):
+        self.opt = opt
+        self.device = device if device is not None else torch.device('cuda', opt.gpu_ids[0])
+        self.A_paths = sorted(make_dataset(os.path.join(opt.dataroot, opt.phase + 'A')))
+        self.B_paths = sorted(make_dataset(os.path.join(opt.dataroot, opt.phase + 'B')))
+        if not self.A_paths or not self.B_paths:
+            raise RuntimeError('no images under %s{A,B}' % os.path.join(opt.dataroot, opt.phase))
+        self.paths = list(range(max(len(self.A_paths), len(self.B_paths))))
+        self.order = list(self.paths)
+
+    def __getitem__(self, index):
+        a, b = self.A_paths[index % len(self.A_paths)], self.B_paths[index % len(self.B_paths)]
+        return {'A': ops.logical_view(self._transform(a), 3), 'B': ops.logical_view(self._transform(b), 3), 'A_paths': [a], 'B_paths': [b]}
+
+
+class AlignedFolderDataset(_FolderDataset):
+    """AlignedDataset (data/aligned_dataset.py:10-46): A|B side by side in one file, bicubic resize to (2 loadSize, loadSize), the
+    same crop offsets and flip for both halves, no rotation."""
+
+    def __init__(self, opt, device=None):
+        assert opt.resize_or_crop == 'resize_and_crop'      # aligned_dataset.py:17
+        super().__init__(opt, device)
+
+    def __getitem__(self, index):
+        from PIL import Image
+        opt, path = self.opt, self.paths[index]
+        AB = Image.open(path).convert('RGB').resize((opt.loadSize * 2, opt.loadSize), Image.BICUBIC)
+        w, h, n = opt.loadSize, opt.loadSize, opt.fineSize
+        w_offset = random.randint(0, max(0, w - n - 1))
+        h_offset = random.randint(0, max(0, h - n - 1))
+        flip = (not opt.no_flip) and random.random() < 0.5
+        dev = self._to_device(AB)
+        A = ops.image_prep(dev, w_offset, h_offset, n, flip, 0)
+        B = ops.image_prep(dev, w + w_offset, h_offset, n, flip, 0)
+        return {'A': ops.logical_view(A, 3), 'B': ops.logical_view(B, 3), 'A_paths': [path], 'B_paths': [path]}
+
+
+def create_dataset(opt, device=None):
+    """CreateDataLoader / CreateDataset (data/custom_dataset_data_loader.py:6-25) at batchSize 1."""
+    if opt.dataset_mode == 'single':
+        return SingleFolderDataset(opt, device)
+    if opt.dataset_mode == 'aligned':
+        return AlignedFolderDataset(opt, device)
+    if opt.dataset_mode == 'unaligned':
+        return UnalignedFolderDataset(opt, device)
+    raise ValueError("Dataset [%s] not recognized." % opt.dataset_mode)

@@ -245,6 +245,17 @@ def bn_running_update(layers, momentum=0.1):
     L.check(L.lib().sgan_bn_running_update(arr, len(layers), momentum, _stream()), "sgan_bn_running_update")
 
 
+def image_prep(img_u8, x0, y0, n, flip, rot, out=None):
+    """img_u8: [H0, W0, 3] uint8 device tensor -> [n, n, 4] fp32 NHWC buffer in [-1, 1] (crop, flip, rot90, ToTensor, Normalize)."""
+    require_gpu(img_u8, "image_prep")
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3 and img_u8.is_contiguous(), (img_u8.shape, img_u8.dtype)
+    if out is None:
+        out = torch.empty((n, n, 4), dtype=torch.float32, device=img_u8.device)
+    L.check(L.lib().sgan_image_prep(_ptr(img_u8), img_u8.shape[0], img_u8.shape[1], int(x0), int(y0), int(n), int(bool(flip)), int(rot),
+                                    _ptr(_act(out)), out.stride(1), out.shape[2], _stream()), "sgan_image_prep")
+    return out
+
+
 def gauss_down_fwd(x, Creal, g, g_chan_stride, k, pad, s, out):
     H, W, Cs = x.shape
     Ho, Wo, _ = out.shape

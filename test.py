@@ -26,13 +26,18 @@ def main(argv=None):
             written.append(path)
 
     if opt.model.startswith('cgan'):       # only cgan needs a label image (test.py:27-41)
-        if opt.dataroot != 'synthetic':
-            raise NotImplementedError("only `--dataroot synthetic` ships with the MI355X path")
-        for i, data in enumerate(SyntheticDataset(opt, opt.how_many)):
+        if opt.dataroot == 'synthetic':
+            dataset = SyntheticDataset(opt, opt.how_many)
+        else:
+            from supervised_gan_amd.data import create_dataset
+            dataset = create_dataset(opt)
+        for i, data in enumerate(dataset):
+            if i >= opt.how_many:
+                break
             model.set_input(data)
             model.test()
             print('process image... %s' % model.get_image_paths())
-            dump(model.get_current_visuals(save_as_single_image=opt.save_as_single_image), os.path.splitext(data['A_paths'][0])[0])
+            dump(model.get_current_visuals(save_as_single_image=opt.save_as_single_image), os.path.splitext(os.path.basename(data['A_paths'][0]))[0])
     else:                                   # fcgan, twostage models (test.py:43-52)
         for i in range(opt.how_many):
             model.test()

@@ -123,3 +123,55 @@ def test_train_graphed(tmp_path):
     assert all(np.isfinite(v) for v in m.get_current_errors().values())
     assert m.optimizer_D.step_count == 2 + 5            # two capture steps on the first batch, then five replays
     assert os.path.exists(tmp_path / "ckpt" / "drv_graph" / "latest_net_G.pth")
+
+
+def _write_images(folder, n, w, h, seed):
+    from PIL import Image
+    os.makedirs(folder, exist_ok=True)
+    rng = np.random.RandomState(seed)
+    for i in range(n):
+        Image.fromarray(rng.randint(0, 256, size=(h, w, 3), dtype=np.uint8), "RGB").save(os.path.join(folder, "img_%02d.png" % i))
+
+
+def test_train_and_test_from_image_folders(tmp_path):
+    """`--dataroot <folder>`: the reference's single and aligned datasets (data/single_dataset.py, data/aligned_dataset.py) with their
+    transforms on the device; fcgan trains from <root>/train/*.png, cgan from side-by-side A|B files and samples from <root>/test."""
+    _need_gpu()
+    import test as test_driver
+    import train as train_driver
+    from supervised_gan_amd.data import SingleFolderDataset
+    from supervised_gan_amd.options import TrainOptions
+    root = tmp_path / "data"
+    _write_images(str(root / "single" / "train"), 5, 150, 140, 1)
+    common = ["--gpu_ids", "0", "--checkpoints_dir", str(tmp_path / "ckpt"), "--manualSeed", "3", "--norm", "instance", "--print_freq", "1"]
+    net = ["--name", "fold_fcgan", "--model", "fcgan", "--which_direction", "A", "--dataset_mode", "single", "--fineSize", "128",
+           "--loadSize", "143", "--input_nc", "2", "--which_model_netG", "deconv", "--n_layers_G", "5", "--ngf", "8", "--noise_nc", "8",
+           "--noiseSize", "2", "--no_dropout", "--which_channel", "rg", "--dataroot", str(root / "single"),
+           "--which_model_netD", "n_layers", "--n_layers_D", "3", "3", "--ndf", "8", "--scale_factor", "1", "2", "--lambda_D", "0.6", "0.4",
+           "--no_lsgan"]
+    m = train_driver.main(net + common + ["--max_steps", "4"])
+    assert m.optimizer_D.step_count == 4 and all(np.isfinite(v) for v in m.get_current_errors().values())
+    opt = TrainOptions().parse(net + common, save=False)
+    item = next(iter(SingleFolderDataset(opt)))
+    assert tuple(item["A"].shape) == (1, 3, 128, 128) and item["A"].is_cuda and float(item["A"].abs().max()) <= 1.0
+    assert os.path.dirname(item["A_paths"][0]) == str(root / "single" / "train")
+
+    _write_images(str(root / "pairs" / "train"), 4, 300, 150, 2)
+    _write_images(str(root / "pairs" / "test"), 2, 300, 150, 3)
+    cnet = ["--name", "fold_cgan", "--model", "cgan", "--which_direction", "AtoB", "--dataset_mode", "aligned", "--fineSize", "128",
+            "--loadSize", "140", "--which_model_netG", "unet_128", "--ngf", "8", "--which_channel", "rg_b", "--dataroot", str(root / "pairs")]
+    m = train_driver.main(cnet + common + ["--which_model_netD", "n_layers", "--n_layers_D", "3", "--ndf", "8", "--scale_factor", "1",
+                                          "--lambda_D", "1.0", "--no_lsgan", "--max_steps", "3"])
+    assert all(np.isfinite(v) for v in m.get_current_errors().values())
+    out = test_driver.main(cnet + ["--gpu_ids", "0", "--checkpoints_dir", str(tmp_path / "ckpt"), "--norm", "instance",
+                                   "--results_dir", str(tmp_path / "res"), "--how_many", "2"])
+    assert len(out) == 4 and all(os.path.exists(p) and os.path.dirname(p).startswith(str(tmp_path / "res")) for p in out)
+
+    _write_images(str(root / "unpaired" / "trainA"), 3, 150, 150, 4)
+    _write_images(str(root / "unpaired" / "trainB"), 2, 160, 150, 5)
+    unet = ["--name", "fold_cgan2", "--model", "cgan2", "--dataset_mode", "unaligned", "--fineSize", "128", "--loadSize", "140",
+            "--which_model_netG", "unet_128", "--ngf", "8", "--which_channel", "rg_b", "--dataroot", str(root / "unpaired"),
+            "--which_model_netD", "n_layers", "--n_layers_D", "3", "--ndf", "8", "--scale_factor", "1", "--lambda_D", "1.0", "--no_lsgan",
+            "--max_steps", "3"]
+    m = train_driver.main(unet + common)
+    assert all(np.isfinite(v) for v in m.get_current_errors().values())

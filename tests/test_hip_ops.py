@@ -622,3 +622,24 @@ def test_c_abi_error_paths(hip):
 def L_raw():
     from supervised_gan_amd import _lib
     return _lib.lib()
+
+
+def test_image_prep_bit_exact(hip):
+    """sgan_image_prep against the Pillow sequence of the reference's transforms: every flip / rotation, windows touching the image
+    border, a non-square source; integer gather and the two fp32 divisions are bit-exact."""
+    import image_prep as IP
+    from hip_utils import from_buf
+    ops = hip
+    rng = np.random.RandomState(6)
+    img = rng.randint(0, 256, size=(70, 131, 3), dtype=np.uint8)
+    dev = torch.from_numpy(img).cuda()
+    for x0, y0, n in ((0, 0, 70), (61, 0, 70), (17, 9, 48), (130, 69, 1)):
+        for flip in (False, True):
+            for rot in range(4):
+                buf = ops.image_prep(dev, x0, y0, n, flip, rot)
+                torch.cuda.synchronize()
+                assert tuple(buf.shape) == (n, n, 4) and float(buf[..., 3].abs().max()) == 0.0
+                assert np.array_equal(from_buf(buf, 3)[0].numpy(), IP.prep_pil(img, x0, y0, n, flip, rot)), (x0, y0, n, flip, rot)
+    from supervised_gan_amd._lib import SganError
+    with pytest.raises(SganError, match="outside"):
+        ops.image_prep(dev, 100, 0, 70, False, 0)

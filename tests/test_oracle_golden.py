@@ -529,3 +529,18 @@ def test_fcgan_g_noisesize1(golden_dir):
     for k in g.files:
         if k.startswith("grad/") and k.endswith(".weight") and sd[k[5:]].dim() == 4:
             assert rel(sd[k[5:]].grad, g[k]) < 1e-4, k
+
+
+def test_image_prep_restatement_matches_pillow():
+    """oracle/image_prep.py: the index-arithmetic restatement of crop -> flip -> rotate(90 k) -> ToTensor -> Normalize equals the
+    Pillow call sequence of the reference (data/base_dataset.py:17-55), bit for bit."""
+    import image_prep as IP
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    for x0, y0, n in ((0, 0, 37), (16, 3, 32), (21, 5, 17)):
+        for flip in (False, True):
+            for rot in range(4):
+                a, b = IP.prep_pil(img, x0, y0, n, flip, rot), IP.prep_numpy(img, x0, y0, n, flip, rot)
+                assert a.dtype == np.float32 and a.shape == (3, n, n)
+                assert np.array_equal(a, b), (x0, y0, n, flip, rot)
+    assert float(IP.prep_numpy(img, 0, 0, 8, False, 0).min()) >= -1.0 and float(IP.prep_numpy(img, 0, 0, 8, False, 0).max()) <= 1.0

@@ -7,7 +7,8 @@ optimize_parameters, error printing, `latest` / per-epoch checkpoints, linear LR
         --scale_factor 1 2 4 --lambda_D 0.5 0.4 0.1 --noise_nc 8 --noiseSize 8 --norm instance --no_dropout --n_update_G 2 \
         --no_lsgan --which_channel rg            (README.md:33 with `--dataroot synthetic`)
 
-Only the synthetic feeder ships (the image-folder pipeline of the reference is outside the hot path); `--max_steps N` bounds a run."""
+`--dataroot synthetic` feeds device-resident random images; any other `--dataroot` is read as the reference's image folder
+(`supervised_gan_amd/data.py`: single / aligned datasets, crop / flip / rotate / normalise on the device).  `--max_steps N` bounds a run."""
 import os
 import random
 import sys
@@ -37,9 +38,11 @@ def main(argv=None):
     random.seed(opt.manualSeed)
     np.random.seed(opt.manualSeed)
     torch.manual_seed(opt.manualSeed)
-    if opt.dataroot != 'synthetic':
-        raise NotImplementedError("only `--dataroot synthetic` ships with the MI355X path (data/ of the reference is out of scope)")
-    dataset = SyntheticDataset(opt, opt.epoch_size)
+    if opt.dataroot == 'synthetic':
+        dataset = SyntheticDataset(opt, opt.epoch_size)
+    else:                                   # an image folder: <dataroot>/<phase>/*.png, transforms of data/base_dataset.py
+        from supervised_gan_amd.data import create_dataset
+        dataset = create_dataset(opt)
     dataset_size = len(dataset)
     print('#training images = %d' % dataset_size)
     model = create_model(opt)

@@ -30,6 +30,9 @@ def test_train_then_test_fcgan(tmp_path):
     assert m.optimizer_D.step_count == 3 and m.optimizer_G.step_count == 6
     files = sorted(os.listdir(tmp_path / "ckpt" / "drv_fcgan"))
     assert [f for f in files if f.endswith(".pth")] == ["latest_net_D_0.pth", "latest_net_D_1.pth", "latest_net_G.pth"]
+    log = open(tmp_path / "ckpt" / "drv_fcgan" / "loss_log.txt").read().splitlines()          # util/visualizer.py:126-133
+    assert log[0].startswith("================ Training Loss") and len(log) == 4 and log[3].startswith("(epoch: 1, iters: 3, time: ")
+    assert "G_GAN: " in log[3] and "D_real: " in log[3] and "D_fake: " in log[3]
     out = test_driver.main(net + ["--results_dir", str(tmp_path / "res"), "--how_many", "2"])
     assert len(out) == 2 and all(os.path.exists(p) for p in out)
     from PIL import Image

@@ -46,6 +46,10 @@ def main(argv=None):
     dataset_size = len(dataset)
     print('#training images = %d' % dataset_size)
     model = create_model(opt)
+    log_name = os.path.join(opt.checkpoints_dir, opt.name, 'loss_log.txt')       # util/visualizer.py:27-30,126-133
+    os.makedirs(os.path.dirname(log_name), exist_ok=True)
+    with open(log_name, "a") as log_file:
+        log_file.write('================ Training Loss (%s) ================\n' % time.strftime("%c"))
     graphed = None
     if opt.graph:
         from supervised_gan_amd.graph_step import GraphedStep
@@ -67,7 +71,10 @@ def main(argv=None):
             if total_steps % opt.print_freq == 0:
                 errors = model.get_current_errors()
                 t = (time.time() - iter_start_time) / opt.batchSize
-                print('(epoch: %d, iters: %d, time: %.3f) ' % (epoch, epoch_iter, t) + ' '.join('%s: %.3f' % kv for kv in errors.items()))
+                message = '(epoch: %d, iters: %d, time: %.3f) ' % (epoch, epoch_iter, t) + ''.join('%s: %.3f ' % kv for kv in errors.items())
+                print(message)
+                with open(log_name, "a") as log_file:
+                    log_file.write('%s\n' % message)
             if total_steps % opt.save_latest_freq == 0:
                 print('saving the latest model (epoch %d, total_steps %d)' % (epoch, total_steps))
                 model.save('latest')

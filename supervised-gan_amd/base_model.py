@@ -34,43 +34,35 @@ class BaseModel:
     def set_input(self, input):
         self.input = input
 
-    def forward(self):
-        pass
-
-    def test(self):
-        pass
-
-    def get_image_paths(self):
-        pass
-
-    def optimize_parameters(self):
-        pass
-
     def get_current_visuals(self):
         return self.input
 
     def get_current_errors(self):
         return {}
 
-    def save(self, label):
-        pass
+    # ---- checkpoints -----------------------------------------------------------------------------
+    def _checkpoint_path(self, network_label, epoch_label, model_dir):
+        """`<epoch>_net_<label>.pth` under the run's directory, or under --pretrained_model_dir when the caller asks for the
+        pretrained copy (any true `model_dir`: the reference ignores its value and reads opt.pretrained_model_dir, :46-49,56-59)."""
+        return os.path.join(self.model_dir if model_dir else self.save_dir, '%s_net_%s.pth' % (epoch_label, network_label))
 
     def save_network(self, network, network_label, epoch_label, gpu_ids=[], model_dir=''):
-        save_filename = '%s_net_%s.pth' % (epoch_label, network_label)
-        save_path = os.path.join(model_dir or self.save_dir, save_filename)
-        os.makedirs(os.path.dirname(save_path), exist_ok=True)
-        # same content as `torch.save(network.cpu().state_dict(), path)` without moving the live module
-        sd = OrderedDict((k, v.detach().to('cpu').contiguous()) for k, v in network.state_dict().items())
-        torch.save(sd, save_path)
+        path = self._checkpoint_path(network_label, epoch_label, model_dir)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        # same file content as torch.save(network.cpu().state_dict(), path), without moving the live module off the GPU
+        torch.save(OrderedDict((k, v.detach().to('cpu').contiguous()) for k, v in network.state_dict().items()), path)
 
     def load_network(self, network, network_label, epoch_label, model_dir=''):
-        save_filename = '%s_net_%s.pth' % (epoch_label, network_label)
-        save_path = os.path.join(model_dir or self.save_dir, save_filename)
-        sd = torch.load(save_path, map_location='cpu')
-        load_state_dict_compat(network, sd)
+        load_state_dict_compat(network, torch.load(self._checkpoint_path(network_label, epoch_label, model_dir), map_location='cpu'))
 
-    def update_learning_rate(self):
-        pass
+
+def _not_overridden(self, *args, **kwargs):
+    return None
+
+
+# the rest of the trainer protocol: hooks a subclass overrides, no-ops here (models/base_model.py:21-39,63-64)
+for _hook in ('forward', 'test', 'get_image_paths', 'optimize_parameters', 'save', 'update_learning_rate'):
+    setattr(BaseModel, _hook, _not_overridden)
 
 
 def load_state_dict_compat(network, sd):

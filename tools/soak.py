@@ -1,4 +1,4 @@
-"""Soak run of the graphed fcgan step: N steps, losses must stay finite and device memory flat (diagnostic)."""
+"""Soak run of a graphed step (fcgan, cgan or twostage_cycle): N steps, losses must stay finite and device memory flat (diagnostic)."""
 import argparse
 import os
 import sys
@@ -12,10 +12,11 @@ from supervised_gan_amd.graph_step import GraphedStep  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=1500)
+ap.add_argument("--workload", default="fcgan", choices=["fcgan", "cgan", "twostage_cycle"])
 a = ap.parse_args()
 args = argparse.Namespace(n_update_G=2, skip_wasted_D_wgrad=False, no_d_streams=False, no_group=False)
 torch.cuda.set_device(0)
-model = bench.build_model(args, 0)
+model = {"fcgan": bench.build_model, "cgan": bench.build_cgan, "twostage_cycle": bench.build_twostage}[a.workload](args, 0)
 ring = bench.synthetic_ring(64, 0, torch.device("cuda", 0))
 gs = GraphedStep(model)
 gs.capture(ring[0])
@@ -30,5 +31,6 @@ for i in range(a.steps):
         assert ok, e
 torch.cuda.synchronize()
 assert torch.cuda.memory_allocated() <= mem0 + (160 << 20), (mem0, torch.cuda.memory_allocated())   # the 50-image pool is 100 MiB
-assert torch.isfinite(model.netG._flat).all() and all(torch.isfinite(d._flat).all() for d in model.netD)
+nets = [model.netG1, model.netG2, model.netF2] + model.netD1 + model.netD2 if a.workload == "twostage_cycle" else [model.netG] + model.netD
+assert all(torch.isfinite(n._flat).all() for n in nets)
 print("soak OK")

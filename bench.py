@@ -336,6 +336,8 @@ def main():
         sdist.broadcast_parameters(nets)
         model.grad_sync = sdist.GradAverager()
 
+    if os.environ.get("SGAN_FORCE_SEGMENTS") and model.grad_sync is None:     # diagnostic: the N > 1 graph cuts without the collectives
+        model.grad_sync = lambda optimizer: None
     if args.eager:
         def step(i):
             model.set_input(ring[i % len(ring)])

@@ -172,6 +172,23 @@ class ChainNet(nn.Module):
         self.compute_param_grads = True   # trainers may clear this while only dX is wanted (G step)
         self._geom_cache = {}
 
+    def _take_call_act(self):
+        """Output activation of THIS call: `final_act`, unless forward() was handed its own callable -- then the chain ends raw
+        (ACT_NONE) and the callable runs on the logical output (the reference's `activation=` argument, models/networks.py:535-540)."""
+        act = getattr(self, "_call_act", None)
+        self._call_act = None
+        return self.final_act if act is None else act
+
+    def _apply_with_activation(self, activation, run):
+        """run() -> output of the autograd node; a non-Tanh `activation` switches the fused tanh off for this call."""
+        custom = activation is not None and not isinstance(activation, nn.Tanh)
+        self._call_act = ACT_NONE if custom else None
+        try:
+            y = run()
+        finally:
+            self._call_act = None
+        return activation(y) if custom else y
+
     def _assign_offsets(self, layers):
         """Place every layer's weight / bias / BN affine in the flat storage; returns the total length."""
         off = 0
@@ -355,6 +372,7 @@ class ChainNet(nn.Module):
         H, W, Cs = x.shape
         assert Cs == self.layers[0].cin_s, (Cs, self.layers[0].cin_s)
         geo = self._geometry(H, W)
+        final_act = self._take_call_act()
         n_stats = sum(2 * L.cout_s for L in self.layers if L.norm)
         # one zero-fill serves the forward statistics and the backward sums (second half, consumed by run_backward)
         arena = torch.zeros(max(2 * n_stats, 1), dtype=torch.float64, device=x.device)
@@ -366,6 +384,7 @@ class ChainNet(nn.Module):
             else:
                 stats.append(None)
         stats.append(_BwdArena(arena[n_stats:]))
+        stats[-1].final_act = final_act
         outs = []
         cur = x
         for li, L in enumerate(self.layers):
@@ -374,7 +393,7 @@ class ChainNet(nn.Module):
             in_norm = self._norm_of(li - 1, stats, h * w) if li > 0 else None
             wt, b = self._wb(L)
             last = li == len(self.layers) - 1
-            ops.conv_fwd(desc, cur, in_norm, wt, b, out, self.final_act if last else ACT_NONE, stats[li])
+            ops.conv_fwd(desc, cur, in_norm, wt, b, out, final_act if last else ACT_NONE, stats[li])
             outs.append(out)
             cur = out
         if update_running and self._bn_boxes:
@@ -395,7 +414,7 @@ class ChainNet(nn.Module):
         if want_wgrad:
             self._ensure_grads()
         dcur = dout
-        if self.final_act == ACT_TANH:
+        if getattr(stats[-1], "final_act", self.final_act) == ACT_TANH:
             d2 = torch.empty_like(outs[-1])
             ops.tanh_bwd(dcur.contiguous(), outs[-1], d2)
             dcur = d2
@@ -724,10 +743,8 @@ class FCGANGenerator(ChainNet):
         return ops.logical_view(dchain, self.layers[0].cin)
 
     def forward(self, x, activation=None):
-        if activation is not None and not isinstance(activation, nn.Tanh):
-            raise NotImplementedError("only the default Tanh output activation is implemented")
         params = list(self.model.parameters())
-        return _ChainFn.apply(self, x, *params)
+        return self._apply_with_activation(activation, lambda: _ChainFn.apply(self, x, *params))
 
     def _wrap_output(self, y):
         return y
@@ -873,10 +890,9 @@ class FCGANGeneratorStar(ChainNet):
         return dxa, dxb
 
     def forward(self, noise, activation=None):
-        if activation is not None and not isinstance(activation, nn.Tanh):
-            raise NotImplementedError("only the default Tanh output activation is implemented")
         ha, hb = _StarFn.apply(self, noise, *list(self.parameters()))
-        return torch.tanh(torch.cat([ha, hb], 1))
+        y = torch.cat([ha, hb], 1)
+        return torch.tanh(y) if activation is None else activation(y)
 
     def _wrap_output(self, y):
         return y
@@ -1016,9 +1032,7 @@ class AutoEncoder(ChainNet):
         return ops.logical_view(dchain, self.input_nc)
 
     def forward(self, x, noise=None, activation=None):
-        if activation is not None and not isinstance(activation, nn.Tanh):
-            raise NotImplementedError("only the default Tanh output activation is implemented")
-        return _ChainFn.apply(self, x, *list(self.model.parameters()))
+        return self._apply_with_activation(activation, lambda: _ChainFn.apply(self, x, *list(self.model.parameters())))
 
     def _wrap_output(self, y):
         return y
@@ -1231,10 +1245,11 @@ class UnetGenerator(ChainNet):
         L = self.up[0]
         wt, b = self._wb(L)
         out = torch.empty((H, W, L.cout_s), dtype=torch.float32, device=dev)
-        ops.conv_fwd(upd[0], cat[1], self._cat_norm(1, hw, catstat), wt, b, out, self.final_act, None)
+        final_act = self._take_call_act()
+        ops.conv_fwd(upd[0], cat[1], self._cat_norm(1, hw, catstat), wt, b, out, final_act, None)
         if self._rng_drawn:
             ops.rng_advance(self._rng_offset, self._rng_drawn)
-        saved = dict(x=x, hw=hw, cat=cat, catw=catw, catstat=catstat, ustat=ustat, xr=xr, xstat=xstat, u=u, masks=masks,
+        saved = dict(final_act=final_act, x=x, hw=hw, cat=cat, catw=catw, catstat=catstat, ustat=ustat, xr=xr, xstat=xstat, u=u, masks=masks,
                      out=out, lay=lay, total=total, bwd=_BwdArena(arena[total:]))
         return [out], saved
 
@@ -1245,8 +1260,11 @@ class UnetGenerator(ChainNet):
         cat, catw, catstat, ustat, xr, xstat, u, masks = (S[k] for k in ("cat", "catw", "catstat", "ustat", "xr", "xstat", "u", "masks"))
         if want_wgrad:
             self._ensure_grads()
-        d0 = torch.empty_like(S["out"])
-        ops.tanh_bwd(dout.contiguous(), S["out"], d0)
+        if S["final_act"] == ACT_TANH:
+            d0 = torch.empty_like(S["out"])
+            ops.tanh_bwd(dout.contiguous(), S["out"], d0)
+        else:
+            d0 = dout.contiguous()
         lay = S["lay"]
         arena = S["bwd"].take(S["total"])
         csum, usum, xsum = [None] * (n + 1), [None] * (n + 1), [None] * n
@@ -1324,10 +1342,8 @@ class UnetGenerator(ChainNet):
 
     def forward(self, x, noise=None, activation=None):
         """`noise` is accepted and ignored like in the reference (models/networks.py:362)."""
-        if activation is not None and not isinstance(activation, nn.Tanh):
-            raise NotImplementedError("only the default Tanh output activation is implemented")
         params = list(self.model.parameters())
-        return _ChainFn.apply(self, x, *params)
+        return self._apply_with_activation(activation, lambda: _ChainFn.apply(self, x, *params))
 
     def _wrap_output(self, y):
         return y
@@ -1435,7 +1451,8 @@ class CascadedRefinementNetwork(ChainNet):
             L = self.lab[s]
             wt, b = self._wb(L)
             ops.conv_fwd(self._desc(L, *res[s]), lv[s], None, wt, b, cat[s][:, :, :ngf], ACT_NONE, st(("cat", s), 2 * C2), C2)
-        saved = dict(label=label, first=x["first"], lv=lv, cat=cat, c={}, u={}, t={}, arena=arena, lay=lay, off=off, res=res)
+        final_act = self._take_call_act()
+        saved = dict(final_act=final_act, label=label, first=x["first"], lv=lv, cat=cat, c={}, u={}, t={}, arena=arena, lay=lay, off=off, res=res)
         out = None
         for s in range(5, -1, -1):
             h, w = res[s]
@@ -1460,7 +1477,7 @@ class CascadedRefinementNetwork(ChainNet):
                 last_i = i == nlb - 1
                 if last_i and s == 0:
                     out = torch.empty((2 * h, 2 * w, L.cout_s), dtype=torch.float32, device=dev)
-                    ops.conv_fwd(self._desc(L, 2 * h, 2 * w), cur, nrm, wt, b, out, self.final_act, None)
+                    ops.conv_fwd(self._desc(L, 2 * h, 2 * w), cur, nrm, wt, b, out, final_act, None)
                 elif last_i:   # feeds the next stage: right half of its concat buffer, statistics into the matching slice
                     dst = cat[s - 1][:, :, ngf:]
                     ops.conv_fwd(self._desc(L, 2 * h, 2 * w), cur, nrm, wt, b, dst, ACT_NONE, st(("cat", s - 1), 2 * C2)[ngf:], C2)
@@ -1489,8 +1506,11 @@ class CascadedRefinementNetwork(ChainNet):
                 gw, gb = self._gwb(L)
                 ops.conv_wgrad(desc, src, nrm, dy, gw, gb)
 
-        d = torch.empty_like(S["out"])
-        ops.tanh_bwd(dout.contiguous(), S["out"], d)
+        if S["final_act"] == ACT_TANH:
+            d = torch.empty_like(S["out"])
+            ops.tanh_bwd(dout.contiguous(), S["out"], d)
+        else:
+            d = dout.contiguous()
         dcat_next = None        # gradient w.r.t. cat[s - 1] produced while walking stage s - 1; consumed by stage s
         dlv = [None] * 6
         dfirst = None
@@ -1545,10 +1565,8 @@ class CascadedRefinementNetwork(ChainNet):
 
     # ---- module protocol ---------------------------------------------------------------------------
     def forward(self, label, noise, activation=None):
-        if activation is not None and not isinstance(activation, nn.Tanh):
-            raise NotImplementedError("only the default Tanh output activation is implemented")
         params = list(self.parameters())
-        return _CrnFn.apply(self, label, noise, *params)
+        return self._apply_with_activation(activation, lambda: _CrnFn.apply(self, label, noise, *params))
 
     def _wrap_output(self, y):
         return y

@@ -391,3 +391,73 @@ def test_fcgan_g_noisesize1(N, golden_dir):
     for k in g.files:
         if k.startswith("grad/") and k.endswith(".weight") and params[k[5:]].dim() == 4:
             assert rel(params[k[5:]].grad, g[k]) < TOL, k
+
+
+def test_generators_with_a_callers_output_activation(N):
+    """The reference's generators take `activation=` (models/networks.py:362,535,708; the segmentation trainer passes the identity,
+    segm_model.py:155): the fused tanh is switched off for that call and the callable runs on the raw output.  fcgan, U-Net and CRN
+    against the oracle's `tanh=False` forward on the CPU: output, input gradient, the first and last weight gradients."""
+    ident = lambda t: t                                                    # noqa: E731
+
+    def grads_of(sd):
+        return {k: v for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+
+    # fcgan generator, softsign as the caller's activation
+    sd = O.init_fcgan_g(11, 8, 2, 8, 5)
+    G = N.define_G(2, 0, 8, "fcgan", "instance", False, n_layers_G=5, use_fcn=True, noise_nc=8, gpu_ids=[0])
+    G.load_state_dict(sd)
+    z = O.np_normal(101, (1, 8, 2, 2))
+    r = O.np_normal(102, (1, 2, 128, 128))
+    zc = z.clone().requires_grad_(True)
+    for v in grads_of(sd).values():
+        v.requires_grad_(True)
+    yo = torch.nn.functional.softsign(O.fcgan_g_forward(sd, zc, 5, tanh=False))
+    (yo * r).sum().backward()
+    zg = z.cuda().requires_grad_(True)
+    y = G.forward(zg, activation=torch.nn.functional.softsign)
+    (y * r.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, yo) < TOL and rel(zg.grad, zc.grad) < TOL
+    P = dict(G.named_parameters())
+    assert rel(P["model.0.weight"].grad, sd["model.0.weight"].grad) < TOL and rel(P["model.15.weight"].grad, sd["model.15.weight"].grad) < TOL
+    y_t = G.forward(zg.detach())                                            # the next plain call is a tanh call again
+    assert rel(y_t, torch.tanh(O.fcgan_g_forward(O.init_fcgan_g(11, 8, 2, 8, 5), z, 5, tanh=False, update_running=False))) < TOL
+
+    # U-Net (no dropout / noise), identity
+    sd = O.init_unet(31, 7, 2, 1, 8, -1)
+    G = N.define_G(2, 1, 8, "unet_128", "instance", False, gpu_ids=[0])
+    G.load_state_dict(sd)
+    x = O.np_uniform(301, (1, 2, 256, 256))
+    r = O.np_normal(302, (1, 1, 256, 256))
+    xc = x.clone().requires_grad_(True)
+    for v in grads_of(sd).values():
+        v.requires_grad_(True)
+    yo = O.unet_forward(sd, xc, 7, 8, tanh=False)
+    (yo * r).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = G.forward(xg, activation=ident)
+    (y * r.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert float(y.abs().max()) > 1.0 or rel(y, yo) < TOL                  # raw logits are not confined to (-1, 1)
+    assert rel(y, yo) < TOL and rel(xg.grad, xc.grad) < TOL
+    P = dict(G.named_parameters())
+    assert rel(P["model.0.weight"].grad, sd["model.0.weight"].grad) < TOL and rel(P["model.3.weight"].grad, sd["model.3.weight"].grad) < TOL
+
+    # CRN (bilinear, 2-layer blocks), identity
+    sd = O.init_crn(41, 2, 1, 8, 8, "bilinear", 2, True)
+    G = N.define_G(2, 1, 8, "crn", "instance", False, n_layers_G=5, noise_nc=8, upsample_mode="bilinear", n_layers_CRN_block=2,
+                   share_label_weights=True, gpu_ids=[0])
+    G.load_state_dict(sd)
+    label, zz, r = O.np_uniform(401, (1, 2, 128, 128)), O.np_normal(402, (1, 8, 2, 2)), O.np_normal(403, (1, 1, 128, 128))
+    lc, zc = label.clone().requires_grad_(True), zz.clone().requires_grad_(True)
+    for v in grads_of(sd).values():
+        v.requires_grad_(True)
+    yo = O.crn_forward(sd, lc, zc, 8, "bilinear", 2, True, tanh=False)
+    (yo * r).sum().backward()
+    lg, zg = label.cuda().requires_grad_(True), zz.cuda().requires_grad_(True)
+    y = G.forward(lg, zg, activation=ident)
+    (y * r.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, yo) < TOL and rel(lg.grad, lc.grad) < TOL and rel(zg.grad, zc.grad) < TOL
+    last = [k for k in sd if k.endswith(".weight")][-1]
+    assert rel(dict(G.named_parameters())[last].grad, sd[last].grad) < TOL

@@ -52,34 +52,66 @@ class _FolderDataset:
     def _to_device(self, img):
         return torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device, non_blocking=True)      # [H, W, 3], a writable copy
 
+    # An item is made in two halves: _host(index) -- file read, decode, resize: no random draws, safe on worker threads (PIL drops
+    # the GIL while it decodes) -- and _device(index, host) -- the random draws in the reference's order, the upload, the kernel.
+    def __getitem__(self, index):
+        return self._device(index, self._host(index))
+
     def __iter__(self):
+        """--nThreads host decodes run ahead of the consumer (the reference's DataLoader workers, data/custom_dataset_data_loader.py:
+        32-37); the random draws and the device work stay on the calling thread, so an epoch is the same with or without them."""
         if not self.opt.serial_batches:
             random.shuffle(self.order)
-        for i in self.order[:len(self)]:
-            yield self[i]
+        order = self.order[:len(self)]
+        workers = int(getattr(self.opt, 'nThreads', 0) or 0)
+        if workers <= 0:
+            for i in order:
+                yield self[i]
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            ahead, todo = deque(), iter(order)
+            for i in todo:
+                ahead.append((i, pool.submit(self._host, i)))
+                if len(ahead) >= 2 * workers:
+                    break
+            while ahead:
+                i, fut = ahead.popleft()
+                nxt = next(todo, None)
+                if nxt is not None:
+                    ahead.append((nxt, pool.submit(self._host, nxt)))
+                yield self._device(i, fut.result())
 
 
 class SingleFolderDataset(_FolderDataset):
     """SingleDataset (data/single_dataset.py:8-31) + get_transform (data/base_dataset.py:17-41)."""
 
-    def __getitem__(self, index):
-        path = self.paths[index]
-        return {'A': ops.logical_view(self._transform(path), 3), 'A_paths': [path]}
+    def _host(self, index):
+        return self._decode(self.paths[index])
 
-    def _transform(self, path):
+    def _device(self, index, img):
+        path = self.paths[index]
+        return {'A': ops.logical_view(self._draw_and_prep(img, path), 3), 'A_paths': [path]}
+
+    def _decode(self, path):
         from PIL import Image
         opt = self.opt
         img = Image.open(path).convert('RGB')
-        n = opt.fineSize
-        crop = True
         if opt.resize_or_crop == 'resize_and_crop':
             img = img.resize((opt.loadSize, opt.loadSize), Image.BILINEAR)      # transforms.Scale([loadSize, loadSize], BILINEAR)
         elif opt.resize_or_crop == 'scale_width':
-            img, crop = _scale_width(img, opt.fineSize), False
+            img = _scale_width(img, opt.fineSize)
         elif opt.resize_or_crop == 'scale_width_and_crop':
             img = _scale_width(img, opt.loadSize)
         elif opt.resize_or_crop != 'crop':
             raise ValueError('--resize_or_crop %s' % opt.resize_or_crop)
+        img.load()
+        return img
+
+    def _draw_and_prep(self, img, path):
+        opt, n = self.opt, self.opt.fineSize
+        crop = opt.resize_or_crop != 'scale_width'
         w, h = img.size
         if crop:
             if w < n or h < n:
@@ -108,9 +140,15 @@ class UnalignedFolderDataset(SingleFolderDataset):
         self.paths = list(range(max(len(self.A_paths), len(self.B_paths))))
         self.order = list(self.paths)
 
-    def __getitem__(self, index):
+    def _host(self, index):
         a, b = self.A_paths[index % len(self.A_paths)], self.B_paths[index % len(self.B_paths)]
-        return {'A': ops.logical_view(self._transform(a), 3), 'B': ops.logical_view(self._transform(b), 3), 'A_paths': [a], 'B_paths': [b]}
+        return self._decode(a), self._decode(b)
+
+    def _device(self, index, imgs):
+        a, b = self.A_paths[index % len(self.A_paths)], self.B_paths[index % len(self.B_paths)]
+        A = self._draw_and_prep(imgs[0], a)          # A's draws first, then B's (unaligned_dataset.py:32-33)
+        B = self._draw_and_prep(imgs[1], b)
+        return {'A': ops.logical_view(A, 3), 'B': ops.logical_view(B, 3), 'A_paths': [a], 'B_paths': [b]}
 
 
 class AlignedFolderDataset(_FolderDataset):
@@ -121,10 +159,13 @@ class AlignedFolderDataset(_FolderDataset):
         assert opt.resize_or_crop == 'resize_and_crop'      # aligned_dataset.py:17
         super().__init__(opt, device)
 
-    def __getitem__(self, index):
+    def _host(self, index):
         from PIL import Image
+        opt = self.opt
+        return Image.open(self.paths[index]).convert('RGB').resize((opt.loadSize * 2, opt.loadSize), Image.BICUBIC)
+
+    def _device(self, index, AB):
         opt, path = self.opt, self.paths[index]
-        AB = Image.open(path).convert('RGB').resize((opt.loadSize * 2, opt.loadSize), Image.BICUBIC)
         w, h, n = opt.loadSize, opt.loadSize, opt.fineSize
         w_offset = random.randint(0, max(0, w - n - 1))
         h_offset = random.randint(0, max(0, h - n - 1))

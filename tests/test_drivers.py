@@ -159,6 +159,15 @@ def test_train_and_test_from_image_folders(tmp_path):
     assert tuple(item["A"].shape) == (1, 3, 128, 128) and item["A"].is_cuda and float(item["A"].abs().max()) <= 1.0
     assert os.path.dirname(item["A_paths"][0]) == str(root / "single" / "train")
 
+    def epoch(threads):            # host decodes on worker threads must not change what an epoch yields
+        import random
+        opt.nThreads = threads
+        random.seed(11)
+        return [(d["A_paths"][0], d["A"].clone()) for d in SingleFolderDataset(opt)]
+    serial, threaded = epoch(0), epoch(3)
+    assert len(serial) == 5 and [p for p, _ in serial] == [p for p, _ in threaded]
+    assert all(torch.equal(x, y) for (_, x), (_, y) in zip(serial, threaded))
+
     _write_images(str(root / "pairs" / "train"), 4, 300, 150, 2)
     _write_images(str(root / "pairs" / "test"), 2, 300, 150, 3)
     cnet = ["--name", "fold_cgan", "--model", "cgan", "--which_direction", "AtoB", "--dataset_mode", "aligned", "--fineSize", "128",

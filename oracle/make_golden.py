@@ -563,6 +563,87 @@ def golden_cgan_step(name, cfg: "O.CGANConfig", seed: int, nsteps: int):
         save(name, **arrs)
 
 
+def build_ref_segm(cfg: "O.SegmConfig", seed: int, tmpdir: str):
+    from options.train_options import TrainOptions
+    from models.segm_model import SegmentationModel
+    chan = "b_" + "rg"[:cfg.label_nc]
+    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "segmentation", "--which_direction", "AtoB",
+            "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize), "--batchSize", "1", "--which_model_netG", {7: "unet_128", 8: "unet_256"}[cfg.num_downs],
+            "--ngf", str(cfg.ngf), "--which_model_netD", "n_layers", "--n_layers_D", *map(str, cfg.n_layers_D), "--ndf", str(cfg.ndf),
+            "--scale_factor", *map(str, cfg.scale_factor), "--lambda_D", *map(str, cfg.lambda_D), "--norm", "instance", "--which_channel", chan,
+            "--gpu_ids", "-1", "--display_id", "0", "--checkpoints_dir", tmpdir, "--pool_size", str(cfg.pool_size), "--no_dropout",
+            "--n_update_G", str(cfg.n_update_G), "--manualSeed", "1"]
+    if cfg.no_lsgan:
+        argv.append("--no_lsgan")
+    if cfg.weights is not None:
+        argv += ["--weights", *map(str, cfg.weights)]
+    if cfg.use_sigmoid_ss:
+        argv.append("--use_sigmoid_ss")
+    if cfg.add_background_onehot:
+        argv.append("--add_background_onehot")
+    old = sys.argv
+    sys.argv = argv
+    try:
+        opt = TrainOptions().parse()
+    finally:
+        sys.argv = old
+    opt.scale_factor = [Py2Int(s) if s > 1 else s for s in opt.scale_factor]
+    model = SegmentationModel()
+    model.initialize(opt)
+    load_sd(model.netG, O.init_unet(seed + 1, cfg.num_downs, cfg.input_nc, cfg.output_nc, cfg.ngf, -1))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D, cfg.scale_factor)):
+        load_sd(model.netD[i], O.init_nlayer_d(seed + 2 + i, cfg.input_nc + cfg.output_nc, cfg.ndf, nl, sf))
+    return model
+
+
+def segm_batch(cfg, step):
+    """Aligned pair: image channel b of A, label channels r(g) of B -- blocky maps so that argmax labels have structure."""
+    n = cfg.fineSize
+    lab = O.np_uniform(7400 + step, (1, 3, n // 8, n // 8))
+    lab = torch.nn.functional.interpolate(lab, scale_factor=8, mode="nearest")
+    return {"A": O.np_uniform(7300 + step, (1, 3, n, n)), "B": lab, "A_paths": ["synthetic"], "B_paths": ["synthetic"]}
+
+
+def golden_segm_step(name, cfg: "O.SegmConfig", seed: int, nsteps: int):
+    """`--model segmentation` (models/segm_model.py): losses of every step, the first step's logits and discriminator gradients,
+    parameter summaries after the last step."""
+    import random
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        model = build_ref_segm(cfg, seed, tmp)
+        random.seed(1234)           # ImagePool's coin flips; after initialize(), which reseeds `random` from --manualSeed (:27)
+        arrs, losses = {}, []
+        for step in range(nsteps):
+            model.set_input(segm_batch(cfg, step))
+            if step > 0:
+                model.optimize_parameters()
+            else:
+                model.forward()
+                arrs["step1/logit_summary"] = np.asarray(O.tensor_summary(model.logit.detach()))
+                arrs["step1/logit_crop"] = model.logit.detach()[:, :, :64, :64].numpy().copy()
+                arrs["step1/label_hist"] = np.bincount(model.label.numpy().reshape(-1), minlength=cfg.output_nc)
+                model.optimizer_D.zero_grad()
+                model.backward_D()
+                for i, d in enumerate(model.netD):
+                    capture_grads(arrs, f"step1/gradD_{i}", d)
+                model.optimizer_D.step()
+                for _ in range(cfg.n_update_G):
+                    model.optimizer_G.zero_grad()
+                    model.backward_G()
+                    if _ == 0:
+                        capture_grads(arrs, "step1/gradG", model.netG)
+                    model.optimizer_G.step()
+                    if cfg.n_update_G > 1:
+                        model.sample_noise()
+            losses.append([float(model.loss_G_CE), float(model.loss_G_GAN), float(model.loss_D_real), float(model.loss_D_fake)])
+        arrs["losses"] = np.asarray(losses, dtype=np.float64)
+        for label, net in [("G", model.netG)] + [(f"D_{i}", d) for i, d in enumerate(model.netD)]:
+            for k, v in net.state_dict().items():
+                if v.is_floating_point():
+                    arrs[f"summary/{label}/{k}"] = np.asarray(O.tensor_summary(v))
+        save(name, **arrs)
+
+
 # ---------------------------------------------------------------------------------------
 # cgan_cycle
 # ---------------------------------------------------------------------------------------
@@ -781,6 +862,11 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
+    if not only or "segmentation" in only:
+        small = dict(num_downs=7, ngf=8, ndf=8, fineSize=256, n_layers_D=(3, 3), scale_factor=(1, 2), lambda_D=(0.6, 0.4), no_lsgan=True)
+        golden_segm_step("segm_step_small.npz", O.SegmConfig(weights=(1.0, 3.0), n_update_G=2, **small), 0, 3)
+        golden_segm_step("segm_step_small_sigmoid_bg.npz",
+                         O.SegmConfig(use_sigmoid_ss=True, add_background_onehot=True, weights=(2.0, 1.0, 0.5), **small), 0, 2)
     if not only or "fcgan_star" in only:
         golden_fcgan_star_small()
     if not only or "autoencoder" in only:

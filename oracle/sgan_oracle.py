@@ -30,6 +30,7 @@ Reference map (paths relative to /root/reference):
   AutoEncoder                                 models/networks.py:421-490
   DCGANGenerator / DCGANDiscriminator         models/networks.py:1015-1129
   FCGANGeneratorStar                          models/networks.py:543-640
+  SegmentationModel step recipe               models/segm_model.py:145-263, models/loss.py:6-12
   CascadedRefinementNetwork / Crn*Block       models/networks.py:642-794
   CGANModel step recipe                       models/cgan_model.py:134-226
   TwoStageCycleModel step recipe              models/twostage_cycle_model.py:193-438
@@ -937,6 +938,58 @@ class CGANOracle:
 
     def losses(self):
         return {"G_GAN": float(self.loss_G.detach()), "G_L1": float(self.loss_G_L1.detach()),
+                "D_real": float(self.loss_D_real.detach()), "D_fake": float(self.loss_D_fake.detach())}
+
+
+# ----------------------------------------------------------------------------------
+# SegmentationModel (models/segm_model.py:15-263, models/loss.py:6-12): the cgan step with class logits
+# ----------------------------------------------------------------------------------
+class SegmConfig(CGANConfig):
+    """`--model segmentation`: U-Net G emits num_classes logits (no tanh, segm_model.py:155), softmax (or `--use_sigmoid_ss`) gives
+    the "fake" one-hot image the discriminators see; generator loss = GAN + (class-weighted) cross-entropy."""
+    def __init__(self, use_sigmoid_ss=False, add_background_onehot=False, **kw):
+        kw.setdefault("input_nc", 1)
+        kw.setdefault("output_nc", 2)
+        kw.setdefault("use_dropout", False)
+        super().__init__(**kw)
+        self.use_sigmoid_ss, self.add_background_onehot = use_sigmoid_ss, add_background_onehot
+        self.label_nc = self.output_nc                                                  # channels picked from the label image
+        self.output_nc = self.label_nc + 1 if add_background_onehot else self.label_nc   # num_classes (:45)
+
+
+class SegmOracle(CGANOracle):
+    def set_input(self, real_A, label_img):
+        """segm_model.py:131-142: label image in [-1, 1] -> [0, 1] one-hot (+ background), index label = argmax."""
+        b = (label_img + 1) / 2.0
+        if self.cfg.add_background_onehot:
+            b = torch.cat([b, 1.0 - torch.clamp(b.sum(dim=1, keepdim=True), 0, 1)], dim=1)
+        self.real_A, self.real_B, self.label = real_A, b, b.max(dim=1)[1]
+
+    def forward(self):
+        c = self.cfg
+        self.logit = unet_forward(self.G, self.real_A, c.num_downs, c.ngf, c.n_layers_G_skip, False, tanh=False)      # :155
+        self.fake_B = torch.sigmoid(self.logit) if c.use_sigmoid_ss else F.softmax(self.logit, dim=1)               # :49,156
+        self.nfwd += 1
+
+    def backward_G(self):
+        c = self.cfg
+        fake = self.fake_B if c.no_cgan else torch.cat((self.real_A, self.fake_B), 1)
+        self.loss_G_GAN = sum(gan_loss(self._d(i, fake), True, not c.no_lsgan) * lam for i, lam in enumerate(c.lambda_D))   # :211-213
+        w = None if c.weights is None else torch.tensor(c.weights, dtype=torch.float32)
+        if c.use_sigmoid_ss:                                                                                          # :216-225
+            wm = None
+            if w is not None:
+                wm = torch.ones(1, 1, c.fineSize, c.fineSize)
+                for i in range(len(c.weights)):
+                    wm = wm + self.real_B.narrow(1, i, 1) * (w[i] - 1.0)
+            self.loss_G_CE = F.binary_cross_entropy(self.fake_B, self.real_B, weight=wm)
+        else:                                                          # CrossEntropyLoss2d = NLLLoss2d(weight)(log_softmax) (loss.py:6-12)
+            self.loss_G_CE = F.nll_loss(F.log_softmax(self.logit, dim=1), self.label, weight=w)
+        self.loss_G = self.loss_G_GAN + self.loss_G_CE
+        self.loss_G.backward()
+
+    def losses(self):
+        return {"G_CE": float(self.loss_G_CE.detach()), "G_GAN": float(self.loss_G_GAN.detach()),
                 "D_real": float(self.loss_D_real.detach()), "D_fake": float(self.loss_D_fake.detach())}
 
 

@@ -30,7 +30,7 @@ class CGANModel(BaseModel):
         self.chnl_idx_input = [[idx_dict[c] for c in s] for s in opt.which_channel.split('_')]
         assert len(self.chnl_idx_input) == 2
         opt.input_nc = len(self.chnl_idx_input[0])
-        opt.output_nc = len(self.chnl_idx_input[1])
+        opt.output_nc = self._output_channels(opt)
         self._chnl_dev = [torch.tensor(ix, dtype=torch.long, device=self.device) for ix in self.chnl_idx_input]
         if 'bilinear' in opt.transform_1to2:
             raise NotImplementedError("--transform_1to2 bilinear_* is a test-time option outside the MI355X training path")
@@ -83,6 +83,10 @@ class CGANModel(BaseModel):
             self.optimizer_D = FusedAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
             self.grad_sync = None
             self._pool_override = None
+
+    def _output_channels(self, opt):
+        """Channels the generator emits / the discriminators see beside real_A (the segmentation trainer emits class scores)."""
+        return len(self.chnl_idx_input[1])
 
     # ---- data ---------------------------------------------------------------------------------
     def set_input(self, input):

@@ -10,8 +10,9 @@ _TRAINERS = {                       # --model         module                    
     'cgan2_cycle':    ('cgan2_cycle_model',    'CGAN2CycleModel'),
     'twostage':       ('twostage_cycle_model', 'TwoStageModel'),
     'twostage_cycle': ('twostage_cycle_model', 'TwoStageCycleModel'),
+    'segmentation':   ('segm_model',           'SegmentationModel'),
 }
-_NOT_ON_THIS_PATH = ('twostage_factd', 'test', 'segmentation', 'segmentation_cycle')
+_NOT_ON_THIS_PATH = ('twostage_factd', 'test', 'segmentation_cycle')
 
 
 def create_model(opt):

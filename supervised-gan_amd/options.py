@@ -60,6 +60,10 @@ class BaseOptions:
         a('--display_title', type=str, default='loss over time')
         a('--n_layers_G_skip', type=int, default=-1)
         a('--weights', type=float, default=None, nargs='+')
+        a('--use_sigmoid_ss', action='store_true')            # segmentation: sigmoid instead of softmax (base_options.py:55)
+        a('--which_metric', default=['None'], nargs='+')
+        a('--add_background_onehot', action='store_true')
+        a('--add_background_onehot_acc', action='store_true')
         a('--upsample_mode', type=str, default='convt')
         a('--no_share_label_block_weights', action='store_true')
         a('--n_layers_CRN_block', type=int, default=1)

@@ -25,7 +25,7 @@ def main(argv=None):
             save_image(tensor2im(t), path)
             written.append(path)
 
-    if opt.model.startswith('cgan'):       # only cgan needs a label image (test.py:27-41)
+    if opt.model.startswith(('cgan', 'segmentation')):       # models that read a label image (test.py:27-41)
         if opt.dataroot == 'synthetic':
             dataset = SyntheticDataset(opt, opt.how_many)
         else:

@@ -128,6 +128,25 @@ def test_train_graphed(tmp_path):
     assert os.path.exists(tmp_path / "ckpt" / "drv_graph" / "latest_net_G.pth")
 
 
+def test_train_then_test_segmentation(tmp_path):
+    """`--model segmentation` (models/segm_model.py) through train.py -- eager and as hipGraphs -- and test.py."""
+    _need_gpu()
+    import test as test_driver
+    import train as train_driver
+    net = ["--name", "drv_segm", "--model", "segmentation", "--which_direction", "AtoB", "--dataset_mode", "aligned", "--fineSize", "256",
+           "--which_model_netG", "unet_128", "--ngf", "8", "--norm", "instance", "--which_channel", "b_rg", "--gpu_ids", "0", "--no_dropout",
+           "--checkpoints_dir", str(tmp_path / "ckpt"), "--dataroot", "synthetic", "--manualSeed", "4"]
+    d = ["--which_model_netD", "n_layers", "--n_layers_D", "3", "--ndf", "8", "--scale_factor", "1", "--lambda_D", "1.0", "--weights", "1", "2",
+         "--no_lsgan", "--max_steps", "3", "--print_freq", "1"]
+    for extra in ([], ["--graph"]):
+        m = train_driver.main(net + d + extra)
+        torch.cuda.synchronize()
+        e = m.get_current_errors()
+        assert list(e) == ["G_CE", "G_GAN", "D_real", "D_fake"] and all(np.isfinite(v) for v in e.values())
+    out = test_driver.main(net + ["--results_dir", str(tmp_path / "res"), "--how_many", "2"])
+    assert len(out) == 6 and all(os.path.exists(p) for p in out)            # image, label, prediction per sample
+
+
 def _write_images(folder, n, w, h, seed):
     from PIL import Image
     os.makedirs(folder, exist_ok=True)

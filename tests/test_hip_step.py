@@ -514,3 +514,81 @@ def test_cgan_cycle_step_vs_reference_golden(golden_dir, name, kw):
         m.optimize_parameters()
         losses.append([float(m.loss_G), float(m.loss_G_real_cycle if two else m.loss_G_cycle), float(m.loss_D)])
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+
+
+# ------------------------------------------------------------------------------------------------
+# SegmentationModel (models/segm_model.py): class logits, softmax / sigmoid, cross-entropy + GAN
+# ------------------------------------------------------------------------------------------------
+SEGM_SMALL = dict(num_downs=7, ngf=8, ndf=8, fineSize=256, n_layers_D=(3, 3), scale_factor=(1, 2), lambda_D=(0.6, 0.4), no_lsgan=True)
+SEGM_CASES = {"segm_step_small.npz": dict(weights=(1.0, 3.0), n_update_G=2, **SEGM_SMALL),
+              "segm_step_small_sigmoid_bg.npz": dict(use_sigmoid_ss=True, add_background_onehot=True, weights=(2.0, 1.0, 0.5), **SEGM_SMALL)}
+
+
+def build_segm(cfg, extra=()):
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")
+    from supervised_gan_amd.models import create_model
+    from supervised_gan_amd.options import TrainOptions
+    argv = ["--name", "t", "--model", "segmentation", "--which_direction", "AtoB", "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize),
+            "--which_model_netG", "unet_128", "--ngf", str(cfg.ngf), "--which_model_netD", "n_layers", "--n_layers_D", *map(str, cfg.n_layers_D),
+            "--ndf", str(cfg.ndf), "--scale_factor", *map(str, cfg.scale_factor), "--lambda_D", *map(str, cfg.lambda_D), "--norm", "instance",
+            "--which_channel", "b_" + "rg"[:cfg.label_nc], "--gpu_ids", "0", "--checkpoints_dir", "/tmp/sgan_ckpt", "--no_dropout", "--no_lsgan",
+            "--weights", *map(str, cfg.weights), "--n_update_G", str(cfg.n_update_G), *extra]
+    if cfg.use_sigmoid_ss:
+        argv.append("--use_sigmoid_ss")
+    if cfg.add_background_onehot:
+        argv.append("--add_background_onehot")
+    m = create_model(TrainOptions().parse(argv, save=False, verbose=False))
+    m.netG.load_state_dict(O.init_unet(1, cfg.num_downs, cfg.input_nc, cfg.output_nc, cfg.ngf, -1))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D, cfg.scale_factor)):
+        m.netD[i].load_state_dict(O.init_nlayer_d(2 + i, cfg.input_nc + cfg.output_nc, cfg.ndf, nl, sf))
+    return m
+
+
+def segm_input(cfg, step):
+    n = cfg.fineSize
+    lab = torch.nn.functional.interpolate(O.np_uniform(7400 + step, (1, 3, n // 8, n // 8)), scale_factor=8, mode="nearest")
+    return {"A": O.np_uniform(7300 + step, (1, 3, n, n)), "B": lab, "A_paths": ["synthetic"], "B_paths": ["synthetic"]}
+
+
+@pytest.mark.parametrize("name", list(SEGM_CASES))
+def test_segm_steps_match_reference(golden_dir, name):
+    """`--model segmentation` on the HIP path against the reference's own steps: first-step logits, label histogram and
+    discriminator gradients, then the losses of every step (two generator updates per step in the softmax case)."""
+    import random
+    g = np.load(os.path.join(golden_dir, name))
+    cfg = O.SegmConfig(**SEGM_CASES[name])
+    random.seed(1234)
+    m = build_segm(cfg)
+    losses = []
+    for step in range(g["losses"].shape[0]):
+        m.set_input(segm_input(cfg, step))
+        if step == 0:
+            m.forward()
+            assert tuple(m.logit.shape) == (1, cfg.output_nc, 256, 256)
+            assert O.rel_err(m.logit[:, :, :64, :64].detach().cpu(), torch.from_numpy(g["step1/logit_crop"])) < 1e-3
+            assert np.array_equal(np.bincount(m.label.cpu().numpy().reshape(-1), minlength=cfg.output_nc), g["step1/label_hist"])
+            m.optimizer_D.zero_grad()
+            m.backward_D()
+            torch.cuda.synchronize()
+            for i, d in enumerate(m.netD):
+                for k, gr in _grads(d).items():
+                    if k.endswith(".weight"):
+                        ref = g[f"step1/gradD_{i}/summary/{k}"]
+                        got = np.asarray(O.tensor_summary(gr.reshape(-1)))
+                        assert np.abs(got - ref).max() < 2e-3 * max(1e-3, np.abs(ref).max()), (i, k, got, ref)
+            m.optimizer_D.step()
+            for _ in range(cfg.n_update_G):
+                m.optimizer_G.zero_grad()
+                m.backward_G()
+                m.optimizer_G.step()
+                if cfg.n_update_G > 1:
+                    m.sample_noise()
+        else:
+            m.optimize_parameters()
+        e = m.get_current_errors()
+        losses.append([e["G_CE"], e["G_GAN"], e["D_real"], e["D_fake"]])
+    assert np.abs(np.asarray(losses) - g["losses"]).max() < 5e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+    m.opt.which_metric = ["meanIU"]
+    m.accum_accs()
+    assert 0.0 <= m.get_current_accs()["meanIU"] <= 1.0

@@ -544,3 +544,47 @@ def test_image_prep_restatement_matches_pillow():
                 assert a.dtype == np.float32 and a.shape == (3, n, n)
                 assert np.array_equal(a, b), (x0, y0, n, flip, rot)
     assert float(IP.prep_numpy(img, 0, 0, 8, False, 0).min()) >= -1.0 and float(IP.prep_numpy(img, 0, 0, 8, False, 0).max()) <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------
+# SegmentationModel (models/segm_model.py): cgan step with class logits, softmax / sigmoid + cross-entropy
+# ------------------------------------------------------------------------------------------------
+SEGM_SMALL = dict(num_downs=7, ngf=8, ndf=8, fineSize=256, n_layers_D=(3, 3), scale_factor=(1, 2), lambda_D=(0.6, 0.4), no_lsgan=True)
+SEGM_CASES = {"segm_step_small.npz": dict(weights=(1.0, 3.0), n_update_G=2, **SEGM_SMALL),
+              "segm_step_small_sigmoid_bg.npz": dict(use_sigmoid_ss=True, add_background_onehot=True, weights=(2.0, 1.0, 0.5), **SEGM_SMALL)}
+
+
+def segm_batch(cfg, step):
+    n = cfg.fineSize
+    lab = torch.nn.functional.interpolate(O.np_uniform(7400 + step, (1, 3, n // 8, n // 8)), scale_factor=8, mode="nearest")
+    a = O.np_uniform(7300 + step, (1, 3, n, n))
+    return a[:, 2:3].contiguous(), lab[:, :cfg.label_nc].contiguous()          # --which_channel b_r / b_rg
+
+
+@pytest.mark.parametrize("name", list(SEGM_CASES))
+def test_segm_step(golden_dir, name):
+    import random
+    g = load(golden_dir, name)
+    cfg = O.SegmConfig(**SEGM_CASES[name])
+    random.seed(1234)
+    m = O.SegmOracle(cfg, seed=0)
+    losses = []
+    for step in range(g["losses"].shape[0]):
+        m.set_input(*segm_batch(cfg, step))
+        if step == 0:
+            m.forward()
+            assert rel(m.logit[:, :, :64, :64], g["step1/logit_crop"]) < 1e-4
+            assert np.array_equal(np.bincount(m.label.numpy().reshape(-1), minlength=cfg.output_nc), g["step1/label_hist"])
+            m.opt_D.zero_grad()
+            m.backward_D()
+            for i, d in enumerate(m.D):
+                for k in g.files:
+                    if k.startswith(f"step1/gradD_{i}/summary/") and not k.endswith(".bias"):
+                        got = O.tensor_summary(d[k.split("/summary/")[1]].grad.reshape(-1))
+                        assert np.abs(np.asarray(got) - g[k]).max() < 1e-4 * max(1e-3, np.abs(g[k]).max()), k
+            m.opt_D.step()
+            m._g_steps()
+        else:
+            m.optimize_parameters()
+        losses.append(list(m.losses().values()))
+    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])

@@ -644,6 +644,67 @@ def golden_segm_step(name, cfg: "O.SegmConfig", seed: int, nsteps: int):
         save(name, **arrs)
 
 
+def build_ref_segm_cycle(cfg: "O.SegmCycleConfig", seed: int, tmpdir: str):
+    from options.train_options import TrainOptions
+    from models.segm_cycle_model import SegmentationCycleModel
+    L = lambda xs: [str(x) for x in xs]
+    unet = {7: "unet_128", 8: "unet_256"}
+    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "segmentation_cycle", "--which_direction", "AtoB",
+            "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize), "--batchSize", "1", "--which_channel", "b_" + "rg"[:cfg.label_nc],
+            "--which_model_netG1", unet[cfg.num_downs1], "--ngf1", str(cfg.ngf1), "--which_model_netG2", unet[cfg.num_downs2], "--ngf2", str(cfg.ngf2),
+            "--which_model_netD2", "n_layers", "--n_layers_D2", *L(cfg.n_layers_D2), "--ndf2", str(cfg.ndf2), "--scale_factor2", *L(cfg.scale_factor2),
+            "--lambda_D2", *L(cfg.lambda_D2), "--lambda_A", str(cfg.lambda_A), "--lambda_B", str(cfg.lambda_B), "--lambda_A_cycle", str(cfg.lambda_A_cycle),
+            "--lr1", str(cfg.lr1), "--lr2", str(cfg.lr2), "--norm", "instance", "--no_dropout1", "--no_dropout2", "--n_update_G", str(cfg.n_update_G),
+            "--pool_size", str(cfg.pool_size), "--gpu_ids", "-1", "--display_id", "0", "--checkpoints_dir", tmpdir, "--manualSeed", "1"]
+    if cfg.no_lsgan2:
+        argv.append("--no_lsgan2")
+    if cfg.weights is not None:
+        argv += ["--weights", *L(cfg.weights)]
+    if cfg.use_sigmoid_ss:
+        argv.append("--use_sigmoid_ss")
+    if cfg.add_background_onehot:
+        argv.append("--add_background_onehot")
+    old = sys.argv
+    sys.argv = argv
+    try:
+        opt = TrainOptions().parse()
+    finally:
+        sys.argv = old
+    opt.scale_factor2 = [Py2Int(s) if s > 1 else s for s in opt.scale_factor2]
+    model = SegmentationCycleModel()
+    model.initialize(opt)
+    load_sd(model.netG1, O.init_unet(seed + 1, cfg.num_downs1, cfg.input_nc, cfg.num_classes, cfg.ngf1, -1))
+    load_sd(model.netG2, O.init_unet(seed + 2, cfg.num_downs2, cfg.num_classes, cfg.input_nc, cfg.ngf2, -1))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D2, cfg.scale_factor2)):
+        load_sd(model.netD2[i], O.init_nlayer_d(seed + 3 + i, cfg.input_nc + cfg.num_classes, cfg.ndf2, nl, sf))
+    return model
+
+
+def golden_segm_cycle(name, cfg: "O.SegmCycleConfig", seed: int, nsteps: int):
+    """`--model segmentation_cycle`: the six loss terms of every step, first-step logits / G2 outputs, parameter summaries at the end."""
+    import random
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        model = build_ref_segm_cycle(cfg, seed, tmp)
+        random.seed(1234)
+        arrs, losses = {}, []
+        for step in range(nsteps):
+            model.set_input(segm_batch(cfg, step))
+            model.optimize_parameters()
+            if step == 0:
+                arrs["step1/logit_crop"] = model.logit.detach()[:, :, :64, :64].numpy().copy()
+                arrs["step1/fake_A_crop"] = model.fake_A.detach()[:, :, :64, :64].numpy().copy()
+                arrs["step1/recon_A_crop"] = model.recon_A.detach()[:, :, :64, :64].numpy().copy()
+            losses.append([float(model.loss_G1_CE), float(model.loss_G2_GAN), float(model.loss_G_L1), float(model.loss_G_cycle),
+                           float(model.loss_D2_real), float(model.loss_D2_fake)])
+        arrs["losses"] = np.asarray(losses, dtype=np.float64)
+        for label, net in [("G1", model.netG1), ("G2", model.netG2)] + [(f"D2_{i}", d) for i, d in enumerate(model.netD2)]:
+            for k, v in net.state_dict().items():
+                if v.is_floating_point():
+                    arrs[f"summary/{label}/{k}"] = np.asarray(O.tensor_summary(v))
+        save(name, **arrs)
+
+
 # ---------------------------------------------------------------------------------------
 # cgan_cycle
 # ---------------------------------------------------------------------------------------
@@ -862,6 +923,8 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
+    if not only or "segmentation_cycle" in only:
+        golden_segm_cycle("segm_cycle_small.npz", O.SegmCycleConfig(weights=(1.0, 3.0), lambda_A=2.0, lambda_B=0.5, lambda_A_cycle=1.5, lr2=1e-4), 0, 3)
     if not only or "segmentation" in only:
         small = dict(num_downs=7, ngf=8, ndf=8, fineSize=256, n_layers_D=(3, 3), scale_factor=(1, 2), lambda_D=(0.6, 0.4), no_lsgan=True)
         golden_segm_step("segm_step_small.npz", O.SegmConfig(weights=(1.0, 3.0), n_update_G=2, **small), 0, 3)

@@ -31,6 +31,7 @@ Reference map (paths relative to /root/reference):
   DCGANGenerator / DCGANDiscriminator         models/networks.py:1015-1129
   FCGANGeneratorStar                          models/networks.py:543-640
   SegmentationModel step recipe               models/segm_model.py:145-263, models/loss.py:6-12
+  SegmentationCycleModel step recipe          models/segm_cycle_model.py:159-281
   CascadedRefinementNetwork / Crn*Block       models/networks.py:642-794
   CGANModel step recipe                       models/cgan_model.py:134-226
   TwoStageCycleModel step recipe              models/twostage_cycle_model.py:193-438
@@ -991,6 +992,97 @@ class SegmOracle(CGANOracle):
     def losses(self):
         return {"G_CE": float(self.loss_G_CE.detach()), "G_GAN": float(self.loss_G_GAN.detach()),
                 "D_real": float(self.loss_D_real.detach()), "D_fake": float(self.loss_D_fake.detach())}
+
+
+class SegmCycleConfig:
+    """`--model segmentation_cycle` (models/segm_cycle_model.py): G1 image -> class logits, G2 one-hot label -> image (run on the real
+    label and on G1's softmax), discriminators D2 on cat(label, image); no dropout / noise."""
+    def __init__(self, input_nc=1, label_nc=2, num_downs1=7, ngf1=8, num_downs2=7, ngf2=8, ndf2=8, n_layers_D2=(3, 3), scale_factor2=(1, 2),
+                 lambda_D2=(0.6, 0.4), lambda_A=1.0, lambda_B=1.0, lambda_A_cycle=1.0, weights=None, use_sigmoid_ss=False,
+                 add_background_onehot=False, fineSize=256, lr1=2e-4, lr2=2e-4, beta1=0.5, pool_size=50, no_lsgan2=True, n_update_G=1):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+        self.num_classes = label_nc + 1 if add_background_onehot else label_nc
+
+
+class SegmCycleOracle:
+    """SegmentationCycleModel restated (forward :159-174, backward_D2 :201-222, backward_G :224-259, optimize_parameters :268-281
+    with n_update_D2 = 1; Adam groups G1 @ lr1, G2 @ lr2, D2 @ lr2 :113-123)."""
+
+    def __init__(self, cfg: SegmCycleConfig, seed: int = 0):
+        self.cfg = c = cfg
+        self.G1 = init_unet(seed + 1, c.num_downs1, c.input_nc, c.num_classes, c.ngf1, -1)
+        self.G2 = init_unet(seed + 2, c.num_downs2, c.num_classes, c.input_nc, c.ngf2, -1)
+        self.D = [init_nlayer_d(seed + 3 + i, c.input_nc + c.num_classes, c.ndf2, nl, sf) for i, (nl, sf) in enumerate(zip(c.n_layers_D2, c.scale_factor2))]
+        for net in [self.G1, self.G2] + self.D:
+            for v in net.values():
+                if v.is_floating_point():
+                    v.requires_grad_(True)
+        self.opt_G1 = Adam(list(self.G1.values()), c.lr1, c.beta1)
+        self.opt_G2 = Adam(list(self.G2.values()), c.lr2, c.beta1)
+        self.opt_D = Adam([v for d in self.D for k, v in d.items() if k.startswith("model.")], c.lr2, c.beta1)
+        self.pool = ImagePool(c.pool_size)
+
+    set_input = SegmOracle.set_input
+
+    def _g2(self, b):
+        return unet_forward(self.G2, b, self.cfg.num_downs2, self.cfg.ngf2, -1, False)
+
+    def forward(self):
+        c = self.cfg
+        self.logit = unet_forward(self.G1, self.real_A, c.num_downs1, c.ngf1, -1, False, tanh=False)
+        self.fake_B = torch.sigmoid(self.logit) if c.use_sigmoid_ss else F.softmax(self.logit, dim=1)
+        self.fake_A = self._g2(self.real_B)              # :173-174: G2 on the real label, then on G1's prediction
+        self.recon_A = self._g2(self.fake_B)
+
+    def _d(self, i, x):
+        c = self.cfg
+        return nlayer_d_forward(self.D[i], x, c.n_layers_D2[i], c.scale_factor2[i], use_sigmoid=c.no_lsgan2)
+
+    def backward_D2(self):
+        c = self.cfg
+        fake = self.pool.query(torch.cat([self.real_B, self.fake_A], 1))
+        self.loss_D2_fake = sum(gan_loss(self._d(i, fake.detach()), False, not c.no_lsgan2) for i in range(len(self.D)))
+        real = torch.cat([self.real_B, self.real_A], 1)
+        self.loss_D2_real = sum(gan_loss(self._d(i, real), True, not c.no_lsgan2) for i in range(len(self.D)))
+        self.loss_D2 = (self.loss_D2_fake + self.loss_D2_real) * 0.5
+        self.loss_D2.backward()
+
+    def backward_G(self):
+        c = self.cfg
+        fake = torch.cat([self.real_B, self.fake_A], 1)
+        self.loss_G2_GAN = sum(gan_loss(self._d(i, fake), True, not c.no_lsgan2) * lam for i, lam in enumerate(c.lambda_D2))
+        w = None if c.weights is None else torch.tensor(c.weights, dtype=torch.float32)
+        if c.use_sigmoid_ss:
+            wm = None
+            if w is not None:
+                wm = torch.ones(1, 1, c.fineSize, c.fineSize)
+                for i in range(len(c.weights)):
+                    wm = wm + self.real_B.narrow(1, i, 1) * (w[i] - 1.0)
+            self.loss_G1_CE = F.binary_cross_entropy(self.fake_B, self.real_B, weight=wm)
+        else:
+            self.loss_G1_CE = F.nll_loss(F.log_softmax(self.logit, dim=1), self.label, weight=w)
+        self.loss_G_L1 = weighted_l1(self.fake_B, self.real_B, None)                  # :250
+        self.loss_G_cycle = weighted_l1(self.recon_A, self.real_A, None)              # :253
+        self.loss_G = self.loss_G1_CE * c.lambda_A + self.loss_G2_GAN + self.loss_G_L1 * c.lambda_B + self.loss_G_cycle * c.lambda_A_cycle
+        self.loss_G.backward()
+
+    def optimize_parameters(self):
+        self.forward()
+        self.opt_D.zero_grad()
+        self.backward_D2()
+        self.opt_D.step()
+        for _ in range(self.cfg.n_update_G):
+            self.opt_G1.zero_grad()
+            self.opt_G2.zero_grad()
+            self.backward_G()
+            self.opt_G1.step()
+            self.opt_G2.step()
+            if self.cfg.n_update_G > 1:
+                self.forward()
+
+    def losses(self):
+        return [float(v.detach()) for v in (self.loss_G1_CE, self.loss_G2_GAN, self.loss_G_L1, self.loss_G_cycle, self.loss_D2_real, self.loss_D2_fake)]
 
 
 # ----------------------------------------------------------------------------------

@@ -11,8 +11,9 @@ _TRAINERS = {                       # --model         module                    
     'twostage':       ('twostage_cycle_model', 'TwoStageModel'),
     'twostage_cycle': ('twostage_cycle_model', 'TwoStageCycleModel'),
     'segmentation':   ('segm_model',           'SegmentationModel'),
+    'segmentation_cycle': ('segm_cycle_model', 'SegmentationCycleModel'),
 }
-_NOT_ON_THIS_PATH = ('twostage_factd', 'test', 'segmentation_cycle')
+_NOT_ON_THIS_PATH = ('twostage_factd', 'test')
 
 
 def create_model(opt):

@@ -43,6 +43,9 @@ class SegmentationModel(CGANModel):
     def set_input(self, input):
         """segm_model.py:120-143: label channels rescaled to [0, 1], optional background class, index label = argmax."""
         CGANModel.set_input(self, input)
+        self._one_hot_label()
+
+    def _one_hot_label(self):
         b = (self.input_B[:, :self.label_nc] + 1) / 2.0
         if self.opt.add_background_onehot:
             b = torch.cat([b, 1.0 - torch.clamp(b.sum(dim=1, keepdim=True), 0, 1)], dim=1)

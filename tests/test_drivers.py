@@ -147,6 +147,28 @@ def test_train_then_test_segmentation(tmp_path):
     assert len(out) == 6 and all(os.path.exists(p) for p in out)            # image, label, prediction per sample
 
 
+def test_train_then_test_segmentation_cycle(tmp_path):
+    """`--model segmentation_cycle` (models/segm_cycle_model.py) through train.py -- eager and as hipGraphs -- and test.py."""
+    _need_gpu()
+    import test as test_driver
+    import train as train_driver
+    net = ["--name", "drv_segc", "--model", "segmentation_cycle", "--which_direction", "AtoB", "--dataset_mode", "aligned", "--fineSize", "256",
+           "--which_model_netG1", "unet_128", "--ngf1", "8", "--which_model_netG2", "unet_128", "--ngf2", "8", "--norm", "instance",
+           "--which_channel", "b_rg", "--gpu_ids", "0", "--no_dropout1", "--no_dropout2", "--checkpoints_dir", str(tmp_path / "ckpt"),
+           "--dataroot", "synthetic", "--manualSeed", "4"]
+    d = ["--which_model_netD2", "n_layers", "--n_layers_D2", "3", "--ndf2", "8", "--scale_factor2", "1", "--lambda_D2", "1.0", "--no_lsgan2",
+         "--max_steps", "3", "--print_freq", "1"]
+    for extra in ([], ["--graph"]):
+        m = train_driver.main(net + d + extra)
+        torch.cuda.synchronize()
+        e = m.get_current_errors()
+        assert list(e) == ["G_CE", "G_GAN", "G_L1", "G_cycle", "D_real", "D_fake"] and all(np.isfinite(v) for v in e.values())
+    files = sorted(f for f in os.listdir(tmp_path / "ckpt" / "drv_segc") if f.endswith(".pth"))
+    assert files == ["latest_net_D2_0.pth", "latest_net_G1.pth", "latest_net_G2.pth"]
+    out = test_driver.main(net + ["--results_dir", str(tmp_path / "res"), "--how_many", "2"])
+    assert len(out) == 6 and all(os.path.exists(p) for p in out)
+
+
 def _write_images(folder, n, w, h, seed):
     from PIL import Image
     os.makedirs(folder, exist_ok=True)

@@ -592,3 +592,39 @@ def test_segm_steps_match_reference(golden_dir, name):
     m.opt.which_metric = ["meanIU"]
     m.accum_accs()
     assert 0.0 <= m.get_current_accs()["meanIU"] <= 1.0
+
+
+def test_segm_cycle_steps_match_reference(golden_dir):
+    """`--model segmentation_cycle` against the reference's own steps: first-step logits / G2 outputs, then all six loss terms."""
+    import random
+    from supervised_gan_amd.models import create_model
+    from supervised_gan_amd.options import TrainOptions
+    from test_oracle_golden import SEGM_CYCLE
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")
+    g = np.load(os.path.join(golden_dir, "segm_cycle_small.npz"))
+    cfg = O.SegmCycleConfig(**SEGM_CYCLE)
+    L = lambda xs: [str(x) for x in xs]          # noqa: E731
+    argv = ["--name", "t", "--model", "segmentation_cycle", "--which_direction", "AtoB", "--dataset_mode", "aligned", "--fineSize", "256",
+            "--which_channel", "b_rg", "--which_model_netG1", "unet_128", "--ngf1", "8", "--which_model_netG2", "unet_128", "--ngf2", "8",
+            "--which_model_netD2", "n_layers", "--n_layers_D2", *L(cfg.n_layers_D2), "--ndf2", "8", "--scale_factor2", *L(cfg.scale_factor2),
+            "--lambda_D2", *L(cfg.lambda_D2), "--lambda_A", "2.0", "--lambda_B", "0.5", "--lambda_A_cycle", "1.5", "--lr1", "2e-4", "--lr2", "1e-4",
+            "--norm", "instance", "--no_dropout1", "--no_dropout2", "--no_lsgan2", "--weights", "1.0", "3.0", "--gpu_ids", "0",
+            "--checkpoints_dir", "/tmp/sgan_ckpt"]
+    random.seed(1234)
+    m = create_model(TrainOptions().parse(argv, save=False, verbose=False))
+    m.netG1.load_state_dict(O.init_unet(1, 7, 1, 2, 8, -1))
+    m.netG2.load_state_dict(O.init_unet(2, 7, 2, 1, 8, -1))
+    for i, (nl, sf) in enumerate(zip(cfg.n_layers_D2, cfg.scale_factor2)):
+        m.netD2[i].load_state_dict(O.init_nlayer_d(3 + i, 3, 8, nl, sf))
+    crop = lambda t: t[:, :, :64, :64].detach().cpu()       # noqa: E731
+    losses = []
+    for step in range(g["losses"].shape[0]):
+        m.set_input(segm_input(cfg, step))
+        m.optimize_parameters()
+        torch.cuda.synchronize()
+        if step == 0:
+            for name, t in (("logit", m.logit), ("fake_A", m.fake_A), ("recon_A", m.recon_A)):
+                assert O.rel_err(crop(t), torch.from_numpy(g[f"step1/{name}_crop"])) < 1e-3, name
+        losses.append(list(m.get_current_errors().values()))
+    assert np.abs(np.asarray(losses) - g["losses"]).max() < 5e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])

@@ -588,3 +588,24 @@ def test_segm_step(golden_dir, name):
             m.optimize_parameters()
         losses.append(list(m.losses().values()))
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+
+
+SEGM_CYCLE = dict(weights=(1.0, 3.0), lambda_A=2.0, lambda_B=0.5, lambda_A_cycle=1.5, lr2=1e-4)
+
+
+def test_segm_cycle_step(golden_dir):
+    """SegmentationCycleModel (models/segm_cycle_model.py): G1 logits, G2 on the real and on the predicted label, six loss terms."""
+    import random
+    g = load(golden_dir, "segm_cycle_small.npz")
+    cfg = O.SegmCycleConfig(**SEGM_CYCLE)
+    random.seed(1234)
+    m = O.SegmCycleOracle(cfg, seed=0)
+    losses = []
+    for step in range(g["losses"].shape[0]):
+        m.set_input(*segm_batch(cfg, step))
+        m.optimize_parameters()
+        if step == 0:
+            assert rel(m.logit[:, :, :64, :64], g["step1/logit_crop"]) < 1e-4
+            assert rel(m.fake_A[:, :, :64, :64], g["step1/fake_A_crop"]) < 1e-4 and rel(m.recon_A[:, :, :64, :64], g["step1/recon_A_crop"]) < 1e-4
+        losses.append(m.losses())
+    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])

@@ -821,7 +821,7 @@ def build_ref_twostage(cfg: "O.TwoStageConfig", seed: int, tmpdir: str):
     from models.twostage_cycle_model import TwoStageCycleModel
     from models.twostage_model import TwoStageModel
     L = lambda xs: [str(x) for x in xs]
-    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "twostage_cycle" if cfg.cycle else "twostage", "--which_direction", "AtoB",
+    argv = ["x", "--dataroot", "/nonexistent", "--name", "golden", "--model", "twostage_cycle" if cfg.cycle else "twostage_factd" if cfg.factd else "twostage", "--which_direction", "AtoB",
             "--dataset_mode", "aligned", "--fineSize", str(cfg.fineSize), "--transform_1to2", cfg.transform_1to2, "--batchSize", "1",
             "--which_channel", "rg_b", "--which_model_netG1", "fcgan", "--n_layers_G1", str(cfg.n_layers_G1), "--ngf1", str(cfg.ngf1),
             "--which_model_netD1", "n_layers", "--n_layers_D1", *L(cfg.n_layers_D1), "--ndf1", str(cfg.ndf1),
@@ -853,7 +853,10 @@ def build_ref_twostage(cfg: "O.TwoStageConfig", seed: int, tmpdir: str):
         sys.argv = old
     opt.scale_factor1 = [Py2Int(s) if s > 1 else s for s in opt.scale_factor1]
     opt.scale_factor2 = [Py2Int(s) if s > 1 else s for s in opt.scale_factor2]
-    model = TwoStageCycleModel() if cfg.cycle else TwoStageModel()
+    if cfg.factd:
+        from models.twostage_factD_model import TwoStageModel as TwoStageFactDModel
+        assert not cfg.cycle
+    model = TwoStageCycleModel() if cfg.cycle else TwoStageFactDModel() if cfg.factd else TwoStageModel()
     model.initialize(opt)
     load_sd(model.netG1, O.init_fcgan_g(seed + 1, cfg.noise_nc1, cfg.input_nc, cfg.ngf1, cfg.n_layers_G1))
     load_sd(model.netG2, O.init_crn(seed + 2, cfg.input_nc, cfg.output_nc, cfg.noise_nc2, cfg.ngf2, cfg.upsample_mode2,
@@ -961,6 +964,12 @@ def main():
                                          GAN_losses_D2=("real_fake", "fake_fake"), GAN_losses_G2=("real_fake", "fake_fake"),
                                          weights=(2.0, 5.0), use_multi_class_GAN=True, no_lsgan2=True, n_layers_D2=(3, 4),
                                          scale_factor2=(1, 2), lambda_D2=(0.6, 0.4)), seed=0, nsteps=3)
+    if not only or "factd" in only:
+        golden_twostage("twostage_factd_small.npz",
+                        O.TwoStageConfig(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8, ndf2=8, n_layers_D1=(4, 4),
+                                         n_layers_D2=(3, 3), scale_factor2=(1, 2), lambda_D2=(0.6, 0.4), no_lsgan2=True,
+                                         GAN_losses_D2=("real_fake", "fake_fake"), GAN_losses_G2=("real_fake", "fake_fake"), cycle=False,
+                                         factd=True, lambda_G1=0.7, lambda_G2=1.3), seed=0, nsteps=3)
     if not only or "twostage" in only:
         golden_twostage("twostage_small.npz", O.TwoStageConfig(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8,
                                                                ndf2=8, GAN_losses_D2=("real_fake", "fake_fake"),

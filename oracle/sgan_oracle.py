@@ -1239,7 +1239,9 @@ class TwoStageConfig:
                  lambda_fake_cycle=1.0, weights=None, no_lsgan1=True, no_lsgan2=False, GAN_losses_D2=("real_fake",),
                  GAN_losses_G2=("real_fake",), lr=2e-4, lr1=2e-4, lr2=2e-4, beta1=0.5, pool_size=50, transform_1to2="bilinear_2",
                  detach_G1_from_G2_x=False, detach_G1_from_G2_y=False, no_logD_trick=False, cycle=True, lambda_G1=1.0, lambda_G2=1.0,
-                 use_multi_class_GAN=False):
+                 use_multi_class_GAN=False, factd=False):
+        # factd (models/twostage_factD_model.py:261-292,356-383): every D2 prediction is multiplied by the x2-upsampled prediction of
+        # the D1 of the same index on the (half-size) label, reflection-padded to D2's map size (util/util.py:131-145)
         # use_multi_class_GAN (twostage_cycle_model.py:86,120-146,302-335,352): D2 ends in 3 logits per pixel, classes
         # 0 = (real_A, real_B), 1 = (real_A, fake_B), 2 = (fake_A, fake_B), cross-entropy, one ImagePool per fake class
         self.__dict__.update(locals())
@@ -1308,6 +1310,20 @@ class TwoStageCycleOracle:
     def _d(self, nets, cfg_nl, cfg_sf, i, x, sig):
         return nlayer_d_forward(nets[i], x, cfg_nl[i], cfg_sf[i], use_sigmoid=sig)
 
+    def _d2(self, i, x, label=None):
+        """D2_i(x); with `factd` times D1_i(label) upsampled x2 and reflection-padded (util.mul: in1 padded up to in2's size)."""
+        c = self.cfg
+        p2 = self._d(self.D2, c.n_layers_D2, c.scale_factor2, i, x, c.no_lsgan2)
+        if not c.factd:
+            return p2
+        p1 = self.transform(self._d(self.D1, c.n_layers_D1, c.scale_factor1, i, label, c.no_lsgan1))
+        if p1.shape == p2.shape:
+            return p1 * p2
+        assert p1.shape[2] < p2.shape[2] and p1.shape[3] < p2.shape[3], "util.mul returns None when the D1 map is the larger one"
+        pl, pb = int((p2.shape[3] - p1.shape[3]) / 2), int((p2.shape[2] - p1.shape[2]) / 2)
+        pr, pt = p2.shape[3] - p1.shape[3] - pl, p2.shape[2] - p1.shape[2] - pb
+        return F.pad(p1, (pl, pr, pt, pb), mode="reflect") * p2
+
     def backward_D1(self):
         c = self.cfg
         fake = self.pool1.query(self.fake_A)
@@ -1338,7 +1354,8 @@ class TwoStageCycleOracle:
         if c.use_multi_class_GAN:
             return self.backward_D2_multiclass()
         n = len(self.D2)
-        d2 = lambda i, x: self._d(self.D2, c.n_layers_D2, c.scale_factor2, i, x, c.no_lsgan2)
+        lab = lambda pair: self.transform_inverse(pair.narrow(1, 0, c.input_nc)).detach() if c.factd else None      # factD :265,276,289
+        d2 = lambda i, x: self._d2(i, x, lab(x))
         self.loss_D2_fake, pairs = 0, 0
         if "real_fake" in c.GAN_losses_D2:
             fake = self.pool2.query(torch.cat([self.real_A, self.fake_B_from_real_A], 1))
@@ -1363,16 +1380,18 @@ class TwoStageCycleOracle:
             g1 = g1 + (gan_loss(pred, True, not c.no_lsgan1) * lam if not c.no_logD_trick else -gan_loss(pred, False, not c.no_lsgan1) * lam)
         self.loss_G1_GAN = g1
         g2, pairs = 0, 0
-        fakes = []
+        fakes, labels = [], []
         if "real_fake" in c.GAN_losses_G2:
             fakes.append(torch.cat([self.real_A, self.fake_B_from_real_A], 1))
+            labels.append(self.transform_inverse(self.real_A))                      # factD :359
         if "fake_fake" in c.GAN_losses_G2:
             fa = self.fake_A.detach() if c.detach_G1_from_G2_y else self.fake_A
             fakes.append(torch.cat([self.transform(fa), self.fake_B_from_fake_A], 1))
-        for fake in fakes:
+            labels.append(fa)                                                       # factD :373,376
+        for fake, label in zip(fakes, labels):
             pairs += 1
             for i, lam in enumerate(c.lambda_D2):
-                pred = self._d(self.D2, c.n_layers_D2, c.scale_factor2, i, fake, c.no_lsgan2)
+                pred = self._d2(i, fake, label)
                 if c.use_multi_class_GAN:      # flipped_label = 0 (:352); criterionGAN2(pred, False) is class 0 as well
                     g2 = g2 + (gan_loss_multiclass(pred, 0) * lam if not c.no_logD_trick else -gan_loss_multiclass(pred, 0) * lam)
                     continue

@@ -10,10 +10,11 @@ _TRAINERS = {                       # --model         module                    
     'cgan2_cycle':    ('cgan2_cycle_model',    'CGAN2CycleModel'),
     'twostage':       ('twostage_cycle_model', 'TwoStageModel'),
     'twostage_cycle': ('twostage_cycle_model', 'TwoStageCycleModel'),
+    'twostage_factd': ('twostage_cycle_model', 'TwoStageFactDModel'),
     'segmentation':   ('segm_model',           'SegmentationModel'),
     'segmentation_cycle': ('segm_cycle_model', 'SegmentationCycleModel'),
 }
-_NOT_ON_THIS_PATH = ('twostage_factd', 'test')
+_NOT_ON_THIS_PATH = ('test',)
 
 
 def create_model(opt):

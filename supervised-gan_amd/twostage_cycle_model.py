@@ -286,6 +286,12 @@ class TwoStageCycleModel(BaseModel):
         self.loss_D2_real, self.loss_D2_fake = ce[0], (ce[1] + ce[2]) / 2
         self._backward(self.loss_D2)
 
+    def _g2_gan_term(self, fake, label, trick):
+        """sum_i lambda_D2[i] * GAN(D2_i(fake), real) of one (label, image) pair (:348-367); `label` is a thunk the factD variant calls."""
+        o = self.opt
+        t, _ = self._gan(self.criterionGAN2, [(d, fake, trick) for d in self.netD2], [l if trick else -l for l in o.lambda_D2])
+        return t
+
     def backward_G(self):
         """(:337-410)"""
         o = self.opt
@@ -294,22 +300,23 @@ class TwoStageCycleModel(BaseModel):
         trick = not o.no_logD_trick
         self.loss_G1_GAN, _ = self._gan(self.criterionGAN1, [(d, self.fake_A, trick) for d in self.netD1],
                                         [l if trick else -l for l in o.lambda_D1])
-        pairs = []
+        pairs, labels = [], []          # `labels`: the half-size label of each pair (what the factD variant shows its D1)
         if 'real_fake' in o.GAN_losses_G2:
             pairs.append(self._pair(self.real_A, self.fake_B_from_real_A))
+            labels.append(lambda: self.transform_inverse(self.real_A))
         if 'fake_fake' in o.GAN_losses_G2:
             fa = self.fake_A.detach() if o.detach_G1_from_G2_y else self.fake_A
             pairs.append(self._pair(self.transform(fa), self.fake_B_from_fake_A))
+            labels.append(lambda: fa)
         num_fake_pairs = len(pairs)
         self.loss_G2_GAN = 0
-        for fake in pairs:
+        for fake, label in zip(pairs, labels):
             if self.multi_class:       # flipped_label = 0 (:352); criterionGAN2(pred, False) addresses class 0 as well
                 preds = networks.multi_forward([(d, fake) for d in self.netD2])
                 for p, lam in zip(preds, o.lambda_D2):
                     self.loss_G2_GAN = self.loss_G2_GAN + self.criterionGAN2(p, 0) * (lam if trick else -lam)
                 continue
-            t, _ = self._gan(self.criterionGAN2, [(d, fake, trick) for d in self.netD2], [l if trick else -l for l in o.lambda_D2])
-            self.loss_G2_GAN = self.loss_G2_GAN + t
+            self.loss_G2_GAN = self.loss_G2_GAN + self._g2_gan_term(fake, label, trick)
         for netD in self.netD1 + self.netD2:
             netD.compute_param_grads = True
         if 'real_fake' in o.GAN_losses_G2:
@@ -396,3 +403,81 @@ class TwoStageModel(TwoStageCycleModel):
 
     def name(self):
         return 'TwoStageModel'
+
+
+class TwoStageFactDModel(TwoStageModel):
+    """TwoStageModel of models/twostage_factD_model.py (`--model twostage_factd`): the image discriminators are factored -- every D2_i
+    prediction is multiplied by the prediction of D1_i on the half-size label, upsampled x2 (`transform`) and reflection-padded to
+    D2_i's map size (util.mul, util/util.py:131-145) -- in the D2 step (:256-296) and in the generators' GAN term (:352-383).
+    The products are formed on probabilities (or raw lsgan scores), so these terms run un-fused: one discriminator call each, the
+    upsample / pad / product / loss on PyTorch's kernels over the 35 x 35-sized maps."""
+
+    def name(self):
+        return 'TwoStageFactDModel'
+
+    def initialize(self, opt):
+        assert not getattr(opt, 'use_multi_class_GAN', False) and not getattr(opt, 'no_cgan', False)          # twostage_factD_model.py:23-24
+        TwoStageModel.initialize(self, opt)
+        if self.isTrain:
+            assert self.n_netD1 == self.n_netD2, "factored discriminators come in (D1_i, D2_i) pairs"
+
+    def graph_spec(self):
+        raise NotImplementedError("twostage_factd runs eagerly (its un-fused discriminator products are not in the graphed step)")
+
+    @staticmethod
+    def _mul(in1, in2):
+        """util.mul (util/util.py:131-145): in1 reflection-padded up to in2's size; the reference returns None when in1 is larger."""
+        if in1.shape == in2.shape:
+            return in1 * in2
+        if not (in1.shape[2] <= in2.shape[2] and in1.shape[3] <= in2.shape[3]):
+            raise ValueError("twostage_factd: the upsampled D1 map %s is larger than D2's %s (the reference's util.mul returns None here); "
+                             "choose --n_layers_D1 / --n_layers_D2 so that it is not" % (tuple(in1.shape[2:]), tuple(in2.shape[2:])))
+        pl, pb = int((in2.shape[3] - in1.shape[3]) / 2), int((in2.shape[2] - in1.shape[2]) / 2)
+        pr, pt = in2.shape[3] - in1.shape[3] - pl, in2.shape[2] - in1.shape[2] - pb
+        return F.pad(in1, (pl, pr, pt, pb), mode='reflect') * in2
+
+    def _plain(self, netD, x):
+        """One discriminator call returning probabilities (--no_lsgan) or raw scores, never the logits-tagged fused form."""
+        fused, netD.fuse_sigmoid_into_loss = netD.fuse_sigmoid_into_loss, False
+        try:
+            return netD.forward(x)
+        finally:
+            netD.fuse_sigmoid_into_loss = fused
+
+    def _factored(self, i, label, pair):
+        p1 = F.interpolate(self._plain(self.netD1[i], label), scale_factor=2, mode='bilinear', align_corners=False)      # self.transform
+        return self._mul(p1, self._plain(self.netD2[i], pair))
+
+    def _crit(self, pred, real):
+        if self.opt.no_lsgan2:
+            return F.binary_cross_entropy(pred, torch.full_like(pred, 1.0 if real else 0.0))
+        return F.mse_loss(pred, torch.full_like(pred, 1.0 if real else 0.0))
+
+    def backward_D2_binary(self):
+        """(twostage_factD_model.py:256-296): the label half of every (pooled) pair goes through transform_inverse to its D1."""
+        o = self.opt
+        n, nc = self.n_netD2, o.input_nc
+        fakes = []
+        if 'real_fake' in o.GAN_losses_D2:
+            fakes.append(self._query(1, self.fake_pool2, lambda: self._pair(self.real_A, self.fake_B_from_real_A)).detach())
+        if 'fake_fake' in o.GAN_losses_D2:
+            fakes.append(self._query(1 + len(fakes), self.fake_pool2,
+                                     lambda: self._pair(self.transform(self.fake_A), self.fake_B_from_fake_A)).detach())
+        self.loss_D2_fake = 0
+        for f in fakes:
+            lab = self.transform_inverse(f.narrow(1, 0, nc)).detach()
+            self.loss_D2_fake = self.loss_D2_fake + sum(self._crit(self._factored(i, lab, f), False) for i in range(n))
+        self.loss_D2_fake = self.loss_D2_fake / len(fakes)
+        real = self._pair(self.real_A, self.real_B)
+        lab = self.transform_inverse(self.real_A)
+        self.loss_D2_real = sum(self._crit(self._factored(i, lab, real), True) for i in range(n))
+        self.loss_D2 = (self.loss_D2_fake + self.loss_D2_real) * 0.5
+        self._backward(self.loss_D2)
+
+    def _g2_gan_term(self, fake, label, trick):
+        lab = label()
+        t = 0
+        for i, lam in enumerate(self.opt.lambda_D2):
+            pred = self._factored(i, lab, fake)
+            t = t + (self._crit(pred, True) * lam if trick else -self._crit(pred, False) * lam)
+        return t

@@ -169,6 +169,33 @@ def test_train_then_test_segmentation_cycle(tmp_path):
     assert len(out) == 6 and all(os.path.exists(p) for p in out)
 
 
+@pytest.mark.parametrize("model", ["twostage", "twostage_factd"])
+def test_train_then_test_twostage(tmp_path, model):
+    """`--model twostage` / `twostage_factd` (models/twostage_model.py, twostage_factD_model.py) through train.py and test.py; the
+    factored variant needs D1 maps that fit inside D2's after the x2 upsampling (n_layers_D1 4 against n_layers_D2 3)."""
+    _need_gpu()
+    import test as test_driver
+    import train as train_driver
+    net = ["--name", "drv_" + model, "--model", model, "--which_direction", "AtoB", "--dataset_mode", "aligned", "--fineSize", "256",
+           "--which_channel", "rg_b", "--which_model_netG1", "fcgan", "--n_layers_G1", "5", "--ngf1", "8", "--noise_nc1", "8", "--noiseSize1", "2",
+           "--which_model_netG2", "crn", "--ngf2", "8", "--noise_nc2", "8", "--noiseSize2", "4", "--upsample_mode2", "bilinear",
+           "--n_layers_CRN_block2", "2", "--transform_1to2", "bilinear_2", "--norm", "instance", "--no_dropout1", "--no_dropout2", "--gpu_ids", "0",
+           "--checkpoints_dir", str(tmp_path / "ckpt"), "--dataroot", "synthetic", "--manualSeed", "5"]
+    d = ["--which_model_netD1", "n_layers", "--n_layers_D1", "4", "4", "--ndf1", "8", "--scale_factor1", "1", "2", "--lambda_D1", "0.5", "0.4",
+         "--which_model_netD2", "n_layers", "--n_layers_D2", "3", "3", "--ndf2", "8", "--scale_factor2", "1", "2", "--lambda_D2", "0.6", "0.4",
+         "--no_lsgan1", "--no_lsgan2", "--GAN_losses_D2", "real_fake", "fake_fake", "--GAN_losses_G2", "real_fake", "fake_fake",
+         "--max_steps", "3", "--print_freq", "1"]
+    m = train_driver.main(net + d)
+    torch.cuda.synchronize()
+    assert m.name() == {"twostage": "TwoStageModel", "twostage_factd": "TwoStageFactDModel"}[model]
+    assert all(np.isfinite(v) for v in m.get_current_errors().values())
+    if model == "twostage_factd":
+        with pytest.raises(NotImplementedError):
+            train_driver.main(net + d + ["--graph"])
+    out = test_driver.main(net + ["--results_dir", str(tmp_path / "res"), "--how_many", "2"])
+    assert out and all(os.path.exists(p) for p in out)
+
+
 def _write_images(folder, n, w, h, seed):
     from PIL import Image
     os.makedirs(folder, exist_ok=True)

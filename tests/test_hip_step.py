@@ -305,7 +305,7 @@ def build_twostage(cfg):
     from supervised_gan_amd.models import create_model
     from supervised_gan_amd.options import TrainOptions
     L = lambda xs: [str(x) for x in xs]
-    argv = ["--name", "t", "--model", "twostage_cycle" if cfg.cycle else "twostage", "--which_direction", "AtoB", "--dataset_mode", "aligned",
+    argv = ["--name", "t", "--model", "twostage_cycle" if cfg.cycle else "twostage_factd" if cfg.factd else "twostage", "--which_direction", "AtoB", "--dataset_mode", "aligned",
             "--fineSize", str(cfg.fineSize), "--transform_1to2", cfg.transform_1to2, "--which_channel", "rg_b",
             "--which_model_netG1", "fcgan", "--n_layers_G1", str(cfg.n_layers_G1), "--ngf1", str(cfg.ngf1),
             "--which_model_netD1", "n_layers", "--n_layers_D1", *L(cfg.n_layers_D1), "--ndf1", str(cfg.ndf1),

@@ -335,7 +335,11 @@ TWOSTAGE_CASES = [("twostage_small.npz", dict(fineSize=256, ngf1=8, noiseSize1=2
                   ("twostage_multiclass_small.npz", dict(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8, ndf2=8,
                                                          GAN_losses_D2=("real_fake", "fake_fake"), GAN_losses_G2=("real_fake", "fake_fake"),
                                                          weights=(2.0, 5.0), use_multi_class_GAN=True, no_lsgan2=True, n_layers_D2=(3, 4),
-                                                         scale_factor2=(1, 2), lambda_D2=(0.6, 0.4)))]     # --use_multi_class_GAN
+                                                         scale_factor2=(1, 2), lambda_D2=(0.6, 0.4))),     # --use_multi_class_GAN
+                  ("twostage_factd_small.npz", dict(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8, ndf2=8,
+                                                    n_layers_D1=(4, 4), n_layers_D2=(3, 3), scale_factor2=(1, 2), lambda_D2=(0.6, 0.4), no_lsgan2=True,
+                                                    GAN_losses_D2=("real_fake", "fake_fake"), GAN_losses_G2=("real_fake", "fake_fake"),
+                                                    cycle=False, factd=True, lambda_G1=0.7, lambda_G2=1.3))]     # --model twostage_factd
 
 
 def twostage_noise(cfg):

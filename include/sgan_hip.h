@@ -73,7 +73,18 @@ typedef struct sgan_conv_desc {
      * channels beyond these counts: the padding channels of a result are then written as if their weights were zero
      * (which they are in every buffer the host mirror builds). */
     int32_t Cin_logical, Cout_logical;
+    /* Arithmetic of the MFMA kernels (the dtype enum of the boundary).  Storage is fp32 in every mode.
+     *   SGAN_MATH_F32    : v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 fma chain (the parity mode);
+     *   SGAN_MATH_BF16X3 : split-bf16 -- every fp32 operand x is cut into hi = bf16(x), lo = bf16(x - hi) and a product is
+     *                      a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-16
+     *                      relative error per product (an fp32-equivalent result, inside the 1e-3 contract) at 16/3 of the
+     *                      fp32 matrix rate.  Needs the job's `w_packed` copy of the weights (sgan_pack_weights); layers the
+     *                      split kernels do not cover (stored channels not a multiple of 8, 4-channel heads) run the fp32
+     *                      kernels whatever this field says. */
+    int32_t math;
 } sgan_conv_desc;
+#define SGAN_MATH_F32 0
+#define SGAN_MATH_BF16X3 1
 
 const char* sgan_version(void);
 const char* sgan_last_error(void);
@@ -132,6 +143,7 @@ typedef struct sgan_conv_fwd_job {
     float* out; int32_t out_ld;
     double* out_stats;
     int32_t out_stats_sq_stride;  /* distance from sum[n] to sumsq[n] in out_stats; 0 = Cout */
+    const void* w_packed;         /* SGAN_MATH_BF16X3: the `packed_fwd` copy of `w` (sgan_pack_weights), same element offset; else NULL */
 } sgan_conv_fwd_job;
 typedef struct sgan_conv_dgrad_job {
     const sgan_conv_desc* d;
@@ -145,6 +157,7 @@ typedef struct sgan_conv_dgrad_job {
     int32_t w_transposed;         /* 1: `w` is the transposed master copy [kh*kw][Cin_s][Cout_s] (sgan_transpose_weights): the
                                    * reduction channel (Cout) is then contiguous and backward-data stages its weights with
                                    * 16-byte LDS stores like the forward pass */
+    const void* w_packed;         /* SGAN_MATH_BF16X3: the `packed_bwd` copy of the weights (sgan_pack_weights); else NULL */
 } sgan_conv_dgrad_job;
 typedef struct sgan_conv_wgrad_job {
     const sgan_conv_desc* d;
@@ -164,6 +177,18 @@ int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* wo
  * parameter buffer are not touched).  Run after each optimizer step on the nets whose backward-data is needed. */
 typedef struct sgan_wt_seg { int64_t off; int32_t taps, cout, cin; } sgan_wt_seg;
 int sgan_transpose_weights(const float* flat, float* flat_t, const sgan_wt_seg* segs, int32_t n /* <= 64 */, void* stream);
+
+/* ---- packed weight copies (the reference keeps one weight tensor per layer, models/networks.py:502-529,815-835; the
+ * kernels read it in three derived forms) ------------------------------------------------------------------------
+ * For every conv segment of the flat parameter buffer (same element offsets in every copy):
+ *   flat_t     [tap][ci][co] fp32                          transposed master copy (as sgan_transpose_weights), or NULL
+ *   packed_fwd [tap][co][ci/8]{8 x bf16 hi | 8 x bf16 lo}  split-bf16 rows for the forward pass   (cin  % 8 == 0), or NULL
+ *   packed_bwd [tap][ci][co/8]{8 x bf16 hi | 8 x bf16 lo}  split-bf16 rows for backward-data      (cout % 8 == 0), or NULL
+ * hi = bf16(x) (round to nearest even), lo = bf16(x - hi).  A copy occupies 4 bytes per weight like the master.  Segments
+ * whose channel count does not divide are left untouched in that copy (such layers run the fp32 kernels).  Run after each
+ * optimizer step / checkpoint load, before the next forward. */
+int sgan_pack_weights(const float* flat, float* flat_t, void* packed_fwd, void* packed_bwd, const sgan_wt_seg* segs,
+                      int32_t n /* <= 64 */, void* stream);
 
 /* ---- backward-weight ---------------------------------------------------------------------------
  * dw += act(norm(in))^T (x) dout over all pixels (master layout), dbias += sum_pixels dout.

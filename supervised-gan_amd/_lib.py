@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGAN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsgan_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+MATH_F32, MATH_BF16X3 = 0, 1
 CONV, CONVT = 0, 1
 
 
@@ -20,7 +21,7 @@ class ConvDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32),
                 ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cout", C.c_int32),
-                ("Cin_logical", C.c_int32), ("Cout_logical", C.c_int32)]
+                ("Cin_logical", C.c_int32), ("Cout_logical", C.c_int32), ("math", C.c_int32)]
 
 
 class GaussJob(C.Structure):
@@ -32,14 +33,14 @@ class GaussJob(C.Structure):
 class ConvFwdJob(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("inp", C.c_void_p), ("in_ld", C.c_int32), ("in_norm", C.POINTER(NormDesc)),
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_stats", C.c_void_p),
-                ("out_stats_sq_stride", C.c_int32)]
+                ("out_stats_sq_stride", C.c_int32), ("w_packed", C.c_void_p)]
 
 
 class ConvDgradJob(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("w", C.c_void_p),
                 ("din", C.c_void_p), ("din_ld", C.c_int32), ("x", C.c_void_p), ("x_ld", C.c_int32),
                 ("x_norm", C.POINTER(NormDesc)), ("bwd_sums", C.c_void_p), ("bwd_sums_sq_stride", C.c_int32),
-                ("accumulate", C.c_int32), ("w_transposed", C.c_int32)]
+                ("accumulate", C.c_int32), ("w_transposed", C.c_int32), ("w_packed", C.c_void_p)]
 
 
 class WtSeg(C.Structure):
@@ -83,6 +84,7 @@ SIGNATURES = {
     "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
     "sgan_norm_bwd_apply_multi": [C.POINTER(NormBwdJob), _I, _P],
     "sgan_transpose_weights": [_P, _P, C.POINTER(WtSeg), _I, _P],
+    "sgan_pack_weights": [_P, _P, _P, _P, C.POINTER(WtSeg), _I, _P],
     "sgan_bce01_fwd": [_P, _I, _P, _I, _I, _I, _P, _P, _I, _P, C.c_int64, _P],
     "sgan_bilinear_up2_fwd": [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "sgan_bilinear_up2_bwd": [_P, _I, _I, _I, _I, _P, _I, _P],

@@ -15,7 +15,7 @@ int sgan_fail(int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" const char* sgan_version(void) { return "sgan_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+extern "C" const char* sgan_version(void) { return "sgan_hip 0.2 (gfx950; fp32 MFMA 16x16x4 + split-bf16 MFMA 32x32x16)"; }
 extern "C" const char* sgan_last_error(void) { return g_sgan_err; }
 extern "C" const char* sgan_last_kernel(void) { return g_sgan_last_kernel; }
 
@@ -443,6 +443,95 @@ extern "C" int sgan_transpose_weights(const float* flat, float* flat_t, const sg
     }
     T.first[n] = tiles;
     hipLaunchKernelGGL(sg_transpose_weights_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, flat, flat_t, T);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Every derived weight copy in one launch (sgan_pack_weights): the fp32 transposed copy and the two split-bf16 copies.
+// One workgroup per 32 x 32 (co, ci) tile of a tap: the tile is read once into LDS; thread (row r = tid >> 3, group
+// q = (tid >> 1) & 3, plane p = tid & 1) then writes one 16-byte chunk {8 x bf16} of the forward copy (row = co, the 8
+// consecutive ci of group q) and one of the backward copy (row = ci, 8 consecutive co).
+// ------------------------------------------------------------------------------------------
+typedef unsigned sg_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned sg_bf16_rne(float x) {   // bits of bf16(x), round to nearest even (NaN stays NaN)
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x);
+}
+
+// plane 0: hi = bf16(x); plane 1: lo = bf16(x - hi)
+__device__ __forceinline__ sg_u32x4 sg_split8(const float* v, int plane) {
+    unsigned h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned hi = sg_bf16_rne(v[e]);
+        h[e] = plane == 0 ? hi : sg_bf16_rne(v[e] - __builtin_bit_cast(float, hi << 16));
+    }
+    return (sg_u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+}
+
+__global__ __launch_bounds__(256) void sg_pack_weights_kernel(const float* flat, float* flat_t, float* pk_f, float* pk_b, const SgWtTable T) {
+    __shared__ float tile[32][33];
+    int i = 0;
+    for (int k = 1; k < T.n; ++k)
+        if ((int64_t)blockIdx.x >= T.first[k]) i = k;
+    const sgan_wt_seg S = T.s[i];
+    int64_t t = blockIdx.x - T.first[i];
+    const int tc = (S.cin + 31) / 32, tr = (S.cout + 31) / 32;
+    const int bx = (int)(t % tc); t /= tc;
+    const int by = (int)(t % tr); t /= tr;      // t = tap
+    const int64_t slab = S.off + t * (int64_t)S.cout * S.cin;
+    const float* src = flat + slab;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int r = ly; r < 32; r += 8) {
+        const int co = by * 32 + r, ci = bx * 32 + lx;
+        tile[r][lx] = (co < S.cout && ci < S.cin) ? src[(int64_t)co * S.cin + ci] : 0.f;
+    }
+    __syncthreads();
+    if (flat_t) {
+        float* dst = flat_t + slab;
+        for (int r = ly; r < 32; r += 8) {
+            const int ci = bx * 32 + r, co = by * 32 + lx;
+            if (ci < S.cin && co < S.cout) dst[(int64_t)ci * S.cout + co] = tile[lx][r];
+        }
+    }
+    const int r = threadIdx.x >> 3, q = (threadIdx.x >> 1) & 3, p = threadIdx.x & 1;
+    if (pk_f && (S.cin & 7) == 0) {
+        const int co = by * 32 + r, ci = bx * 32 + q * 8;
+        if (co < S.cout && ci < S.cin) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[r][q * 8 + e];
+            *reinterpret_cast<sg_u32x4*>(pk_f + slab + (int64_t)co * S.cin + ci + 4 * p) = sg_split8(v, p);
+        }
+    }
+    if (pk_b && (S.cout & 7) == 0) {
+        const int ci = bx * 32 + r, co = by * 32 + q * 8;
+        if (ci < S.cin && co < S.cout) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[q * 8 + e][r];
+            *reinterpret_cast<sg_u32x4*>(pk_b + slab + (int64_t)ci * S.cout + co + 4 * p) = sg_split8(v, p);
+        }
+    }
+}
+
+extern "C" int sgan_pack_weights(const float* flat, float* flat_t, void* packed_fwd, void* packed_bwd, const sgan_wt_seg* segs,
+                                 int32_t n, void* stream) {
+    SGAN_CHECK(flat && segs && n >= 1 && n <= 64, "1..64 segments");
+    SGAN_CHECK(flat_t || packed_fwd || packed_bwd, "no destination");
+    SgWtTable T;
+    T.n = n;
+    int64_t tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        SGAN_CHECK(segs[i].taps > 0 && segs[i].cout > 0 && segs[i].cin > 0 && (segs[i].off & 3) == 0, "bad segment %d", i);
+        T.s[i] = segs[i];
+        T.first[i] = tiles;
+        tiles += (int64_t)segs[i].taps * ((segs[i].cout + 31) / 32) * ((segs[i].cin + 31) / 32);
+    }
+    T.first[n] = tiles;
+    hipLaunchKernelGGL(sg_pack_weights_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, flat, flat_t,
+                       (float*)packed_fwd, (float*)packed_bwd, T);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
 }

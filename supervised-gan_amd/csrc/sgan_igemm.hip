@@ -23,102 +23,11 @@
 // as instantiated at models/networks.py:502-529 (FCGANGenerator) and :815-835 (NLayerDiscriminator).
 #include <type_traits>
 
-#include "sgan_common.h"
+#include "sgan_igemm.h"
 
 #ifndef SG_ABLATE
 #define SG_ABLATE 0   // diagnostics build only: 1 = skip MFMAs, 2 = skip global loads, 4 = skip LDS stores
 #endif
-
-#define SG_MAX_PROB 8
-
-// One launch serves up to SG_MAX_PROB independent problems of the SAME layer type (same kind / k / stride /
-// pad / channels, hence the same taps) but their own tensors and spatial sizes -- e.g. the matching layer of
-// the three discriminators on the fake and on the real batch.  blockIdx.x walks the concatenated M tiles of
-// every (problem, phase); `tile0` is the prefix table.
-struct SgProb {
-    const float* in;    // gathered tensor
-    float* out;         // result tensor
-    const float* w;     // master weight
-    const float* bias;  // [N] or null
-    const float* xref;  // dact epilogue: forward tensor at the output positions, or null
-    double* stats;      // [2N]: fwd (sum, sumsq) of the result, or bwd sums (s1, s2); or null
-    const double* pro_stats;  // prologue norm of the gathered tensor (or null)
-    const float* pro_gamma;
-    const float* pro_beta;
-    const double* xn_stats;   // norm the forward consumer applied to xref (or null)
-    const float* xn_gamma;
-    const float* xn_beta;
-    int32_t Hin, Win, in_ld;     // gathered tensor geometry
-    int32_t Hout, Wout, out_ld;  // result tensor geometry
-    int32_t xref_ld, pro_count, xn_count;
-    int32_t pro_sq, xn_sq;   // sum -> sumsq distance of the two norm statistics (0 = channel count)
-    int32_t stats_sq;        // same for the statistics this launch accumulates (0 = N)
-    int32_t accum;           // out += result (backward-data into a tensor with two forward consumers)
-    int32_t Hp[SGAN_MAX_PHASES], Wp[SGAN_MAX_PHASES];
-    int32_t tile0[SGAN_MAX_PHASES];  // first blockIdx.x of (this problem, phase)
-};
-
-struct SgIgemmParams {   // the kernel argument (~2.3 KB)
-    int32_t Ck, N;        // GEMM-K channels (gathered tensor), GEMM-N channels (result tensor)
-    int32_t is, os;
-    int32_t w_ns, w_ks;   // element strides of B[k-channel][n] inside a tap slab
-    int32_t out_act;
-    int32_t nphase, nprob;
-    int32_t ksplit;       // > 1 (single problem only): split-K, raw partial tiles go to `slab`
-    int32_t n_real;       // result channels that carry data (<= N; the rest is zero padding), small-N kernel only
-    int32_t pro_act, xn_act;
-    float pro_slope, xn_slope, pro_eps, xn_eps;
-    int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
-    SgTap taps[SGAN_MAX_PHASES][SGAN_MAX_TAPS];
-    float* slab;          // [ksplit][Hout*Wout][N] fp32 partials (caller workspace)
-    int64_t slab_stride;  // Hout*Wout*N
-    SgProb q[SG_MAX_PROB];
-};
-
-// The view of ONE problem the kernel bodies work with (scalarised by the compiler).
-struct SgLocal {
-    const float* in; float* out; const float* w; const float* bias; const float* xref; double* stats;
-    int32_t Hin, Win, Ck, in_ld, Hout, Wout, N, out_ld, xref_ld, is, os, w_ns, w_ks, out_act, ksplit;
-    float* slab; int64_t slab_stride;
-    int32_t stats_sq, accum;
-    SgNorm pro, xn;
-};
-
-__device__ __forceinline__ SgLocal sg_local(const SgIgemmParams& G, int g) {
-    const SgProb& Q = G.q[g];
-    SgLocal P;
-    P.in = Q.in; P.out = Q.out; P.w = Q.w; P.bias = Q.bias; P.xref = Q.xref; P.stats = Q.stats;
-    P.Hin = Q.Hin; P.Win = Q.Win; P.Ck = G.Ck; P.in_ld = Q.in_ld; P.Hout = Q.Hout; P.Wout = Q.Wout; P.N = G.N;
-    P.out_ld = Q.out_ld; P.xref_ld = Q.xref_ld; P.is = G.is; P.os = G.os; P.w_ns = G.w_ns; P.w_ks = G.w_ks;
-    P.out_act = G.out_act; P.ksplit = G.ksplit; P.slab = G.slab; P.slab_stride = G.slab_stride;
-    P.pro.stats = Q.pro_stats; P.pro.gamma = Q.pro_gamma; P.pro.beta = Q.pro_beta; P.pro.count = Q.pro_count;
-    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope; P.pro.sq_stride = Q.pro_sq;
-    P.stats_sq = Q.stats_sq ? Q.stats_sq : G.N; P.accum = Q.accum;
-    P.xn.stats = Q.xn_stats; P.xn.gamma = Q.xn_gamma; P.xn.beta = Q.xn_beta; P.xn.count = Q.xn_count;
-    P.xn.eps = G.xn_eps; P.xn.act = G.xn_act; P.xn.slope = G.xn_slope; P.xn.sq_stride = Q.xn_sq;
-    return P;
-}
-
-// XCD-aware work-item order (MI355X: 8 XCDs, each with a private 4 MB L2; workgroups are dealt round-robin
-// over the XCDs in launch order, so launch id b lands on the XCD "b % 8").  Give every XCD one CONTIGUOUS
-// range of work items: tiles that share operand rows (same M tile, neighbouring M tiles, all N tiles) then
-// hit the same L2 instead of every L2 having to hold the whole activation tensor plus the weights.
-// Bijective for any count (placement is a speed matter only, never correctness).
-__device__ __forceinline__ int sg_xcd_remap(int b, int nb) {
-    const int q = nb >> 3, r = nb & 7;
-    const int xcd = b & 7, idx = b >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-// blockIdx.x -> (problem, phase, M tile) through the prefix table
-__device__ __forceinline__ void sg_decode_tile(const SgIgemmParams& G, int bx, int& g, int& phz, int& mtile) {
-    g = 0;
-    phz = 0;
-    for (int gi = 0; gi < G.nprob; ++gi)
-        for (int ph = 0; ph < G.nphase; ++ph)
-            if (bx >= G.q[gi].tile0[ph]) { g = gi; phz = ph; }
-    mtile = bx - G.q[g].tile0[phz];
-}
 
 __device__ __forceinline__ int sg_swz(int row, int kslot) { return (kslot ^ ((row >> 1) & 7)) << 2; }
 
@@ -712,7 +621,6 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
     }
 }
 
-static int sg_fill_tiles(SgIgemmParams& P, int rows_per_tile);   // prefix table; returns total tiles
 
 template <int LPP, int R, int U, int NR>
 static int sg_launch_small_n_nr(SgIgemmParams& P, hipStream_t st) {
@@ -1051,7 +959,7 @@ int sg_build_phases(const sgan_conv_desc* d, bool dgrad, SgPhase* ph, int* nphas
     return SGAN_OK;
 }
 
-static int sg_fill_tiles(SgIgemmParams& P, int rows_per_tile) {
+int sg_fill_tiles(SgIgemmParams& P, int rows_per_tile) {
     int t = 0;
     for (int g = 0; g < P.nprob; ++g)
         for (int ph = 0; ph < P.nphase; ++ph) {
@@ -1063,13 +971,13 @@ static int sg_fill_tiles(SgIgemmParams& P, int rows_per_tile) {
     return t;
 }
 
-static int sg_max_k(const SgIgemmParams& P) {
+int sg_max_k(const SgIgemmParams& P) {
     int k = 0;
     for (int i = 0; i < P.nphase; ++i) k = max(k, P.ktot[i]);
     return k;
 }
 
-static long sg_total_tiles(const SgIgemmParams& P, int BM) {
+long sg_total_tiles(const SgIgemmParams& P, int BM) {
     long t = 0;
     for (int g = 0; g < P.nprob; ++g)
         for (int ph = 0; ph < P.nphase; ++ph) t += sg_cdiv(P.q[g].Hp[ph] * P.q[g].Wp[ph], BM);
@@ -1087,7 +995,7 @@ static double sg_time_model(long wgs, int nkt_wg) {
 // Split-K plan (single problem only): deep reductions on small grids (a 17x17 layer is 24 workgroups walking
 // 64-128 k-tiles one after the other) are cut so that ~2 workgroups land on every CU.  Needs N % 4 == 0 channels
 // with 256 % (N/4) == 0 for the epilogue.
-static int sg_plan_ksplit(const SgIgemmParams& P, int BM, int BN) {
+int sg_plan_ksplit(const SgIgemmParams& P, int BM, int BN) {
     if (P.nprob != 1) return 1;
     const SgProb& Q = P.q[0];
     const int NQ = P.N >> 2;
@@ -1130,6 +1038,17 @@ static int sg_plan_ksplit(const SgIgemmParams& P, int BM, int BN) {
     return sg_cdiv(nkt, per);   // every split non-empty
 }
 
+int sg_launch_splitk_epilogue(const SgIgemmParams& P, hipStream_t st) {
+    const int NQ = P.N >> 2;
+    const int64_t total = (int64_t)P.q[0].Hout * P.q[0].Wout * NQ;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;   // 256 % NQ == 0, so blocks * 256 is a multiple of NQ
+    const size_t elds = (size_t)8 * P.N * 4;
+    hipLaunchKernelGGL(sg_splitk_epilogue_kernel, dim3(blocks), dim3(256), elds, st, P);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
 template <int BM, int BN, int WGM, int WGN>
 static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes) {
     const bool bkc = P.w_ks == 1;
@@ -1170,15 +1089,7 @@ static int sg_launch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_t 
         g_sgan_last_kernel = (BM == 64 && BN == 32) ? "sg_igemm_kernel<64,32,2,2,false>" : BM == 64 ? "sg_igemm_kernel<64,64,2,2,false>" : BN == 64 ? "sg_igemm_kernel<128,64,2,2,false>"
                              : BN == 32 ? "sg_igemm_kernel<128,32,4,1,false>" : "sg_igemm_kernel<128,16,4,1,false>";
     sg_prof_end(st, g_sgan_last_kernel);
-    if (ks > 1) {
-        const int NQ = P.N >> 2;
-        const int64_t total = (int64_t)P.q[0].Hout * P.q[0].Wout * NQ;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 1024) blocks = 1024;   // 256 % NQ == 0, so blocks * 256 is a multiple of NQ
-        const size_t elds = (size_t)8 * P.N * 4;
-        hipLaunchKernelGGL(sg_splitk_epilogue_kernel, dim3(blocks), dim3(256), elds, st, P);
-        SGAN_LAUNCH_CHECK();
-    }
+    if (ks > 1) return sg_launch_splitk_epilogue(P, st);
     return SGAN_OK;
 }
 
@@ -1211,6 +1122,9 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
         if (ktot >= 256) return sg_launch_small_n<16, 2, 4>(P, st);
         return sg_launch_small_n<8, 4, 4>(P, st);
     }
+    const int e3 = sg_igemm3_eligible(P);   // split-bf16 MFMA (sgan_igemm3.hip)
+    if (e3 < 0) return e3;
+    if (e3) return sg_launch_igemm3(P, st, ws, ws_bytes);
     int BM, BN;
     sg_pick_tile(P, &BM, &BN);
     if (BN == 16) return sg_launch_igemm<128, 16, 4, 1>(P, st, ws, ws_bytes);
@@ -1235,6 +1149,7 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
 
 static int64_t sg_workspace_need(const SgIgemmParams& P) {
     if (sg_use_small_n(P)) return 0;
+    if (sg_igemm3_eligible(P) > 0) return sg_igemm3_workspace_need(P);
     int BM, BN;
     sg_pick_tile(P, &BM, &BN);
     const int ks = sg_plan_ksplit(P, BM, BN);
@@ -1306,6 +1221,7 @@ extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, i
     const sgan_conv_desc* d0 = jobs[0].d;
     P.Ck = d0->Cin; P.N = d0->Cout;
     P.w_ns = d0->Cin; P.w_ks = 1;  // B[k=ci][n=co] = W[tap][co][ci]
+    P.math = d0->math;
     P.out_act = out_act;
     const sgan_norm_desc* n0 = jobs[0].in_norm;
     P.pro_act = n0 ? n0->act : SGAN_ACT_NONE; P.pro_slope = n0 ? n0->slope : 0.f; P.pro_eps = n0 ? n0->eps : 0.f;
@@ -1317,7 +1233,8 @@ extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, i
         SGAN_CHECK(J.in_ld >= J.d->Cin && J.out_ld >= J.d->Cout && (J.in_ld & 3) == 0, "bad leading dims in job %d", g);
         SGAN_CHECK((J.in_norm ? J.in_norm->act : SGAN_ACT_NONE) == P.pro_act, "grouped jobs must share the prologue activation");
         SgProb& Q = P.q[g];
-        Q.in = J.in; Q.out = J.out; Q.w = J.w; Q.bias = J.bias; Q.xref = nullptr; Q.stats = J.out_stats;
+        SGAN_CHECK(J.d->math == d0->math, "grouped jobs must share the math mode");
+        Q.in = J.in; Q.out = J.out; Q.w = J.w; Q.wp = J.w_packed; Q.bias = J.bias; Q.xref = nullptr; Q.stats = J.out_stats;
         Q.Hin = J.d->Hin; Q.Win = J.d->Win; Q.in_ld = J.in_ld; Q.Hout = J.d->Hout; Q.Wout = J.d->Wout; Q.out_ld = J.out_ld;
         sg_set_norm(J.in_norm, &Q.pro_stats, &Q.pro_gamma, &Q.pro_beta, &Q.pro_count, &Q.pro_sq);
         Q.xn_count = 1;
@@ -1339,6 +1256,7 @@ extern "C" int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t 
     P.Ck = d0->Cout; P.N = d0->Cin;
     if (jobs[0].w_transposed) { P.w_ns = d0->Cout; P.w_ks = 1; }   // B[k=co][n=ci] = Wt[tap][ci][co]: k contiguous
     else { P.w_ns = 1; P.w_ks = d0->Cin; }                          // B[k=co][n=ci] = W[tap][co][ci]: n contiguous
+    P.math = d0->math;
     P.out_act = SGAN_ACT_NONE;
     P.pro_act = SGAN_ACT_NONE;
     const sgan_norm_desc* x0 = jobs[0].x ? jobs[0].x_norm : nullptr;
@@ -1354,7 +1272,8 @@ extern "C" int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t 
         const sgan_norm_desc* xn = J.x ? J.x_norm : nullptr;
         SGAN_CHECK((xn ? xn->act : SGAN_ACT_NONE) == P.xn_act, "grouped jobs must share the activation");
         SgProb& Q = P.q[g];
-        Q.in = J.dout; Q.out = J.din; Q.w = J.w; Q.bias = nullptr; Q.xref = J.x; Q.stats = J.bwd_sums;
+        SGAN_CHECK(J.d->math == d0->math, "grouped jobs must share the math mode");
+        Q.in = J.dout; Q.out = J.din; Q.w = J.w; Q.wp = J.w_transposed ? J.w_packed : nullptr; Q.bias = nullptr; Q.xref = J.x; Q.stats = J.bwd_sums;
         Q.Hin = J.d->Hout; Q.Win = J.d->Wout; Q.in_ld = J.dout_ld; Q.Hout = J.d->Hin; Q.Wout = J.d->Win; Q.out_ld = J.din_ld;
         Q.xref_ld = J.x_ld;
         Q.pro_count = 1;
@@ -1370,7 +1289,7 @@ extern "C" int sgan_conv_fwd(const sgan_conv_desc* d, const float* in, int32_t i
                              const float* w, const float* bias, float* out, int32_t out_ld, int32_t out_act,
                              double* out_stats, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
-    sgan_conv_fwd_job j = {d, in, in_ld, in_norm, w, bias, out, out_ld, out_stats, 0};
+    sgan_conv_fwd_job j = {d, in, in_ld, in_norm, w, bias, out, out_ld, out_stats, 0, nullptr};   // no packed copy: fp32 kernels
     return sgan_conv_fwd_grouped(&j, 1, out_act, workspace, workspace_bytes, stream);
 }
 
@@ -1378,6 +1297,6 @@ extern "C" int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32
                                float* din, int32_t din_ld, const float* x, int32_t x_ld, const sgan_norm_desc* x_norm,
                                double* bwd_sums, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
-    sgan_conv_dgrad_job j = {d, dout, dout_ld, w, din, din_ld, x, x_ld, x_norm, bwd_sums, 0, 0, 0};
+    sgan_conv_dgrad_job j = {d, dout, dout_ld, w, din, din_ld, x, x_ld, x_norm, bwd_sums, 0, 0, 0, nullptr};
     return sgan_conv_dgrad_grouped(&j, 1, workspace, workspace_bytes, stream);
 }

@@ -1,0 +1,483 @@
+// Implicit-GEMM Conv2d / ConvTranspose2d forward and backward-data for gfx950 (CDNA4), split-bf16 arithmetic
+// (SGAN_MATH_BF16X3): fp32 tensors in HBM, fp32 accumulation, every product evaluated as
+//     a * b  ~=  a_hi * b_hi + a_hi * b_lo + a_lo * b_hi,      x_hi = bf16(x),  x_lo = bf16(x - x_hi)
+// on v_mfma_f32_32x32x16_bf16 (16x the per-clock rate of the fp32 MFMA, so three of them still retire 16/3 of the fp32
+// rate).  What is dropped is a_lo * b_lo (<= 2^-16 |a b|) and the rounding of the lo parts (<= 2^-17): the result is an
+// fp32-equivalent product, measured 1e-6 .. 1e-5 of the output scale per layer against the exact-fp32 kernel.
+//
+// Same GEMM view, gather, prologue ("normalise-on-load") and epilogue as sg_igemm_kernel (sgan_igemm.hip); what differs:
+//  * weights come pre-split from the packed copy (sgan_pack_weights): rows [n][k/8]{8 hi | 8 lo}, so the B operand is
+//    staged with plain 16-byte copies; activations are split while they are staged (after the prologue transform):
+//    6 VALU per 2 elements (cvt_pk, shift, and, 2 sub, cvt_pk);
+//  * LDS tile rows are 128 bytes = one 32-deep k-tile of one row: 8 chunks {8 bf16} = (k-group 0..3) x (hi, lo) at
+//    slot 2 * kgroup + plane, chunk position XOR-swizzled with (row >> 1) & 7 -- conflict free for the ds_read_b128
+//    fragment reads (a lane group reads one slot of 16 rows) and for the ds_write_b128 of both operands (A: eight lanes
+//    write four k-groups of rows r and r + 2; B: eight lanes write the eight slots of one row);
+//  * MFMA 32x32x16: lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8h + j] / B[k = 8h + j][col r], j < 8, i.e.
+//    exactly one LDS chunk per (k16 step, plane); the 32x32 shape leaves 24 of every 32 cycles of VALU issue beside an
+//    MFMA (16x16x32: 8 of 16), which the staging arithmetic needs;
+//  * tiles: 128x128 with eight waves (wave tile 64x32), 128x64 / 64x64 / 128x32 with four.  LDS traffic, not the MFMA
+//    pipe, bounds the small tiles (a 64x64 tile moves 256 LDS-array cycles per k-tile against 192 MFMA cycles; 128x128:
+//    640 against 768), so the dispatcher takes the largest tile that still fills the chip.
+//
+// Reference ops replaced: nn.Conv2d / nn.ConvTranspose2d forward + convolution_backward(input) as instantiated at
+// models/networks.py:502-529 (FCGANGenerator), :815-835 (NLayerDiscriminator), :356-398 (U-Net), :686-774 (CRN).
+#include <type_traits>
+
+#include "sgan_igemm.h"
+
+typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 fp32 -> {8 x bf16 hi, 8 x bf16 lo}.  hi = RNE(x); lo = RNE(x - hi) (the subtraction is exact).
+__device__ __forceinline__ void sg_split8(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo) {
+    float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 p = {x[2 * i], x[2 * i + 1]};
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(p, sg_bf16x2));   // v_cvt_pk_bf16_f32
+        const f32x2 r = {x[2 * i] - __builtin_bit_cast(float, h << 16), x[2 * i + 1] - __builtin_bit_cast(float, h & 0xffff0000u)};
+        hi[i] = h;
+        lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sg_bf16x2));
+    }
+}
+
+// byte offset of 16-byte chunk `slot` of tile row `row` (128-byte rows)
+__device__ __forceinline__ int sg3_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int BM, int BN, int WGM, int WGN, bool PRO>
+__global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemmParams G) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, MB = WTM / 32, NB = WTN / 32;
+    constexpr int A_IT = BM * 4 / NT;              // tasks of 8 consecutive k of one row (two 16-byte loads) per thread
+    constexpr int B_IT = (BN * 8 + NT - 1) / NT;   // 16-byte chunks of the packed weight rows per thread
+    static_assert(BM * 4 % NT == 0 && A_IT >= 1, "A tile");
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                         // [2][BM * 128]
+    char* Bs = smem + 2 * BM * 128;          // [2][BN * 128]
+    double* red = reinterpret_cast<double*>(smem + 2 * (BM + BN) * 128);   // [2 * BN]
+    int4* ttab = reinterpret_cast<int4*>(red + 2 * BN);                     // [16] {dy, dx, gather offset, weight slab offset}
+    float* pscale = reinterpret_cast<float*>(ttab + SGAN_MAX_TAPS);         // [Ck]
+    float* pshift = pscale + G.Ck;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int ntn = (G.N + BN - 1) / BN;
+    const int item = sg_xcd_remap(blockIdx.x, gridDim.x);
+    int g, phz, mtile;
+    sg_decode_tile(G, item / ntn, g, phz, mtile);
+    const SgLocal P = sg_local(G, g);
+    const int split = blockIdx.z;
+    const int Hp = G.q[g].Hp[phz], Wp = G.q[g].Wp[phz];
+    const int M = Hp * Wp;
+    const int m0 = mtile * BM, n0 = (item % ntn) * BN;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(G.q[g].wp), 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int OOB = (int)0x80000000u;
+    const int oa = G.oa[phz], ob = G.ob[phz];
+    const int ktot = G.ktot[phz];
+    const int Ck = P.Ck, N = P.N;
+    const int nkt_total = (ktot + 31) >> 5;
+    const int kt_per = (nkt_total + P.ksplit - 1) / P.ksplit;
+    const int kt0 = split * kt_per;
+    const int nkt = max(min(nkt_total, kt0 + kt_per) - kt0, 0);   // may be 0 for a trailing split: writes zeros
+
+    // ---- one-time setup: tap table, prologue scale/shift, reduction scratch ----
+    if (tid < SGAN_MAX_TAPS) {
+        const bool v = tid < G.ntaps[phz];
+        const int dy = v ? (int)G.taps[phz][tid].dy : 0, dx = v ? (int)G.taps[phz][tid].dx : 0;
+        ttab[tid] = make_int4(dy, dx, (dy * P.Win + dx) * P.in_ld, v ? G.taps[phz][tid].w_off : 0);
+    }
+    for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.0;
+    if constexpr (PRO) {
+        for (int c = tid; c < Ck; c += NT) {
+            float sc = 1.f, sh = 0.f;
+            if (P.pro.stats) {
+                float mean, rstd;
+                sg_mean_rstd(P.pro, Ck, c, mean, rstd);
+                const float gm = P.pro.gamma ? P.pro.gamma[c] : 1.f;
+                const float bt = P.pro.beta ? P.pro.beta[c] : 0.f;
+                sc = gm * rstd;
+                sh = bt - mean * sc;
+            }
+            pscale[c] = sc;
+            pshift[c] = sh;
+        }
+    }
+
+    // ---- per-thread staging state ----
+    // Every thread works on k-group kg = tid & 3 (8 consecutive k = 8 consecutive channels of one tap, Ck % 8 == 0) of its A
+    // rows and of its B rows, so one (tap, channel) walk serves both: + 32 k per tile = adv_tap taps + adv_c channels.
+    const int kg = tid & 3;
+    const int adv_tap = 32 / Ck, adv_c = 32 - adv_tap * Ck;
+    const int ntaps = G.ntaps[phz];
+    const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
+    int a_iy[A_IT], a_ix[A_IT], a_base[A_IT], a_dst[A_IT];
+    bool a_rowok[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int e = tid + it * NT;
+        const int j = e >> 3, u = (e >> 2) & 1;
+        const int row = 4 * (j >> 1) + (j & 1) + 2 * u;     // eight consecutive lanes: rows r and r + 2 (bank-conflict-free stores)
+        const int m = m0 + row;
+        a_rowok[it] = m < M;
+        const int py = m / Wp, px = m - py * Wp;
+        a_iy[it] = py * P.is;
+        a_ix[it] = px * P.is;
+        a_base[it] = (a_iy[it] * P.Win + a_ix[it]) * P.in_ld;
+        a_dst[it] = sg3_off(row, 2 * kg);        // hi chunk; the lo chunk is slot + 1: byte offset ^ 16
+    }
+    int a_tap = (kt0 * 32 + kg * 8) / Ck;
+    int a_c = kt0 * 32 + kg * 8 - a_tap * Ck;
+    int b_base[B_IT], b_dst[B_IT];
+    bool b_rowok[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int e = tid + it * NT;
+        const int n = e >> 3, t = e & 7;             // t & 3 == kg; plane = t >> 2
+        b_rowok[it] = (B_IT * NT == BN * 8 || e < BN * 8) && n0 + n < N;
+        b_base[it] = (n0 + n) * P.w_ns + 4 * (t >> 2);
+        b_dst[it] = sg3_off(n, 2 * (t & 3) + (t >> 2));
+    }
+
+    constexpr int NSET = 4;     // register ring: tile kt+1 being written to LDS, tiles kt+2 .. kt+NSET in flight (see sgan_igemm.hip)
+    f32x4 a_reg[NSET][A_IT][2];
+    bool a_ok[NSET][A_IT];
+    int a_cs[NSET] = {0, 0, 0, 0};
+    u32x4 b_reg[NSET][B_IT];
+    int a_off_n[A_IT], b_off_n[B_IT], a_cs_n = 0;
+    bool a_ok_n[A_IT];
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    __syncthreads();  // tap table visible
+
+    int ld_left = nkt;
+    auto next_addrs = [&]() {
+        const bool in_range = ld_left > 0;
+        --ld_left;
+        const bool kok = (a_tap < ntaps) & in_range;
+        const int4 t = ttab[kok ? a_tap : 0];
+        a_cs_n = kok ? a_c : 0;
+        const int toff = t.z + a_c;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int iy = a_iy[it] + t.x, ix = a_ix[it] + t.y;
+            // bitwise on purpose: a short-circuit becomes a branch and ends the scheduling region shared with the MFMA block
+            const bool ok = a_rowok[it] & kok & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
+            a_off_n[it] = ok ? (a_base[it] + toff) << 2 : OOB;
+            if constexpr (PRO) a_ok_n[it] = ok;
+        }
+        const int woff = t.w + a_c;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) b_off_n[it] = (b_rowok[it] & kok) ? (b_base[it] + woff) << 2 : OOB;
+        a_tap += adv_tap;
+        a_c += adv_c;
+        if (a_c >= Ck) { a_c -= Ck; ++a_tap; }
+    };
+
+    auto issue_loads = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            a_reg[S][it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off_n[it], 0, 0));
+            a_reg[S][it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off_n[it] + 16, 0, 0));
+            if constexpr (PRO) a_ok[S][it] = a_ok_n[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            b_reg[S][it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off_n[it], 0, 0));
+        if constexpr (PRO) a_cs[S] = a_cs_n;
+    };
+
+    // prologue transform (norm + activation of the producer layer), split, write register set S to LDS buffer S & 1
+    auto store_tile = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        char* Ab = As + (S & 1) * BM * 128;
+        char* Bb = Bs + (S & 1) * BN * 128;
+        f32x4 sc0, sc1, sh0, sh1;
+        if constexpr (PRO) {
+            sc0 = *reinterpret_cast<const f32x4*>(pscale + a_cs[S]);
+            sc1 = *reinterpret_cast<const f32x4*>(pscale + a_cs[S] + 4);
+            sh0 = *reinterpret_cast<const f32x4*>(pshift + a_cs[S]);
+            sh1 = *reinterpret_cast<const f32x4*>(pshift + a_cs[S] + 4);
+        }
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            f32x4 v0 = a_reg[S][it][0], v1 = a_reg[S][it][1];
+            if constexpr (PRO) {
+                // okf * act(y) = max(okf * y, okf * neg * y), neg <= 1 (host-checked): zero padding applies AFTER norm + activation
+                const float okf = a_ok[S][it] ? 1.f : 0.f;
+                const float okn = okf * pro_neg;
+                const f32x4 y0 = v0 * sc0 + sh0, y1 = v1 * sc1 + sh1;
+                const f32x4 p0 = y0 * okf, q0 = y0 * okn, p1 = y1 * okf, q1 = y1 * okn;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(p0[j], q0[j]); v1[j] = fmaxf(p1[j], q1[j]); }
+            }
+            u32x4 hi, lo;
+            sg_split8(v0, v1, hi, lo);
+            *reinterpret_cast<u32x4*>(Ab + a_dst[it]) = hi;
+            *reinterpret_cast<u32x4*>(Ab + (a_dst[it] ^ 16)) = lo;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int e = tid + it * NT;
+            if (B_IT * NT == BN * 8 || e < BN * 8) *reinterpret_cast<u32x4*>(Bb + b_dst[it]) = b_reg[S][it];
+        }
+    };
+
+    // fragment addresses: lane (r = lane & 31, h = lane >> 5) reads chunk slot 2 * (2 s + h) + plane of its row
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fswz = (fr >> 1) & 7;
+    int f_off[2][2];   // [k16 step][plane]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) f_off[s][p] = ((2 * (2 * s + fh) + p) ^ fswz) << 4;
+    const int fa_row = (wm * WTM + fr) * 128, fb_row = (wn * WTN + fr) * 128;
+
+    auto mfma_tile = [&](int buf) {
+        const char* Ab = As + buf * BM * 128 + fa_row;
+        const char* Bb = Bs + buf * BN * 128 + fb_row;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            sg_bf16x8 ah[MB], al[MB], bh[NB], bl[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                ah[i] = *reinterpret_cast<const sg_bf16x8*>(Ab + i * 32 * 128 + f_off[s][0]);
+                al[i] = *reinterpret_cast<const sg_bf16x8*>(Ab + i * 32 * 128 + f_off[s][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                bh[j] = *reinterpret_cast<const sg_bf16x8*>(Bb + j * 32 * 128 + f_off[s][0]);
+                bl[j] = *reinterpret_cast<const sg_bf16x8*>(Bb + j * 32 * 128 + f_off[s][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    // Same software pipeline as sg_igemm_kernel: one barrier per k-tile; iteration kt issues the loads of tile kt + NSET, then
+    // one scheduling region holds the MFMA block on tile kt, the transform + split + LDS store of tile kt + 1 and the address
+    // arithmetic of tile kt + NSET + 1.
+    auto iteration = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        issue_loads(std::integral_constant<int, S>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile(S & 1);
+        store_tile(std::integral_constant<int, (S + 1) % NSET>{});
+        next_addrs();
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    next_addrs();
+    issue_loads(I0{});
+    next_addrs();
+    issue_loads(I1{});
+    next_addrs();
+    issue_loads(I2{});
+    next_addrs();
+    issue_loads(I3{});
+    next_addrs();
+    store_tile(I0{});
+    __syncthreads();
+    {
+        int kt = 0;
+        for (; kt + 3 < nkt; kt += 4) {
+            iteration(I0{});
+            iteration(I1{});
+            iteration(I2{});
+            iteration(I3{});
+        }
+        if (kt < nkt) iteration(I0{});
+        if (kt + 1 < nkt) iteration(I1{});
+        if (kt + 2 < nkt) iteration(I2{});
+    }
+
+    // ---- epilogue: acc[i][j][r] = out[m = m0 + wm*WTM + i*32 + (r & 3) + 8 (r >> 2) + 4 fh][n = n0 + wn*WTN + j*32 + fr] ----
+    const bool want_stats = P.stats != nullptr;
+    if (P.ksplit > 1) {   // split-K: raw partial tile to this split's slab; sg_splitk_epilogue_kernel finishes
+        float* sl = P.slab + (int64_t)split * P.slab_stride;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m < M) {
+                    const int py = m / Wp, px = m - py * Wp;
+                    const int64_t pix = (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int n = n0 + wn * WTN + j * 32 + fr;
+                        if (n < N) sl[pix * N + n] = acc[i][j][r];
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const bool dact = P.xref != nullptr;
+    const bool xnorm = dact && P.xn.stats != nullptr;
+    const float xn_neg = P.xn.act == SGAN_ACT_NONE ? 1.f : (P.xn.act == SGAN_ACT_RELU ? 0.f : P.xn.slope);
+    float bias_v[NB], x_mean[NB], x_rstd[NB], x_g[NB], x_b[NB];
+    bool nvalid[NB];
+    double s1[NB], s2[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + fr;
+        nvalid[j] = n < N;
+        bias_v[j] = (P.bias && nvalid[j]) ? P.bias[n] : 0.f;
+        x_mean[j] = 0.f; x_rstd[j] = 1.f; x_g[j] = 1.f; x_b[j] = 0.f;
+        if (xnorm && nvalid[j]) {
+            sg_mean_rstd(P.xn, N, n, x_mean[j], x_rstd[j]);
+            x_g[j] = P.xn.gamma ? P.xn.gamma[n] : 1.f;
+            x_b[j] = P.xn.beta ? P.xn.beta[n] : 0.f;
+        }
+        s1[j] = 0.0;
+        s2[j] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (m < M) {
+                const int py = m / Wp, px = m - py * Wp;
+                const int64_t pix = (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int n = n0 + wn * WTN + j * 32 + fr;
+                    if (nvalid[j]) {
+                        float v = acc[i][j][r] + bias_v[j];
+                        if (dact) {
+                            const float x = P.xref[pix * P.xref_ld + n];
+                            const float xhat = (x - x_mean[j]) * x_rstd[j];
+                            const float y = xnorm ? (x_g[j] * xhat + x_b[j]) : x;
+                            v *= (y > 0.f ? 1.f : xn_neg);
+                            s1[j] += (double)v;
+                            s2[j] += (double)(v * xhat);
+                        } else {
+                            s1[j] += (double)v;
+                            s2[j] += (double)v * (double)v;
+                            if (P.out_act == SGAN_ACT_TANH) v = tanhf(v);
+                        }
+                        if (P.accum) v += P.out[pix * P.out_ld + n];
+                        P.out[pix * P.out_ld + n] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (want_stats) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int nl = wn * WTN + j * 32 + fr;
+            double a = s1[j], b = s2[j];
+            a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 32);
+            if (fh == 0 && nvalid[j]) {
+                atomicAdd(&red[nl], a);
+                atomicAdd(&red[BN + nl], b);
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+            atomicAdd(&P.stats[n0 + tid], red[tid]);
+            atomicAdd(&P.stats[P.stats_sq + n0 + tid], red[BN + tid]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static inline int sg3_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// 1: runs on the split-bf16 kernels; 0: not covered (the fp32 kernels serve it); < 0: asked for, covered, but a job lacks its packed weights
+int sg_igemm3_eligible(const SgIgemmParams& P) {
+    if (P.math != SGAN_MATH_BF16X3 || P.w_ks != 1 || (P.Ck & 7) || P.Ck < 16 || P.N < 16 || P.w_ns != P.Ck) return 0;
+    for (int g = 0; g < P.nprob; ++g)
+        if (!P.q[g].wp)
+            return sgan_fail(SGAN_ERR_INVALID, "SGAN_MATH_BF16X3: job %d has no w_packed copy of its weights (sgan_pack_weights)", g);
+    return 1;
+}
+
+struct Sg3Tile { int BM, BN; };
+
+// Largest tile that still gives the chip about two workgroups of four waves per CU (LDS traffic per flop falls with the
+// tile: see the file header); SGAN_TILE3 = "BMxBN" overrides (tuning).
+static Sg3Tile sg3_pick_tile(const SgIgemmParams& P) {
+    const char* force = getenv("SGAN_TILE3");    // read per call: tests walk the tile shapes in one process
+    if (force) {
+        int bm = 0, bn = 0;
+        if (sscanf(force, "%dx%d", &bm, &bn) == 2) {
+            if (bm == 128 && bn == 128 && P.N > 64) return {128, 128};
+            if (bm == 128 && bn == 64 && P.N > 32) return {128, 64};
+            if (bm == 64 && bn == 64 && P.N > 32) return {64, 64};
+        }
+    }
+    if (P.N <= 32) return {128, 32};
+    static const long want = getenv("SGAN_TILE3_WANT") ? atol(getenv("SGAN_TILE3_WANT")) : 384;
+    if (P.N > 64 && sg_total_tiles(P, 128) * sg3_cdiv(P.N, 128) >= want / 2) return {128, 128};   // eight waves per workgroup
+    if (sg_total_tiles(P, 128) * sg3_cdiv(P.N, 64) >= want) return {128, 64};
+    return {64, 64};
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int sg3_launch(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes, const char* name) {
+    constexpr int NT = 64 * WGM * WGN;
+    const int tiles = sg_fill_tiles(P, BM);
+    if (tiles == 0) return SGAN_OK;
+    int ks = sg_plan_ksplit(P, BM, BN);
+    const int64_t slab = (int64_t)P.q[0].Hout * P.q[0].Wout * P.N;
+    if (ks > 1 && (!ws || ws_bytes < (int64_t)ks * slab * 4)) ks = 1;   // no workspace: unsplit (still correct)
+    P.ksplit = ks;
+    P.slab = ks > 1 ? ws : nullptr;
+    P.slab_stride = slab;
+    dim3 grid(tiles * sg3_cdiv(P.N, BN), 1, ks);
+    const size_t lds = (size_t)2 * (BM + BN) * 128 + (size_t)4 * BN * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
+    if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
+    bool pro = P.pro_act != SGAN_ACT_NONE;
+    for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
+    sg_prof_begin(st);
+    if (pro) hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, true>), grid, dim3(NT), lds, st, P);
+    else hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, false>), grid, dim3(NT), lds, st, P);
+    SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = name;
+    sg_prof_end(st, g_sgan_last_kernel);
+    if (ks > 1) return sg_launch_splitk_epilogue(P, st);
+    return SGAN_OK;
+}
+
+int sg_launch_igemm3(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes) {
+    const Sg3Tile t = sg3_pick_tile(P);
+    if (t.BN == 32) return sg3_launch<128, 32, 4, 1>(P, st, ws, ws_bytes, "sg_igemm3_kernel<128,32,4,1>");
+    if (t.BM == 128 && t.BN == 128) return sg3_launch<128, 128, 2, 4>(P, st, ws, ws_bytes, "sg_igemm3_kernel<128,128,2,4>");
+    if (t.BM == 128) return sg3_launch<128, 64, 2, 2>(P, st, ws, ws_bytes, "sg_igemm3_kernel<128,64,2,2>");
+    return sg3_launch<64, 64, 2, 2>(P, st, ws, ws_bytes, "sg_igemm3_kernel<64,64,2,2>");
+}
+
+int64_t sg_igemm3_workspace_need(const SgIgemmParams& P) {
+    const Sg3Tile t = sg3_pick_tile(P);
+    const int ks = sg_plan_ksplit(P, t.BM, t.BN);
+    return ks > 1 ? (int64_t)ks * P.q[0].Hout * P.q[0].Wout * P.N * 4 : 0;
+}

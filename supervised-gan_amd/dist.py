@@ -38,6 +38,8 @@ def broadcast_parameters(nets, src=0):
         flat = getattr(net, "_flat", None)
         if flat is not None:
             dist.broadcast(flat, src)
+            if hasattr(net, "invalidate_derived"):   # c10d writes the buffer without moving a version counter
+                net.invalidate_derived()
         for b in net.buffers():
             dist.broadcast(b, src)
         for p in getattr(net, "_extra_parameters", lambda: [])():

@@ -59,6 +59,9 @@ def weights_init(m):
     kind = getattr(m, "_sgan_kind", None)
     if kind == "conv":
         m.weight.data.normal_(0.0, 0.02)
+        seg = getattr(m.weight, "_sgan_seg", None)
+        if seg is not None:      # a write through `.data` moves no version counter: tell the net its derived copies are stale
+            seg[0].invalidate_derived()
     elif kind == "bn":
         m.weight.data.normal_(1.0, 0.02)
         m.bias.data.fill_(0)
@@ -326,25 +329,62 @@ class ChainNet(nn.Module):
         return self._geom_cache[key]
 
     def _wb(self, L: LayerSpec):
-        w = self._flat[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s]
+        """(weight, bias) of layer L for the forward pass; the weight slice carries the matching slice of the split-bf16
+        forward copy for the bf16x3 kernels."""
+        n = L.k * L.k * L.cout_s * L.cin_s
+        w = self._flat[L.w_off: L.w_off + n]
+        if ops.get_math() == "bf16x3":
+            self._refresh_derived()
+            ops.with_packed(w, self._pk_f[L.w_off: L.w_off + n])
         b = self._flat[L.b_off: L.b_off + L.cout_s] if L.bias else None
         return w, b
 
     def _wt(self, L: LayerSpec):
-        """Weights of layer L from the transposed copy [tap][Cin][Cout] that backward-data reads (refreshed lazily: after an
-        optimizer step -- FusedAdam bumps `_wt_epoch` -- or any in-place torch write to the flat storage)."""
-        key = (self._flat.data_ptr(), self._flat._version, getattr(self, "_wt_epoch", 0))
-        if getattr(self, "_wt_key", None) != key:
-            if getattr(self, "_flat_t", None) is None or self._flat_t.shape != self._flat.shape or self._flat_t.device != self._flat.device:
-                self._flat_t = torch.zeros_like(self._flat)
-            segs, seen = [], set()
-            for Lx in self.layers:
-                if Lx.w_off not in seen:
-                    seen.add(Lx.w_off)
-                    segs.append((Lx.w_off, Lx.k * Lx.k, Lx.cout_s, Lx.cin_s))
-            ops.transpose_weights(self._flat, self._flat_t, segs)
-            self._wt_key = key
-        return self._flat_t[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s]
+        """Weights of layer L from the transposed copy [tap][Cin][Cout] that backward-data reads (+ its split-bf16 twin)."""
+        self._refresh_derived()
+        n = L.k * L.k * L.cout_s * L.cin_s
+        return ops.with_packed(self._flat_t[L.w_off: L.w_off + n], self._pk_b[L.w_off: L.w_off + n])
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_derived()
+        return out
+
+    def invalidate_derived(self):
+        """Call after writing the parameters behind torch's back (e.g. through `.data` of a foreign alias): the derived weight
+        copies are re-made before the next kernel that reads them."""
+        self._wt_epoch = getattr(self, "_wt_epoch", 0) + 1
+
+    def _derived_key(self):
+        # Every way the flat storage changes must move this key: FusedAdam.step() / load_state_dict / _apply / weights_init bump
+        # `_wt_epoch`; torch optimizers, `param.copy_` and the like bump the Parameters' own version counters (set_data gave each
+        # Parameter a counter of its own, so `_flat._version` alone misses them); in-place ops on `_flat` itself bump its counter.
+        return (self._flat.data_ptr(), self._flat._version, getattr(self, "_wt_epoch", 0),
+                tuple(p._version for p in self._conv_weight_params()))
+
+    def _conv_weight_params(self):
+        ps = getattr(self, "_cw_params", None)
+        if ps is None:
+            ps = self._cw_params = [self._box(L).weight for L in self.layers]
+        return ps
+
+    def _refresh_derived(self):
+        """The three derived weight copies (fp32 transposed, split-bf16 forward / backward: sgan_pack_weights), refreshed lazily
+        by ONE launch whenever the parameters changed since they were made."""
+        key = self._derived_key()
+        if getattr(self, "_wt_key", None) == key:
+            return
+        if getattr(self, "_flat_t", None) is None or self._flat_t.shape != self._flat.shape or self._flat_t.device != self._flat.device:
+            self._flat_t = torch.zeros_like(self._flat)
+            self._pk_f = torch.zeros_like(self._flat)
+            self._pk_b = torch.zeros_like(self._flat)
+        segs, seen = [], set()
+        for Lx in self.layers:
+            if Lx.w_off not in seen:
+                seen.add(Lx.w_off)
+                segs.append((Lx.w_off, Lx.k * Lx.k, Lx.cout_s, Lx.cin_s))
+        ops.pack_weights(self._flat, self._flat_t, self._pk_f, self._pk_b, segs)
+        self._wt_key = key
 
     def _gwb(self, L: LayerSpec):
         w = self._gflat[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s]

@@ -16,6 +16,33 @@ def pad4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
+# Arithmetic of the MFMA conv kernels (sgan_conv_desc.math): "bf16x3" = split-bf16 (fp32-equivalent, ~2^-16 per product,
+# 16/3 of the fp32 matrix rate; the default), "f32" = exact fp32 MFMA (the parity mode).  SGAN_MATH selects at start-up,
+# set_math() at run time (every conv call stamps the current mode into its descriptor).
+_MATH_NAMES = {"f32": L.MATH_F32, "fp32": L.MATH_F32, "bf16x3": L.MATH_BF16X3}
+_math = _MATH_NAMES[__import__("os").environ.get("SGAN_MATH", "bf16x3").lower()]
+
+
+def set_math(name: str):
+    global _math
+    _math = _MATH_NAMES[name.lower()]
+
+
+def get_math() -> str:
+    return "bf16x3" if _math == L.MATH_BF16X3 else "f32"
+
+
+def with_packed(w: torch.Tensor, packed) -> torch.Tensor:
+    """Tag a weight slice with the matching slice of the split-bf16 copy (sgan_pack_weights) for the job builders."""
+    w._sgan_pk = packed
+    return w
+
+
+def _pk(w):
+    pk = getattr(w, "_sgan_pk", None)
+    return pk.data_ptr() if (pk is not None and _math == L.MATH_BF16X3) else None
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -37,7 +64,7 @@ def _act(t):
 
 def conv_desc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin=0, Cout=0):
     """Cin / Cout: logical channel counts (0 = unknown), a hint that lets kernels skip the zero padding channels."""
-    return L.ConvDesc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin, Cout)
+    return L.ConvDesc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin, Cout, _math)
 
 
 def norm_desc(stats=None, gamma=None, beta=None, count=1, eps=1e-5, act=ACT_NONE, slope=0.0, sq_stride=0):
@@ -63,26 +90,17 @@ def _workspace(kib, device):
 
 
 def conv_fwd(desc, x, in_norm, w, bias, out, out_act=ACT_NONE, out_stats=None, stats_sq=0):
-    if stats_sq:
-        return conv_fwd_grouped([(desc, x, in_norm, w, bias, out, out_stats, stats_sq)], out_act)
-    args = (C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(w), _ptr(bias), _ptr(_act(out)), out.stride(1),
-            out_act, _ptr(out_stats))
-    ws = _workspace(L.lib().sgan_conv_fwd(*args, None, -1, None), x.device)
-    L.check(L.lib().sgan_conv_fwd(*args, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "sgan_conv_fwd")
+    return conv_fwd_grouped([(desc, x, in_norm, w, bias, out, out_stats, stats_sq)], out_act)
 
 
 def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None, sums_sq=0, accumulate=False, w_transposed=False):
     """accumulate: din += result (a tensor with two consumers); sums_sq: see norm_desc; w_transposed: `w` is the
-    [tap][Cin][Cout] copy made by transpose_weights."""
-    if sums_sq or accumulate or w_transposed:
-        return conv_dgrad_grouped([(desc, dout, w, din, x, x_norm, bwd_sums, sums_sq, accumulate, w_transposed)])
-    args = (C.byref(desc), _ptr(_act(dout)), dout.stride(1), _ptr(w), _ptr(_act(din)), din.stride(1),
-            _ptr(x), x.stride(1) if x is not None else 0, _nd(x_norm), _ptr(bwd_sums))
-    ws = _workspace(L.lib().sgan_conv_dgrad(*args, None, -1, None), dout.device)
-    L.check(L.lib().sgan_conv_dgrad(*args, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "sgan_conv_dgrad")
+    [tap][Cin][Cout] copy made by pack_weights."""
+    return conv_dgrad_grouped([(desc, dout, w, din, x, x_norm, bwd_sums, sums_sq, accumulate, w_transposed)])
 
 
 def conv_wgrad(desc, x, in_norm, dout, dw, dbias):
+    desc.math = _math
     args = (C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(_act(dout)), dout.stride(1), _ptr(dw), _ptr(dbias))
     ws = _workspace(L.lib().sgan_conv_wgrad(*args, None, -1, None), x.device) if min(desc.Cin, desc.Cout) <= 4 else None
     L.check(L.lib().sgan_conv_wgrad(*args, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "sgan_conv_wgrad")
@@ -97,8 +115,9 @@ def conv_fwd_grouped(jobs, out_act=ACT_NONE):
     arr = (L.ConvFwdJob * len(jobs))()
     for i, job in enumerate(jobs):
         desc, x, in_norm, w, bias, out, st = job[:7]
+        desc.math = _math
         arr[i] = L.ConvFwdJob(C.pointer(desc), _ptr(_act(x)).value, x.stride(1), _pn(in_norm), _ptr(w).value, _ptr(bias).value,
-                              _ptr(_act(out)).value, out.stride(1), _ptr(st).value, int(job[7]) if len(job) > 7 else 0)
+                              _ptr(_act(out)).value, out.stride(1), _ptr(st).value, int(job[7]) if len(job) > 7 else 0, _pk(w))
     ws = _workspace(L.lib().sgan_conv_fwd_grouped(arr, len(jobs), out_act, None, -1, None), jobs[0][1].device)
     L.check(L.lib().sgan_conv_fwd_grouped(arr, len(jobs), out_act, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_fwd_grouped")
@@ -109,10 +128,11 @@ def conv_dgrad_grouped(jobs):
     arr = (L.ConvDgradJob * len(jobs))()
     for i, job in enumerate(jobs):
         desc, dout, w, din, x, x_norm, sums = job[:7]
+        desc.math = _math
         arr[i] = L.ConvDgradJob(C.pointer(desc), _ptr(_act(dout)).value, dout.stride(1), _ptr(w).value, _ptr(_act(din)).value,
                                 din.stride(1), _ptr(x).value, x.stride(1) if x is not None else 0, _pn(x_norm), _ptr(sums).value,
                                 int(job[7]) if len(job) > 7 else 0, int(bool(job[8])) if len(job) > 8 else 0,
-                                int(bool(job[9])) if len(job) > 9 else 0)
+                                int(bool(job[9])) if len(job) > 9 else 0, _pk(w))
     ws = _workspace(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device)
     L.check(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_dgrad_grouped")
@@ -122,6 +142,7 @@ def conv_wgrad_grouped(jobs):
     """jobs: list of (desc, x, in_norm, dout, dw, dbias)."""
     arr = (L.ConvWgradJob * len(jobs))()
     for i, (desc, x, in_norm, dout, dw, dbias) in enumerate(jobs):
+        desc.math = _math
         arr[i] = L.ConvWgradJob(C.pointer(desc), _ptr(_act(x)).value, x.stride(1), _pn(in_norm), _ptr(_act(dout)).value,
                                 dout.stride(1), _ptr(dw).value, _ptr(dbias).value)
     d0 = jobs[0][0]
@@ -136,6 +157,16 @@ def transpose_weights(flat, flat_t, segs):
         part = segs[i0:i0 + 64]
         arr = (L.WtSeg * len(part))(*[L.WtSeg(int(o), int(t), int(co), int(ci)) for o, t, co, ci in part])
         L.check(L.lib().sgan_transpose_weights(_ptr(flat), _ptr(flat_t), arr, len(part), _stream()), "sgan_transpose_weights")
+
+
+def pack_weights(flat, flat_t, pk_fwd, pk_bwd, segs):
+    """Every derived weight copy of the conv ranges `segs` = [(off, taps, cout_s, cin_s)] of a flat parameter buffer in one
+    launch per 64 ranges: fp32 transposed copy + the two split-bf16 copies (sgan_pack_weights)."""
+    for i0 in range(0, len(segs), 64):
+        part = segs[i0:i0 + 64]
+        arr = (L.WtSeg * len(part))(*[L.WtSeg(int(o), int(t), int(co), int(ci)) for o, t, co, ci in part])
+        L.check(L.lib().sgan_pack_weights(_ptr(flat), _ptr(flat_t), _ptr(pk_fwd), _ptr(pk_bwd), arr, len(part), _stream()),
+                "sgan_pack_weights")
 
 
 def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None, sums_sq=0):

@@ -34,7 +34,19 @@ def master_weight(w, transposed, dev="cuda"):
         wm = w.permute(2, 3, 0, 1)
     m = torch.zeros(k, k, pad4(cout), pad4(cin), dtype=torch.float32)
     m[:, :, :cout, :cin] = wm
-    return m.reshape(-1).to(dev)
+    return derived_copies(m.reshape(-1).to(dev), k, pad4(cout), pad4(cin))[0]
+
+
+def derived_copies(wm, k, cout_s, cin_s):
+    """(wm, wt): the master weight tagged with its split-bf16 forward copy, and the transposed copy [tap][Cin][Cout] tagged with
+    the split-bf16 backward copy -- what ChainNet._wb / _wt hand to the conv calls (one sgan_pack_weights launch)."""
+    from supervised_gan_amd import ops
+    wt, pf, pb = torch.zeros_like(wm), torch.zeros_like(wm), torch.zeros_like(wm)
+    ops.pack_weights(wm, wt, pf, pb, [(0, k * k, cout_s, cin_s)])
+    ops.with_packed(wm, pf)
+    ops.with_packed(wt, pb)
+    wm._sgan_wt = wt
+    return wm, wt
 
 
 def from_master(m, k, cin, cout, transposed):

@@ -1,0 +1,188 @@
+"""The split-bf16 ("bf16x3") arithmetic mode of the conv kernels: the packed weight copies bit for bit, every tile shape of
+sg_igemm3_kernel against the exact-fp32 kernel and against an fp64 CPU result, ragged sizes, grouped launches and split-K."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")
+    from supervised_gan_amd import _lib, ops
+    _lib.lib()
+    prev = ops.get_math()
+    yield ops
+    ops.set_math(prev)
+    os.environ.pop("SGAN_TILE3", None)
+
+
+def _bf16_rne_bits(x):
+    """uint16 bits of bf16(x), round to nearest even -- numpy restatement of what v_cvt_pk_bf16_f32 does on finite values."""
+    u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+
+def _split(x):
+    hi = _bf16_rne_bits(x)
+    hif = (hi.astype(np.uint32) << 16).view(np.float32)
+    lo = _bf16_rne_bits(x.astype(np.float32) - hif)
+    return hi, lo
+
+
+def test_pack_weights_bit_exact(ops):
+    """flat_t / packed_fwd / packed_bwd of two segments (one with Cin % 8 != 0: its forward copy is left untouched)."""
+    rng = np.random.default_rng(5)
+    segs = [(0, 16, 40, 24), (16 * 40 * 24 + 8, 9, 16, 12)]      # (off, taps, cout, cin); 8 floats of bias between them
+    total = segs[1][0] + 9 * 16 * 12
+    flat = (rng.standard_normal(total) * np.exp(rng.uniform(-12, 3, total))).astype(np.float32)
+    f = torch.from_numpy(flat).cuda()
+    ft, pf, pb = torch.zeros_like(f), torch.zeros_like(f), torch.zeros_like(f)
+    ops.pack_weights(f, ft, pf, pb, segs)
+    torch.cuda.synchronize()
+    ft, pf, pb = ft.cpu().numpy(), pf.cpu().numpy().view(np.uint16), pb.cpu().numpy().view(np.uint16)
+    for off, taps, co, ci in segs:
+        w = flat[off: off + taps * co * ci].reshape(taps, co, ci)
+        assert np.array_equal(ft[off: off + taps * co * ci].reshape(taps, ci, co), w.transpose(0, 2, 1))
+        for name, pk, rows, cols, m in (("fwd", pf, co, ci, w), ("bwd", pb, ci, co, w.transpose(0, 2, 1))):
+            got = pk[2 * off: 2 * (off + taps * co * ci)].reshape(taps, rows, cols // 8 if cols % 8 == 0 else 1, -1)
+            if cols % 8:
+                assert not got.any(), name       # untouched (zeros from the allocation)
+                continue
+            hi, lo = _split(np.ascontiguousarray(m))
+            want = np.stack([hi.reshape(taps, rows, cols // 8, 8), lo.reshape(taps, rows, cols // 8, 8)], axis=3)
+            assert np.array_equal(got.reshape(taps, rows, cols // 8, 2, 8), want), name
+
+
+SHAPES = [
+    # kind, k, s, p, cin, cout, H, W, norm, act
+    ("conv", 4, 2, 2, 32, 64, 67, 45, None, 2),
+    ("conv", 4, 1, 2, 128, 256, 33, 29, "in", 2),
+    ("conv", 3, 1, 1, 64, 64, 40, 56, "in", 1),
+    ("convT", 4, 2, 1, 256, 128, 16, 12, "bn", 1),
+    ("convT", 4, 2, 1, 64, 32, 31, 33, "bn", 1),
+    ("conv", 4, 2, 1, 24, 40, 30, 30, "in", 2),        # channel counts that are multiples of 8 but not of 32
+]
+TILES = ["auto", "64x64", "128x64", "128x128"]
+
+
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"{c[0]}_k{c[1]}s{c[2]}_{c[4]}to{c[5]}_{c[6]}x{c[7]}" for c in SHAPES])
+def test_igemm3_vs_fp32_kernel_and_fp64(ops, shape, tile):
+    from hip_utils import from_buf, master_weight, pad_vec, rel, stats_of, to_buf
+    kind, k, s, p, cin, cout, H, W, norm, act = shape
+    tr = kind == "convT"
+    if tile == "auto":
+        os.environ.pop("SGAN_TILE3", None)
+    else:
+        os.environ["SGAN_TILE3"] = tile
+    g = torch.Generator().manual_seed(99)
+    x = (torch.randn(1, cin, H, W, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = (torch.randn(*wshape, generator=g) * 0.05).double()
+    b = (torch.randn(cout, generator=g) * 0.1).double()
+    gamma = (1 + 0.2 * torch.randn(cin, generator=g)).double() if norm == "bn" else None
+    beta = (0.1 * torch.randn(cin, generator=g)).double() if norm == "bn" else None
+    a = x
+    if norm == "in":
+        a = F.instance_norm(a, eps=1e-5)
+    elif norm == "bn":
+        a = F.batch_norm(a, None, None, gamma, beta, training=True, eps=1e-5)
+    a = F.relu(a) if act == 1 else (F.leaky_relu(a, 0.2) if act == 2 else a)
+    out = F.conv_transpose2d(a, w, b, stride=s, padding=p) if tr else F.conv2d(a, w, b, stride=s, padding=p)
+    R = torch.randn(out.shape, generator=g).double()
+    (out * R).sum().backward()
+    Ho, Wo = out.shape[2:]
+    desc = ops.conv_desc(1 if tr else 0, k, s, p, H, W, cin, Ho, Wo, cout, cin, cout)
+    xb, wm, bb, Rb = to_buf(x.detach().float()), master_weight(w.float(), tr), pad_vec(b.float()), to_buf(R.float())
+    st_in = stats_of(x.detach()) if norm else None
+    in_norm = ops.norm_desc(st_in, pad_vec(gamma.float()) if gamma is not None else None, pad_vec(beta.float()) if beta is not None else None,
+                            H * W, 1e-5, act, 0.2)
+    res = {}
+    for mode in ("f32", "bf16x3"):
+        ops.set_math(mode)
+        ob = torch.full((Ho, Wo, cout), float("nan"), device="cuda")
+        ost = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+        ops.conv_fwd(desc, xb, in_norm, wm, bb, ob, 0, ost)
+        din = torch.full((H, W, cin), float("nan"), device="cuda")
+        sums = torch.zeros(2 * cin, dtype=torch.float64, device="cuda") if norm else None
+        ops.conv_dgrad(desc, Rb, wm._sgan_wt, din, xb, in_norm, sums, w_transposed=True)
+        if norm:
+            ops.norm_bwd_apply(din, xb, in_norm, sums)
+        torch.cuda.synchronize()
+        res[mode] = (ob, ost, din)
+        assert torch.isfinite(ob).all() and torch.isfinite(din).all()
+    ops.set_math("bf16x3")
+    e32 = rel(from_buf(res["f32"][0], cout), out)
+    e3 = rel(from_buf(res["bf16x3"][0], cout), out)
+    d32 = rel(from_buf(res["f32"][2], cin), x.grad)
+    d3 = rel(from_buf(res["bf16x3"][2], cin), x.grad)
+    print(f"fwd err vs fp64: f32 {e32:.2e} bf16x3 {e3:.2e}; dgrad: f32 {d32:.2e} bf16x3 {d3:.2e}")
+    assert e3 < 3e-5 and d3 < 1e-4, (e3, d3)                     # an fp32-equivalent result: 30x inside the 1e-3 contract
+    assert rel(res["bf16x3"][1], stats_of(out.detach(), "cpu")) < 1e-4
+    assert rel(res["bf16x3"][0], res["f32"][0]) < 3e-5
+
+
+def test_igemm3_grouped_and_splitk(ops):
+    """Three problems of one layer type and different sizes in one grouped launch, and a deep reduction on a tiny map (split-K
+    through the slab epilogue), both in split-bf16 against the exact-fp32 kernels."""
+    from hip_utils import master_weight, pad_vec, rel, stats_of, to_buf
+    os.environ.pop("SGAN_TILE3", None)
+    g = torch.Generator().manual_seed(3)
+    cin, cout = 128, 256
+    w = torch.randn(cout, cin, 4, 4, generator=g) * 0.03
+    wm, bb = master_weight(w, False), pad_vec(torch.randn(cout, generator=g) * 0.1)
+    sizes = [(65, 65), (33, 33), (17, 19)]
+    xs = [torch.randn(1, cin, H, W, generator=g) for H, W in sizes]
+    out = {}
+    for mode in ("f32", "bf16x3"):
+        ops.set_math(mode)
+        jobs, keep = [], []
+        for (H, W), x in zip(sizes, xs):
+            desc = ops.conv_desc(0, 4, 1, 2, H, W, cin, H + 1, W + 1, cout)
+            nd = ops.norm_desc(stats_of(x), None, None, H * W, 1e-5, 2, 0.2)
+            ob = torch.full((H + 1, W + 1, cout), float("nan"), device="cuda")
+            ost = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+            jobs.append((desc, to_buf(x), nd, wm, bb, ob, ost))
+            keep.append((ob, ost))
+        ops.conv_fwd_grouped(jobs)
+        torch.cuda.synchronize()
+        out[mode] = keep
+    for (o3, s3), (o1, s1) in zip(out["bf16x3"], out["f32"]):
+        assert rel(o3, o1) < 3e-5 and rel(s3, s1) < 1e-5
+    # split-K: 512 -> 512 on an 8x8 map (U-Net inner block)
+    cin = cout = 512
+    w = torch.randn(cout, cin, 4, 4, generator=g) * 0.02
+    wm = master_weight(w, False)
+    x = torch.randn(1, cin, 8, 8, generator=g)
+    desc = ops.conv_desc(0, 4, 2, 1, 8, 8, cin, 4, 4, cout)
+    nd = ops.norm_desc(stats_of(x), None, None, 64, 1e-5, 2, 0.2)
+    got = {}
+    for mode in ("f32", "bf16x3"):
+        ops.set_math(mode)
+        ob = torch.full((4, 4, cout), float("nan"), device="cuda")
+        ost = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+        ops.conv_fwd(desc, to_buf(x), nd, wm, None, ob, 0, ost)
+        torch.cuda.synchronize()
+        got[mode] = (ob, ost)
+    ops.set_math("bf16x3")
+    assert rel(got["bf16x3"][0], got["f32"][0]) < 3e-5 and rel(got["bf16x3"][1], got["f32"][1]) < 1e-5
+
+
+def test_bf16x3_needs_packed_weights(ops):
+    """No silent change of arithmetic: a layer the split kernels cover, asked for in bf16x3 without the packed copy, raises."""
+    from supervised_gan_amd._lib import SganError
+    ops.set_math("bf16x3")
+    x = torch.zeros(16, 16, 32, device="cuda")
+    w = torch.zeros(16 * 32 * 32, device="cuda")        # not tagged with a packed copy
+    y = torch.zeros(9, 9, 32, device="cuda")
+    with pytest.raises(SganError, match="w_packed"):
+        ops.conv_fwd(ops.conv_desc(0, 4, 2, 2, 16, 16, 32, 9, 9, 32), x, None, w, None, y)
+    ops.set_math("f32")
+    ops.conv_fwd(ops.conv_desc(0, 4, 2, 2, 16, 16, 32, 9, 9, 32), x, None, w, None, y)
+    ops.set_math("bf16x3")

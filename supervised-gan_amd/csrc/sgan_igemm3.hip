@@ -201,18 +201,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
         if constexpr (PRO) a_cs[S] = a_cs_n;
     };
 
-    // prologue transform (norm + activation of the producer layer), split, write register set S to LDS buffer S & 1
-    auto store_tile = [&](auto S_) {
+    // prologue transform (norm + activation of the producer layer), split, write register set S to LDS buffer S & 1.  The
+    // scale / shift chunks of the set's channels are read from LDS by load_scales() ahead of the fragment reads, so the
+    // counted lgkmcnt wait in front of the transform does not cover the fragments.
+    f32x4 sc0, sc1, sh0, sh1;
+    auto load_scales = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
-        char* Ab = As + (S & 1) * BM * 128;
-        char* Bb = Bs + (S & 1) * BN * 128;
-        f32x4 sc0, sc1, sh0, sh1;
         if constexpr (PRO) {
             sc0 = *reinterpret_cast<const f32x4*>(pscale + a_cs[S]);
             sc1 = *reinterpret_cast<const f32x4*>(pscale + a_cs[S] + 4);
             sh0 = *reinterpret_cast<const f32x4*>(pshift + a_cs[S]);
             sh1 = *reinterpret_cast<const f32x4*>(pshift + a_cs[S] + 4);
         }
+    };
+    auto store_tile = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        char* Ab = As + (S & 1) * BM * 128;
+        char* Bb = Bs + (S & 1) * BN * 128;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             f32x4 v0 = a_reg[S][it][0], v1 = a_reg[S][it][1];
@@ -247,42 +252,58 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
         for (int p = 0; p < 2; ++p) f_off[s][p] = ((2 * (2 * s + fh) + p) ^ fswz) << 4;
     const int fa_row = (wm * WTM + fr) * 128, fb_row = (wn * WTN + fr) * 128;
 
-    auto mfma_tile = [&](int buf) {
-        const char* Ab = As + buf * BM * 128 + fa_row;
-        const char* Bb = Bs + buf * BN * 128 + fb_row;
+    // One k-tile per iteration, one barrier.  A wave issues in order, so the order below IS the schedule (pinned with
+    // sched_barrier; inside the last phase sched_group_barrier deals the address arithmetic into the MFMA shadows):
+    //   (1) global loads of tile kt + NSET, LDS reads of the scale / shift chunks, then every fragment read of tile kt;
+    //   (2) transform + split + LDS store of tile kt + 1 (its global loads were issued NSET - 1 iterations ago): VALU work that
+    //       needs no fragment -- it covers the LDS latency of (1);
+    //   (3) the MFMAs of tile kt, each followed by its share of the address arithmetic of tile kt + NSET + 1.
+    // Measured alternatives (D 128 -> 256 @65^2 x 6 problems, 12.2 GFLOP): compiler-scheduled 67 us; these phases 62 us; the two
+    // wave halves of an 8-wave workgroup in opposite phase order 73 us; fully software-pipelined (fragments of tile kt + 1 and
+    // the store of tile kt + 2 dealt between the MFMAs of tile kt, 40 more VGPRs) 62 us.  The instruction schedule is not what
+    // bounds this kernel: it moves 16 KB (64x64 tile) per k-tile through L2 -> L1 -> VGPR -> LDS and the L2s deliver ~12 TB/s
+    // chip-wide (TCC_HIT * 128 B / time), which is 190 TFLOP/s at 0.125 B per MAC -- see DESIGN.md for what lifts that.
+    auto iteration = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        const char* Ab = As + (S & 1) * BM * 128 + fa_row;
+        const char* Bb = Bs + (S & 1) * BN * 128 + fb_row;
+        issue_loads(std::integral_constant<int, S>{});
+        load_scales(std::integral_constant<int, (S + 1) % NSET>{});
+        sg_bf16x8 ah[2][MB], al[2][MB], bh[2][NB], bl[2][NB];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            sg_bf16x8 ah[MB], al[MB], bh[NB], bl[NB];
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
-                ah[i] = *reinterpret_cast<const sg_bf16x8*>(Ab + i * 32 * 128 + f_off[s][0]);
-                al[i] = *reinterpret_cast<const sg_bf16x8*>(Ab + i * 32 * 128 + f_off[s][1]);
+                ah[s][i] = *reinterpret_cast<const sg_bf16x8*>(Ab + i * 32 * 128 + f_off[s][0]);
+                al[s][i] = *reinterpret_cast<const sg_bf16x8*>(Ab + i * 32 * 128 + f_off[s][1]);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                bh[j] = *reinterpret_cast<const sg_bf16x8*>(Bb + j * 32 * 128 + f_off[s][0]);
-                bl[j] = *reinterpret_cast<const sg_bf16x8*>(Bb + j * 32 * 128 + f_off[s][1]);
+                bh[s][j] = *reinterpret_cast<const sg_bf16x8*>(Bb + j * 32 * 128 + f_off[s][0]);
+                bl[s][j] = *reinterpret_cast<const sg_bf16x8*>(Bb + j * 32 * 128 + f_off[s][1]);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(std::integral_constant<int, (S + 1) % NSET>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
                 }
-        }
-    };
-    // Same software pipeline as sg_igemm_kernel: one barrier per k-tile; iteration kt issues the loads of tile kt + NSET, then
-    // one scheduling region holds the MFMA block on tile kt, the transform + split + LDS store of tile kt + 1 and the address
-    // arithmetic of tile kt + NSET + 1.
-    auto iteration = [&](auto S_) {
-        constexpr int S = decltype(S_)::value;
-        issue_loads(std::integral_constant<int, S>{});
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_tile(S & 1);
-        store_tile(std::integral_constant<int, (S + 1) % NSET>{});
         next_addrs();
+        constexpr int NMFMA = 6 * MB * NB;
+        constexpr int PER = (40 + 6 * A_IT + 2 * B_IT + NMFMA - 1) / NMFMA;   // next_addrs is ~40 + 6 A_IT + 2 B_IT VALU / SALU
+#pragma unroll
+        for (int q = 0; q < NMFMA; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x006, PER, 0);    // VALU / SALU in its shadow
+        }
         __syncthreads();
     };
     using I0 = std::integral_constant<int, 0>;
@@ -298,6 +319,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     next_addrs();
     issue_loads(I3{});
     next_addrs();
+    load_scales(I0{});
     store_tile(I0{});
     __syncthreads();
     {
@@ -415,6 +437,11 @@ static inline int sg3_cdiv(int a, int b) { return (a + b - 1) / b; }
 // 1: runs on the split-bf16 kernels; 0: not covered (the fp32 kernels serve it); < 0: asked for, covered, but a job lacks its packed weights
 int sg_igemm3_eligible(const SgIgemmParams& P) {
     if (P.math != SGAN_MATH_BF16X3 || P.w_ks != 1 || (P.Ck & 7) || P.Ck < 16 || P.N < 16 || P.w_ns != P.Ck) return 0;
+    // Tiny maps stay on the exact-fp32 kernels: they cost nothing (latency bound), and an InstanceNorm over a 2x2 .. 8x8 map
+    // (the inner U-Net levels) divides by the standard deviation of a handful of values -- it amplifies the 5e-6 of the
+    // split products by orders of magnitude where it leaves the 3e-7 of the fp32 chain inside the 1e-3 contract.
+    for (int g = 0; g < P.nprob; ++g)
+        if (P.q[g].Hin * P.q[g].Win < SGAN_BF16X3_MIN_PIXELS || P.q[g].Hout * P.q[g].Wout < SGAN_BF16X3_MIN_PIXELS) return 0;
     for (int g = 0; g < P.nprob; ++g)
         if (!P.q[g].wp)
             return sgan_fail(SGAN_ERR_INVALID, "SGAN_MATH_BF16X3: job %d has no w_packed copy of its weights (sgan_pack_weights)", g);

@@ -17,43 +17,7 @@
 // nn.ConvTranspose2d on the path (models/networks.py:502-529, :815-835).
 #include <type_traits>
 
-#include "sgan_common.h"
-
-#define SGW_MAX_PROB 8
-
-struct SgWgradProb {
-    const float* in;
-    const float* dout;
-    float* dw;
-    float* dbias;
-    const double* pro_stats;
-    const float* pro_gamma;
-    const float* pro_beta;
-    int32_t Hin, Win, in_ld;
-    int32_t Hout, Wout, dout_ld;
-    int32_t pro_count, pro_sq;
-    int32_t nsplit;  // pixel-range splits of this problem
-    int32_t z0;      // first blockIdx.z of this problem (z = z0 + phase * nsplit + split)
-    int32_t Hp[SGAN_MAX_PHASES], Wp[SGAN_MAX_PHASES];
-};
-
-struct SgWgradParams {   // kernel argument: common layer description + up to 8 problems (see sgan_igemm.hip)
-    int32_t Cin, Cout;
-    int32_t is, os;
-    int32_t w_ns;
-    int32_t nphase, nprob;
-    int32_t pro_act;
-    float pro_slope, pro_eps;
-    int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
-    SgTap taps[SGAN_MAX_PHASES][SGAN_MAX_TAPS];
-    SgWgradProb q[SGW_MAX_PROB];
-};
-
-struct SgWgradLocal {
-    const float* in; const float* dout; float* dw; float* dbias;
-    int32_t Hin, Win, Cin, in_ld, Hout, Wout, Cout, dout_ld, is, os, w_ns, nsplit;
-    SgNorm pro;
-};
+#include "sgan_wgrad.h"
 
 // PRO: the forward input gets the producer's norm + activation applied while it is staged
 template <int BCO, int BKC, int WGC, int WGK, bool PRO>
@@ -776,7 +740,7 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
         SGAN_CHECK(J.in && J.dout && J.dw, "null tensor in job %d", g);
         SGAN_CHECK(J.in_ld >= d->Cin && J.dout_ld >= d->Cout && (J.in_ld & 3) == 0 && (J.dout_ld & 3) == 0, "bad leading dims in job %d", g);
         SGAN_CHECK(d->kind == d0->kind && d->k == d0->k && d->stride == d0->stride && d->pad == d0->pad && d->Cin == d0->Cin &&
-                       d->Cout == d0->Cout, "grouped problems must be the same layer type");
+                       d->Cout == d0->Cout && d->math == d0->math, "grouped problems must be the same layer type and math mode");
         SGAN_CHECK((J.in_norm ? J.in_norm->act : SGAN_ACT_NONE) == P.pro_act, "grouped jobs must share the prologue activation");
         SgPhase ph[SGAN_MAX_PHASES];
         int nphase, is, os;
@@ -817,7 +781,11 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
             if (rc != 1 || workspace_bytes == -1) return rc;
         }
     }
-    if (workspace_bytes == -1) return 0;   // the tiled kernel combines its splits with atomics: no workspace
+    if (workspace_bytes == -1) return 0;   // the tiled kernels combine their splits with atomics: no workspace
+    if (d0->math == SGAN_MATH_BF16X3) {      // split-bf16 MFMA (sgan_wgrad3.hip) where it covers the layer
+        const int r3 = sg_launch_wgrad3(P, st);
+        if (r3 != 0) return r3 < 0 ? r3 : SGAN_OK;
+    }
     if (d0->Cout <= 16) return sg_launch_wgrad<16, 128, 1, 4>(P, st);
     if (d0->Cout <= 32) return sg_launch_wgrad<32, 64, 1, 4>(P, st);
     return sg_launch_wgrad<64, 64, 2, 2>(P, st);

@@ -1223,7 +1223,25 @@ class UnetGenerator(ChainNet):
         return mask, noise
 
     # ---- programs -------------------------------------------------------------------------------
+    # A U-Net whose bottleneck normalises maps of a handful of pixels (unet_256 at 512^2: InstanceNorm over 4x4 .. 2x2) is ill
+    # conditioned there: the normalisation divides by the standard deviation of 4 - 64 values and amplifies whatever error the
+    # outer layers carry by ~10^3 (measured: the 5e-6 of split-bf16 layers became 5e-3 .. 1e-2 in the weight gradients, the
+    # 3e-7 of the fp32 chain stays inside the 1e-3 contract).  Such a net runs the exact-fp32 kernels whatever ops.get_math() says.
+    MIN_NORM_POPULATION = 256
+
+    def _call_math(self, H, W):
+        small = (H >> (self.n - 1)) * (W >> (self.n - 1))
+        return "f32" if small < self.MIN_NORM_POPULATION else None
+
     def run_forward(self, x, update_running=True):
+        with ops.math_scope(self._call_math(x.shape[0], x.shape[1])):
+            return self._run_forward(x, update_running)
+
+    def run_backward(self, x, outs, S, dout, need_dx, want_wgrad):
+        with ops.math_scope(self._call_math(x.shape[0], x.shape[1])):
+            return self._run_backward(x, outs, S, dout, need_dx, want_wgrad)
+
+    def _run_forward(self, x, update_running=True):
         ops.require_gpu(x, type(self).__name__)
         if self._flat.device != x.device:
             raise SganError(f"module parameters are on {self._flat.device}, input on {x.device}")
@@ -1293,7 +1311,7 @@ class UnetGenerator(ChainNet):
                      out=out, lay=lay, total=total, bwd=_BwdArena(arena[total:]))
         return [out], saved
 
-    def run_backward(self, x, outs, S, dout, need_dx, want_wgrad):
+    def _run_backward(self, x, outs, S, dout, need_dx, want_wgrad):
         n, c, skip = self.n, self.c, self.skip
         dev = x.device
         hw, dn, upd = self._unet_geometry(x.shape[0], x.shape[1])

@@ -32,6 +32,24 @@ def get_math() -> str:
     return "bf16x3" if _math == L.MATH_BF16X3 else "f32"
 
 
+class math_scope:
+    """`with ops.math_scope("f32"):` -- the conv calls inside run in that arithmetic mode (None: leave the current one)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _math
+        self.prev = _math
+        if self.name is not None:
+            _math = _MATH_NAMES[self.name.lower()]
+
+    def __exit__(self, *exc):
+        global _math
+        _math = self.prev
+        return False
+
+
 def with_packed(w: torch.Tensor, packed) -> torch.Tensor:
     """Tag a weight slice with the matching slice of the split-bf16 copy (sgan_pack_weights) for the job builders."""
     w._sgan_pk = packed

@@ -84,8 +84,8 @@ def test_igemm3_vs_fp32_kernel_and_fp64(ops, shape, tile):
     g = torch.Generator().manual_seed(99)
     x = (torch.randn(1, cin, H, W, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
     wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
-    w = (torch.randn(*wshape, generator=g) * 0.05).double()
-    b = (torch.randn(cout, generator=g) * 0.1).double()
+    w = (torch.randn(*wshape, generator=g) * 0.05).double().requires_grad_(True)
+    b = (torch.randn(cout, generator=g) * 0.1).double().requires_grad_(True)
     gamma = (1 + 0.2 * torch.randn(cin, generator=g)).double() if norm == "bn" else None
     beta = (0.1 * torch.randn(cin, generator=g)).double() if norm == "bn" else None
     a = x
@@ -99,7 +99,7 @@ def test_igemm3_vs_fp32_kernel_and_fp64(ops, shape, tile):
     (out * R).sum().backward()
     Ho, Wo = out.shape[2:]
     desc = ops.conv_desc(1 if tr else 0, k, s, p, H, W, cin, Ho, Wo, cout, cin, cout)
-    xb, wm, bb, Rb = to_buf(x.detach().float()), master_weight(w.float(), tr), pad_vec(b.float()), to_buf(R.float())
+    xb, wm, bb, Rb = to_buf(x.detach().float()), master_weight(w.detach().float(), tr), pad_vec(b.detach().float()), to_buf(R.float())
     st_in = stats_of(x.detach()) if norm else None
     in_norm = ops.norm_desc(st_in, pad_vec(gamma.float()) if gamma is not None else None, pad_vec(beta.float()) if beta is not None else None,
                             H * W, 1e-5, act, 0.2)
@@ -114,16 +114,22 @@ def test_igemm3_vs_fp32_kernel_and_fp64(ops, shape, tile):
         ops.conv_dgrad(desc, Rb, wm._sgan_wt, din, xb, in_norm, sums, w_transposed=True)
         if norm:
             ops.norm_bwd_apply(din, xb, in_norm, sums)
+        dw, db = torch.zeros_like(wm), torch.zeros_like(bb)
+        ops.conv_wgrad(desc, xb, in_norm, Rb, dw, db)
         torch.cuda.synchronize()
-        res[mode] = (ob, ost, din)
-        assert torch.isfinite(ob).all() and torch.isfinite(din).all()
+        res[mode] = (ob, ost, din, dw, db)
+        assert torch.isfinite(ob).all() and torch.isfinite(din).all() and torch.isfinite(dw).all()
     ops.set_math("bf16x3")
     e32 = rel(from_buf(res["f32"][0], cout), out)
     e3 = rel(from_buf(res["bf16x3"][0], cout), out)
     d32 = rel(from_buf(res["f32"][2], cin), x.grad)
     d3 = rel(from_buf(res["bf16x3"][2], cin), x.grad)
-    print(f"fwd err vs fp64: f32 {e32:.2e} bf16x3 {e3:.2e}; dgrad: f32 {d32:.2e} bf16x3 {d3:.2e}")
-    assert e3 < 3e-5 and d3 < 1e-4, (e3, d3)                     # an fp32-equivalent result: 30x inside the 1e-3 contract
+    from hip_utils import from_master
+    w32 = rel(from_master(res["f32"][3], k, cin, cout, tr), w.grad)
+    w3 = rel(from_master(res["bf16x3"][3], k, cin, cout, tr), w.grad)
+    b3 = rel(res["bf16x3"][4][:cout], b.grad)
+    print(f"fwd err vs fp64: f32 {e32:.2e} bf16x3 {e3:.2e}; dgrad: f32 {d32:.2e} bf16x3 {d3:.2e}; wgrad: f32 {w32:.2e} bf16x3 {w3:.2e}")
+    assert e3 < 3e-5 and d3 < 1e-4 and w3 < 3e-5 and b3 < 1e-5, (e3, d3, w3, b3)   # fp32-equivalent results: 30x inside the 1e-3 contract
     assert rel(res["bf16x3"][1], stats_of(out.detach(), "cpu")) < 1e-4
     assert rel(res["bf16x3"][0], res["f32"][0]) < 3e-5
 
@@ -178,11 +184,13 @@ def test_bf16x3_needs_packed_weights(ops):
     """No silent change of arithmetic: a layer the split kernels cover, asked for in bf16x3 without the packed copy, raises."""
     from supervised_gan_amd._lib import SganError
     ops.set_math("bf16x3")
-    x = torch.zeros(16, 16, 32, device="cuda")
+    x = torch.zeros(40, 40, 32, device="cuda")
     w = torch.zeros(16 * 32 * 32, device="cuda")        # not tagged with a packed copy
-    y = torch.zeros(9, 9, 32, device="cuda")
+    y = torch.zeros(21, 21, 32, device="cuda")
     with pytest.raises(SganError, match="w_packed"):
-        ops.conv_fwd(ops.conv_desc(0, 4, 2, 2, 16, 16, 32, 9, 9, 32), x, None, w, None, y)
+        ops.conv_fwd(ops.conv_desc(0, 4, 2, 2, 40, 40, 32, 21, 21, 32), x, None, w, None, y)
     ops.set_math("f32")
-    ops.conv_fwd(ops.conv_desc(0, 4, 2, 2, 16, 16, 32, 9, 9, 32), x, None, w, None, y)
+    ops.conv_fwd(ops.conv_desc(0, 4, 2, 2, 40, 40, 32, 21, 21, 32), x, None, w, None, y)
     ops.set_math("bf16x3")
+    # maps under SGAN_BF16X3_MIN_PIXELS stay on the exact-fp32 kernels in either mode: no packed copy needed
+    ops.conv_fwd(ops.conv_desc(0, 4, 2, 2, 16, 16, 32, 9, 9, 32), torch.zeros(16, 16, 32, device="cuda"), None, w, None, torch.zeros(9, 9, 32, device="cuda"))

@@ -26,6 +26,10 @@
 
 #include "sgan_igemm.h"
 
+#ifndef SG3_ABL
+#define SG3_ABL 0   // diagnostics builds only (wrong results): 1 no global loads, 2 no transform / split, 4 no LDS stores, 8 no address arithmetic, 16 no MFMA, 32 no fragment reads
+#endif
+
 typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sg_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -145,10 +149,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
         b_dst[it] = sg3_off(n, 2 * (t & 3) + (t >> 2));
     }
 
-    constexpr int NSET = 4;     // register ring: tile kt+1 being written to LDS, tiles kt+2 .. kt+NSET in flight (see sgan_igemm.hip)
+    // Register ring: tile kt+1 being written to LDS, tiles kt+2 .. kt+NSET in flight.  The kernel is bound by the latency x
+    // bandwidth of the L2 -> CU path (16 KB per 64x64 k-tile): the more tiles in flight, the more bytes per CU cover it.
+#ifndef SG3_NSET
+#define SG3_NSET 0
+#endif
+    constexpr int NSET = SG3_NSET ? SG3_NSET : ((2 * A_IT + B_IT <= 4) ? 6 : 4);
     f32x4 a_reg[NSET][A_IT][2];
     bool a_ok[NSET][A_IT];
-    int a_cs[NSET] = {0, 0, 0, 0};
+    int a_cs[NSET];
+#pragma unroll
+    for (int i = 0; i < NSET; ++i) a_cs[i] = 0;
     u32x4 b_reg[NSET][B_IT];
     int a_off_n[A_IT], b_off_n[B_IT], a_cs_n = 0;
     bool a_ok_n[A_IT];
@@ -189,6 +200,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
 
     auto issue_loads = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
+        if constexpr (SG3_ABL & 1) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) { a_reg[S][it][0] = (f32x4){1.f, 2.f, 3.f, 4.f}; a_reg[S][it][1] = (f32x4){1.f, 2.f, 3.f, 4.f}; if constexpr (PRO) a_ok[S][it] = a_ok_n[it]; }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) b_reg[S][it] = (u32x4){1u, 2u, 3u, 4u};
+            if constexpr (PRO) a_cs[S] = a_cs_n;
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             a_reg[S][it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off_n[it], 0, 0));
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             f32x4 v0 = a_reg[S][it][0], v1 = a_reg[S][it][1];
-            if constexpr (PRO) {
+            if constexpr (PRO && !(SG3_ABL & 2)) {
                 // okf * act(y) = max(okf * y, okf * neg * y), neg <= 1 (host-checked): zero padding applies AFTER norm + activation
                 const float okf = a_ok[S][it] ? 1.f : 0.f;
                 const float okn = okf * pro_neg;
@@ -231,14 +250,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
                 for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(p0[j], q0[j]); v1[j] = fmaxf(p1[j], q1[j]); }
             }
             u32x4 hi, lo;
-            sg_split8(v0, v1, hi, lo);
-            *reinterpret_cast<u32x4*>(Ab + a_dst[it]) = hi;
-            *reinterpret_cast<u32x4*>(Ab + (a_dst[it] ^ 16)) = lo;
+            if constexpr (SG3_ABL & 2) { hi = __builtin_bit_cast(u32x4, v0); lo = __builtin_bit_cast(u32x4, v1); }
+            else sg_split8(v0, v1, hi, lo);
+            if (!(SG3_ABL & 4) || G.nprob > 100) {
+                *reinterpret_cast<u32x4*>(Ab + a_dst[it]) = hi;
+                *reinterpret_cast<u32x4*>(Ab + (a_dst[it] ^ 16)) = lo;
+            }
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int e = tid + it * NT;
-            if (B_IT * NT == BN * 8 || e < BN * 8) *reinterpret_cast<u32x4*>(Bb + b_dst[it]) = b_reg[S][it];
+            if ((!(SG3_ABL & 4) || G.nprob > 100) && (B_IT * NT == BN * 8 || e < BN * 8)) *reinterpret_cast<u32x4*>(Bb + b_dst[it]) = b_reg[S][it];
         }
     };
 
@@ -270,6 +292,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
         issue_loads(std::integral_constant<int, S>{});
         load_scales(std::integral_constant<int, (S + 1) % NSET>{});
         sg_bf16x8 ah[2][MB], al[2][MB], bh[2][NB], bl[2][NB];
+        if constexpr (SG3_ABL & 32) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) { ah[s][i] = __builtin_bit_cast(sg_bf16x8, a_reg[0][0][0]); al[s][i] = __builtin_bit_cast(sg_bf16x8, a_reg[1][0][0]); }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { bh[s][j] = __builtin_bit_cast(sg_bf16x8, b_reg[0][0]); bl[s][j] = __builtin_bit_cast(sg_bf16x8, b_reg[1][0]); }
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -292,11 +323,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
+                    if constexpr (SG3_ABL & 16) { acc[i][j][0] += __builtin_bit_cast(f32x4, al[s][i])[0] + __builtin_bit_cast(f32x4, ah[s][i])[1] + __builtin_bit_cast(f32x4, bl[s][j])[2] + __builtin_bit_cast(f32x4, bh[s][j])[3]; continue; }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
                 }
-        next_addrs();
+        if constexpr (!(SG3_ABL & 8)) next_addrs();
         constexpr int NMFMA = 6 * MB * NB;
         constexpr int PER = (40 + 6 * A_IT + 2 * B_IT + NMFMA - 1) / NMFMA;   // next_addrs is ~40 + 6 A_IT + 2 B_IT VALU / SALU
 #pragma unroll
@@ -306,34 +338,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
         }
         __syncthreads();
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
+    auto prefetch = [&](auto K_) { next_addrs(); issue_loads(K_); };
+    auto maybe = [&](auto K_, int kt) { if (kt + decltype(K_)::value < nkt) iteration(K_); };
+#define SG3_FOR_SETS(F, ...)                                                                                              \
+    do {                                                                                                                  \
+        F(std::integral_constant<int, 0>{}, ##__VA_ARGS__); F(std::integral_constant<int, 1>{}, ##__VA_ARGS__);           \
+        F(std::integral_constant<int, 2>{}, ##__VA_ARGS__); F(std::integral_constant<int, 3>{}, ##__VA_ARGS__);           \
+        if constexpr (NSET > 4) { F(std::integral_constant<int, 4 % NSET>{}, ##__VA_ARGS__); F(std::integral_constant<int, 5 % NSET>{}, ##__VA_ARGS__); } \
+        if constexpr (NSET > 6) { F(std::integral_constant<int, 6 % NSET>{}, ##__VA_ARGS__); F(std::integral_constant<int, 7 % NSET>{}, ##__VA_ARGS__); } \
+    } while (0)
+    static_assert(NSET == 4 || NSET == 6 || NSET == 8, "ring depth");
+    SG3_FOR_SETS(prefetch);
     next_addrs();
-    issue_loads(I0{});
-    next_addrs();
-    issue_loads(I1{});
-    next_addrs();
-    issue_loads(I2{});
-    next_addrs();
-    issue_loads(I3{});
-    next_addrs();
-    load_scales(I0{});
-    store_tile(I0{});
+    load_scales(std::integral_constant<int, 0>{});
+    store_tile(std::integral_constant<int, 0>{});
     __syncthreads();
     {
         int kt = 0;
-        for (; kt + 3 < nkt; kt += 4) {
-            iteration(I0{});
-            iteration(I1{});
-            iteration(I2{});
-            iteration(I3{});
-        }
-        if (kt < nkt) iteration(I0{});
-        if (kt + 1 < nkt) iteration(I1{});
-        if (kt + 2 < nkt) iteration(I2{});
+        for (; kt + NSET - 1 < nkt; kt += NSET) SG3_FOR_SETS(iteration);
+        SG3_FOR_SETS(maybe, kt);     // the last one is never taken (kt + NSET - 1 >= nkt here)
     }
+#undef SG3_FOR_SETS
 
     // ---- epilogue: acc[i][j][r] = out[m = m0 + wm*WTM + i*32 + (r & 3) + 8 (r >> 2) + 4 fh][n = n0 + wn*WTN + j*32 + fr] ----
     const bool want_stats = P.stats != nullptr;

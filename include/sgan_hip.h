@@ -345,7 +345,9 @@ int sgan_scale(const float* gout, const float* g, float* dx, int64_t n, void* st
 
 /* ---- elementwise helpers ---------------------------------------------------------------------
  * tanh backward: dx = dy * (1 - y*y)                                   (nn.Tanh, networks.py:540)
- * strided gather into NHWC with zero channel padding (layout boundary of the module API). */
+ * strided gather into NHWC with zero channel padding (layout boundary of the module API).  `src` of sgan_to_nhwc may also
+ * be PINNED (page-locked, device-mapped) HOST memory: the gather kernel is then the host-to-device copy of the batch
+ * (the transforms.ToTensor() -> .cuda() step of the reference's loop, train.py:25-29), queued with the step's kernels. */
 int sgan_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 int sgan_to_nhwc(const float* src, int64_t sc, int64_t sh, int64_t sw, int32_t H, int32_t W, int32_t Creal,
                  float* dst, int32_t dst_ld, int32_t Cstore, void* stream);

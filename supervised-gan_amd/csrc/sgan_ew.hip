@@ -1310,9 +1310,32 @@ __global__ __launch_bounds__(256) void sg_to_nhwc_kernel(const float* src, int64
     }
 }
 
+// planar source with unit pixel stride and <= 4 channels (an NCHW image batch): one thread per pixel reads each plane
+// coalesced and writes one 16-byte NHWC pixel.  `src` may be PINNED HOST memory (it is mapped into the device's address
+// space): the kernel then IS the host-to-device copy of the batch, on the compute queue of the step's stream.
+__global__ __launch_bounds__(256) void sg_planes_to_nhwc4_kernel(const float* src, int64_t sc, int64_t sh, int H, int W, int Creal,
+                                                                 float* dst, int dst_ld) {
+    const int64_t total = (int64_t)H * W;
+    for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (int64_t)gridDim.x * 256) {
+        const int x = (int)(pix % W), y = (int)(pix / W);
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < Creal) v[c] = src[c * sc + y * sh + x];
+        *reinterpret_cast<f32x4*>(dst + pix * dst_ld) = v;
+    }
+}
+
 extern "C" int sgan_to_nhwc(const float* src, int64_t sc, int64_t sh, int64_t sw, int32_t H, int32_t W, int32_t Creal,
                             float* dst, int32_t dst_ld, int32_t Cstore, void* stream) {
     SGAN_CHECK(src && dst && H > 0 && W > 0 && Creal <= Cstore && dst_ld >= Cstore, "bad argument");
+    if (sw == 1 && Cstore == 4 && (dst_ld & 3) == 0 && ((uintptr_t)dst & 15) == 0) {
+        int blocks = ew_cdiv((int64_t)H * W, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(sg_planes_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, sc, sh, H, W, Creal, dst, dst_ld);
+        SGAN_LAUNCH_CHECK();
+        return SGAN_OK;
+    }
     const int64_t total = (int64_t)H * W * Cstore;
     int blocks = ew_cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;

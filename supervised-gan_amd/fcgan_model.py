@@ -100,8 +100,22 @@ class FCGANModel(BaseModel):
     def set_input(self, input):
         AorB = self.opt.which_direction == 'A'
         data = input['A' if AorB else 'B']
-        data = data.to(self.device, non_blocking=True).index_select(1, self._chnl_dev)
-        self.input.resize_(data.size()).copy_(data)
+        idx = self.chnl_idx_input
+        run = idx == list(range(idx[0], idx[0] + len(idx)))       # a contiguous channel range ('rg', 'gb', 'r', ...)
+        if (self.device.type == 'cuda' and run and data.dim() == 4 and data.shape[0] == 1 and data.dtype == torch.float32
+                and data.stride(3) == 1 and (data.is_cuda or data.is_pinned())):
+            # one gather kernel reads the batch where it lies (pinned host memory is device-mapped: the kernel IS the H2D copy,
+            # queued with the step's kernels), picks the channels and writes the padded NHWC buffer the discriminators read
+            _, _, H, W = data.shape
+            if getattr(self, '_input_buf', None) is None or self._input_buf.shape[:2] != (H, W):
+                self._input_buf = torch.zeros((H, W, 4), dtype=torch.float32, device=self.device)
+                self.input = ops.logical_view(self._input_buf, len(idx))
+            ops.host_batch_to_nhwc(data[:, idx[0]: idx[0] + len(idx)], self._input_buf)
+        else:
+            data = data.to(self.device, non_blocking=True).index_select(1, self._chnl_dev)
+            self._input_buf = None
+            self.input = self.input if self.input.is_contiguous() else torch.empty(0, device=self.device)
+            self.input.resize_(data.size()).copy_(data)
         self.image_paths = input.get('A_paths' if AorB else 'B_paths')
 
     def forward(self):
@@ -141,6 +155,11 @@ class FCGANModel(BaseModel):
                 losses.append(self.criterionGAN(netD.forward(x), is_real))
         else:
             cur = torch.cuda.current_stream()
+            # The same net may run on two side streams (fake and real batch): make its derived weight copies (one launch, keyed on the
+            # host) on the CURRENT stream before the fork, so that no chain reads a copy another stream is still writing.
+            for netD in {id(d): d for d, _, _ in jobs}.values():
+                if hasattr(netD, "_refresh_derived"):
+                    netD._refresh_derived()
             for st, (netD, x, is_real) in zip(streams, jobs):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):

@@ -438,6 +438,17 @@ def buffer_of(t: torch.Tensor):
     return None
 
 
+def host_batch_to_nhwc(t: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """Pinned-host (or device) logical [1, C <= 4, H, W] fp32 batch -> the padded NHWC device buffer `out` [H, W, 4], by ONE gather
+    kernel that reads the source where it lies: for a pinned host tensor that kernel is the H2D copy, on the current stream."""
+    assert t.dim() == 4 and t.shape[0] == 1 and t.dtype == torch.float32 and t.stride(3) == 1, (t.shape, t.stride(), t.dtype)
+    assert t.is_cuda or t.is_pinned(), "host batches must be pinned (page-locked) to be read by the device"
+    _, Cr, H, W = t.shape
+    assert out.shape == (H, W, 4) and Cr <= 4
+    L.check(L.lib().sgan_to_nhwc(_ptr(t), t.stride(1), t.stride(2), 1, H, W, Cr, _ptr(out), out.stride(1), 4, _stream()), "sgan_to_nhwc")
+    return out
+
+
 def as_nhwc(t: torch.Tensor) -> torch.Tensor:
     """Logical [1, C, H, W] tensor (any strides) -> padded NHWC buffer [H, W, pad4(C)]."""
     require_gpu(t, "as_nhwc")

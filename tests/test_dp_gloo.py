@@ -18,7 +18,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
+RENDEZVOUS_ERRORS = ("address already in use", "eaddrinuse", "connection refused", "connection reset", "failed to bind")
+
+
 def _worker(rank, world, port, q):
+    """Everything a rank does; any exception travels to the parent as ("error", traceback) -- a crash is never swallowed."""
+    try:
+        _rank_body(rank, world, port, q)
+    except BaseException:      # noqa: BLE001
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+        raise
+
+
+def _rank_body(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -53,27 +66,45 @@ def _worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
+def run_ranks(worker, world, timeout=180):
+    """Start `world` spawned ranks on a fresh loopback port and collect one result dict per rank.  Retried ONCE, and only when a
+    rank reports a bind / rendezvous error (the port race of a busy host); any other failure -- a worker exception, a non-zero
+    exit code, a missing result -- fails the test with the worker's traceback."""
+    ctx = mp.get_context("spawn")
+    for attempt in range(2):
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = {}
+        try:
+            for _ in range(world):
+                r, out = q.get(timeout=timeout)
+                res[r] = out
+                if "error" in out:
+                    break
+        except Exception:      # noqa: BLE001  (queue.Empty: a rank died without a word)
+            pass
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+        errors = [o["error"] for o in res.values() if "error" in o]
+        if errors:
+            if attempt == 0 and all(any(k in e.lower() for k in RENDEZVOUS_ERRORS) for e in errors):
+                continue
+            pytest.fail("worker failed:\n" + "\n".join(errors))
+        assert len(res) == world and all(p.exitcode == 0 for p in procs), (sorted(res), [p.exitcode for p in procs])
+        return res
+    pytest.fail("rendezvous failed twice")
+
+
 @pytest.mark.timeout(300)
 def test_two_rank_gloo_broadcast_and_grad_average():
     world = 2
     ctx = mp.get_context("spawn")
-    for attempt in range(2):      # a loopback rendezvous can lose the port race on a busy host: one retry on a new port
-        port = _free_port()
-        q = ctx.Queue()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-        for p in procs:
-            p.start()
-        try:
-            res = dict(q.get(timeout=120) for _ in range(world))
-        except Exception:
-            res = None
-        for p in procs:
-            p.join(60)
-            if p.is_alive():
-                p.kill()
-        if res is not None and all(p.exitcode == 0 for p in procs):
-            break
-    assert res is not None and all(p.exitcode == 0 for p in procs)
+    res = run_ranks(_worker, world)
     assert torch.equal(res[0]["w"], res[1]["w"])                     # broadcast: identical weights
     assert torch.equal(res[0]["gauss"], res[1]["gauss"])
     n = len(res[0]["g"])

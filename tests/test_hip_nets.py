@@ -461,3 +461,59 @@ def test_generators_with_a_callers_output_activation(N):
     assert rel(y, yo) < TOL and rel(lg.grad, lc.grad) < TOL and rel(zg.grad, zc.grad) < TOL
     last = [k for k in sd if k.endswith(".weight")][-1]
     assert rel(dict(G.named_parameters())[last].grad, sd[last].grad) < TOL
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f32"])
+def test_derived_weight_copies_follow_every_write(math):
+    """The kernels read three copies made from the master weights (transposed fp32, split-bf16 forward / backward).  Whatever
+    writes the parameters -- torch.optim.Adam on the Parameter views, load_state_dict after a backward, param.copy_,
+    net.apply(weights_init), FusedAdam -- the next forward / backward must see the new weights: results equal those after an
+    explicit invalidate_derived() (a stale copy would keep the old weights in y or in dx)."""
+    from supervised_gan_amd import networks as N
+    from supervised_gan_amd import ops
+    from supervised_gan_amd.optim import FusedAdam
+    prev = ops.get_math()
+    ops.set_math(math)
+    try:
+        torch.manual_seed(0)
+        D = N.define_D(2, 16, "n_layers", n_layers_D=3, norm="instance", use_sigmoid=False, scale_factor=1).cuda()
+        D.apply(N.weights_init)
+        x = torch.randn(1, 2, 96, 96, device="cuda")
+
+        def run():
+            xi = x.clone().requires_grad_(True)
+            y = D.forward(xi)
+            y.square().sum().backward()
+            torch.cuda.synchronize()
+            return y.detach().clone(), xi.grad.detach().clone()
+
+        def check(what):
+            y1, dx1 = run()
+            D.invalidate_derived()
+            y2, dx2 = run()
+            assert torch.equal(y1, y2) and float((dx1 - dx2).abs().max()) <= 1e-6 * float(dx2.abs().max()), what
+            return y1, dx1
+
+        y0, dx0 = check("initial")
+        opt = torch.optim.Adam(D.model.parameters(), lr=1e-2)
+        opt.step()                                        # gradients of run() are in place
+        y1, dx1 = check("torch.optim.Adam step")
+        assert float((y1 - y0).abs().max()) > 0 and float((dx1 - dx0).abs().max()) > 0
+        sd = {k: v.clone() + 0.01 for k, v in D.state_dict().items()}
+        D.load_state_dict(sd)
+        y2, _ = check("load_state_dict after a backward")
+        assert float((y2 - y1).abs().max()) > 0
+        with torch.no_grad():
+            for p in D.model.parameters():
+                p.copy_(p * 0.5)
+        y3, _ = check("param.copy_")
+        assert float((y3 - y2).abs().max()) > 0
+        D.apply(N.weights_init)
+        y4, _ = check("net.apply(weights_init)")
+        assert float((y4 - y3).abs().max()) > 0
+        fa = FusedAdam(D.model.parameters(), lr=1e-2, betas=(0.5, 0.999))
+        fa.step()
+        y5, _ = check("FusedAdam step")
+        assert float((y5 - y4).abs().max()) > 0
+    finally:
+        ops.set_math(prev)

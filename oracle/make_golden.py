@@ -11,6 +11,12 @@ none of which touch arithmetic:
     Dropout(0.5) masks and the optional Gaussian noise are injected the same way (F.dropout /
     Tensor.normal_ patched to numpy-seeded tensors keyed on the shape).
 
+fp64 arbitration vectors (`python oracle/make_golden.py f64`): the SAME reference trainers, weights, inputs and injected
+noise with every tensor of the model object converted to double after initialize() (dtype only, no arithmetic of the
+reference is touched): `<name>_f64.npz` holds the strided gradient samples / summaries / losses of the full-size cases, so
+that the GPU tests can tell an error of the HIP path from the reference's own fp32 rounding (tests/test_oracle_golden.py
+`check_grads(..., f64=...)`).
+
 Usage:  python oracle/make_golden.py            (writes tests/golden/)
 """
 import os
@@ -58,8 +64,43 @@ def to_np(d):
     return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
 
 
+F64 = False      # "f64" target: run the reference in double and keep only what the arbitration needs
+
+
+def to_double(model):
+    """Every tensor / module / tensor-type attribute of a reference trainer object -> double (after initialize())."""
+    if not F64:
+        return model
+
+    def conv(v):
+        if isinstance(v, torch.nn.Module):
+            v.double()
+            if getattr(v, "Tensor", None) is torch.FloatTensor:
+                v.Tensor = torch.DoubleTensor          # GANLoss builds its target tensors with it (GANLossMultiClass keeps its LongTensor)
+            for attr in ("real_label_var", "fake_label_var"):
+                if getattr(v, attr, None) is not None:
+                    setattr(v, attr, None)
+            return v
+        if torch.is_tensor(v) and v.is_floating_point():
+            return v.double()
+        if isinstance(v, (list, tuple)):
+            return type(v)(conv(x) for x in v)
+        return v
+    for k, v in list(model.__dict__.items()):
+        model.__dict__[k] = conv(v)
+    model.Tensor = torch.DoubleTensor
+    return model
+
+
+def f64_exists(name):
+    return F64 and os.path.exists(os.path.join(OUT, name.replace(".npz", "_f64.npz")))
+
+
 def save(name, **arrs):
     os.makedirs(OUT, exist_ok=True)
+    if F64:
+        name = name.replace(".npz", "_f64.npz")
+        arrs = {k: v for k, v in arrs.items() if ("/sample/" in k or "/summary/" in k or "loss" in k) and not k.startswith("summary/")}
     path = os.path.join(OUT, name)
     np.savez_compressed(path, **arrs)
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
@@ -199,7 +240,7 @@ def build_ref_fcgan(cfg: O.FCGANConfig, seed: int, tmpdir: str):
     load_sd(model.netG, O.init_fcgan_g(seed + 1, cfg.noise_nc, cfg.input_nc, cfg.ngf, cfg.n_layers_G))
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D, cfg.scale_factor)):
         load_sd(model.netD[i], O.init_nlayer_d(seed + 2 + i, cfg.input_nc, cfg.ndf, nl, sf))
-    return model
+    return to_double(model)
 
 
 def grad_sample_idx(n, k=512):
@@ -498,7 +539,7 @@ def build_ref_cgan(cfg: "O.CGANConfig", seed: int, tmpdir: str):
     load_sd(model.netG, O.init_unet(seed + 1, cfg.num_downs, cfg.input_nc, cfg.output_nc, cfg.ngf, cfg.n_layers_G_skip))
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D, cfg.scale_factor)):
         load_sd(model.netD[i], O.init_nlayer_d(seed + 2 + i, cfg.input_nc + cfg.output_nc, cfg.ndf, nl, sf))
-    return model
+    return to_double(model)
 
 
 def cgan_batch(cfg, step):
@@ -746,7 +787,7 @@ def build_ref_cgan_cycle(cfg: "O.CGANCycleConfig", seed: int, tmpdir: str):
     load_sd(model.netG2, O.init_unet(seed + 2, cfg.num_downs2, cfg.output_nc, cfg.input_nc, cfg.ngf2, -1))
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D1, cfg.scale_factor1)):
         load_sd(model.netD1[i], O.init_nlayer_d(seed + 3 + i, cfg.input_nc + cfg.output_nc, cfg.ndf1, nl, sf))
-    return model
+    return to_double(model)
 
 
 def golden_cgan_cycle(name, cfg: "O.CGANCycleConfig", seed: int, nsteps: int):
@@ -868,11 +909,13 @@ def build_ref_twostage(cfg: "O.TwoStageConfig", seed: int, tmpdir: str):
     for i, (nl, sf) in enumerate(zip(cfg.n_layers_D2, cfg.scale_factor2)):
         load_sd(model.netD2[i], O.init_nlayer_d(seed + 20 + i, cfg.input_nc + cfg.output_nc, cfg.ndf2, nl, sf,
                                                 3 if cfg.use_multi_class_GAN else 1))
-    return model
+    return to_double(model)
 
 
 def golden_twostage(name, cfg: "O.TwoStageConfig", seed: int, nsteps: int):
     import random
+    if f64_exists(name):
+        return
     import tempfile
     z1 = (1, cfg.noise_nc1, cfg.noiseSize1, cfg.noiseSize1)
     z2 = (1, cfg.noise_nc2, cfg.noiseSize2, cfg.noiseSize2)
@@ -923,9 +966,38 @@ def golden_twostage(name, cfg: "O.TwoStageConfig", seed: int, nsteps: int):
 
 
 def main():
+    global F64
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
+    if only and only[0] == "f64":      # fp64 arbitration vectors of the full-size (README) cases
+        F64 = True
+        which = only[1:] or ["fcgan", "cgan", "twostage", "small"]
+        if "fcgan" in which:
+            golden_step("fcgan_step_full.npz", O.FCGANConfig(), seed=0, nsteps=3, full_params=False)
+            golden_step("fcgan_step_full_nug1.npz", O.FCGANConfig(n_update_G=1), seed=0, nsteps=2, full_params=False)
+        if "cgan" in which:
+            golden_cgan_step("cgan_step_full.npz", O.CGANConfig(**O.CGAN_README), seed=0, nsteps=2)
+        if "twostage" in which:
+            golden_twostage("twostage_full.npz", O.TwoStageConfig(), seed=0, nsteps=2)
+        if "small" in which:      # the small cases whose chains end in 2x2 / 4x4 normalisations (gated through the fp64 run too)
+            tw = dict(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8, ndf2=8)
+            ff = dict(GAN_losses_D2=("real_fake", "fake_fake"), GAN_losses_G2=("real_fake", "fake_fake"))
+            golden_twostage("twostage_small.npz", O.TwoStageConfig(**tw, **ff, weights=(2.0, 5.0)), seed=0, nsteps=3)
+            golden_twostage("twostage_nocycle_small.npz", O.TwoStageConfig(**tw, **ff, cycle=False, lambda_G1=0.7, lambda_G2=1.3), seed=0, nsteps=3)
+            golden_twostage("twostage_multiclass_small.npz",
+                            O.TwoStageConfig(**tw, **ff, weights=(2.0, 5.0), use_multi_class_GAN=True, no_lsgan2=True, n_layers_D2=(3, 4),
+                                             scale_factor2=(1, 2), lambda_D2=(0.6, 0.4)), seed=0, nsteps=3)
+            golden_twostage("twostage_factd_small.npz",
+                            O.TwoStageConfig(**tw, **ff, n_layers_D1=(4, 4), n_layers_D2=(3, 3), scale_factor2=(1, 2), lambda_D2=(0.6, 0.4),
+                                             no_lsgan2=True, cycle=False, factd=True, lambda_G1=0.7, lambda_G2=1.3), seed=0, nsteps=3)
+            golden_cgan_cycle("cgan_cycle_small.npz", O.CGANCycleConfig(), 0, 3)
+            golden_cgan_cycle("cgan_cycle_small_d34.npz", O.CGANCycleConfig(scale_factor1=(1, 1), n_layers_D1=(3, 4), weights=None, no_lsgan1=False), 0, 2)
+            two = dict(variant="cgan2_cycle", lambda_fake_cycle=0.5)
+            golden_cgan_cycle("cgan2_cycle_small.npz", O.CGANCycleConfig(**two), 0, 2)
+            golden_cgan_cycle("cgan2_cycle_small_fakefake.npz",
+                              O.CGANCycleConfig(**dict(two, train_D_on_fake_fake_pair=True, train_G_on_fake_fake_pair=True, n_update_G=2)), 0, 2)
+        return
     if not only or "segmentation_cycle" in only:
         golden_segm_cycle("segm_cycle_small.npz", O.SegmCycleConfig(weights=(1.0, 3.0), lambda_A=2.0, lambda_B=0.5, lambda_A_cycle=1.5, lr2=1e-4), 0, 3)
     if not only or "segmentation" in only:

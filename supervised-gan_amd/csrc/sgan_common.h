@@ -42,6 +42,7 @@ void sg_prof_end(hipStream_t st, const char* name);
 //   Conv2d fwd / ConvT dgrad : 1 phase, k*k taps, is = stride, os = 1, dy = ky - pad
 //   ConvT fwd / Conv dgrad   : stride^2 phases, (k/stride)^2 taps each, is = 1, os = stride
 // ------------------------------------------------------------------------------------------
+#define SGAN_F16_WEIGHT_SHIFT 10        // forward (fp16-plane) weight copy holds w * 2^10: |w| down to 2^-24 / 2^10 resolved, |w| < 64 representable
 #define SGAN_BF16X3_MIN_PIXELS 256   // smaller maps always run the exact-fp32 MFMA kernels (see sg_igemm3_eligible)
 #define SGAN_MAX_TAPS 16
 #define SGAN_MAX_PHASES 4

@@ -448,7 +448,8 @@ extern "C" int sgan_transpose_weights(const float* flat, float* flat_t, const sg
 }
 
 // ------------------------------------------------------------------------------------------
-// Every derived weight copy in one launch (sgan_pack_weights): the fp32 transposed copy and the two split-bf16 copies.
+// Every derived weight copy in one launch (sgan_pack_weights): the fp32 transposed copy, the split-fp16 forward copy and the
+// split-bf16 backward copy.
 // One workgroup per 32 x 32 (co, ci) tile of a tap: the tile is read once into LDS; thread (row r = tid >> 3, group
 // q = (tid >> 1) & 3, plane p = tid & 1) then writes one 16-byte chunk {8 x bf16} of the forward copy (row = co, the 8
 // consecutive ci of group q) and one of the backward copy (row = ci, 8 consecutive co).
@@ -466,6 +467,19 @@ __device__ __forceinline__ sg_u32x4 sg_split8(const float* v, int plane) {
     for (int e = 0; e < 8; ++e) {
         const unsigned hi = sg_bf16_rne(v[e]);
         h[e] = plane == 0 ? hi : sg_bf16_rne(v[e] - __builtin_bit_cast(float, hi << 16));
+    }
+    return (sg_u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+}
+
+// fp16 planes of x * 2^SGAN_F16_WEIGHT_SHIFT: hi = fp16(x s), lo = fp16(x s - hi)  (round to nearest even)
+__device__ __forceinline__ sg_u32x4 sg_split8_f16(const float* v, int plane) {
+    unsigned h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e] * (float)(1 << SGAN_F16_WEIGHT_SHIFT);
+        const _Float16 hi = (_Float16)x;
+        const _Float16 r = plane == 0 ? hi : (_Float16)(x - (float)hi);
+        h[e] = (unsigned)__builtin_bit_cast(unsigned short, r);
     }
     return (sg_u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
 }
@@ -502,7 +516,7 @@ __global__ __launch_bounds__(256) void sg_pack_weights_kernel(const float* flat,
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = tile[r][q * 8 + e];
-            *reinterpret_cast<sg_u32x4*>(pk_f + slab + (int64_t)co * S.cin + ci + 4 * p) = sg_split8(v, p);
+            *reinterpret_cast<sg_u32x4*>(pk_f + slab + (int64_t)co * S.cin + ci + 4 * p) = sg_split8_f16(v, p);
         }
     }
     if (pk_b && (S.cout & 7) == 0) {

@@ -43,6 +43,7 @@ struct SgIgemmParams {   // the kernel argument (~2.3 KB)
     int32_t n_real;       // result channels that carry data (<= N; the rest is zero padding), small-N kernel only
     int32_t pro_act, xn_act;
     int32_t math;         // SGAN_MATH_*
+    int32_t planes_f16;   // split kernels: operand planes are fp16 (forward) instead of bf16 (backward-data)
     float pro_slope, xn_slope, pro_eps, xn_eps;
     int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
     SgTap taps[SGAN_MAX_PHASES][SGAN_MAX_TAPS];

@@ -1222,6 +1222,7 @@ extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, i
     P.Ck = d0->Cin; P.N = d0->Cout;
     P.w_ns = d0->Cin; P.w_ks = 1;  // B[k=ci][n=co] = W[tap][co][ci]
     P.math = d0->math;
+    P.planes_f16 = 1;      // forward: post-normalisation activations and 2^10-scaled weights fit fp16's range: fp32-equivalent products
     P.out_act = out_act;
     const sgan_norm_desc* n0 = jobs[0].in_norm;
     P.pro_act = n0 ? n0->act : SGAN_ACT_NONE; P.pro_slope = n0 ? n0->slope : 0.f; P.pro_eps = n0 ? n0->eps : 0.f;

@@ -32,27 +32,47 @@
 
 typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sg_f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// 8 fp32 -> {8 x bf16 hi, 8 x bf16 lo}.  hi = RNE(x); lo = RNE(x - hi) (the subtraction is exact).
+// 8 fp32 -> {8 x 16-bit hi, 8 x 16-bit lo}.  hi = RNE(x); lo = RNE(x - hi) (the subtraction is exact).  F16: fp16 planes
+// (11 significant bits each: x = hi + lo to 2^-23 |x| as long as lo stays a normal fp16, i.e. |x| >= 0.25; below, to 3e-8 absolute --
+// the forward operands are post-normalisation activations of order 1 and weights scaled by 2^10); else bf16 planes (8 bits each,
+// 2^-17 |x|, the fp32 exponent range: gradients).
+template <bool F16>
 __device__ __forceinline__ void sg_split8(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo) {
     float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 p = {x[2 * i], x[2 * i + 1]};
-        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(p, sg_bf16x2));   // v_cvt_pk_bf16_f32
-        const f32x2 r = {x[2 * i] - __builtin_bit_cast(float, h << 16), x[2 * i + 1] - __builtin_bit_cast(float, h & 0xffff0000u)};
-        hi[i] = h;
-        lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sg_bf16x2));
+        if constexpr (F16) {
+            const sg_f16x2 h = __builtin_convertvector(p, sg_f16x2);                     // v_cvt_pk_f16_f32
+            const f32x2 r = p - __builtin_convertvector(h, f32x2);
+            hi[i] = __builtin_bit_cast(unsigned, h);
+            lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sg_f16x2));
+        } else {
+            const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(p, sg_bf16x2));   // v_cvt_pk_bf16_f32
+            const f32x2 r = {x[2 * i] - __builtin_bit_cast(float, h << 16), x[2 * i + 1] - __builtin_bit_cast(float, h & 0xffff0000u)};
+            hi[i] = h;
+            lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sg_bf16x2));
+        }
     }
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x16 sg3_mfma(const u32x4 a, const u32x4 b, const f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sg_f16x8, a), __builtin_bit_cast(sg_f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sg_bf16x8, a), __builtin_bit_cast(sg_bf16x8, b), c, 0, 0, 0);
 }
 
 // byte offset of 16-byte chunk `slot` of tile row `row` (128-byte rows)
 __device__ __forceinline__ int sg3_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <int BM, int BN, int WGM, int WGN, bool PRO>
+// F16: operand planes are fp16 (forward pass: fp32-equivalent products) instead of bf16 (backward-data)
+template <int BM, int BN, int WGM, int WGN, bool PRO, bool F16>
 __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemmParams G) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MB = WTM / 32, NB = WTN / 32;
@@ -251,7 +271,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
             }
             u32x4 hi, lo;
             if constexpr (SG3_ABL & 2) { hi = __builtin_bit_cast(u32x4, v0); lo = __builtin_bit_cast(u32x4, v1); }
-            else sg_split8(v0, v1, hi, lo);
+            else sg_split8<F16>(v0, v1, hi, lo);
             if (!(SG3_ABL & 4) || G.nprob > 100) {
                 *reinterpret_cast<u32x4*>(Ab + a_dst[it]) = hi;
                 *reinterpret_cast<u32x4*>(Ab + (a_dst[it] ^ 16)) = lo;
@@ -291,27 +311,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
         const char* Bb = Bs + (S & 1) * BN * 128 + fb_row;
         issue_loads(std::integral_constant<int, S>{});
         load_scales(std::integral_constant<int, (S + 1) % NSET>{});
-        sg_bf16x8 ah[2][MB], al[2][MB], bh[2][NB], bl[2][NB];
+        u32x4 ah[2][MB], al[2][MB], bh[2][NB], bl[2][NB];
         if constexpr (SG3_ABL & 32) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
 #pragma unroll
-                for (int i = 0; i < MB; ++i) { ah[s][i] = __builtin_bit_cast(sg_bf16x8, a_reg[0][0][0]); al[s][i] = __builtin_bit_cast(sg_bf16x8, a_reg[1][0][0]); }
+                for (int i = 0; i < MB; ++i) { ah[s][i] = __builtin_bit_cast(u32x4, a_reg[0][0][0]); al[s][i] = __builtin_bit_cast(u32x4, a_reg[1][0][0]); }
 #pragma unroll
-                for (int j = 0; j < NB; ++j) { bh[s][j] = __builtin_bit_cast(sg_bf16x8, b_reg[0][0]); bl[s][j] = __builtin_bit_cast(sg_bf16x8, b_reg[1][0]); }
+                for (int j = 0; j < NB; ++j) { bh[s][j] = b_reg[0][0]; bl[s][j] = b_reg[1][0]; }
             }
         } else
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
-                ah[s][i] = *reinterpret_cast<const sg_bf16x8*>(Ab + i * 32 * 128 + f_off[s][0]);
-                al[s][i] = *reinterpret_cast<const sg_bf16x8*>(Ab + i * 32 * 128 + f_off[s][1]);
+                ah[s][i] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * 128 + f_off[s][0]);
+                al[s][i] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * 128 + f_off[s][1]);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                bh[s][j] = *reinterpret_cast<const sg_bf16x8*>(Bb + j * 32 * 128 + f_off[s][0]);
-                bl[s][j] = *reinterpret_cast<const sg_bf16x8*>(Bb + j * 32 * 128 + f_off[s][1]);
+                bh[s][j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * 128 + f_off[s][0]);
+                bl[s][j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * 128 + f_off[s][1]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -324,9 +344,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     if constexpr (SG3_ABL & 16) { acc[i][j][0] += __builtin_bit_cast(f32x4, al[s][i])[0] + __builtin_bit_cast(f32x4, ah[s][i])[1] + __builtin_bit_cast(f32x4, bl[s][j])[2] + __builtin_bit_cast(f32x4, bh[s][j])[3]; continue; }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][i], bh[s][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][i], bl[s][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][i], bh[s][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = sg3_mfma<F16>(al[s][i], bh[s][j], acc[i][j]);
+                    acc[i][j] = sg3_mfma<F16>(ah[s][i], bl[s][j], acc[i][j]);
+                    acc[i][j] = sg3_mfma<F16>(ah[s][i], bh[s][j], acc[i][j]);
                 }
         if constexpr (!(SG3_ABL & 8)) next_addrs();
         constexpr int NMFMA = 6 * MB * NB;
@@ -360,6 +380,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     }
 #undef SG3_FOR_SETS
 
+    if constexpr (F16) {     // the fp16 weight planes hold w * 2^SGAN_F16_WEIGHT_SHIFT (an exact power of two)
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] *= 1.f / (float)(1 << SGAN_F16_WEIGHT_SHIFT);
+    }
     // ---- epilogue: acc[i][j][r] = out[m = m0 + wm*WTM + i*32 + (r & 3) + 8 (r >> 2) + 4 fh][n = n0 + wn*WTN + j*32 + fr] ----
     const bool want_stats = P.stats != nullptr;
     if (P.ksplit > 1) {   // split-K: raw partial tile to this split's slab; sg_splitk_epilogue_kernel finishes
@@ -511,8 +537,13 @@ static int sg3_launch(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_by
     bool pro = P.pro_act != SGAN_ACT_NONE;
     for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
     sg_prof_begin(st);
-    if (pro) hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, true>), grid, dim3(NT), lds, st, P);
-    else hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, false>), grid, dim3(NT), lds, st, P);
+    if (P.planes_f16) {
+        if (pro) hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, true, true>), grid, dim3(NT), lds, st, P);
+        else hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, false, true>), grid, dim3(NT), lds, st, P);
+    } else {
+        if (pro) hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, true, false>), grid, dim3(NT), lds, st, P);
+        else hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(NT), lds, st, P);
+    }
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = name;
     sg_prof_end(st, g_sgan_last_kernel);

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import sgan_oracle as O
-from test_oracle_golden import check_probe, check_step1, real_batch
+from test_oracle_golden import check_losses, check_probe, check_step1, load_f64, real_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -101,23 +101,28 @@ def test_fcgan_step_vs_reference_golden(golden_dir, name, kw, extra, full):
     if extra:
         assert all(float(v.abs().max()) == 0.0 for gd in pr["gradD"] for v in gd.values())   # really skipped
         pr["gradD"] = []
-    check_probe(pr, g, cfg, tol=1e-3, robust=full, tally=tally)
+    f64 = load_f64(golden_dir, name)          # full-size cases: arbitrated by the reference run in double (check_grads)
+    assert (f64 is not None) == full
+    check_probe(pr, g, cfg, tol=1e-3, f64=f64, tally=tally)
     # (2) step 1 in optimize_parameters' order: fake, D losses, D gradients before the optimizer acts
     m = build_model(cfg, int(g["n_init_noise_draws"]), extra)
     cap = step1_with_captures(m, real3(cfg, 0))
     torch.cuda.synchronize()
-    check_step1(cap, g, cfg, tol=1e-3, robust=full, tally=tally, check_gradG=False)
-    strict = sum(1 for _, _, e_max, _ in tally if e_max <= 1e-3)
-    worst = max(tally, key=lambda t: t[3])
-    print(f"{name}: {strict}/{len(tally)} gradient tensors within 1e-3 (max-abs/max|g|); worst rel-L2 {worst[3]:.2e} at {worst[0]}/{worst[1]}")
-    assert float(np.median([t[3] for t in tally])) <= 5e-3, tally
-    # (3) trajectory: losses only, at the spread two CPU runs of the reference itself show (~1e-2 by step 3)
+    check_step1(cap, g, cfg, tol=1e-3, f64=f64, tally=tally, check_gradG=False)
+    worst = max(tally, key=lambda t: t[2])
+    n_ref32 = sum(1 for t in tally if t[3] <= 1e-3)
+    print(f"{name}: {len(tally)} gradient tensors vs {'the fp64 reference' if f64 is not None else 'the fp32 golden'}: "
+          f"{sum(1 for t in tally if t[4] == 'strict')} within 1e-3 (the reference's own fp32: {n_ref32}), "
+          f"{sum(1 for t in tally if t[4] == 'ref')} within 4x the reference's own fp32 error, "
+          f"{sum(1 for t in tally if t[4] == 'flips')} with isolated activation-flip rows; "
+          f"worst {worst[2]:.2e} at {worst[0]}/{worst[1]} (reference fp32 there: {worst[3]:.2e})")
+    # (3) trajectory: losses only (Adam's sign-like first steps make the parameters themselves chaotic)
     losses = [list(m.get_current_errors().values())]
     for step in range(1, g["losses"].shape[0]):
         m.set_input({"A": real3(cfg, step), "A_paths": ["synthetic"]})
         m.optimize_parameters()
         losses.append(list(m.get_current_errors().values()))
-    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2, (losses, g["losses"])
+    print(f"{name}: loss trajectory deviation (this, reference fp32) from fp64 / golden:", check_losses(losses, g, f64))
     assert m.optimizer_D.step_count == g["losses"].shape[0]
     assert m.optimizer_G.step_count == g["losses"].shape[0] * cfg.n_update_G
 
@@ -225,7 +230,9 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
     p.backward_G()
     torch.cuda.synchronize()
     pr = {"gradG": _grads(p.netG), "gradD": [_grads(d) for d in p.netD], "loss_G": [float(p.loss_G), float(p.loss_G_L1)]}
-    check_cgan_probe(pr, g, cfg, tol=1e-3, robust=full, tally=tally)
+    f64 = load_f64(golden_dir, name)
+    assert (f64 is not None) == full
+    check_cgan_probe(pr, g, cfg, tol=1e-3, f64=f64, tally=tally)
     # (2) step 1: fake_B, D losses, D gradients before the optimizer acts
     random.seed(1234)
     m = build_cgan(cfg)
@@ -238,7 +245,7 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
     m.backward_D()
     cap["gradD"] = [_grads(d) for d in m.netD]
     cap["loss_D"] = [float(m.loss_D_real), float(m.loss_D_fake)]
-    check_cgan_step1(cap, g, cfg, tol=1e-3, robust=full, tally=tally)
+    check_cgan_step1(cap, g, cfg, tol=1e-3, f64=f64, tally=tally)
     m.optimizer_D.step()
     for _ in range(cfg.n_update_G):
         m.optimizer_G.zero_grad()
@@ -246,10 +253,13 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
         m.optimizer_G.step()
         if cfg.n_update_G > 1:
             m.sample_noise()
-    strict = sum(1 for _, _, e_max, _ in tally if e_max <= 1e-3)
-    worst = max(tally, key=lambda t: t[3])
-    print(f"{name}: {strict}/{len(tally)} gradient tensors within 1e-3 (max-abs/max|g|); worst rel-L2 {worst[3]:.2e} at {worst[0]}/{worst[1]}")
-    assert float(np.median([t[3] for t in tally])) <= 5e-3, tally
+    worst = max(tally, key=lambda t: t[2])
+    n_ref32 = sum(1 for t in tally if t[3] <= 1e-3)
+    print(f"{name}: {len(tally)} gradient tensors vs {'the fp64 reference' if f64 is not None else 'the fp32 golden'}: "
+          f"{sum(1 for t in tally if t[4] == 'strict')} within 1e-3 (the reference's own fp32: {n_ref32}), "
+          f"{sum(1 for t in tally if t[4] == 'ref')} within 4x the reference's own fp32 error, "
+          f"{sum(1 for t in tally if t[4] == 'flips')} with isolated activation-flip rows; "
+          f"worst {worst[2]:.2e} at {worst[0]}/{worst[1]} (reference fp32 there: {worst[3]:.2e})")
     # (3) trajectory through the losses
     def errs():     # the golden rows are (loss_G, loss_G_L1, D_real, D_fake); cgan2's get_current_errors has no G_L1 entry
         return [float(m.loss_G), float(m.loss_G_L1), float(m.loss_D_real), float(m.loss_D_fake)]
@@ -258,7 +268,7 @@ def test_cgan_step_vs_reference_golden(golden_dir, name, kw):
         m.set_input(cgan_input(cfg, step))
         m.optimize_parameters()
         losses.append(errs())
-    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+    print(f"{name}: loss trajectory deviation:", check_losses(losses, g, f64))
 
 
 def test_cgan_with_crn_generator():
@@ -375,12 +385,17 @@ def test_twostage_cycle_vs_reference_golden(golden_dir, name, kw):
     cap["gradF2"] = _grads(p.netF2) if cfg.cycle else {}
     cap["losses"] = p.get_current_errors()
     # G1's gradient arrives through seven networks (D1 x2, and via the bilinear transform G2, D2 x4, F2) and ends in a BatchNorm over
-    # 4x4 samples, F2's inner blocks normalise 2x2 maps: the per-tensor criterion is the robust one (relative L2 <= 2e-2) at both sizes, the strict count is reported
-    check_twostage_probe(cap, g, cfg, tol=1e-3, robust=True, tally=tally)
-    strict = sum(1 for _, _, e_max, _ in tally if e_max <= 1e-3)
-    worst = max(tally, key=lambda t: t[3])
-    print(f"{name}: {strict}/{len(tally)} gradient tensors within 1e-3 (max-abs/max|g|); worst rel-L2 {worst[3]:.2e} at {worst[0]}/{worst[1]}")
-    assert float(np.median([t[3] for t in tally])) <= 5e-3, tally
+    # 4x4 samples, F2's inner blocks normalise 2x2 maps: every case of this trainer is arbitrated by the reference run in double
+    f64 = load_f64(golden_dir, name)
+    assert f64 is not None
+    check_twostage_probe(cap, g, cfg, tol=1e-3, f64=f64, tally=tally)
+    worst = max(tally, key=lambda t: t[2])
+    n_ref32 = sum(1 for t in tally if t[3] <= 1e-3)
+    print(f"{name}: {len(tally)} gradient tensors vs {'the fp64 reference' if f64 is not None else 'the fp32 golden'}: "
+          f"{sum(1 for t in tally if t[4] == 'strict')} within 1e-3 (the reference's own fp32: {n_ref32}), "
+          f"{sum(1 for t in tally if t[4] == 'ref')} within 4x the reference's own fp32 error, "
+          f"{sum(1 for t in tally if t[4] == 'flips')} with isolated activation-flip rows; "
+          f"worst {worst[2]:.2e} at {worst[0]}/{worst[1]} (reference fp32 there: {worst[3]:.2e})")
     random.seed(1234)
     m = build_twostage(cfg)
     losses = []
@@ -388,7 +403,7 @@ def test_twostage_cycle_vs_reference_golden(golden_dir, name, kw):
         m.set_input(cgan_input(cfg, step))
         m.optimize_parameters()
         losses.append(list(m.get_current_errors().values()))
-    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+    print(f"{name}: loss trajectory deviation:", check_losses(losses, g, f64))
 
 
 def test_checkpoints_cgan_and_twostage(tmp_path):
@@ -499,13 +514,18 @@ def test_cgan_cycle_step_vs_reference_golden(golden_dir, name, kw):
     pr["gradG1"], pr["gradG2"] = _grads(p.netG1), _grads(p.netG2)
     pr["loss_G"] = [float(p.loss_G), float(p.loss_G_GAN), float(p.loss_G_L1), float(p.loss_G_CE),
                     float(p.loss_G_real_cycle if two else p.loss_G_cycle)]
-    # the inner U-Net blocks normalise 2x2 - 4x4 maps: robust per-tensor criterion + median, strict count reported
+    # the inner U-Net blocks normalise 2x2 - 4x4 maps: arbitrated by the reference run in double
     tally = []
-    check_cgan_cycle_probe(pr, g, cfg, tol=1e-3, robust=True, tally=tally)
-    strict = sum(1 for _, _, e_max, _ in tally if e_max <= 1e-3)
-    print(f"{name}: {strict}/{len(tally)} gradient tensors within 1e-3 (max-abs/max|g|); over: "
-          + ", ".join(f"{a}/{b} {e:.1e}" for a, b, e, _ in tally if e > 1e-3))
-    assert float(np.median([t[3] for t in tally])) <= 5e-3, tally
+    f64 = load_f64(golden_dir, name)
+    assert f64 is not None
+    check_cgan_cycle_probe(pr, g, cfg, tol=1e-3, f64=f64, tally=tally)
+    worst = max(tally, key=lambda t: t[2])
+    n_ref32 = sum(1 for t in tally if t[3] <= 1e-3)
+    print(f"{name}: {len(tally)} gradient tensors vs {'the fp64 reference' if f64 is not None else 'the fp32 golden'}: "
+          f"{sum(1 for t in tally if t[4] == 'strict')} within 1e-3 (the reference's own fp32: {n_ref32}), "
+          f"{sum(1 for t in tally if t[4] == 'ref')} within 4x the reference's own fp32 error, "
+          f"{sum(1 for t in tally if t[4] == 'flips')} with isolated activation-flip rows; "
+          f"worst {worst[2]:.2e} at {worst[0]}/{worst[1]} (reference fp32 there: {worst[3]:.2e})")
     random.seed(1234)
     m = build_cgan_cycle(cfg)
     losses = []
@@ -513,7 +533,7 @@ def test_cgan_cycle_step_vs_reference_golden(golden_dir, name, kw):
         m.set_input(cgan_input(cfg, step))
         m.optimize_parameters()
         losses.append([float(m.loss_G), float(m.loss_G_real_cycle if two else m.loss_G_cycle), float(m.loss_D)])
-    assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-2 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+    print(f"{name}: loss trajectory deviation:", check_losses(losses, g, f64))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -132,26 +132,69 @@ def grad_errors(grad, g, prefix, name, scale_key=None):
     return float(e_max), float(e_l2)
 
 
-def check_grads(grads, g, prefix, undet, tol=TOL, robust=False, tally=None):
-    """strict: every tensor within tol (max-abs / max|g|).  robust (full-size GPU runs): a ReLU/LeakyReLU
-    input within ~1e-7 of zero makes the reference's own gradient jump by O(1e-2) in one channel, and two
-    fp32 implementations cannot agree on such a sign (27 M activations per 512x512 step => a couple per
-    step); so every tensor must be within 2e-2 in relative L2 and `tally` records how many also meet the
-    strict bound ('What parity means')."""
+def load_f64(golden_dir, name):
+    """`<name>_f64.npz`: the same reference trainer on the same inputs run in double (oracle/make_golden.py f64), or None."""
+    path = os.path.join(golden_dir, name.replace(".npz", "_f64.npz"))
+    return np.load(path) if os.path.exists(path) else None
+
+
+def check_grads(grads, g, prefix, undet, tol=TOL, f64=None, tally=None):
+    """Every gradient tensor within `tol` (max-abs error / max|g|) of the reference's fp32 golden.
+
+    Where an fp64 run of the same reference code exists (`f64`, see load_f64) it arbitrates instead.  The gradient of these nets
+    is a DISCONTINUOUS function of the rounding: a LeakyReLU / ReLU input that lands within an implementation's forward error
+    of zero takes the other slope, and because a weight gradient is a sum of ~N random-sign pixel terms, ONE such element moves
+    one output channel's row of it by ~1/sqrt(N) of max|g| (measured, tools/diag_bf16x3.py: 1e-3 .. 1e-2 at 512^2; the exact-fp32
+    kernels and the reference's own fp32 CPU run show the same jumps against fp64, each on its own elements).  So with
+    e = error against fp64 and e_ref = error of the reference's fp32 golden against fp64 (on the golden's strided sample, over
+    max|g_fp64|) a tensor passes when
+        e <= max(tol, 4 e_ref)                                   -- as accurate as the reference itself is there, or
+        <= 10 % of its sampled elements (or <= 8 of them: a bias gradient has 32 .. 512) are beyond max(tol, 4 e_ref) and its
+        relative L2 error is <= 5e-3                              -- isolated rows moved by single activation flips.
+    A kernel error would move most elements (and fails the exact adjoint identities of test_hip_ops at the same shapes).
+    `tally` collects (prefix, name, e, e_ref, clause)."""
     for k, v in grads.items():
         if f"{prefix}/summary/{k}" not in g.files:
             continue
-        if k in undet:   # analytically zero: compare on the scale of the same layer's weight gradient
-            e_max, _ = grad_errors(v, g, prefix, k, k.replace(".bias", ".weight"))
-            assert e_max <= (2e-2 if robust else tol), (prefix, k, e_max)
+        scale_key = k.replace(".bias", ".weight") if k in undet else None    # analytically zero: scale of the same layer's weight gradient
+        if f64 is not None and f"{prefix}/sample/{k}" in f64.files:
+            scale = f64[f"{prefix}/summary/{scale_key or k}"][1] + 1e-30
+            flat = v.detach().reshape(-1).cpu()
+            smp = flat[torch.from_numpy(O.grad_sample_idx(flat.numel()))].double().numpy()
+            truth = f64[f"{prefix}/sample/{k}"]
+            err = np.abs(smp - truth) / scale
+            e = float(err.max())
+            e_ref = float(np.abs(g[f"{prefix}/sample/{k}"].astype(np.float64) - truth).max() / scale)
+            bound = max(tol, 4.0 * e_ref)
+            clause = "strict" if e <= tol else ("ref" if e <= bound else "flips")
+            if tally is not None:
+                tally.append((prefix, k, e, e_ref, clause))
+            if e > bound:
+                nbad = int((err > bound).sum())
+                l2 = float(np.linalg.norm(smp - truth) / (np.linalg.norm(truth) + 1e-30)) if scale_key is None else 0.0
+                assert nbad <= max(8, 0.10 * err.size) and l2 <= 5e-3 and e <= 5e-2, (prefix, k, e, e_ref, nbad, err.size, l2)
             continue
-        e_max, e_l2 = grad_errors(v, g, prefix, k)
+        e_max, e_l2 = grad_errors(v, g, prefix, k, scale_key)
         if tally is not None:
-            tally.append((prefix, k, e_max, e_l2))
-        if robust:
-            assert e_l2 <= 2e-2, (prefix, k, e_max, e_l2)
-        else:
-            assert e_max <= tol, (prefix, k, e_max, e_l2)
+            tally.append((prefix, k, e_max, 0.0, "strict"))
+        assert e_max <= tol, (prefix, k, e_max, e_l2)
+
+
+def check_losses(losses, g, f64, tol=TOL):
+    """A loss trajectory against the golden one.  With an fp64 run: the trajectory is chaotic (Adam's first steps are
+    sign(g)), so the yardstick is the reference's own fp32 deviation from its fp64 trajectory -- every entry within
+    max(tol * scale, 4 * max deviation of the fp32 golden).  Without: the 2e-2 band of round 1."""
+    losses = np.asarray(losses, dtype=np.float64)
+    ref = np.asarray(g["losses"], dtype=np.float64)
+    scale = max(1.0, float(np.abs(ref).max()))
+    if f64 is not None and "losses" in f64.files:
+        truth = np.asarray(f64["losses"], dtype=np.float64)
+        dev_ref = float(np.abs(ref - truth).max())
+        dev = float(np.abs(losses - truth).max())
+        assert dev <= max(tol * scale, 4.0 * dev_ref), (dev, dev_ref, losses, truth)
+        return dev, dev_ref
+    assert np.abs(losses - ref).max() < 2e-2 * scale, (losses, ref)
+    return float(np.abs(losses - ref).max()), None
 
 
 def check_forward(cap, g, tol=TOL):
@@ -161,22 +204,22 @@ def check_forward(cap, g, tol=TOL):
     assert np.abs(np.asarray(cap["loss_D"]) - g["step1/loss_D"]).max() < tol
 
 
-def check_step1(cap, g, cfg, tol=TOL, robust=False, tally=None, check_gradG=True):
+def check_step1(cap, g, cfg, tol=TOL, f64=None, tally=None, check_gradG=True):
     check_forward(cap, g, tol)
     for i, gd in enumerate(cap["gradD"]):
         check_grads(gd, g, f"step1/gradD_{i}", O.norm_cancelled_keys_d(cfg.input_nc, cfg.ndf, cfg.n_layers_D[i]),
-                    tol, robust, tally)
+                    tol, f64, tally)
     if check_gradG:   # taken after D's first Adam update: only reproducible by bit-identical arithmetic
         assert abs(cap["loss_G"] - float(g["step1/loss_G"])) < tol
-        check_grads(cap["gradG"], g, "step1/gradG", O.norm_cancelled_keys_g(cfg.n_layers_G), tol, robust, tally)
+        check_grads(cap["gradG"], g, "step1/gradG", O.norm_cancelled_keys_g(cfg.n_layers_G), tol, f64, tally)
 
 
-def check_probe(pr, g, cfg, tol=TOL, robust=False, tally=None):
+def check_probe(pr, g, cfg, tol=TOL, f64=None, tally=None):
     assert abs(pr["loss_G"] - float(g["probeG/loss_G"])) < tol
-    check_grads(pr["gradG"], g, "probeG/gradG", O.norm_cancelled_keys_g(cfg.n_layers_G), tol, robust, tally)
+    check_grads(pr["gradG"], g, "probeG/gradG", O.norm_cancelled_keys_g(cfg.n_layers_G), tol, f64, tally)
     for i, gd in enumerate(pr["gradD"]):
         check_grads(gd, g, f"probeG/gradD_{i}", O.norm_cancelled_keys_d(cfg.input_nc, cfg.ndf, cfg.n_layers_D[i]),
-                    tol, robust, tally)
+                    tol, f64, tally)
 
 
 @pytest.mark.parametrize("name,kw", [
@@ -248,21 +291,21 @@ def cgan_undet_D(cfg, i):
     return O.norm_cancelled_keys_d(cfg.input_nc + cfg.output_nc, cfg.ndf, cfg.n_layers_D[i])
 
 
-def check_cgan_step1(cap, g, cfg, tol=TOL, robust=False, tally=None):
+def check_cgan_step1(cap, g, cfg, tol=TOL, f64=None, tally=None):
     check_forward(cap, g, tol)
     if "fake2" in cap:
         check_forward({"fake": cap["fake2"], "loss_D": cap["loss_D"]}, {"step1/fake_summary": g["step1/fake2_summary"],
                       "step1/fake_crop": g["step1/fake2_crop"], "step1/loss_D": g["step1/loss_D"]}, tol)
     for i, gd in enumerate(cap["gradD"]):
-        check_grads(gd, g, f"step1/gradD_{i}", cgan_undet_D(cfg, i), tol, robust, tally)
+        check_grads(gd, g, f"step1/gradD_{i}", cgan_undet_D(cfg, i), tol, f64, tally)
 
 
-def check_cgan_probe(pr, g, cfg, tol=TOL, robust=False, tally=None):
+def check_cgan_probe(pr, g, cfg, tol=TOL, f64=None, tally=None):
     assert np.abs(np.asarray(pr["loss_G"]) - g["probeG/loss_G"]).max() < tol * max(1.0, float(g["probeG/loss_G"][0]))
     check_grads(pr["gradG"], g, "probeG/gradG", O.norm_cancelled_keys_unet(cfg.num_downs, cfg.ngf, cfg.n_layers_G_skip),
-                tol, robust, tally)
+                tol, f64, tally)
     for i, gd in enumerate(pr["gradD"]):
-        check_grads(gd, g, f"probeG/gradD_{i}", cgan_undet_D(cfg, i), tol, robust, tally)
+        check_grads(gd, g, f"probeG/gradD_{i}", cgan_undet_D(cfg, i), tol, f64, tally)
 
 
 CGAN2_SMALL = dict(num_downs=7, ngf=8, ndf=8, fineSize=256, weights=(2.0, 5.0), variant="cgan2", n_layers_D=(3, 3), scale_factor=(1, 2),
@@ -359,16 +402,16 @@ def twostage_undet(cfg):
     return u
 
 
-def check_twostage_probe(cap, g, cfg, tol=TOL, robust=False, tally=None):
+def check_twostage_probe(cap, g, cfg, tol=TOL, f64=None, tally=None):
     for key in ("fake_A", "fake_B_from_fake_A") + (("recon_fake_A",) if cfg.cycle else ()):
         assert rel(cap[key][:, :, :64, :64], g[f"probe/{key}_crop"]) < tol, key
     assert np.abs(np.asarray(list(cap["losses"].values())) - g["probe/losses"]).max() < tol * max(1.0, np.abs(g["probe/losses"]).max())
     u = twostage_undet(cfg)
     for tag in ("G1", "G2") + (("F2",) if cfg.cycle else ()):
-        check_grads(cap["grad" + tag], g, f"probe/grad{tag}", u[tag], tol, robust, tally)
+        check_grads(cap["grad" + tag], g, f"probe/grad{tag}", u[tag], tol, f64, tally)
     for tag in ("D1", "D2"):
         for i, gd in enumerate(cap["grad" + tag]):
-            check_grads(gd, g, f"probe/grad{tag}_{i}", u[tag][i], tol, robust, tally)
+            check_grads(gd, g, f"probe/grad{tag}_{i}", u[tag][i], tol, f64, tally)
 
 
 @pytest.mark.parametrize("name,kw", TWOSTAGE_CASES)
@@ -429,7 +472,7 @@ def cgan_cycle_batch(cfg, step):
     return A[:, :2].contiguous(), B[:, 2:3].contiguous()
 
 
-def check_cgan_cycle_probe(pr, g, cfg, tol=TOL, robust=False, tally=None):
+def check_cgan_cycle_probe(pr, g, cfg, tol=TOL, f64=None, tally=None):
     for key in ("fake_B", "fake_A", "recon_A") + (("recon_fake_A",) if "recon_fake_A" in pr else ()):
         assert rel(pr[key][:, :, :64, :64], g[f"probe/{key}_crop"]) < tol, key
         assert abs(O.tensor_summary(pr[key])[2] - g[f"probe/{key}_summary"][2]) <= tol * g[f"probe/{key}_summary"][2], key
@@ -437,9 +480,9 @@ def check_cgan_cycle_probe(pr, g, cfg, tol=TOL, robust=False, tally=None):
     assert np.abs(np.asarray(pr["loss_G"]) - g["probe/loss_G"]).max() < tol * max(1.0, float(np.abs(g["probe/loss_G"]).max()))
     for i, gd in enumerate(pr["gradD_Dstep"]):
         check_grads(gd, g, f"probe/gradD_{i}", O.norm_cancelled_keys_d(cfg.input_nc + cfg.output_nc, cfg.ndf1, cfg.n_layers_D1[i]),
-                    tol, robust, tally)
-    check_grads(pr["gradG1"], g, "probe/gradG1", O.norm_cancelled_keys_unet(cfg.num_downs1, cfg.ngf1, -1), tol, robust, tally)
-    check_grads(pr["gradG2"], g, "probe/gradG2", O.norm_cancelled_keys_unet(cfg.num_downs2, cfg.ngf2, -1), tol, robust, tally)
+                    tol, f64, tally)
+    check_grads(pr["gradG1"], g, "probe/gradG1", O.norm_cancelled_keys_unet(cfg.num_downs1, cfg.ngf1, -1), tol, f64, tally)
+    check_grads(pr["gradG2"], g, "probe/gradG2", O.norm_cancelled_keys_unet(cfg.num_downs2, cfg.ngf2, -1), tol, f64, tally)
 
 
 @pytest.mark.parametrize("name,kw", CGAN_CYCLE_CASES)

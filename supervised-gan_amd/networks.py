@@ -14,6 +14,7 @@ names (models/networks.py:95,123)."""
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -1223,22 +1224,12 @@ class UnetGenerator(ChainNet):
         return mask, noise
 
     # ---- programs -------------------------------------------------------------------------------
-    # A U-Net whose bottleneck normalises maps of a handful of pixels (unet_256 at 512^2: InstanceNorm over 4x4 .. 2x2) is ill
-    # conditioned there: the normalisation divides by the standard deviation of 4 - 64 values and amplifies whatever error the
-    # outer layers carry by ~10^3 (measured: the 5e-6 of split-bf16 layers became 5e-3 .. 1e-2 in the weight gradients, the
-    # 3e-7 of the fp32 chain stays inside the 1e-3 contract).  Such a net runs the exact-fp32 kernels whatever ops.get_math() says.
-    MIN_NORM_POPULATION = 256
-
-    def _call_math(self, H, W):
-        small = (H >> (self.n - 1)) * (W >> (self.n - 1))
-        return "f32" if small < self.MIN_NORM_POPULATION else None
-
     def run_forward(self, x, update_running=True):
-        with ops.math_scope(self._call_math(x.shape[0], x.shape[1])):
+        with ops.math_scope(os.environ.get("SGAN_UNET_MATH")):      # diagnostics: force an arithmetic mode for the U-Nets only
             return self._run_forward(x, update_running)
 
     def run_backward(self, x, outs, S, dout, need_dx, want_wgrad):
-        with ops.math_scope(self._call_math(x.shape[0], x.shape[1])):
+        with ops.math_scope(os.environ.get("SGAN_UNET_MATH")):
             return self._run_backward(x, outs, S, dout, need_dx, want_wgrad)
 
     def _run_forward(self, x, update_running=True):

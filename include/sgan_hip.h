@@ -377,6 +377,12 @@ typedef struct sgan_adam_seg {
 int sgan_adam_multi(const sgan_adam_seg* segs, int32_t nseg, const float* lr_dev, float beta1, float beta2,
                     float eps, int32_t* state_dev, void* stream);
 
+/* ---- SGD over the same segment table: buf = momentum * buf + g ; p -= lr * buf  (torch.optim.SGD with dampening 0, no Nesterov,
+ * no weight decay; `m` of a segment is the momentum buffer, NULL / momentum 0 = plain gradient descent; `v` is ignored).
+ * The reference's trainers are hard-wired to Adam (options/train_options.py:30 parses --optimizer and nobody reads it); this
+ * is the second update rule of the boundary for callers that do read it. */
+int sgan_sgd_multi(const sgan_adam_seg* segs, int32_t nseg, const float* lr_dev, float momentum, void* stream);
+
 /* ---- N(0,1) fill (Philox4x32-10 + Box-Muller), counter-based -----------------------------------
  * Replaces: noise_.normal_(0, 1) (models/fcgan_model.py:126-127).  `offset_dev` is a device uint64
  * the kernels read; with advance != 0 it is moved on by ceil(n / 4) afterwards (graph-replay safe).  Fills with different

@@ -1434,6 +1434,43 @@ extern "C" int sgan_adam_multi(const sgan_adam_seg* segs, int32_t nseg, const fl
 }
 
 // ------------------------------------------------------------------------------------------
+// SGD (torch.optim.SGD form: buf = mu * buf + g, p -= lr * buf; dampening 0, no Nesterov, no weight decay) over the same
+// segment table as Adam; `m` is the momentum buffer (NULL or momentum == 0: plain p -= lr * g), `v` is unused.  The first
+// step of torch's SGD sets buf = g, which the zero-initialised buffer reproduces.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_sgd_kernel(SgAdamTable T, const float* lr_dev, float mu) {
+    const sgan_adam_seg& S = T.s[blockIdx.y];
+    const float lr = lr_dev[0];
+    const bool mom = mu != 0.f && S.m != nullptr;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < S.n; e += (int64_t)gridDim.x * 256) {
+        float g = S.g[e];
+        if (mom) {
+            g = mu * S.m[e] + g;
+            S.m[e] = g;
+        }
+        S.p[e] -= lr * g;
+    }
+}
+
+extern "C" int sgan_sgd_multi(const sgan_adam_seg* segs, int32_t nseg, const float* lr_dev, float momentum, void* stream) {
+    SGAN_CHECK(segs && nseg > 0 && nseg <= 64 && lr_dev, "bad argument");
+    SgAdamTable T;
+    int64_t maxn = 0;
+    for (int i = 0; i < nseg; ++i) {
+        T.s[i] = segs[i];
+        SGAN_CHECK(segs[i].p && segs[i].g && segs[i].n > 0, "bad segment %d", i);
+        if (segs[i].n > maxn) maxn = segs[i].n;
+    }
+    T.nseg = nseg;
+    int bx = ew_cdiv(maxn, 256 * 4);
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(sg_sgd_kernel, dim3(bx, nseg), dim3(256), 0, (hipStream_t)stream, T, lr_dev, momentum);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // N(0,1) fill: Philox4x32-10, Box-Muller
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sg_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,

@@ -401,6 +401,14 @@ def adam_multi(segs, lr_dev, beta1, beta2, eps, state_dev):
     L.check(L.lib().sgan_adam_multi(arr, len(segs), _ptr(lr_dev), beta1, beta2, eps, _ptr(state_dev), _stream()), "sgan_adam_multi")
 
 
+def sgd_multi(segs, lr_dev, momentum):
+    """segs: list of (p, g, buf or None, n) flat fp32 tensors."""
+    arr = (L.AdamSeg * len(segs))()
+    for i, (p, g, m, n) in enumerate(segs):
+        arr[i] = L.AdamSeg(p.data_ptr(), g.data_ptr(), m.data_ptr() if m is not None else None, None, n)
+    L.check(L.lib().sgan_sgd_multi(arr, len(segs), _ptr(lr_dev), float(momentum), _stream()), "sgan_sgd_multi")
+
+
 def normal_fill(dst, seed, offset_dev=None, advance=True):
     assert dst.is_contiguous() and dst.dtype == torch.float32
     L.check(L.lib().sgan_normal_fill(_ptr(dst), dst.numel(), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(offset_dev), int(bool(advance)),

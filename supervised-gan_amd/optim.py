@@ -91,6 +91,34 @@ class FusedAdam:
         return int(self._state[0].item()) if self._state is not None else 0
 
 
+class FusedSGD(FusedAdam):
+    """`torch.optim.SGD(params, lr=, momentum=)` over the flat storage (one sgan_sgd_multi launch): the second update rule of the
+    boundary.  Same segment handling, LR-in-device-memory and derived-weight-copy invalidation as FusedAdam."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0):
+        super().__init__(params, lr=lr)
+        self.param_groups[0]["momentum"] = float(momentum)
+
+    def _lazy_state(self):
+        if self._state is not None:
+            return
+        dev = self._segs[0][0].device
+        mu = self.param_groups[0]["momentum"]
+        self._m = [torch.zeros(n, dtype=torch.float32, device=dev) if mu else None for _, _, _, n in self._segs]
+        self._state = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    @torch.no_grad()
+    def step(self):
+        self._lazy_state()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        segs = [(ap[off: off + n], ag[off: off + n], m, n) for (ap, ag, off, n), m in zip(self._segs, self._m)]
+        ops.sgd_multi(segs, self._lr_dev, self.param_groups[0]["momentum"])
+        for net in self._nets.values():
+            net._wt_epoch = getattr(net, "_wt_epoch", 0) + 1
+
+
 class AdamGroups:
     """`torch.optim.Adam([{'name':, 'params':, 'lr':}, ...], betas=)` as the two-stage trainers build it
     (models/twostage_cycle_model.py:141-144): one FusedAdam per named group, stepped together."""

@@ -193,5 +193,6 @@ class SegmentationCycleModel(CGANCycleModel):
 
     reset_accs = SegmentationModel.reset_accs
     accum_accs = SegmentationModel.accum_accs
+    compute_current_Rand_score = SegmentationModel.compute_current_Rand_score
     compute_current_accuracy = SegmentationModel.compute_current_accuracy
     get_current_accs = SegmentationModel.get_current_accs

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from . import networks
 from .cgan_model import CGANModel
+from .util import compute_Rand_F_scores
 
 
 def _identity(x):
@@ -103,16 +104,25 @@ class SegmentationModel(CGANModel):
         return OrderedDict([('image', self.real_A.detach()), ('label', three(self.real_B.detach() * 2 - 1)),
                             ('prediction', three(self.fake_B.detach() * 2 - 1))])
 
-    # ---- accuracy (segm_model.py:265-341; the Rand F-score of util.compute_Rand_F_scores is not carried) --------------
+    # ---- accuracy (segm_model.py:265-341) ---------------------------------------------------------------------------
     def reset_accs(self):
-        self.confusion, self.numAveragedPixels = 0, 0
-        self.pixelAcc = self.meanAcc = self.meanIU = 0
+        self.confusion, self.numAveragedPixels, self.numAveragedImages = 0, 0, 0
+        self.pixelAcc = self.meanAcc = self.meanIU = self.RandScore = 0
 
     def accum_accs(self):
         if 'RandScore' in self.opt.which_metric:
-            raise NotImplementedError("RandScore (util.compute_Rand_F_scores) is not on the MI355X path; use meanIU")
+            self.compute_current_Rand_score()
         if 'meanIU' in self.opt.which_metric:
             self.compute_current_accuracy()
+
+    def compute_current_Rand_score(self):
+        """Running mean of the Rand F-score of the predicted against the true boundary map (segm_model.py:299-307): a host metric
+        (connected components of a 512x512 map), computed on the CPU copy like the reference does."""
+        assert self.num_classes == 2      # binary segmentation only, as in the reference
+        RIs = compute_Rand_F_scores(self.fake_B.detach().cpu().numpy(), self.real_B.detach().cpu().numpy(), do_thin=False)
+        n = self.numAveragedImages
+        self.numAveragedImages = n + RIs.size
+        self.RandScore = (n * self.RandScore + RIs.sum()) / self.numAveragedImages
 
     def compute_current_accuracy(self):
         if self.opt.add_background_onehot_acc:
@@ -129,4 +139,5 @@ class SegmentationModel(CGANModel):
         self.meanIU = float(np.mean(tp / np.maximum(1, rel + sel - tp)))
 
     def get_current_accs(self):
-        return OrderedDict([('meanIU', self.meanIU)] if 'meanIU' in self.opt.which_metric else [])
+        return OrderedDict(([('RandScore', self.RandScore)] if 'RandScore' in self.opt.which_metric else [])
+                           + ([('meanIU', self.meanIU)] if 'meanIU' in self.opt.which_metric else []))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sampling driver with the reference's loop (test.py:10-60): load `<which_epoch>_net_*.pth`, run `model.test()` how_many
-times, write the visuals as PNGs under results_dir/name/<phase>_<which_epoch>/images/ (the HTML index page of the
-reference's util/html.py is not reproduced)."""
+times, write the visuals as PNGs under results_dir/name/<phase>_<which_epoch>/images/ and the index.html result page beside
+them (util/visualizer.py:136-154, util/html.py)."""
 import os
 import sys
 
@@ -9,21 +9,21 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from supervised_gan_amd.models import create_model  # noqa: E402
 from supervised_gan_amd.options import TestOptions  # noqa: E402
 from supervised_gan_amd.synthetic_data import SyntheticDataset  # noqa: E402
-from supervised_gan_amd.util import save_image, tensor2im  # noqa: E402
+from supervised_gan_amd import html  # noqa: E402
+from supervised_gan_amd.visualizer import Visualizer  # noqa: E402
 
 
 def main(argv=None):
     opt = TestOptions().parse(argv, save=False)
     opt.nThreads, opt.batchSize, opt.serial_batches, opt.no_flip, opt.no_rotate = 1, 1, True, True, True
     model = create_model(opt)
-    img_dir = os.path.join(opt.results_dir, opt.name, '%s_%s' % (opt.phase, opt.which_epoch), 'images')
+    visualizer = Visualizer(opt)
+    web_dir = os.path.join(opt.results_dir, opt.name, '%s_%s' % (opt.phase, opt.which_epoch))
+    webpage = html.HTML(web_dir, 'Experiment = %s, Phase = %s, Epoch = %s' % (opt.name, opt.phase, opt.which_epoch))
     written = []
 
     def dump(visuals, stem):
-        for label, t in visuals.items():
-            path = os.path.join(img_dir, '%s_%s.png' % (stem, label))
-            save_image(tensor2im(t), path)
-            written.append(path)
+        written.extend(visualizer.save_images(webpage, visuals, [stem + '.png']))
 
     if opt.model.startswith(('cgan', 'segmentation')):       # models that read a label image (test.py:27-41)
         if opt.dataroot == 'synthetic':
@@ -43,6 +43,7 @@ def main(argv=None):
             model.test()
             print('produce image... %04d.png' % (i + 1))
             dump(model.get_current_visuals(save_as_single_image=opt.save_as_single_image), '%04d' % (i + 1))
+    webpage.save()
     return written
 
 

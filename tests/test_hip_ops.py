@@ -365,6 +365,28 @@ def test_adam_matches_reference_form(hip):
     assert float((m.cpu() - opt.m[0]).abs().max()) < 1e-6 * float(opt.m[0].abs().max()) + 1e-12
 
 
+@pytest.mark.parametrize("momentum", [0.0, 0.9])
+def test_sgd_matches_torch(hip, momentum):
+    """sgan_sgd_multi against torch.optim.SGD (CPU) over five steps, plain and with momentum; odd length (tail elements)."""
+    ops = hip
+    n = 10007
+    g = torch.Generator().manual_seed(6)
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref_p], lr=0.05, momentum=momentum)
+    p, gr = p0.clone().cuda(), torch.zeros(n, device="cuda")
+    buf = torch.zeros(n, device="cuda") if momentum else None
+    lr = torch.full((1,), 0.05, device="cuda")
+    for step in range(5):
+        grad = torch.randn(n, generator=g)
+        ref_p.grad = grad.clone()
+        opt.step()
+        gr.copy_(grad)
+        ops.sgd_multi([(p, gr, buf, n)], lr, momentum)
+    torch.cuda.synchronize()
+    assert float((p.cpu() - ref_p.detach()).abs().max()) < 1e-5
+
+
 def test_bn_running_update(hip):
     from hip_utils import stats_of
     ops = hip

@@ -173,3 +173,62 @@ def test_phase_tables_cover_every_output_exactly_once():
                     assert (ky, kx) not in taps_seen
                     taps_seen.add((ky, kx))
     assert (cover == 1).all() and len(taps_seen) == k * k
+
+
+def test_rand_f_score_vs_restatement():
+    """compute_Rand_F_scores (scipy labelling + one bincount) == the plain-loop restatement of util/util.py:86-128, on hand-built
+    boundary maps (a perfect prediction scores 1, a merged and a split region less) and on random ones."""
+    import rand_score as R
+    from supervised_gan_amd.util import compute_Rand_F_scores
+    t = np.zeros((24, 24))
+    t[:, 8] = t[:, 16] = t[12, :] = 1                       # six regions
+    assert abs(compute_Rand_F_scores(t, t)[0] - 1.0) < 1e-12
+    merged = t.copy()
+    merged[:, 8] = 0
+    merged[12, :] = 1
+    split = t.copy()
+    split[6, :] = 1
+    diag = np.zeros((24, 24))
+    diag[np.arange(24), np.arange(24)] = 1                  # 8-connectivity: a diagonal line does NOT separate two regions
+    for s in (merged, split, diag):
+        got = compute_Rand_F_scores(s, t)[0]
+        assert abs(got - R.rand_f_score(s, t)) < 1e-12 and 0 < got < 1
+    rng = np.random.default_rng(3)
+    S = (rng.random((3, 1, 20, 28)) < 0.3).astype(np.float32) * 0.9
+    T = (rng.random((3, 1, 20, 28)) < 0.25).astype(np.float32)
+    got = compute_Rand_F_scores(S, T)
+    for k in range(3):
+        assert abs(got[k] - R.rand_f_score(S[k, 0], T[k, 0])) < 1e-12
+    with pytest.raises(NotImplementedError):
+        compute_Rand_F_scores(S, T, do_thin=True)
+
+
+def test_visualizer_and_html_page(tmp_path):
+    """util/visualizer.py + util/html.py: loss_log.txt lines, images/epoch%.3d_<label>.png, index.html rebuilt with every epoch so far
+    (newest first) with the reference's table structure; test.py's result page through save_images()."""
+    from types import SimpleNamespace
+    from supervised_gan_amd import html
+    from supervised_gan_amd.visualizer import Visualizer
+    opt = SimpleNamespace(isTrain=True, no_html=False, display_winsize=128, name="exp", checkpoints_dir=str(tmp_path), display_id=0)
+    vis = Visualizer(opt)
+    img = (np.arange(8 * 8 * 3) % 255).astype(np.uint8).reshape(8, 8, 3)
+    t = torch.zeros(1, 2, 8, 8)                                   # trainers hand tensors in [-1, 1]: two channels -> zero blue plane
+    for epoch in (1, 2):
+        vis.display_current_results({"fake": img, "real": t}, epoch)
+    vis.print_current_errors(2, 64, {"G_GAN": 0.5, "D_real": 1.25}, 0.0031)
+    web = tmp_path / "exp" / "web"
+    assert sorted(os.listdir(web / "images")) == ["epoch001_fake.png", "epoch001_real.png", "epoch002_fake.png", "epoch002_real.png"]
+    page = (web / "index.html").read_text()
+    assert page.index("epoch [2]") < page.index("epoch [1]")
+    assert '<table border="1" style="table-layout: fixed;">' in page and 'href="images/epoch002_fake.png"' in page
+    assert '<img style="width:128px" src="images/epoch001_real.png">' in page and "<title>Experiment name = exp</title>" in page
+    log = (tmp_path / "exp" / "loss_log.txt").read_text().splitlines()
+    assert log[0].startswith("================ Training Loss") and log[-1] == "(epoch: 2, iters: 64, time: 0.003) G_GAN: 0.500 D_real: 1.250 "
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(web / "images" / "epoch002_fake.png")), img)
+    # test.py's page
+    wp = html.HTML(str(tmp_path / "res"), "Experiment = exp, Phase = test, Epoch = latest")
+    written = vis.save_images(wp, {"fake_B": img}, ["/data/testA/0007_x.png"])
+    wp.save()
+    assert written == [str(tmp_path / "res" / "images" / "0007_x_fake_B.png")] and os.path.exists(written[0])
+    assert "<h3>0007_x</h3>" in (tmp_path / "res" / "index.html").read_text()

@@ -21,6 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from supervised_gan_amd.models import create_model  # noqa: E402
 from supervised_gan_amd.options import TrainOptions  # noqa: E402
 from supervised_gan_amd.synthetic_data import SyntheticDataset  # noqa: E402
+from supervised_gan_amd.visualizer import Visualizer  # noqa: E402
 
 
 def main(argv=None):
@@ -46,10 +47,7 @@ def main(argv=None):
     dataset_size = len(dataset)
     print('#training images = %d' % dataset_size)
     model = create_model(opt)
-    log_name = os.path.join(opt.checkpoints_dir, opt.name, 'loss_log.txt')       # util/visualizer.py:27-30,126-133
-    os.makedirs(os.path.dirname(log_name), exist_ok=True)
-    with open(log_name, "a") as log_file:
-        log_file.write('================ Training Loss (%s) ================\n' % time.strftime("%c"))
+    visualizer = Visualizer(opt)       # loss_log.txt + web/index.html (util/visualizer.py)
     graphed = None
     if opt.graph:
         from supervised_gan_amd.graph_step import GraphedStep
@@ -68,13 +66,10 @@ def main(argv=None):
                 graphed.capture(data)          # = warmup_steps ordinary steps on this batch
             else:
                 graphed.step(data)
+            if total_steps % opt.display_freq == 0:
+                visualizer.display_current_results(model.get_current_visuals(), epoch)
             if total_steps % opt.print_freq == 0:
-                errors = model.get_current_errors()
-                t = (time.time() - iter_start_time) / opt.batchSize
-                message = '(epoch: %d, iters: %d, time: %.3f) ' % (epoch, epoch_iter, t) + ''.join('%s: %.3f ' % kv for kv in errors.items())
-                print(message)
-                with open(log_name, "a") as log_file:
-                    log_file.write('%s\n' % message)
+                visualizer.print_current_errors(epoch, epoch_iter, model.get_current_errors(), (time.time() - iter_start_time) / opt.batchSize)
             if total_steps % opt.save_latest_freq == 0:
                 print('saving the latest model (epoch %d, total_steps %d)' % (epoch, total_steps))
                 model.save('latest')

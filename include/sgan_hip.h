@@ -308,6 +308,20 @@ int sgan_norm_apply_bwd_sums(float* dt, int32_t dt_ld, const float* mask, const 
 /* mask[i] = uniform(Philox(seed, *offset_dev + i)) < p ? 0 : 1/(1-p); advances *offset_dev (nn.Dropout). */
 int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t* offset_dev, int32_t advance, void* stream);
 
+/* ---- nn.ReflectionPad2d in front of a conv (resnet generators: models/networks.py:232,258 ReflectionPad2d(3) + Conv k7;
+ * :282-300 ReflectionPad2d(1) + Conv k3 inside every ResnetBlock) -------------------------------------------------------
+ * out [H + 2 pad][W + 2 pad][C] = mask * act(norm(x)) gathered at the reflected positions (what the reference normalises,
+ * activates and drops out BEFORE it pads); the conv that follows takes `out` with pad 0 and no in_norm.  pad == 0 just
+ * materialises mask * act(norm(x)).  `mask` is dense [H][W][C] (nn.Dropout: 0 or 1 / (1 - p)) or NULL.
+ * Backward: din [H][W][C] = act'(norm(x)) * mask * (sum of dout over the <= 4 padded positions that mirror the pixel);
+ * with x_norm->stats it also accumulates bwd_sums (sum din, sum din * xhat) for sgan_norm_bwd_apply, like sgan_conv_dgrad.
+ * x == NULL: a plain fold (the padded tensor was the input itself). */
+int sgan_pad_reflect_fwd(const float* x, int32_t x_ld, int32_t H, int32_t W, int32_t C, const sgan_norm_desc* x_norm,
+                         const float* mask, int32_t pad, float* out, int32_t out_ld, void* stream);
+int sgan_pad_reflect_bwd(const float* dout, int32_t dout_ld, int32_t H, int32_t W, int32_t C, int32_t pad, const float* x,
+                         int32_t x_ld, const sgan_norm_desc* x_norm, const float* mask, float* din, int32_t din_ld,
+                         double* bwd_sums, int32_t bwd_sums_sq_stride, void* stream);
+
 /* ---- BCELoss on rescaled tanh outputs (two-stage trainers): loss = mean BCE((x + 1) / 2, (t + 1) / 2) over npix * C
  * with torch's -100 log clamp; g = dloss/dx for a unit upstream gradient (backward: dx = gout * g, sgan_scale).
  * Replaces: torch.nn.BCELoss()((x + 1) / 2, (t + 1) / 2) at models/twostage_cycle_model.py:398-403. */

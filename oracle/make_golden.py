@@ -393,6 +393,47 @@ def golden_unet_small():
         save(f"unet_small_{tag}.npz", **arrs)
 
 
+class SeqDropoutInjector:
+    """F.dropout -> numpy-seeded masks: the i-th dropout call of the scope gets O.dropout_mask_np(seed + i, shape) (ResnetBlocks
+    all drop tensors of one shape, so the mask is keyed on the call order)."""
+    def __init__(self, seed):
+        self.seed, self.n = seed, 0
+        self._orig = torch.nn.functional.dropout
+
+    def __enter__(self):
+        inj = self
+
+        def dropout(x, p=0.5, training=True, inplace=False):
+            assert p == 0.5 and training
+            m = O.dropout_mask_np(inj.seed + inj.n, x.shape)
+            inj.n += 1
+            return x * m
+        torch.nn.functional.dropout = dropout
+        return self
+
+    def __exit__(self, *exc):
+        torch.nn.functional.dropout = self._orig
+
+
+def golden_resnet_small():
+    """resnet_6blocks without dropout and resnet_9blocks with dropout at 64x64, ngf 8, 2 -> 1 channels (models/networks.py:221-311)."""
+    for tag, which, nb, drop in (("6", "resnet_6blocks", 6, False), ("9_dropout", "resnet_9blocks", 9, True)):
+        ngf, in_nc, out_nc, hw = 8, 2, 1, 64
+        sd = O.init_resnet(41, in_nc, out_nc, ngf, nb, drop)
+        g = RN.define_G(in_nc, out_nc, ngf, which, "instance", drop, gpu_ids=[])
+        load_sd(g, sd)
+        x = O.np_uniform(311, (1, in_nc, hw, hw)).requires_grad_(True)
+        r = O.np_normal(312, (1, out_nc, hw, hw))
+        with SeqDropoutInjector(60):
+            y = g.forward(x)
+        loss = (y * r).sum()
+        loss.backward()
+        arrs = {"y": y.detach().numpy(), "dx": x.grad.numpy(), "loss": np.float64(loss.item())}
+        for k, p in g.named_parameters():
+            arrs["grad/" + k] = p.grad.numpy()
+        save(f"resnet_small_{tag}.npz", **arrs)
+
+
 def golden_autoencoder_small():
     in_nc, out_nc, nl, ngf, hw = 2, 1, 3, 8, 128
     sd = O.init_autoencoder(61, in_nc, out_nc, nl, ngf)
@@ -1007,6 +1048,8 @@ def main():
                          O.SegmConfig(use_sigmoid_ss=True, add_background_onehot=True, weights=(2.0, 1.0, 0.5), **small), 0, 2)
     if not only or "fcgan_star" in only:
         golden_fcgan_star_small()
+    if not only or "resnet" in only:
+        golden_resnet_small()
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
     if not only or "dcgan" in only:

@@ -482,6 +482,48 @@ def init_unet(seed: int, num_downs: int, input_nc: int, output_nc: int, ngf: int
     return sd
 
 
+def init_resnet(seed: int, input_nc: int, output_nc: int, ngf: int, n_blocks: int, use_dropout: bool = False):
+    """numpy-seeded state dict with ResnetGenerator's keys / shapes (models/networks.py:232-262, :282-300, norm 'instance'):
+    N(0, 0.02) conv weights (weights_init :13-19), torch-default uniform biases."""
+    sd = OrderedDict()
+    C = 4 * ngf
+    second = 6 if use_dropout else 5
+    convs = [("model.1", False, input_nc, ngf, 7), ("model.4", False, ngf, 2 * ngf, 3), ("model.7", False, 2 * ngf, C, 3)]
+    for i in range(n_blocks):
+        convs += [(f"model.{10 + i}.conv_block.1", False, C, C, 3), (f"model.{10 + i}.conv_block.{second}", False, C, C, 3)]
+    nb = 10 + n_blocks
+    convs += [(f"model.{nb}", True, C, 2 * ngf, 3), (f"model.{nb + 3}", True, 2 * ngf, ngf, 3), (f"model.{nb + 7}", False, ngf, output_nc, 7)]
+    for k, (key, tr, ci, co, ks) in enumerate(convs):
+        sd[key + ".weight"] = np_normal(seed * 1000 + 2 * k, (ci, co, ks, ks) if tr else (co, ci, ks, ks), 0.0, 0.02)
+        b = 1.0 / math.sqrt((co if tr else ci) * ks * ks)      # torch computes fan_in from weight.size(1)
+        sd[key + ".bias"] = np_uniform(seed * 1000 + 2 * k + 1, (co,), -b, b)
+    return sd
+
+
+def resnet_forward(sd, x, n_blocks: int, use_dropout: bool = False, mask_seed: int = 0, tanh: bool = True):
+    """ResnetGenerator.forward (models/networks.py:221-268) with ResnetBlock (:271-311), padding_type 'reflect', InstanceNorm:
+    the i-th block's Dropout(0.5) mask is dropout_mask_np(mask_seed + i, shape)."""
+    inorm = lambda t: F.instance_norm(t, eps=1e-5)      # noqa: E731
+    rpad = lambda t, p: F.pad(t, (p, p, p, p), mode="reflect")      # noqa: E731
+    h = F.relu(inorm(F.conv2d(rpad(x, 3), sd["model.1.weight"], sd["model.1.bias"])))
+    for key in ("model.4", "model.7"):
+        h = F.relu(inorm(F.conv2d(h, sd[key + ".weight"], sd[key + ".bias"], stride=2, padding=1)))
+    second = 6 if use_dropout else 5
+    for i in range(n_blocks):
+        p = f"model.{10 + i}.conv_block."
+        t = F.relu(inorm(F.conv2d(rpad(h, 1), sd[p + "1.weight"], sd[p + "1.bias"])))
+        if use_dropout:
+            t = t * dropout_mask_np(mask_seed + i, t.shape)
+        h = h + inorm(F.conv2d(rpad(t, 1), sd[p + f"{second}.weight"], sd[p + f"{second}.bias"]))
+    nb = 10 + n_blocks
+    for key in (f"model.{nb}", f"model.{nb + 3}"):
+        h = F.relu(inorm(F.conv_transpose2d(h, sd[key + ".weight"], sd[key + ".bias"], stride=2, padding=1, output_padding=1)))
+    y = F.conv2d(rpad(h, 3), sd[f"model.{nb + 7}.weight"], sd[f"model.{nb + 7}.bias"])
+    # the reference applies Tanh TWICE without --use_residual: once as the last module of self.model (:261-262) and again in
+    # forward() (:268: `nn.Tanh()(y)`)
+    return torch.tanh(torch.tanh(y)) if tanh else y
+
+
 def dropout_mask_np(seed: int, shape) -> torch.Tensor:
     """Deterministic Dropout(0.5) keep-mask (0 or 2), keyed on the tensor shape (make_golden.py injects
     the same masks into the reference)."""

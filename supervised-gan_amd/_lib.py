@@ -92,6 +92,8 @@ SIGNATURES = {
     "sgan_avgpool_pyramid_bwd": [_P, _P, _I, _I, _P, _I, _I, _P],
     "sgan_norm_apply_fwd": [_P, _I, C.POINTER(NormDesc), _P, _P, _F, _P, _I, _I, _I, _P],
     "sgan_norm_apply_bwd_sums": [_P, _I, _P, _P, _I, C.POINTER(NormDesc), _P, _I, _I, _P],
+    "sgan_pad_reflect_fwd": [_P, _I, _I, _I, _I, C.POINTER(NormDesc), _P, _I, _P, _I, _P],
+    "sgan_pad_reflect_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, C.POINTER(NormDesc), _P, _P, _I, _P, _I, _P],
     "sgan_dropout_mask": [_P, _L, _F, C.c_uint64, _P, _I, _P],
     "sgan_rng_advance": [_P, C.c_uint64, _P],
     "sgan_l1w_fwd": [_P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _F, _P, _P, _I, _P, C.c_int64, _P],

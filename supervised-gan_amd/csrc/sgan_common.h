@@ -44,7 +44,7 @@ void sg_prof_end(hipStream_t st, const char* name);
 // ------------------------------------------------------------------------------------------
 #define SGAN_F16_WEIGHT_SHIFT 10        // forward (fp16-plane) weight copy holds w * 2^10: |w| down to 2^-24 / 2^10 resolved, |w| < 64 representable
 #define SGAN_BF16X3_MIN_PIXELS 256   // smaller maps always run the exact-fp32 MFMA kernels (see sg_igemm3_eligible)
-#define SGAN_MAX_TAPS 16
+#define SGAN_MAX_TAPS 49              // k <= 7 (the resnet generators' k7 layers, models/networks.py:234,260)
 #define SGAN_MAX_PHASES 4
 
 struct SgTap {

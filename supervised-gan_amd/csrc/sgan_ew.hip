@@ -280,6 +280,143 @@ extern "C" int sgan_norm_apply_bwd_sums(float* dt, int32_t dt_ld, const float* m
 }
 
 // ------------------------------------------------------------------------------------------
+// nn.ReflectionPad2d in front of a conv (resnet generators, models/networks.py:232,258,282-300): the padded tensor is
+// materialised together with everything the reference applies before the padding --
+//     out[py][px][c] = mask * act(norm(x[refl(py - pad)][refl(px - pad)][c])),    refl(i) = |i| for i < 0, 2 (n - 1) - i for i >= n
+// (pad = 0: plain materialisation of act(norm(x)), e.g. the first resnet block's input).  The conv that follows runs with pad 0
+// and no prologue.  Backward: the gradient of the padded tensor is folded back (every interior pixel collects the <= 4 padded
+// positions that mirror it), multiplied by mask and act'(norm(x)), and the two norm-backward sums are accumulated (as the
+// backward-data epilogue of the conv kernels does); sgan_norm_bwd_apply finishes.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sg_refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+__global__ __launch_bounds__(256) void sg_pad_reflect_fwd_kernel(const float* x, int x_ld, int H, int W, int C, SgNorm xn, const float* mask,
+                                                                 int pad, float* out, int out_ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cSc = reinterpret_cast<float*>(smem);
+    float* cSh = cSc + C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sc = 1.f, sh = 0.f;
+        if (xn.stats) {
+            float mean, rstd;
+            sg_mean_rstd(xn, C, c, mean, rstd);
+            const float gm = xn.gamma ? xn.gamma[c] : 1.f, bt = xn.beta ? xn.beta[c] : 0.f;
+            sc = gm * rstd;
+            sh = bt - mean * sc;
+        }
+        cSc[c] = sc;
+        cSh[c] = sh;
+    }
+    __syncthreads();
+    const int CQ = C >> 2, Wp = W + 2 * pad, Hp = H + 2 * pad;
+    const int64_t total = (int64_t)Hp * Wp * CQ;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % CQ) * 4;
+        const int64_t pp = e / CQ;
+        const int px = (int)(pp % Wp), py = (int)(pp / Wp);
+        const int64_t src = (int64_t)sg_refl(py - pad, H) * W + sg_refl(px - pad, W);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + src * x_ld + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sg_act(v[j] * cSc[c + j] + cSh[c + j], xn.act, xn.slope);
+        if (mask) v *= *reinterpret_cast<const f32x4*>(mask + src * C + c);
+        *reinterpret_cast<f32x4*>(out + pp * out_ld + c) = v;
+    }
+}
+
+extern "C" int sgan_pad_reflect_fwd(const float* x, int32_t x_ld, int32_t H, int32_t W, int32_t C, const sgan_norm_desc* x_norm,
+                                    const float* mask, int32_t pad, float* out, int32_t out_ld, void* stream) {
+    SGAN_CHECK(x && out && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (x_ld & 3) == 0 && (out_ld & 3) == 0 && x_ld >= C && out_ld >= C,
+               "bad argument");
+    SGAN_CHECK(pad >= 0 && pad < H && pad < W, "reflection padding must be smaller than the image");
+    const int64_t total = (int64_t)(H + 2 * pad) * (W + 2 * pad) * (C >> 2);
+    int blocks = ew_cdiv(total, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sg_pad_reflect_fwd_kernel, dim3(blocks), dim3(256), (size_t)2 * C * 4, (hipStream_t)stream, x, x_ld, H, W, C,
+                       sg_norm_from(x_norm), mask, pad, out, out_ld);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+__global__ __launch_bounds__(256) void sg_pad_reflect_bwd_kernel(const float* dout, int dout_ld, int H, int W, int C, int pad, const float* x,
+                                                                 int x_ld, SgNorm xn, const float* mask, float* din, int din_ld,
+                                                                 double* sums, int sums_sq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cMean = reinterpret_cast<float*>(smem);
+    float* cRstd = cMean + C;
+    float* cG = cRstd + C;
+    float* cB = cG + C;
+    double* red = reinterpret_cast<double*>(cB + C);   // [2C]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mean = 0.f, rstd = 1.f;
+        if (xn.stats) sg_mean_rstd(xn, C, c, mean, rstd);
+        cMean[c] = mean;
+        cRstd[c] = rstd;
+        cG[c] = (xn.stats && xn.gamma) ? xn.gamma[c] : 1.f;
+        cB[c] = (xn.stats && xn.beta) ? xn.beta[c] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.0;
+    __syncthreads();
+    const int CQ = C >> 2, Wp = W + 2 * pad;
+    const int64_t total = (int64_t)H * W * CQ;
+    const bool has_x = x != nullptr;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % CQ) * 4;
+        const int64_t pix = e / CQ;
+        const int xx = (int)(pix % W), yy = (int)(pix / W);
+        // padded rows / columns that mirror this pixel: itself, and one reflection at most on each side (pad < H / 2 checked on the host)
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = yy + pad;
+        if (yy >= 1 && yy <= pad) ys[ny++] = pad - yy;
+        if (yy <= H - 2 && yy >= H - 1 - pad) ys[ny++] = pad + 2 * (H - 1) - yy;
+        xs[nx++] = xx + pad;
+        if (xx >= 1 && xx <= pad) xs[nx++] = pad - xx;
+        if (xx <= W - 2 && xx >= W - 1 - pad) xs[nx++] = pad + 2 * (W - 1) - xx;
+        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) d += *reinterpret_cast<const f32x4*>(dout + ((int64_t)ys[a] * Wp + xs[b]) * dout_ld + c);
+        if (mask) d *= *reinterpret_cast<const f32x4*>(mask + pix * C + c);
+        if (has_x) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + pix * x_ld + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xhat = (xv[j] - cMean[c + j]) * cRstd[c + j];
+                const float y = xn.stats ? cG[c + j] * xhat + cB[c + j] : xv[j];
+                d[j] *= sg_act_grad(y, xn.act, xn.slope);
+                if (sums) {
+                    atomicAdd(&red[c + j], (double)d[j]);
+                    atomicAdd(&red[C + c + j], (double)(d[j] * xhat));
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(din + pix * din_ld + c) = d;
+    }
+    if (sums) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            atomicAdd(&sums[c], red[c]);
+            atomicAdd(&sums[(sums_sq ? sums_sq : C) + c], red[C + c]);
+        }
+    }
+}
+
+extern "C" int sgan_pad_reflect_bwd(const float* dout, int32_t dout_ld, int32_t H, int32_t W, int32_t C, int32_t pad, const float* x,
+                                    int32_t x_ld, const sgan_norm_desc* x_norm, const float* mask, float* din, int32_t din_ld,
+                                    double* bwd_sums, int32_t bwd_sums_sq_stride, void* stream) {
+    SGAN_CHECK(dout && din && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (dout_ld & 3) == 0 && (din_ld & 3) == 0 && dout_ld >= C && din_ld >= C,
+               "bad argument");
+    SGAN_CHECK(pad >= 0 && 2 * pad < H && 2 * pad < W, "reflection padding must be smaller than half the image");
+    SGAN_CHECK(!(bwd_sums && !x), "bwd_sums needs x");
+    SGAN_CHECK(!x || ((x_ld & 3) == 0 && x_ld >= C), "bad x_ld");
+    const int64_t total = (int64_t)H * W * (C >> 2);
+    int blocks = ew_cdiv(total, 256 * 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sg_pad_reflect_bwd_kernel, dim3(blocks), dim3(256), (size_t)4 * C * 4 + (size_t)2 * C * 8, (hipStream_t)stream, dout,
+                       dout_ld, H, W, C, pad, x, x_ld, sg_norm_from(x ? x_norm : nullptr), mask, din, din_ld, bwd_sums, bwd_sums_sq_stride);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // weighted L1 / BCE on rescaled maps: image-sized losses.  One pixel per thread over up to SG_IMGLOSS_BLOCKS workgroups
 // (a single workgroup walking 512x512 pixels took 400 us); block partial sums (fp64) go to the caller's scratch and a
 // one-wave kernel finishes the mean -- a kernel boundary instead of atomics or a zero-initialised accumulator.

@@ -46,7 +46,8 @@ struct SgIgemmParams {   // the kernel argument (~2.3 KB)
     int32_t planes_f16;   // split kernels: operand planes are fp16 (forward) instead of bf16 (backward-data)
     float pro_slope, xn_slope, pro_eps, xn_eps;
     int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
-    SgTap taps[SGAN_MAX_PHASES][SGAN_MAX_TAPS];
+    SgTap taps[SGAN_MAX_TAPS];          // every phase's taps back to back (k * k in all)
+    int32_t tap0[SGAN_MAX_PHASES];     // first tap of a phase
     float* slab;          // [ksplit][Hout*Wout][N] fp32 partials (caller workspace)
     int64_t slab_stride;  // Hout*Wout*N
     SgProb q[SG_MAX_PROB];

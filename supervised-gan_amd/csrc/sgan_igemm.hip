@@ -92,8 +92,9 @@ __global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams 
     // ---- one-time setup: tap table, prologue scale/shift, reduction scratch ----
     if (threadIdx.x < SGAN_MAX_TAPS) {
         const bool v = tid < G.ntaps[phz];
-        const int dy = v ? (int)G.taps[phz][tid].dy : 0, dx = v ? (int)G.taps[phz][tid].dx : 0;
-        ttab[tid] = make_int4(dy, dx, (dy * P.Win + dx) * P.in_ld, v ? G.taps[phz][tid].w_off : 0);
+        const SgTap tp = G.taps[v ? G.tap0[phz] + tid : 0];
+        const int dy = v ? (int)tp.dy : 0, dx = v ? (int)tp.dx : 0;
+        ttab[tid] = make_int4(dy, dx, (dy * P.Win + dx) * P.in_ld, v ? tp.w_off : 0);
     }
     for (int i = threadIdx.x; i < 2 * BN; i += 256 * KW) red[i] = 0.0;
     {   // always present (identity when there is no prologue) so the main loop is branch-free
@@ -497,9 +498,10 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
     const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
     if (tid < SGAN_MAX_TAPS) {
         const bool v = tid < ntaps;
-        tdy[tid] = v ? (int)G.taps[phz][tid].dy : 0;
-        tdx[tid] = v ? (int)G.taps[phz][tid].dx : 0;
-        two[tid] = v ? G.taps[phz][tid].w_off : 0;
+        const SgTap tp = G.taps[v ? G.tap0[phz] + tid : 0];
+        tdy[tid] = v ? (int)tp.dy : 0;
+        tdx[tid] = v ? (int)tp.dx : 0;
+        two[tid] = v ? tp.w_off : 0;
     }
     if (has_pro) {
         for (int c = tid; c < Ck; c += 256) {
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmPara
 #pragma unroll
     for (int j = 0; j < 4; ++j) {      // column n = j*16 + fr = (phase j, tap fr >> 2, co fr & 3)
         const int t = fr >> 2, co = fr & 3;
-        b_off[j] = (G.taps[j][t].w_off + co * P.w_ns + fq * 4) << 2;
+        b_off[j] = (G.taps[G.tap0[j] + t].w_off + co * P.w_ns + fq * 4) << 2;
     }
     f32x4 acc[4][4];
 #pragma unroll
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmPara
         f32x4 v = bias;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int my = py + G.taps[ph][t].dy - (y0 - 1), mx = px + G.taps[ph][t].dx - (x0 - 1);
+            const int my = py + G.taps[G.tap0[ph] + t].dy - (y0 - 1), mx = px + G.taps[G.tap0[ph] + t].dx - (x0 - 1);
             v += *reinterpret_cast<const f32x4*>(Zs + (my * SG_SC_TW + mx) * SG_SC_LDZ + ph * 16 + t * 4);
         }
         if (P.out_act == SGAN_ACT_TANH) {
@@ -777,7 +779,7 @@ static bool sg_use_scatter4(const SgIgemmParams& P) {
     for (int ph = 0; ph < 4; ++ph) {
         if (P.ntaps[ph] != 4 || P.oa[ph] != (ph >> 1) || P.ob[ph] != (ph & 1)) return false;
         for (int t = 0; t < 4; ++t)
-            if (P.taps[ph][t].dy < -1 || P.taps[ph][t].dy > 1 || P.taps[ph][t].dx < -1 || P.taps[ph][t].dx > 1) return false;
+            if (P.taps[P.tap0[ph] + t].dy < -1 || P.taps[P.tap0[ph] + t].dy > 1 || P.taps[P.tap0[ph] + t].dx < -1 || P.taps[P.tap0[ph] + t].dx > 1) return false;
     }
     return true;
 }
@@ -898,7 +900,10 @@ int sg_build_phases(const sgan_conv_desc* d, bool dgrad, SgPhase* ph, int* nphas
         if (d->Hout != (d->Hin + 2 * p - k) / s + 1 || d->Wout != (d->Win + 2 * p - k) / s + 1)
             return sgan_fail(SGAN_ERR_INVALID, "conv geometry mismatch");
     } else if (d->kind == SGAN_CONVT) {
-        if (d->Hout != (d->Hin - 1) * s - 2 * p + k || d->Wout != (d->Win - 1) * s - 2 * p + k)
+        // output_padding (nn.ConvTranspose2d(k3, s2, p1, output_padding=1) of the resnet generators, models/networks.py:250-252): up to
+        // s - 1 extra rows / columns; they are ordinary outputs of the taps that still reach an input pixel
+        const int h0 = (d->Hin - 1) * s - 2 * p + k, w0 = (d->Win - 1) * s - 2 * p + k;
+        if (d->Hout < h0 || d->Hout >= h0 + s || d->Wout < w0 || d->Wout >= w0 + s)
             return sgan_fail(SGAN_ERR_INVALID, "convT geometry mismatch");
     } else {
         return sgan_fail(SGAN_ERR_INVALID, "bad conv kind %d", d->kind);
@@ -1192,7 +1197,8 @@ static int sg_group_geometry(SgIgemmParams& P, const sgan_conv_desc* const* desc
             P.nphase = nphase; P.is = is; P.os = os;
             for (int i = 0; i < nphase; ++i) {
                 P.oa[i] = ph[i].oa; P.ob[i] = ph[i].ob; P.ntaps[i] = ph[i].ntaps; P.ktot[i] = ph[i].ktot;
-                for (int t = 0; t < ph[i].ntaps; ++t) P.taps[i][t] = ph[i].taps[t];
+                P.tap0[i] = i == 0 ? 0 : P.tap0[i - 1] + ph[i - 1].ntaps;
+                for (int t = 0; t < ph[i].ntaps; ++t) P.taps[P.tap0[i] + t] = ph[i].taps[t];
             }
         }
         for (int i = 0; i < nphase; ++i) { P.q[g].Hp[i] = ph[i].Hp; P.q[g].Wp[i] = ph[i].Wp; }

@@ -114,8 +114,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     // ---- one-time setup: tap table, prologue scale/shift, reduction scratch ----
     if (tid < SGAN_MAX_TAPS) {
         const bool v = tid < G.ntaps[phz];
-        const int dy = v ? (int)G.taps[phz][tid].dy : 0, dx = v ? (int)G.taps[phz][tid].dx : 0;
-        ttab[tid] = make_int4(dy, dx, (dy * P.Win + dx) * P.in_ld, v ? G.taps[phz][tid].w_off : 0);
+        const SgTap tp = G.taps[v ? G.tap0[phz] + tid : 0];
+        const int dy = v ? (int)tp.dy : 0, dx = v ? (int)tp.dx : 0;
+        ttab[tid] = make_int4(dy, dx, (dy * P.Win + dx) * P.in_ld, v ? tp.w_off : 0);
     }
     for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.0;
     if constexpr (PRO) {

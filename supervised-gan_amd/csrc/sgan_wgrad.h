@@ -28,7 +28,8 @@ struct SgWgradParams {   // kernel argument: common layer description + up to 8 
     int32_t pro_act;
     float pro_slope, pro_eps;
     int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
-    SgTap taps[SGAN_MAX_PHASES][SGAN_MAX_TAPS];
+    SgTap taps[SGAN_MAX_TAPS];          // every phase's taps back to back (k * k in all)
+    int32_t tap0[SGAN_MAX_PHASES];     // first tap of a phase
     SgWgradProb q[SGW_MAX_PROB];
 };
 

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     const bool a_kok = a_kcol < ktot;
     const int a_tap = a_kok ? a_kcol / Cin : 0;
     const int a_c = a_kcol - a_tap * Cin;
-    const int a_dy = G.taps[phz][a_tap].dy, a_dx = G.taps[phz][a_tap].dx;
+    const int a_dy = G.taps[G.tap0[phz] + a_tap].dy, a_dx = G.taps[G.tap0[phz] + a_tap].dx;
     // D staging
     const int d_c4 = tid % DQ, d_row0 = tid / DQ;
     constexpr int D_ROWS_PER_IT = 256 / DQ;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
         const int kcol = kc0 + wk * WTK + j * 16 + fr;
         if (kcol >= ktot) continue;
         const int tap = kcol / Cin, ci = kcol - tap * Cin;
-        float* base = P.dw + G.taps[phz][tap].w_off + ci;
+        float* base = P.dw + G.taps[G.tap0[phz] + tap].w_off + ci;
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
 #pragma unroll
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
 
     // lane constants: column group = tap fr, rows r0 + fr*MB + i
     const bool kok = fr < G.ntaps[phz];
-    const int tdy = kok ? (int)G.taps[phz][fr].dy : 0, tdx = kok ? (int)G.taps[phz][fr].dx : 0;
+    const int tdy = kok ? (int)G.taps[G.tap0[phz] + fr].dy : 0, tdx = kok ? (int)G.taps[G.tap0[phz] + fr].dx : 0;
     const int row_l = r0 + fr * MB;
     const bool rok = row_l < rows_total;
     const int gs = G.is, os = G.os, oa = G.oa[phz], ob = G.ob[phz];
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
             const int rl = e / COLS, kl = e - rl * COLS, t = kl >> 2, c4 = kl & 3;
             const int row = r0 + rl;
             if (row < rows_total && t < G.ntaps[phz] && c4 < (SWAP ? G.Cout : G.Cin))
-                atomicAdd(Q.dw + G.taps[phz][t].w_off + (SWAP ? (int64_t)c4 * G.w_ns + row : (int64_t)row * G.w_ns + c4), v);
+                atomicAdd(Q.dw + G.taps[G.tap0[phz] + t].w_off + (SWAP ? (int64_t)c4 * G.w_ns + row : (int64_t)row * G.w_ns + c4), v);
         }
     }
     if (tid < ROWS) {
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_reduce_kernel(const SgWgrad
         const int rl = e / COLS, kl = e - rl * COLS, tp = kl >> 2, c4 = kl & 3;
         const int row = rb * ROWS + rl;
         if (row < rows_total && tp < G.ntaps[phz] && c4 < (SWAP ? G.Cout : G.Cin))
-            atomicAdd(Q.dw + G.taps[phz][tp].w_off + (SWAP ? (int64_t)c4 * G.w_ns + row : (int64_t)row * G.w_ns + c4), sum);
+            atomicAdd(Q.dw + G.taps[G.tap0[phz] + tp].w_off + (SWAP ? (int64_t)c4 * G.w_ns + row : (int64_t)row * G.w_ns + c4), sum);
     } else if (!SWAP && Q.dbias && rb * ROWS + (e - ROWS * COLS) < rows_total) {
         atomicAdd(Q.dbias + rb * ROWS + (e - ROWS * COLS), sum);
     }
@@ -703,6 +703,7 @@ static void sg_thin_swap_geometry(SgWgradParams& P, const sgan_conv_desc* d0, co
     const int k = d0->k, p = d0->pad;
     const bool tr = d0->kind == SGAN_CONVT;
     P.nphase = 1;
+    P.tap0[0] = 0;
     P.is = tr ? d0->stride : 1;
     P.os = 1;
     P.oa[0] = P.ob[0] = 0;
@@ -710,7 +711,7 @@ static void sg_thin_swap_geometry(SgWgradParams& P, const sgan_conv_desc* d0, co
     P.ktot[0] = 64;
     for (int ky = 0; ky < k; ++ky)
         for (int kx = 0; kx < k; ++kx) {
-            SgTap& t = P.taps[0][ky * k + kx];
+            SgTap& t = P.taps[ky * k + kx];
             t.dy = (int16_t)(tr ? ky - p : p - ky);
             t.dx = (int16_t)(tr ? kx - p : p - kx);
             t.w_off = (ky * k + kx) * d0->Cout * d0->Cin;
@@ -750,7 +751,8 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
             P.nphase = nphase; P.is = is; P.os = os;
             for (int i = 0; i < nphase; ++i) {
                 P.oa[i] = ph[i].oa; P.ob[i] = ph[i].ob; P.ntaps[i] = ph[i].ntaps; P.ktot[i] = ph[i].ktot;
-                for (int t = 0; t < ph[i].ntaps; ++t) P.taps[i][t] = ph[i].taps[t];
+                P.tap0[i] = i == 0 ? 0 : P.tap0[i - 1] + ph[i - 1].ntaps;
+                for (int t = 0; t < ph[i].ntaps; ++t) P.taps[P.tap0[i] + t] = ph[i].taps[t];
             }
         }
         SgWgradProb& Q = P.q[g];

@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
         a_kok[it] = (a_blk[it] < BKC / 32) && kcol < ktot;
         const int tap = a_kok[it] ? kcol / Cin : 0;
         a_c[it] = a_kok[it] ? kcol - tap * Cin : 0;
-        a_dy[it] = G.taps[phz][tap].dy;
-        a_dx[it] = G.taps[phz][tap].dx;
+        a_dy[it] = G.taps[G.tap0[phz] + tap].dy;
+        a_dx[it] = G.taps[G.tap0[phz] + tap].dx;
         a_iy[it] = a_py * P.is + a_dy[it];
         a_ix[it] = a_px * P.is + a_dx[it];
         a_lin[it] = (a_iy[it] * P.Win + a_ix[it]) * P.in_ld + a_c[it];
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
         const int kcol = kc0 + wk * WTK + j * 32 + fr;
         if (kcol >= ktot) continue;
         const int tap = kcol / Cin, ci = kcol - tap * Cin;
-        float* base = P.dw + G.taps[phz][tap].w_off + ci;
+        float* base = P.dw + G.taps[G.tap0[phz] + tap].w_off + ci;
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
 #pragma unroll

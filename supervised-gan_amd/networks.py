@@ -1079,6 +1079,224 @@ class AutoEncoder(ChainNet):
         return y
 
 
+class ResnetGenerator(ChainNet):
+    """ResnetGenerator + ResnetBlock (models/networks.py:221-311; `resnet_6blocks` / `resnet_9blocks`, padding_type 'reflect'):
+        ReflectionPad(3) Conv(k7) IN ReLU -> 2 x [Conv(k3,s2,p1) IN ReLU] -> n x ResnetBlock -> 2 x [ConvT(k3,s2,p1,op1) IN ReLU]
+        -> ReflectionPad(3) Conv(k7) -> Tanh,     ResnetBlock: x + [ReflectionPad(1) Conv(k3) IN ReLU (Dropout) ReflectionPad(1) Conv(k3) IN](x)
+
+    On the MI355X path the reflection-padded tensors are materialised by one gather pass each (`sgan_pad_reflect_fwd`, which also
+    applies the InstanceNorm + ReLU (+ dropout mask) the reference runs before the padding); the convs behind them run with pad 0
+    and no prologue.  The stride-2 convs and the second ConvT normalise on load like every other net.  A block's output
+    x + IN(conv) is one `norm_apply_fwd` pass (the residual rides in its additive input).  49-tap k7 layers: SGAN_MAX_TAPS."""
+    final_act = ACT_TANH
+
+    def __init__(self, input_nc, output_nc, ngf=64, norm="instance", use_dropout=False, n_blocks=6, use_residual=False, gpu_ids=[]):
+        if norm != "instance":
+            raise NotImplementedError("ResnetGenerator on the MI355X path implements --norm instance")
+        if use_residual:
+            raise NotImplementedError("ResnetGenerator --use_residual (tanh(x + y)) is not on the MI355X path")
+        self.n_blocks, self.use_dropout, self.input_nc, self.output_nc = int(n_blocks), bool(use_dropout), input_nc, output_nc
+        C = 4 * ngf
+        self.c0 = LayerSpec("1", CONV, 7, 1, 0, input_nc, ngf, True, "in", ACT_RELU)
+        self.d1 = LayerSpec("4", CONV, 3, 2, 1, ngf, 2 * ngf, True, "in", ACT_RELU)
+        self.d2 = LayerSpec("7", CONV, 3, 2, 1, 2 * ngf, C, True, "in", ACT_RELU)
+        second = 6 if use_dropout else 5
+        self.blocks = [(LayerSpec("%d.conv_block.1" % (10 + i), CONV, 3, 1, 0, C, C, True, "in", ACT_RELU),
+                        LayerSpec("%d.conv_block.%d" % (10 + i, second), CONV, 3, 1, 0, C, C, True, "in", ACT_NONE)) for i in range(n_blocks)]
+        nb = 10 + n_blocks
+        self.u1 = LayerSpec(str(nb), CONVT, 3, 2, 1, C, 2 * ngf, True, "in", ACT_RELU)
+        self.u2 = LayerSpec(str(nb + 3), CONVT, 3, 2, 1, 2 * ngf, ngf, True, "in", ACT_RELU)
+        self.cl = LayerSpec(str(nb + 7), CONV, 7, 1, 0, ngf, output_nc, True, None, ACT_NONE)
+        super().__init__([self.c0, self.d1, self.d2] + [l for ab in self.blocks for l in ab] + [self.u1, self.u2, self.cl])
+        self.gpu_ids = gpu_ids
+        self._rng_seed, self._rng_offset = 0, None
+
+    # ---- module API ----------------------------------------------------------------------------
+    def _prepare_input(self, x, memo=None):
+        return {"chain_in": ops.as_nhwc(x)}
+
+    def _finish_input_grad(self, xb, dchain):
+        return ops.logical_view(dchain, self.input_nc)
+
+    def forward(self, x, noise=None, activation=None):
+        # the reference's forward() applies nn.Tanh() to the output of self.model, which (without --use_residual) already ends in
+        # nn.Tanh() (models/networks.py:261-262,268): tanh(tanh(conv)).  The first is the conv epilogue, the second one elementwise op
+        # on the output image.
+        return torch.tanh(_ChainFn.apply(self, x, *list(self.model.parameters())))
+
+    def _wrap_output(self, y):
+        return y
+
+    # ---- geometry ------------------------------------------------------------------------------
+    def _desc(self, L, hin, win, hout, wout):
+        key = (L.key, hin, win)
+        if key not in self._geom_cache:
+            self._geom_cache[key] = ops.conv_desc(L.kind, L.k, L.stride, L.pad, hin, win, L.cin_s, hout, wout, L.cout_s, L.cin, L.cout)
+        return self._geom_cache[key]
+
+    def _in(self, st, count, act):
+        return ops.norm_desc(st, None, None, count, IN_EPS, act, 0.0)
+
+    # ---- programs ------------------------------------------------------------------------------
+    def run_forward(self, x, update_running=True):
+        ops.require_gpu(x, type(self).__name__)
+        if self._flat.device != x.device:
+            raise SganError(f"module parameters are on {self._flat.device}, input on {x.device}")
+        H, W, Cs = x.shape
+        assert Cs == self.c0.cin_s and H % 4 == 0 and W % 4 == 0, (x.shape, "resnet generators need H, W divisible by 4")
+        dev = x.device
+        final_act = self._take_call_act()
+        E = lambda h, w, c: torch.empty((h, w, c), dtype=torch.float32, device=dev)      # noqa: E731
+        normed = [self.c0, self.d1, self.d2] + [l for ab in self.blocks for l in ab] + [self.u1, self.u2]
+        n_stats = sum(2 * L.cout_s for L in normed)
+        arena = torch.zeros(2 * n_stats, dtype=torch.float64, device=dev)      # forward statistics | backward sums
+        st, o = {}, 0
+        for L in normed:
+            st[L.key] = arena[o: o + 2 * L.cout_s]
+            o += 2 * L.cout_s
+        h2, w2, h4, w4 = H // 2, W // 2, H // 4, W // 4
+        ngf, C = self.c0.cout_s, self.d2.cout_s
+        S = dict(final_act=final_act, x=x, st=st, bwd=_BwdArena(arena[n_stats:]), n_stats=n_stats)
+        xp = E(H + 6, W + 6, Cs)
+        ops.pad_reflect_fwd(x, None, 3, xp)
+        c0 = E(H, W, ngf)
+        ops.conv_fwd(self._desc(self.c0, H + 6, W + 6, H, W), xp, None, *self._wb(self.c0), c0, ACT_NONE, st[self.c0.key])
+        d1 = E(h2, w2, self.d1.cout_s)
+        ops.conv_fwd(self._desc(self.d1, H, W, h2, w2), c0, self._in(st[self.c0.key], H * W, ACT_RELU), *self._wb(self.d1), d1, ACT_NONE, st[self.d1.key])
+        d2 = E(h4, w4, C)
+        ops.conv_fwd(self._desc(self.d2, h2, w2, h4, w4), d1, self._in(st[self.d1.key], h2 * w2, ACT_RELU), *self._wb(self.d2), d2, ACT_NONE, st[self.d2.key])
+        b = E(h4, w4, C)
+        ops.pad_reflect_fwd(d2, self._in(st[self.d2.key], h4 * w4, ACT_RELU), 0, b)
+        if self.use_dropout and (self._rng_offset is None or self._rng_offset.device != dev):
+            self._rng_offset = torch.zeros(1, dtype=torch.int64, device=dev)
+        d3 = self._desc(self.blocks[0][0], h4 + 2, w4 + 2, h4, w4) if self.blocks else None
+        blk = []
+        for i, (A, B) in enumerate(self.blocks):
+            p1 = E(h4 + 2, w4 + 2, C)
+            ops.pad_reflect_fwd(b, None, 1, p1)
+            a = E(h4, w4, C)
+            ops.conv_fwd(d3, p1, None, *self._wb(A), a, ACT_NONE, st[A.key])
+            mask = None
+            if self.use_dropout:
+                mask = E(h4, w4, C)
+                src = getattr(self, "mask_source", None)        # tests inject the reference's masks
+                if src is not None:
+                    mask.copy_(src(i, (h4, w4, C)))
+                else:
+                    ops.dropout_mask(mask, 0.5, self._rng_seed + i, self._rng_offset, advance=False)
+            p2 = E(h4 + 2, w4 + 2, C)
+            ops.pad_reflect_fwd(a, self._in(st[A.key], h4 * w4, ACT_RELU), 1, p2, mask)
+            c = E(h4, w4, C)
+            ops.conv_fwd(d3, p2, None, *self._wb(B), c, ACT_NONE, st[B.key])
+            bn = E(h4, w4, C)
+            ops.norm_apply_fwd(c, self._in(st[B.key], h4 * w4, ACT_NONE), bn, None, b, 1.0)      # x + IN(conv)
+            blk.append((p1, a, mask, p2, c))
+            b = bn
+        if self.use_dropout and getattr(self, "mask_source", None) is None and self.blocks:
+            ops.rng_advance(self._rng_offset, (h4 * w4 * C + 3) // 4)
+        u1 = E(h2, w2, self.u1.cout_s)
+        ops.conv_fwd(self._desc(self.u1, h4, w4, h2, w2), b, None, *self._wb(self.u1), u1, ACT_NONE, st[self.u1.key])
+        u2 = E(H, W, ngf)
+        ops.conv_fwd(self._desc(self.u2, h2, w2, H, W), u1, self._in(st[self.u1.key], h2 * w2, ACT_RELU), *self._wb(self.u2), u2, ACT_NONE, st[self.u2.key])
+        pl = E(H + 6, W + 6, ngf)
+        ops.pad_reflect_fwd(u2, self._in(st[self.u2.key], H * W, ACT_RELU), 3, pl)
+        y = E(H, W, self.cl.cout_s)
+        ops.conv_fwd(self._desc(self.cl, H + 6, W + 6, H, W), pl, None, *self._wb(self.cl), y, final_act, None)
+        S.update(xp=xp, c0=c0, d1=d1, d2=d2, blk=blk, b_last=b, u1=u1, u2=u2, pl=pl, y=y)
+        return [y], S
+
+    def run_backward(self, x, outs, S, dout, need_dx, want_wgrad):
+        H, W, Cs = x.shape
+        dev = x.device
+        h2, w2, h4, w4 = H // 2, W // 2, H // 4, W // 4
+        ngf, C = self.c0.cout_s, self.d2.cout_s
+        st = S["st"]
+        E = lambda h, w, c: torch.empty((h, w, c), dtype=torch.float32, device=dev)      # noqa: E731
+        if want_wgrad:
+            self._ensure_grads()
+        arena = S["bwd"].take(S["n_stats"])
+        sums, o = {}, 0
+        for key, t in st.items():
+            sums[key] = arena[o: o + t.numel()]
+            o += t.numel()
+        if S["final_act"] == ACT_TANH:
+            dy = torch.empty_like(S["y"])
+            ops.tanh_bwd(dout.contiguous(), S["y"], dy)
+        else:
+            dy = dout.contiguous()
+
+        def wgrad(L, desc, src, nrm, d):
+            if want_wgrad:
+                ops.conv_wgrad(desc, src, nrm, d, *self._gwb(L))
+
+        def norm_bwd(d, xraw, L, count, act):
+            ops.norm_bwd_apply(d, xraw, self._in(st[L.key], count, act), sums[L.key])
+
+        # last conv (k7 over the padded, activated u2)
+        dcl = self._desc(self.cl, H + 6, W + 6, H, W)
+        wgrad(self.cl, dcl, S["pl"], None, dy)
+        dpl = E(H + 6, W + 6, ngf)
+        ops.conv_dgrad(dcl, dy, self._wt(self.cl), dpl, None, None, None, w_transposed=True)
+        du2 = E(H, W, ngf)
+        ops.pad_reflect_bwd(dpl, 3, du2, S["u2"], self._in(st[self.u2.key], H * W, ACT_RELU), None, sums[self.u2.key])
+        norm_bwd(du2, S["u2"], self.u2, H * W, ACT_RELU)
+        # the two transposed convs
+        n_u1 = self._in(st[self.u1.key], h2 * w2, ACT_RELU)
+        du = self._desc(self.u2, h2, w2, H, W)
+        wgrad(self.u2, du, S["u1"], n_u1, du2)
+        du1 = E(h2, w2, self.u1.cout_s)
+        ops.conv_dgrad(du, du2, self._wt(self.u2), du1, S["u1"], n_u1, sums[self.u1.key], w_transposed=True)
+        norm_bwd(du1, S["u1"], self.u1, h2 * w2, ACT_RELU)
+        du = self._desc(self.u1, h4, w4, h2, w2)
+        wgrad(self.u1, du, S["b_last"], None, du1)
+        db = E(h4, w4, C)
+        ops.conv_dgrad(du, du1, self._wt(self.u1), db, None, None, None, w_transposed=True)
+        # residual blocks, last to first: b_out = b_in + IN(conv_b(pad(mask * relu(IN(conv_a(pad(b_in)))))))
+        d3 = self._desc(self.blocks[0][0], h4 + 2, w4 + 2, h4, w4) if self.blocks else None
+        for (A, B), (p1, a, mask, p2, c) in zip(reversed(self.blocks), reversed(S["blk"])):
+            dc = db.clone()
+            n_c = self._in(st[B.key], h4 * w4, ACT_NONE)
+            ops.norm_apply_bwd_sums(dc, c, n_c, sums[B.key])
+            ops.norm_bwd_apply(dc, c, n_c, sums[B.key])
+            wgrad(B, d3, p2, None, dc)
+            dp2 = E(h4 + 2, w4 + 2, C)
+            ops.conv_dgrad(d3, dc, self._wt(B), dp2, None, None, None, w_transposed=True)
+            da = E(h4, w4, C)
+            ops.pad_reflect_bwd(dp2, 1, da, a, self._in(st[A.key], h4 * w4, ACT_RELU), mask, sums[A.key])
+            norm_bwd(da, a, A, h4 * w4, ACT_RELU)
+            wgrad(A, d3, p1, None, da)
+            dp1 = E(h4 + 2, w4 + 2, C)
+            ops.conv_dgrad(d3, da, self._wt(A), dp1, None, None, None, w_transposed=True)
+            dbi = E(h4, w4, C)
+            ops.pad_reflect_bwd(dp1, 1, dbi)
+            db.add_(dbi)
+        # block input = relu(IN(d2)), materialised with pad 0
+        dd2 = E(h4, w4, C)
+        ops.pad_reflect_bwd(db, 0, dd2, S["d2"], self._in(st[self.d2.key], h4 * w4, ACT_RELU), None, sums[self.d2.key])
+        norm_bwd(dd2, S["d2"], self.d2, h4 * w4, ACT_RELU)
+        n_d1 = self._in(st[self.d1.key], h2 * w2, ACT_RELU)
+        dd = self._desc(self.d2, h2, w2, h4, w4)
+        wgrad(self.d2, dd, S["d1"], n_d1, dd2)
+        dd1 = E(h2, w2, self.d1.cout_s)
+        ops.conv_dgrad(dd, dd2, self._wt(self.d2), dd1, S["d1"], n_d1, sums[self.d1.key], w_transposed=True)
+        norm_bwd(dd1, S["d1"], self.d1, h2 * w2, ACT_RELU)
+        n_c0 = self._in(st[self.c0.key], H * W, ACT_RELU)
+        dd = self._desc(self.d1, H, W, h2, w2)
+        wgrad(self.d1, dd, S["c0"], n_c0, dd1)
+        dc0 = E(H, W, ngf)
+        ops.conv_dgrad(dd, dd1, self._wt(self.d1), dc0, S["c0"], n_c0, sums[self.c0.key], w_transposed=True)
+        norm_bwd(dc0, S["c0"], self.c0, H * W, ACT_RELU)
+        d0 = self._desc(self.c0, H + 6, W + 6, H, W)
+        wgrad(self.c0, d0, S["xp"], None, dc0)
+        if not need_dx:
+            return None
+        dxp = E(H + 6, W + 6, Cs)
+        ops.conv_dgrad(d0, dc0, self._wt(self.c0), dxp, None, None, None, w_transposed=True)
+        dx = E(H, W, Cs)
+        ops.pad_reflect_bwd(dxp, 3, dx)
+        return dx
+
+
 class UnetGenerator(ChainNet):
     """UnetGenerator + UnetSkipConnectionBlock (models/networks.py:318-419) as a layer program over a DAG.
 
@@ -1985,7 +2203,8 @@ def define_G(input_nc, output_nc, ngf, which_model_netG, norm='batch', use_dropo
         netG = FCGANGeneratorStar(noise_nc, input_nc, ngf, n_layers=n_layers_G, use_dropout=use_dropout, use_fcn=use_fcn,
                                   gpu_ids=gpu_ids)
     elif which_model_netG in ('resnet_9blocks', 'resnet_6blocks'):
-        raise NotImplementedError('Generator model name [%s] is not on the MI355X path yet' % which_model_netG)
+        netG = ResnetGenerator(input_nc, output_nc, ngf, norm=norm, use_dropout=use_dropout, n_blocks=9 if which_model_netG == 'resnet_9blocks' else 6,
+                               use_residual=use_residual, gpu_ids=gpu_ids)
     else:
         raise NotImplementedError('Generator model name [%s] is not recognized' % which_model_netG)
     netG.apply(weights_init)

@@ -220,6 +220,23 @@ def norm_apply_bwd_sums(dt, u, u_norm, bwd_sums, mask=None):
                                              _ptr(bwd_sums), H * W, Cs, _stream()), "sgan_norm_apply_bwd_sums")
 
 
+def pad_reflect_fwd(x, x_norm, pad, out, mask=None):
+    """out [H + 2 pad, W + 2 pad, C] = mask * act(norm(x)) at the reflected positions (nn.ReflectionPad2d after norm / act / dropout)."""
+    H, W, Cs = x.shape
+    assert out.shape == (H + 2 * pad, W + 2 * pad, Cs)
+    L.check(L.lib().sgan_pad_reflect_fwd(_ptr(_act(x)), x.stride(1), H, W, Cs, _nd(x_norm), _ptr(mask), int(pad), _ptr(_act(out)),
+                                         out.stride(1), _stream()), "sgan_pad_reflect_fwd")
+
+
+def pad_reflect_bwd(dout, pad, din, x=None, x_norm=None, mask=None, bwd_sums=None, sums_sq=0):
+    """din = act'(norm(x)) * mask * fold(dout); bwd_sums += (sum din, sum din * xhat)."""
+    H, W, Cs = din.shape
+    assert dout.shape == (H + 2 * pad, W + 2 * pad, Cs)
+    L.check(L.lib().sgan_pad_reflect_bwd(_ptr(_act(dout)), dout.stride(1), H, W, Cs, int(pad), _ptr(x), x.stride(1) if x is not None else 0,
+                                         _nd(x_norm), _ptr(mask), _ptr(_act(din)), din.stride(1), _ptr(bwd_sums), int(sums_sq), _stream()),
+            "sgan_pad_reflect_bwd")
+
+
 def bilinear_up2_fwd(x, out, out_stats=None, stats_sq=0):
     H, W, Cs = x.shape
     L.check(L.lib().sgan_bilinear_up2_fwd(_ptr(_act(x)), x.stride(1), H, W, Cs, _ptr(_act(out)), out.stride(1), _ptr(out_stats),

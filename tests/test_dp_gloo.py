@@ -5,6 +5,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
@@ -16,6 +17,12 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def by_value(out):
+    """Tensors in a result dict as numpy arrays: pickled by value.  A torch tensor on an mp queue travels as a shared-memory
+    handle that dies with the sending rank, which may have exited before the parent reads it."""
+    return {k: v.detach().cpu().numpy() if torch.is_tensor(v) else v for k, v in out.items()}
 
 
 RENDEZVOUS_ERRORS = ("address already in use", "eaddrinuse", "connection refused", "connection reset", "failed to bind")
@@ -61,7 +68,7 @@ def _rank_body(rank, world, port, q):
         "bytes": avg.bytes, "calls": avg.calls,
         "gauss": nets[1].state_dict()["gauss_filter.0.weight"].clone(),
     }
-    q.put((rank, out))
+    q.put((rank, by_value(out)))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -77,15 +84,15 @@ def run_ranks(worker, world, timeout=180):
         procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
         for p in procs:
             p.start()
-        res = {}
+        res, lost = {}, None
         try:
             for _ in range(world):
                 r, out = q.get(timeout=timeout)
-                res[r] = out
+                res[r] = {k: torch.from_numpy(v) if isinstance(v, np.ndarray) else v for k, v in out.items()}
                 if "error" in out:
                     break
-        except Exception:      # noqa: BLE001  (queue.Empty: a rank died without a word)
-            pass
+        except Exception as e:      # noqa: BLE001  (queue.Empty: a rank died without a word)
+            lost = repr(e)
         for p in procs:
             p.join(30)
             if p.is_alive():
@@ -95,7 +102,7 @@ def run_ranks(worker, world, timeout=180):
             if attempt == 0 and all(any(k in e.lower() for k in RENDEZVOUS_ERRORS) for e in errors):
                 continue
             pytest.fail("worker failed:\n" + "\n".join(errors))
-        assert len(res) == world and all(p.exitcode == 0 for p in procs), (sorted(res), [p.exitcode for p in procs])
+        assert len(res) == world and all(p.exitcode == 0 for p in procs), (sorted(res), [p.exitcode for p in procs], lost)
         return res
     pytest.fail("rendezvous failed twice")
 

@@ -9,7 +9,7 @@ import sys
 import pytest
 import torch
 
-from test_dp_gloo import ROOT, run_ranks
+from test_dp_gloo import ROOT, by_value, run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -41,8 +41,8 @@ def _worker(rank, world, port, q):
         avg = sdist.GradAverager()
         avg(m.optimizer_D)
         torch.cuda.synchronize()
-        q.put((rank, {"local": local.cpu(), "synced": seg[0][1].detach().cpu().clone(), "backend": torch.distributed.get_backend(),
-                      "bytes": avg.bytes, "weights": torch.cat([d._flat.detach().cpu() for d in m.netD])}))
+        q.put((rank, by_value({"local": local, "synced": seg[0][1], "backend": torch.distributed.get_backend(),
+                               "bytes": avg.bytes, "weights": torch.cat([d._flat.detach() for d in m.netD])})))
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     except BaseException:      # noqa: BLE001

@@ -62,18 +62,23 @@ def test_train_then_test_fcgan_star(tmp_path):
     assert len(out) == 2 and all(os.path.exists(p) for p in out)
 
 
-def test_train_then_test_cgan(tmp_path):
+@pytest.mark.parametrize("netG", ["unet_128", "resnet_9blocks"])
+def test_train_then_test_cgan(tmp_path, netG):
     _need_gpu()
     import test as test_driver
     import train as train_driver
     net = ["--name", "drv_cgan", "--model", "cgan", "--which_direction", "AtoB", "--dataset_mode", "single", "--fineSize", "256",
-           "--which_model_netG", "unet_128", "--ngf", "8", "--norm", "instance", "--which_channel", "rg_b", "--gpu_ids", "0",
+           "--which_model_netG", netG, "--ngf", "8", "--norm", "instance", "--which_channel", "rg_b", "--gpu_ids", "0",
            "--checkpoints_dir", str(tmp_path / "ckpt"), "--dataroot", "synthetic", "--manualSeed", "4"]
     m = train_driver.main(net + ["--which_model_netD", "n_layers", "--n_layers_D", "3", "4", "--ndf", "8", "--scale_factor", "1", "1",
-                                 "--lambda_D", "0.5", "0.5", "--weights", "2", "4", "--no_lsgan", "--max_steps", "2", "--print_freq", "1"])
+                                 "--lambda_D", "0.5", "0.5", "--weights", "2", "4", "--no_lsgan", "--max_steps", "2", "--print_freq", "1",
+                                 "--display_freq", "1"])
     assert all(np.isfinite(v) for v in m.get_current_errors().values())
+    web = tmp_path / "ckpt" / "drv_cgan" / "web"          # the training run's result page (util/visualizer.py:77-93)
+    assert (web / "index.html").exists() and any(f.startswith("epoch001_") for f in os.listdir(web / "images"))
     out = test_driver.main(net + ["--results_dir", str(tmp_path / "res"), "--how_many", "2"])
     assert len(out) == 4 and all(os.path.exists(p) for p in out)            # real_A + fake_B per image
+    assert (tmp_path / "res" / "drv_cgan" / "test_latest" / "index.html").exists()
 
 
 def test_train_cgan2(tmp_path):

@@ -228,6 +228,43 @@ def test_unet_small(N, golden_dir, tag):
             assert rel(params[name].grad, g[k]) < TOL, name
 
 
+@pytest.mark.parametrize("tag,which,nb,drop", [("6", "resnet_6blocks", 6, False), ("9_dropout", "resnet_9blocks", 9, True)])
+def test_resnet_small(N, golden_dir, tag, which, nb, drop):
+    """--which_model_netG resnet_6blocks / resnet_9blocks (models/networks.py:221-311) on the HIP path against the reference golden:
+    reflection padding (materialised gather), 49-tap k7 layers, stride-2 convs, residual blocks with dropout, ConvT k3 s2 with
+    output padding; state_dict keys and order as the reference's nn.Sequential."""
+    g = load(golden_dir, f"resnet_small_{tag}.npz")
+    G = N.define_G(2, 1, 8, which, "instance", drop, gpu_ids=[0])
+    sd = O.init_resnet(41, 2, 1, 8, nb, drop)
+    assert list(G.state_dict().keys()) == list(sd.keys())
+    G.load_state_dict(sd)
+    G.mask_source = lambda i, shape: O.dropout_mask_np(60 + i, (1, shape[2], shape[0], shape[1]))[0].permute(1, 2, 0).contiguous().cuda()
+    x = O.np_uniform(311, (1, 2, 64, 64)).cuda().requires_grad_(True)
+    r = O.np_normal(312, (1, 1, 64, 64)).cuda()
+    y = G.forward(x)
+    assert y.shape == (1, 1, 64, 64)
+    (y * r).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, g["y"]) < TOL
+    assert rel(x.grad, g["dx"]) < TOL
+    params = dict(G.named_parameters())
+    last = f"model.{17 + nb}.bias"
+    for k in g.files:
+        if not k.startswith("grad/"):
+            continue
+        name = k[5:]
+        if name.endswith(".bias") and name != last:
+            scale = np.abs(params[name.replace(".bias", ".weight")].grad.cpu().numpy()).max()
+            assert np.abs(params[name].grad.cpu().numpy()).max() < TOL * scale, name
+        else:
+            assert rel(params[name].grad, g[k]) < TOL, name
+    if drop:      # without injected masks: Philox masks, a fresh set per forward, still a valid tanh image
+        G.mask_source = None
+        y1, y2 = G.forward(x.detach()), G.forward(x.detach())
+        torch.cuda.synchronize()
+        assert float((y1 - y2).abs().max()) > 0 and float(y1.abs().max()) <= 1.0
+
+
 def test_unet_own_dropout_and_noise(N):
     """Without injected tensors the masks come from the Philox kernel: half the entries kept (scaled by 2), a fresh
     mask per forward."""

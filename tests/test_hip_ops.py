@@ -640,7 +640,7 @@ def test_c_abi_error_paths(hip):
     with pytest.raises(SganError, match="too large"):
         ops.conv_fwd(ops.conv_desc(0, 4, 1, 2, 16384, 16384, 4, 16385, 16385, 4), x, None, w, None, y)
     with pytest.raises(SganError, match="kernel size"):
-        ops.conv_fwd(ops.conv_desc(0, 7, 1, 3, 16, 16, 8, 16, 16, 8), x, None, w, None, y)
+        ops.conv_fwd(ops.conv_desc(0, 9, 1, 4, 16, 16, 8, 16, 16, 8), x, None, w, None, y)
     with pytest.raises(SganError, match="bad conv kind"):
         ops.conv_fwd(ops.conv_desc(5, 4, 2, 2, 16, 16, 8, 9, 9, 8), x, None, w, None, y)
     with pytest.raises(SganError, match="same layer type"):

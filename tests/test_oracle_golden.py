@@ -279,6 +279,32 @@ def test_unet_small(golden_dir, tag):
             assert rel(v.grad, g["grad/" + k]) < 1e-4, k
 
 
+RESNET_SMALL = {"6": dict(n_blocks=6, use_dropout=False), "9_dropout": dict(n_blocks=9, use_dropout=True)}
+
+
+@pytest.mark.parametrize("tag", list(RESNET_SMALL))
+def test_resnet_small(golden_dir, tag):
+    """resnet_6blocks / resnet_9blocks (+ dropout) restated (ReflectionPad, k7 / k3 convs, residual blocks, ConvT with output padding)
+    against the reference's own nets."""
+    g = load(golden_dir, f"resnet_small_{tag}.npz")
+    kw = RESNET_SMALL[tag]
+    sd = O.init_resnet(41, 2, 1, 8, kw["n_blocks"], kw["use_dropout"])
+    assert {"grad/" + k for k in sd} == {k for k in g.files if k.startswith("grad/")}
+    for v in sd.values():
+        v.requires_grad_(True)
+    x, r = O.np_uniform(311, (1, 2, 64, 64)).requires_grad_(True), O.np_normal(312, (1, 1, 64, 64))
+    y = O.resnet_forward(sd, x, kw["n_blocks"], kw["use_dropout"], mask_seed=60)
+    (y * r).sum().backward()
+    assert rel(y, g["y"]) < TIGHT * 5
+    assert rel(x.grad, g["dx"]) < 1e-4
+    last = f"model.{17 + kw['n_blocks']}.bias"
+    for k, v in sd.items():
+        if k.endswith(".bias") and k != last:       # a bias in front of an InstanceNorm: analytically zero gradient
+            assert float(v.grad.abs().max()) <= 1e-3 * float(sd[k.replace(".bias", ".weight")].grad.abs().max())
+        else:
+            assert rel(v.grad, g["grad/" + k]) < 1e-4, k
+
+
 def cgan_batch(cfg, step):
     A = O.np_uniform(7100 + step, (1, 3, cfg.fineSize, cfg.fineSize))
     B = O.np_uniform(7200 + step, (1, 3, cfg.fineSize, cfg.fineSize))

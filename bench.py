@@ -473,7 +473,8 @@ def main():
             peak = 2500.0 if split else 157.3
             traffic = None     # HBM bytes per launch from the committed PMC passes (profiles/), same kernel
             try:      # the committed counter passes were taken on the fcgan step: only that workload's launch mix matches them
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                import glob
+                pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))["kernels"]
                 traffic = pm[dom]["hbm_bytes_per_launch"] if (dom in pm and args.workload == "fcgan") else None
             except Exception:
                 traffic = None

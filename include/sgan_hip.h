@@ -367,12 +367,24 @@ int sgan_to_nhwc(const float* src, int64_t sc, int64_t sh, int64_t sw, int32_t H
                  float* dst, int32_t dst_ld, int32_t Cstore, void* stream);
 
 /* ---- input pipeline tail (data/base_dataset.py:17-55, data/aligned_dataset.py:31-42) ------------
- * From a decoded (and, if asked, host-resized) RGB image `img` [H0][W0][3] uint8 already in device memory: crop the n x n window at
+ * From a decoded (and, if asked, resized: sgan_image_resize) RGB image `img` [H0][W0][3] uint8 already in device memory: crop the n x n window at
  * (x0, y0) (transforms.RandomCrop / the aligned dataset's offsets) -> horizontal flip (RandomHorizontalFlip) -> rotate by
  * 90 deg * rot counter-clockwise (__rotate: PIL's exact transpose path for square images) -> ToTensor (/255) -> Normalize(0.5, 0.5),
  * written as an NHWC fp32 buffer [n][n][Cstore >= 3] (extra channels zero).  The random draws stay with the caller. */
 int sgan_image_prep(const unsigned char* img, int32_t H0, int32_t W0, int32_t x0, int32_t y0, int32_t n, int32_t flip, int32_t rot,
                     float* dst, int32_t dst_ld, int32_t Cstore, void* stream);
+
+/* ---- Image.resize in front of the crop (data/base_dataset.py:19-21 transforms.Scale(.., BILINEAR), :43-50 __scale_width;
+ * data/aligned_dataset.py:25 AB.resize((2 loadSize, loadSize), BICUBIC)) --------------------------
+ * `src` [H][W][C] uint8 (C <= 4, interleaved) -> `dst` [Ho][Wo][C] uint8, both in device memory, bit-exact with Pillow's 8-bit
+ * two-pass resampler (Resample.c): horizontal pass then vertical pass, filter support stretched by the down-scale factor, taps
+ * normalised in double and rounded to 22-bit fixed point, each pass rounded and clipped to 8 bits.  `filter` uses Pillow's numbers.
+ * `ws` is scratch of at least sgan_image_resize_workspace() bytes (the intermediate image and the two tap tables). */
+#define SGAN_RESAMPLE_BILINEAR 2
+#define SGAN_RESAMPLE_BICUBIC 3
+int64_t sgan_image_resize_workspace(int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t filter);
+int sgan_image_resize(const unsigned char* src, int32_t H, int32_t W, int32_t C, unsigned char* dst, int32_t Ho, int32_t Wo,
+                      int32_t filter, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- Adam over up to 64 contiguous fp32 segments in one launch --------------------------------
  * torch.optim.Adam default form (models/fcgan_model.py:98-109):

@@ -100,6 +100,7 @@ SIGNATURES = {
     "sgan_scale": [_P, _P, _P, _L, _P],
     "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],
     "sgan_image_prep": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    "sgan_image_resize": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _L, _P],
     "sgan_gauss_down_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "sgan_gauss_down_multi_fwd": [C.POINTER(GaussJob), _I, _I, _I, _P],
     "sgan_gauss_down_multi_bwd": [C.POINTER(GaussJob), _I, _I, _I, _I, _P],
@@ -145,6 +146,8 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_int
+        l.sgan_image_resize_workspace.argtypes = [_I, _I, _I, _I, _I, _I]
+        l.sgan_image_resize_workspace.restype = C.c_int64
         l.sgan_version.restype = C.c_char_p
         l.sgan_last_error.restype = C.c_char_p
         l.sgan_last_kernel.restype = C.c_char_p

@@ -763,6 +763,127 @@ extern "C" int sgan_image_prep(const unsigned char* img, int32_t H0, int32_t W0,
 }
 
 // ------------------------------------------------------------------------------------------
+// Image.resize(size, BILINEAR | BICUBIC) of an 8-bit interleaved image, bit-exact with Pillow's two-pass resampler
+// (src/libImaging/Resample.c: precompute_coeffs + normalize_coeffs_8bpc + ImagingResampleHorizontal/Vertical_8bpc; called from
+// data/base_dataset.py:19-21,43-50 and data/aligned_dataset.py:25).  Per axis: the filter stretched by the down-scale factor, taps
+// normalised in double and rounded to 22-bit fixed point (one thread per output coordinate; fp contraction off so every double
+// operation rounds as the C source's does), then an integer gather-MAC per output byte, rounded and clipped to 8 bits after each pass.
+// ------------------------------------------------------------------------------------------
+#define SG_RESAMPLE_BITS (32 - 8 - 2)
+
+__device__ inline double sg_resample_filter(int bicubic, double x) {
+#pragma clang fp contract(off)
+    if (x < 0.0) x = -x;
+    if (!bicubic) return x < 1.0 ? 1.0 - x : 0.0;
+    const double a = -0.5;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+__global__ __launch_bounds__(256) void sg_resample_coeffs_kernel(int in_size, int out_size, int bicubic, int ksize, int* bounds, int* kk) {
+#pragma clang fp contract(off)
+    const int xx = blockIdx.x * 256 + threadIdx.x;
+    if (xx >= out_size) return;
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = (bicubic ? 2.0 : 1.0) * filterscale;
+    const double ss = 1.0 / filterscale;
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) ww += sg_resample_filter(bicubic, (x + xmin - center + 0.5) * ss);
+    int* k = kk + (int64_t)xx * ksize;
+    for (int x = 0; x < ksize; ++x) {
+        double w = 0.0;
+        if (x < xmax) {
+            w = sg_resample_filter(bicubic, (x + xmin - center + 0.5) * ss);
+            if (ww != 0.0) w /= ww;
+        }
+        k[x] = w < 0 ? (int)(-0.5 + w * (1 << SG_RESAMPLE_BITS)) : (int)(0.5 + w * (1 << SG_RESAMPLE_BITS));
+    }
+    bounds[2 * xx] = xmin;
+    bounds[2 * xx + 1] = xmax;
+}
+
+// one thread per output byte (consecutive threads -> consecutive bytes of a row)
+template <bool HORIZ>
+__global__ __launch_bounds__(256) void sg_resample_pass_kernel(const unsigned char* src, int Ws, int C, unsigned char* dst, int Hd, int Wd,
+                                                               const int* bounds, const int* kk, int ksize) {
+    const int64_t total = (int64_t)Hd * Wd * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int64_t pix = e / C;
+        const int x = (int)(pix % Wd), y = (int)(pix / Wd);
+        const int xx = HORIZ ? x : y;
+        const int x0 = bounds[2 * xx], n = bounds[2 * xx + 1];
+        const int* k = kk + (int64_t)xx * ksize;
+        const unsigned char* p = HORIZ ? src + ((int64_t)y * Ws + x0) * C + c : src + ((int64_t)x0 * Ws + x) * C + c;
+        const int64_t step = HORIZ ? C : (int64_t)Ws * C;
+        int acc = 1 << (SG_RESAMPLE_BITS - 1);
+        for (int t = 0; t < n; ++t) acc += (int)p[t * step] * k[t];
+        acc >>= SG_RESAMPLE_BITS;
+        dst[e] = (unsigned char)(acc < 0 ? 0 : acc > 255 ? 255 : acc);
+    }
+}
+
+static int sg_resample_ksize(int in_size, int out_size, int filter) {
+    double scale = (double)in_size / out_size;
+    if (scale < 1.0) scale = 1.0;
+    return (int)ceil((filter == SGAN_RESAMPLE_BICUBIC ? 2.0 : 1.0) * scale) * 2 + 1;
+}
+
+static inline int64_t sg_up16(int64_t v) { return (v + 15) & ~(int64_t)15; }
+
+extern "C" int64_t sgan_image_resize_workspace(int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo, int32_t filter) {
+    if (H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return 0;
+    return sg_up16((int64_t)H * Wo * C) + sg_up16((int64_t)Wo * (2 + sg_resample_ksize(W, Wo, filter)) * 4) +
+           sg_up16((int64_t)Ho * (2 + sg_resample_ksize(H, Ho, filter)) * 4);
+}
+
+extern "C" int sgan_image_resize(const unsigned char* src, int32_t H, int32_t W, int32_t C, unsigned char* dst, int32_t Ho, int32_t Wo,
+                                 int32_t filter, void* ws, int64_t ws_bytes, void* stream) {
+    SGAN_CHECK(src && dst && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C <= 4, "bad argument");
+    SGAN_CHECK(filter == SGAN_RESAMPLE_BILINEAR || filter == SGAN_RESAMPLE_BICUBIC, "resample filter %d not supported (2 bilinear, 3 bicubic)", filter);
+    SGAN_CHECK(H < (1 << 24) && W < (1 << 24) && Ho < (1 << 24) && Wo < (1 << 24), "image too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (Ho == H && Wo == W) {      // Image.resize returns a copy
+        hipError_t e = hipMemcpyAsync(dst, src, (size_t)H * W * C, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return sgan_fail(SGAN_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+        return SGAN_OK;
+    }
+    SGAN_CHECK(ws && ws_bytes >= sgan_image_resize_workspace(H, W, C, Ho, Wo, filter), "workspace too small (sgan_image_resize_workspace)");
+    const int bic = filter == SGAN_RESAMPLE_BICUBIC;
+    unsigned char* tmp = (unsigned char*)ws;
+    int* bh = (int*)(tmp + sg_up16((int64_t)H * Wo * C));
+    const int ksh = sg_resample_ksize(W, Wo, filter), ksv = sg_resample_ksize(H, Ho, filter);
+    int* kh = bh + 2 * Wo;
+    int* bv = (int*)((char*)bh + sg_up16((int64_t)Wo * (2 + ksh) * 4));
+    int* kv = bv + 2 * Ho;
+    const unsigned char* cur = src;
+    if (Wo != W) {                 // horizontal pass first (ImagingResample)
+        unsigned char* out = Ho != H ? tmp : dst;
+        hipLaunchKernelGGL(sg_resample_coeffs_kernel, dim3(ew_cdiv(Wo, 256)), dim3(256), 0, st, W, Wo, bic, ksh, bh, kh);
+        int blocks = ew_cdiv((int64_t)H * Wo * C, 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL((sg_resample_pass_kernel<true>), dim3(blocks), dim3(256), 0, st, cur, W, C, out, H, Wo, bh, kh, ksh);
+        cur = out;
+    }
+    if (Ho != H) {
+        hipLaunchKernelGGL(sg_resample_coeffs_kernel, dim3(ew_cdiv(Ho, 256)), dim3(256), 0, st, H, Ho, bic, ksv, bv, kv);
+        int blocks = ew_cdiv((int64_t)Ho * Wo * C, 256);
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL((sg_resample_pass_kernel<false>), dim3(blocks), dim3(256), 0, st, cur, Wo, C, dst, Ho, Wo, bv, kv, ksv);
+    }
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Gaussian pre-filter: depthwise (diagonal of the dense reference weight), strided outputs only
 // ------------------------------------------------------------------------------------------
 // one thread per (pixel, channel quad): 16-byte loads, the k x k taps of the channel's Gaussian from LDS

@@ -48,6 +48,9 @@ struct SgIgemmParams {   // the kernel argument (~2.3 KB)
     int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
     SgTap taps[SGAN_MAX_TAPS];          // every phase's taps back to back (k * k in all)
     int32_t tap0[SGAN_MAX_PHASES];     // first tap of a phase
+    // patch-stationary split kernel (sgan_igemm3.hip: sg_igemm3p_kernel): per phase, the first tap offset and the patch extent
+    // (an 8 x 8 block of result pixels reads patch rows [pdy0, pdy0 + pph) x columns [pdx0, pdx0 + ppw) relative to its corner)
+    int32_t pdy0[SGAN_MAX_PHASES], pdx0[SGAN_MAX_PHASES], pph[SGAN_MAX_PHASES], ppw[SGAN_MAX_PHASES];
     float* slab;          // [ksplit][Hout*Wout][N] fp32 partials (caller workspace)
     int64_t slab_stride;  // Hout*Wout*N
     SgProb q[SG_MAX_PROB];

@@ -71,6 +71,112 @@ __device__ __forceinline__ f32x16 sg3_mfma(const u32x4 a, const u32x4 b, const f
 // byte offset of 16-byte chunk `slot` of tile row `row` (128-byte rows)
 __device__ __forceinline__ int sg3_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
+// ------------------------------------------------------------------------------------------
+// Epilogue shared by the split kernels: acc[i][j][r] is tile row wm*WTM + i*32 + (r & 3) + 8 (r >> 2) + 4 fh, column
+// n0 + wn*WTN + j*32 + fr; `rowpix(row)` gives the pixel index of a tile row in the result tensor (< 0: outside the problem).
+// Bias, fp64 statistics of the result (forward) or act'(norm(x)) and the two norm-backward sums (backward-data), tanh, accumulate;
+// or the raw partial tile to the split-K slab.  `red` is [2 BN] fp64 of LDS, zeroed before the main loop.
+// ------------------------------------------------------------------------------------------
+template <int BN, int WTM, int WTN, int MB, int NB, bool F16, typename RowPix>
+__device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB][NB], double* red, int split, int n0, int wm, int wn,
+                                             int tid, RowPix rowpix) {
+    const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+    const int N = P.N;
+    if constexpr (F16) {     // the fp16 weight planes hold w * 2^SGAN_F16_WEIGHT_SHIFT (an exact power of two)
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] *= 1.f / (float)(1 << SGAN_F16_WEIGHT_SHIFT);
+    }
+    const bool want_stats = P.stats != nullptr;
+    if (P.ksplit > 1) {   // split-K: raw partial tile to this split's slab; sg_splitk_epilogue_kernel finishes
+        float* sl = P.slab + (int64_t)split * P.slab_stride;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t pix = rowpix(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh);
+                if (pix >= 0) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int n = n0 + wn * WTN + j * 32 + fr;
+                        if (n < N) sl[pix * N + n] = acc[i][j][r];
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const bool dact = P.xref != nullptr;
+    const bool xnorm = dact && P.xn.stats != nullptr;
+    const float xn_neg = P.xn.act == SGAN_ACT_NONE ? 1.f : (P.xn.act == SGAN_ACT_RELU ? 0.f : P.xn.slope);
+    float bias_v[NB], x_mean[NB], x_rstd[NB], x_g[NB], x_b[NB];
+    bool nvalid[NB];
+    double s1[NB], s2[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + fr;
+        nvalid[j] = n < N;
+        bias_v[j] = (P.bias && nvalid[j]) ? P.bias[n] : 0.f;
+        x_mean[j] = 0.f; x_rstd[j] = 1.f; x_g[j] = 1.f; x_b[j] = 0.f;
+        if (xnorm && nvalid[j]) {
+            sg_mean_rstd(P.xn, N, n, x_mean[j], x_rstd[j]);
+            x_g[j] = P.xn.gamma ? P.xn.gamma[n] : 1.f;
+            x_b[j] = P.xn.beta ? P.xn.beta[n] : 0.f;
+        }
+        s1[j] = 0.0;
+        s2[j] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t pix = rowpix(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh);
+            if (pix >= 0) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int n = n0 + wn * WTN + j * 32 + fr;
+                    if (nvalid[j]) {
+                        float v = acc[i][j][r] + bias_v[j];
+                        if (dact) {
+                            const float x = P.xref[pix * P.xref_ld + n];
+                            const float xhat = (x - x_mean[j]) * x_rstd[j];
+                            const float y = xnorm ? (x_g[j] * xhat + x_b[j]) : x;
+                            v *= (y > 0.f ? 1.f : xn_neg);
+                            s1[j] += (double)v;
+                            s2[j] += (double)(v * xhat);
+                        } else {
+                            s1[j] += (double)v;
+                            s2[j] += (double)v * (double)v;
+                            if (P.out_act == SGAN_ACT_TANH) v = tanhf(v);
+                        }
+                        if (P.accum) v += P.out[pix * P.out_ld + n];
+                        P.out[pix * P.out_ld + n] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (want_stats) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int nl = wn * WTN + j * 32 + fr;
+            double a = s1[j], b = s2[j];
+            a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 32);
+            if (fh == 0 && nvalid[j]) {
+                atomicAdd(&red[nl], a);
+                atomicAdd(&red[BN + nl], b);
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+            atomicAdd(&P.stats[n0 + tid], red[tid]);
+            atomicAdd(&P.stats[P.stats_sq + n0 + tid], red[BN + tid]);
+        }
+    }
+}
+
 // F16: operand planes are fp16 (forward pass: fp32-equivalent products) instead of bf16 (backward-data)
 template <int BM, int BN, int WGM, int WGN, bool PRO, bool F16>
 __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemmParams G) {
@@ -381,104 +487,350 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     }
 #undef SG3_FOR_SETS
 
-    if constexpr (F16) {     // the fp16 weight planes hold w * 2^SGAN_F16_WEIGHT_SHIFT (an exact power of two)
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) acc[i][j] *= 1.f / (float)(1 << SGAN_F16_WEIGHT_SHIFT);
+    sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, split, n0, wm, wn, tid, [&](int row) -> int64_t {
+        const int m = m0 + row;
+        if (m >= M) return -1;
+        const int py = m / Wp, px = m - py * Wp;
+        return (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);
+    });
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Patch-stationary variant for unit-stride gathers (Conv2d stride 1 forward and backward-data, every phase of a
+// ConvTranspose2d forward / strided-Conv2d backward-data).  sg_igemm3_kernel walks K as (tap, channel): a result tile re-loads,
+// re-normalises and re-splits each input element once per tap that touches it -- 16 times for a 4x4 kernel -- and that staging
+// (VALU split, L2 -> L1 -> VGPR -> LDS traffic), not the MFMA pipe, is what bounds it.  Here K is walked as (32-channel block, tap):
+//  * the M tile is an 8 x 8 block of result pixels; per channel block its input PATCH ((8 + span - 1)^2 pixels, 11 x 11 for
+//    4x4 taps) is loaded, transformed and split ONCE and stays in LDS: pixel stride 144 B (32 channels x {hi, lo} + 16 pad),
+//    row stride = 128 mod 256 B, so the 16 lanes of a ds_read_b128 group (two tile rows of eight pixels) hit 16 distinct
+//    16-byte slots at any tap offset;
+//  * per tap the A fragments are read straight out of the patch at a per-tap byte offset (no copy); only the weight tile
+//    [BN][32 k] of (tap, channel block) is staged per step, a plain 16-byte copy of the packed rows through a register ring;
+//  * one barrier per tap; at a channel-block boundary one more around the patch store (its loads were issued a block ahead).
+// Same prologue / epilogue / packed weights / problem grouping as sg_igemm3_kernel; rectangular tiles waste the ragged edge
+// (66 x 66 result: 81 tiles for 68 tiles' worth of pixels), which the dispatcher prices in.
+// ------------------------------------------------------------------------------------------
+#define SG3P_PS 144
+#ifndef SG3P_ABL
+#define SG3P_ABL 0   // diagnostics builds only (wrong results): 1 no weight loads, 2 no weight LDS stores, 4 no fragment reads, 8 no MFMA, 16 no per-tap barrier
+#endif
+__host__ __device__ __forceinline__ int sg3p_row_stride(int ppw) { return ((ppw * SG3P_PS + 127) & ~255) + 128; }
+
+#ifdef SG3P_STAMP      // diagnostics build: per-workgroup s_memtime stamps (tools/stamp3p.py reads them through sgan_debug_stamps)
+__device__ unsigned long long sg3p_stamps[8 * 4096];
+#define SG3P_MARK(i)                                                                                       \
+    do {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                                       \
+            unsigned long long t_;                                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+            sg3p_stamps[blockIdx.x * 8 + (i)] = t_;                                                        \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    } while (0)
+extern "C" int sgan_debug_stamps(void* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sg3p_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define SG3P_MARK(i)
+#endif
+#ifdef SG3P_STAMP2     // diagnostics build: cycles per phase of the tap loop, summed over the units of a workgroup (wave 0)
+__device__ unsigned long long sg3p_phase[8 * 4096];
+#define SG3P_T(var)                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                            \
+    __builtin_amdgcn_sched_barrier(0);
+extern "C" int sgan_debug_phases(void* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sg3p_phase), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+template <int BN, int A_IT, bool PRO, bool F16>
+__global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) {
+    constexpr int NT = 256, WGN = 2, WTM = 32, WTN = BN / WGN, MB = 1, NB = WTN / 32;
+    constexpr int B_IT = BN * 8 / NT;
+    constexpr int NSET = 4;          // weight-tile register ring (even: the LDS buffer of a step is its slot's parity)
+    static_assert(BN % 64 == 0 && B_IT >= 1, "N tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    SG3P_MARK(0);
+#ifdef SG3P_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 4096) sg3p_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int ntn = (G.N + BN - 1) / BN;
+    const int item = sg_xcd_remap(blockIdx.x, gridDim.x);
+    int g, phz, mtile;
+    sg_decode_tile(G, item / ntn, g, phz, mtile);
+    const SgLocal P = sg_local(G, g);
+    const int Hp = G.q[g].Hp[phz], Wp = G.q[g].Wp[phz];
+    const int tiles_x = (Wp + 7) >> 3;
+    const int ty0 = (mtile / tiles_x) * 8, tx0 = (mtile % tiles_x) * 8;
+    const int n0 = (item % ntn) * BN;
+    const int PH = G.pph[phz], PW = G.ppw[phz];
+    const int RS = sg3p_row_stride(PW);
+    const int npix = PH * PW;
+
+    char* Ap = smem;                                         // [PH][RS] patch of the current channel block
+    char* Bs = smem + ((PH * RS + 255) & ~255);              // [2][BN * 128]
+    double* red = reinterpret_cast<double*>(Bs + 2 * BN * 128);            // [2 * BN]
+    int4* ttab = reinterpret_cast<int4*>(red + 2 * BN);                    // per tap {patch byte offset, -, -, weight slab offset}
+    float* pscale = reinterpret_cast<float*>(ttab + SGAN_MAX_TAPS);        // [Ck]
+    float* pshift = pscale + G.Ck;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(G.q[g].wp), 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int OOB = (int)0x80000000u;
+    const int oa = G.oa[phz], ob = G.ob[phz];
+    const int Ck = P.Ck, N = P.N;
+    const int ntaps = G.ntaps[phz];
+    const int ncb = Ck >> 5;
+    const int nunits = ntaps * ncb;
+    const int dy0 = G.pdy0[phz], dx0 = G.pdx0[phz];
+
+    if (tid < SGAN_MAX_TAPS) {
+        const bool v = tid < ntaps;
+        const SgTap tp = G.taps[v ? G.tap0[phz] + tid : 0];
+        ttab[tid] = make_int4(v ? ((int)tp.dy - dy0) * RS + ((int)tp.dx - dx0) * SG3P_PS : 0, 0, 0, v ? tp.w_off : 0);
     }
-    // ---- epilogue: acc[i][j][r] = out[m = m0 + wm*WTM + i*32 + (r & 3) + 8 (r >> 2) + 4 fh][n = n0 + wn*WTN + j*32 + fr] ----
-    const bool want_stats = P.stats != nullptr;
-    if (P.ksplit > 1) {   // split-K: raw partial tile to this split's slab; sg_splitk_epilogue_kernel finishes
-        float* sl = P.slab + (int64_t)split * P.slab_stride;
+    for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.0;
+    if constexpr (PRO) {
+        for (int c = tid; c < Ck; c += NT) {
+            float sc = 1.f, sh = 0.f;
+            if (P.pro.stats) {
+                float mean, rstd;
+                sg_mean_rstd(P.pro, Ck, c, mean, rstd);
+                const float gm = P.pro.gamma ? P.pro.gamma[c] : 1.f;
+                const float bt = P.pro.beta ? P.pro.beta[c] : 0.f;
+                sc = gm * rstd;
+                sh = bt - mean * sc;
+            }
+            pscale[c] = sc;
+            pshift[c] = sh;
+        }
+    }
+
+    // ---- patch staging: item e = 4 * patch pixel + k-group (8 channels = two 16-byte loads -> one hi and one lo chunk).  Runs once
+    // per channel block, so the per-item addresses are recomputed there instead of living in registers across the tap loop. ----
+    const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
+    const int kg = tid & 3;
+    auto a_item = [&](int it, int& goff, int& dst, bool& ok, bool& use) {
+        const int p = (tid + it * NT) >> 2;
+        const int pr = p / PW, pc = p - pr * PW;
+        const int iy = (ty0 + pr) * P.is + dy0, ix = (tx0 + pc) * P.is + dx0;
+        use = p < npix;
+        ok = use & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
+        goff = ((iy * P.Win + ix) * P.in_ld + kg * 8) << 2;
+        dst = pr * RS + pc * SG3P_PS + kg * 32;
+    };
+    f32x4 a_reg[A_IT][2];
+    auto issue_a = [&](int cb) {
 #pragma unroll
-        for (int i = 0; i < MB; ++i) {
+        for (int it = 0; it < A_IT; ++it) {
+            int goff, dst;
+            bool ok, use;
+            a_item(it, goff, dst, ok, use);
+            const int o = (ok & (cb < ncb)) ? goff + cb * 128 : OOB;     // past the last block: zeros, never used
+            a_reg[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o, 0, 0));
+            a_reg[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o + 16, 0, 0));
+        }
+    };
+    auto store_a = [&](int cb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m < M) {
-                    const int py = m / Wp, px = m - py * Wp;
-                    const int64_t pix = (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);
+        for (int it = 0; it < A_IT; ++it) {
+            int goff, dst;
+            bool ok, use;
+            a_item(it, goff, dst, ok, use);
+            f32x4 v0 = a_reg[it][0], v1 = a_reg[it][1];
+            if constexpr (PRO) {   // zero padding applies AFTER norm + activation (see sg_igemm3_kernel)
+                const int c = cb * 32 + kg * 8;
+                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(pscale + c), sc1 = *reinterpret_cast<const f32x4*>(pscale + c + 4);
+                const f32x4 sh0 = *reinterpret_cast<const f32x4*>(pshift + c), sh1 = *reinterpret_cast<const f32x4*>(pshift + c + 4);
+                const float okf = ok ? 1.f : 0.f;
+                const float okn = okf * pro_neg;
+                const f32x4 y0 = v0 * sc0 + sh0, y1 = v1 * sc1 + sh1;
+                const f32x4 p0 = y0 * okf, q0 = y0 * okn, p1 = y1 * okf, q1 = y1 * okn;
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) {
-                        const int n = n0 + wn * WTN + j * 32 + fr;
-                        if (n < N) sl[pix * N + n] = acc[i][j][r];
-                    }
-                }
+                for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(p0[j], q0[j]); v1[j] = fmaxf(p1[j], q1[j]); }
+            }
+            u32x4 hi, lo;
+            sg_split8<F16>(v0, v1, hi, lo);
+            if (use) {
+                *reinterpret_cast<u32x4*>(Ap + dst) = hi;
+                *reinterpret_cast<u32x4*>(Ap + dst + 16) = lo;
             }
         }
-        return;
-    }
-    const bool dact = P.xref != nullptr;
-    const bool xnorm = dact && P.xn.stats != nullptr;
-    const float xn_neg = P.xn.act == SGAN_ACT_NONE ? 1.f : (P.xn.act == SGAN_ACT_RELU ? 0.f : P.xn.slope);
-    float bias_v[NB], x_mean[NB], x_rstd[NB], x_g[NB], x_b[NB];
-    bool nvalid[NB];
-    double s1[NB], s2[NB];
+    };
+
+    // ---- weight-tile staging (as sg_igemm3_kernel): thread -> (row n, 16-byte chunk t of the 128-byte k-row) ----
+    int b_base[B_IT], b_dst[B_IT];
+    bool b_rowok[B_IT];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + fr;
-        nvalid[j] = n < N;
-        bias_v[j] = (P.bias && nvalid[j]) ? P.bias[n] : 0.f;
-        x_mean[j] = 0.f; x_rstd[j] = 1.f; x_g[j] = 1.f; x_b[j] = 0.f;
-        if (xnorm && nvalid[j]) {
-            sg_mean_rstd(P.xn, N, n, x_mean[j], x_rstd[j]);
-            x_g[j] = P.xn.gamma ? P.xn.gamma[n] : 1.f;
-            x_b[j] = P.xn.beta ? P.xn.beta[n] : 0.f;
+    for (int it = 0; it < B_IT; ++it) {
+        const int e = tid + it * NT;
+        const int n = e >> 3, t = e & 7;
+        b_rowok[it] = n0 + n < N;
+        b_base[it] = (n0 + n) * P.w_ns + 8 * (t & 3) + 4 * (t >> 2);
+        b_dst[it] = sg3_off(n, 2 * (t & 3) + (t >> 2));
+    }
+    u32x4 b_reg[NSET][B_IT];
+    int b_off_n[B_IT];
+    int ld_tap = 0, ld_cb = 0;
+    auto next_b_addrs = [&]() {
+        const bool in_range = ld_cb < ncb;
+        const int woff = ttab[in_range ? ld_tap : 0].w + ld_cb * 32;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) b_off_n[it] = (b_rowok[it] & in_range) ? (b_base[it] + woff) << 2 : OOB;
+        ++ld_tap;
+        if (ld_tap == ntaps) { ld_tap = 0; ++ld_cb; }
+    };
+    auto issue_b = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            if constexpr (SG3P_ABL & 1) b_reg[S][it] = (u32x4){(unsigned)b_off_n[it], 2u, 3u, 4u};
+            else b_reg[S][it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off_n[it], 0, 0));
         }
-        s1[j] = 0.0;
-        s2[j] = 0.0;
-    }
+    };
+    auto store_b = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+        char* Bb = Bs + (S & 1) * BN * 128;
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
+        for (int it = 0; it < B_IT; ++it)
+            if (!(SG3P_ABL & 2) || G.nprob > 100) *reinterpret_cast<u32x4*>(Bb + b_dst[it]) = b_reg[S][it];
+    };
+
+    f32x16 acc[MB][NB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            if (m < M) {
-                const int py = m / Wp, px = m - py * Wp;
-                const int64_t pix = (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const int n = n0 + wn * WTN + j * 32 + fr;
-                    if (nvalid[j]) {
-                        float v = acc[i][j][r] + bias_v[j];
-                        if (dact) {
-                            const float x = P.xref[pix * P.xref_ld + n];
-                            const float xhat = (x - x_mean[j]) * x_rstd[j];
-                            const float y = xnorm ? (x_g[j] * xhat + x_b[j]) : x;
-                            v *= (y > 0.f ? 1.f : xn_neg);
-                            s1[j] += (double)v;
-                            s2[j] += (double)(v * xhat);
-                        } else {
-                            s1[j] += (double)v;
-                            s2[j] += (double)v * (double)v;
-                            if (P.out_act == SGAN_ACT_TANH) v = tanhf(v);
-                        }
-                        if (P.accum) v += P.out[pix * P.out_ld + n];
-                        P.out[pix * P.out_ld + n] = v;
-                    }
-                }
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    // fragment addresses.  A: lane (r = lane & 31, h = lane >> 5) is tile pixel (4 wm + (r >> 3), r & 7), chunk 2 (2 s + h) + plane
+    const int fr = lane & 31, fh = lane >> 5;
+    const int fa_base = (4 * wm + (fr >> 3)) * RS + (fr & 7) * SG3P_PS + fh * 32;
+    const int fswz = (fr >> 1) & 7;
+    int f_off[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) f_off[s][p] = ((2 * (2 * s + fh) + p) ^ fswz) << 4;
+    const int fb_row = (wn * WTN + fr) * 128;
+
+    __syncthreads();   // tap table, scale / shift visible
+    SG3P_MARK(1);
+
+    int cur_tap = 0, cur_cb = 0;
+    int tapoff = ttab[0].x;
+#ifdef SG3P_STAMP2
+    unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    auto iteration = [&](auto S_) {
+        constexpr int S = decltype(S_)::value;
+#ifdef SG3P_STAMP2
+        unsigned long long q0, q1, q2, q3, q4, q5;
+        SG3P_T(q0)
+#endif
+        const char* Ab = Ap + fa_base + tapoff;
+        const char* Bb = Bs + (S & 1) * BN * 128 + fb_row;
+        issue_b(std::integral_constant<int, S>{});
+        u32x4 ah[2], al[2], bh[2][NB], bl[2][NB];
+        if constexpr (SG3P_ABL & 4) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                ah[s] = b_reg[0][0]; al[s] = b_reg[1][0];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { bh[s][j] = b_reg[2][0]; bl[s][j] = b_reg[3][0]; }
+            }
+        } else
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            ah[s] = *reinterpret_cast<const u32x4*>(Ab + s * 64);
+            al[s] = *reinterpret_cast<const u32x4*>(Ab + s * 64 + 16);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                bh[s][j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * 128 + f_off[s][0]);
+                bl[s][j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * 128 + f_off[s][1]);
             }
         }
-    }
-    if (want_stats) {
+        ++cur_tap;
+        const bool wrap = cur_tap == ntaps;
+        if (wrap) { cur_tap = 0; ++cur_cb; }
+        tapoff = ttab[cur_tap].x;
+#ifdef SG3P_STAMP2
+        SG3P_T(q1)      // fragment reads issued AND returned (the stamp drains lgkmcnt)
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        store_b(std::integral_constant<int, (S + 1) % NSET>{});
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef SG3P_STAMP2
+        SG3P_T(q2)      // weight tile of the next step in LDS (vmcnt wait + 2 stores)
+#endif
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int nl = wn * WTN + j * 32 + fr;
-            double a = s1[j], b = s2[j];
-            a += __shfl_xor(a, 32);
-            b += __shfl_xor(b, 32);
-            if (fh == 0 && nvalid[j]) {
-                atomicAdd(&red[nl], a);
-                atomicAdd(&red[BN + nl], b);
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if constexpr (SG3P_ABL & 8) { acc[0][j][0] += __builtin_bit_cast(f32x4, al[s])[0] + __builtin_bit_cast(f32x4, ah[s])[1] + __builtin_bit_cast(f32x4, bl[s][j])[2] + __builtin_bit_cast(f32x4, bh[s][j])[3]; continue; }
+                acc[0][j] = sg3_mfma<F16>(al[s], bh[s][j], acc[0][j]);
+                acc[0][j] = sg3_mfma<F16>(ah[s], bl[s][j], acc[0][j]);
+                acc[0][j] = sg3_mfma<F16>(ah[s], bh[s][j], acc[0][j]);
             }
+#ifdef SG3P_STAMP2
+        SG3P_T(q3)      // MFMAs issued
+#endif
+        next_b_addrs();
+#ifdef SG3P_STAMP2
+        SG3P_T(q4)
+#endif
+        if (wrap && cur_cb < ncb) {       // channel-block boundary: every wave is done with the patch -> replace it
+            __syncthreads();
+            store_a(cur_cb);
+            issue_a(cur_cb + 1);
         }
-        __syncthreads();
-        if (tid < BN && n0 + tid < N) {
-            atomicAdd(&P.stats[n0 + tid], red[tid]);
-            atomicAdd(&P.stats[P.stats_sq + n0 + tid], red[BN + tid]);
+        if constexpr (!(SG3P_ABL & 16)) __syncthreads();
+#ifdef SG3P_STAMP2
+        SG3P_T(q5)
+        ph_acc[0] += q1 - q0; ph_acc[1] += q2 - q1; ph_acc[2] += q3 - q2; ph_acc[3] += q4 - q3; ph_acc[4] += q5 - q4; ph_acc[5] += 1;
+#endif
+    };
+    auto prefetch = [&](auto K_) { next_b_addrs(); issue_b(K_); };
+    auto maybe = [&](auto K_, int u) { if (u + decltype(K_)::value < nunits) iteration(K_); };
+
+    issue_a(0);
+    prefetch(std::integral_constant<int, 0>{}); prefetch(std::integral_constant<int, 1>{});
+    prefetch(std::integral_constant<int, 2>{}); prefetch(std::integral_constant<int, 3>{});
+    next_b_addrs();
+    store_a(0);
+    issue_a(1);
+    store_b(std::integral_constant<int, 0>{});
+    __syncthreads();
+    SG3P_MARK(2);
+    {
+        int u = 0;
+        for (; u + NSET - 1 < nunits; u += NSET) {
+            iteration(std::integral_constant<int, 0>{}); iteration(std::integral_constant<int, 1>{});
+            iteration(std::integral_constant<int, 2>{}); iteration(std::integral_constant<int, 3>{});
         }
+        maybe(std::integral_constant<int, 0>{}, u); maybe(std::integral_constant<int, 1>{}, u);
+        maybe(std::integral_constant<int, 2>{}, u);
     }
+    SG3P_MARK(3);
+#ifdef SG3P_STAMP2
+    if (threadIdx.x == 0 && blockIdx.x < 4096)
+        for (int i = 0; i < 6; ++i) sg3p_phase[blockIdx.x * 8 + i] = ph_acc[i];
+#endif
+
+    sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, 0, n0, wm, wn, tid, [&](int row) -> int64_t {
+        const int py = ty0 + (row >> 3), px = tx0 + (row & 7);
+        if (py >= Hp || px >= Wp) return -1;
+        return (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);
+    });
+    SG3P_MARK(4);
+#ifdef SG3P_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 4096) sg3p_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -552,7 +904,92 @@ static int sg3_launch(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_by
     return SGAN_OK;
 }
 
+// ---- patch-stationary kernel: plan (patch extents per phase) and launch ----
+struct Sg3pPlan { bool ok; int a_it; long tiles; double waste; int min_taps; };
+
+static Sg3pPlan sg3p_plan(SgIgemmParams& P) {
+    Sg3pPlan pl = {false, 0, 0, 1.0, 1 << 30};
+    if (P.is != 1 || (P.Ck & 31) || P.N <= 32) return pl;
+    int maxpix = 0;
+    for (int ph = 0; ph < P.nphase; ++ph) {
+        int dy0 = 1 << 30, dy1 = -(1 << 30), dx0 = 1 << 30, dx1 = -(1 << 30);
+        if (P.ntaps[ph] <= 0) return pl;
+        for (int t = 0; t < P.ntaps[ph]; ++t) {
+            const SgTap& tp = P.taps[P.tap0[ph] + t];
+            dy0 = min(dy0, (int)tp.dy); dy1 = max(dy1, (int)tp.dy);
+            dx0 = min(dx0, (int)tp.dx); dx1 = max(dx1, (int)tp.dx);
+        }
+        P.pdy0[ph] = dy0; P.pdx0[ph] = dx0;
+        P.pph[ph] = 8 + dy1 - dy0; P.ppw[ph] = 8 + dx1 - dx0;
+        maxpix = max(maxpix, P.pph[ph] * P.ppw[ph]);
+        pl.min_taps = min(pl.min_taps, P.ntaps[ph]);
+    }
+    if (maxpix > 256) return pl;
+    pl.a_it = maxpix <= 128 ? 2 : 4;
+    long padded = 0, real = 0;
+    for (int g = 0; g < P.nprob; ++g)
+        for (int ph = 0; ph < P.nphase; ++ph) {
+            const long t = (long)sg3_cdiv(P.q[g].Hp[ph], 8) * sg3_cdiv(P.q[g].Wp[ph], 8);
+            pl.tiles += t;
+            padded += t * 64;
+            real += (long)P.q[g].Hp[ph] * P.q[g].Wp[ph];
+        }
+    if (real == 0) return pl;
+    pl.waste = (double)padded / (double)real;
+    pl.ok = true;
+    return pl;
+}
+
+// The patch kernel stages each input element once per channel block instead of once per tap: it wins where a result pixel has many
+// taps (4x4 stride 1: 16) and the 8 x 8 tiles do not waste much of the map; SGAN_IGEMM3P = 0 / 1 forces the choice (tuning, tests).
+static bool sg3p_wanted(const Sg3pPlan& pl) {
+    if (!pl.ok) return false;
+    const char* force = getenv("SGAN_IGEMM3P");
+    if (force) return atoi(force) != 0;
+    if (pl.min_taps >= 9) return pl.waste < 1.6;
+    return pl.min_taps >= 4 && pl.waste < 1.3;
+}
+
+template <int BN, int A_IT>
+static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {
+    int t = 0, maxlds = 0;
+    for (int g = 0; g < P.nprob; ++g)
+        for (int ph = 0; ph < P.nphase; ++ph) {
+            P.q[g].tile0[ph] = t;
+            t += sg3_cdiv(P.q[g].Hp[ph], 8) * sg3_cdiv(P.q[g].Wp[ph], 8);
+        }
+    for (int g = 0; g < P.nprob; ++g)
+        for (int ph = P.nphase; ph < SGAN_MAX_PHASES; ++ph) P.q[g].tile0[ph] = 1 << 30;
+    if (t == 0) return SGAN_OK;
+    for (int ph = 0; ph < P.nphase; ++ph) maxlds = max(maxlds, (P.pph[ph] * sg3p_row_stride(P.ppw[ph]) + 255) & ~255);
+    P.ksplit = 1;
+    P.slab = nullptr;
+    P.slab_stride = 0;
+    dim3 grid(t * sg3_cdiv(P.N, BN), 1, 1);
+    const size_t lds = (size_t)maxlds + (size_t)2 * BN * 128 + (size_t)4 * BN * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
+    if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
+    bool pro = P.pro_act != SGAN_ACT_NONE;
+    for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
+    sg_prof_begin(st);
+    if (P.planes_f16) {
+        if (pro) hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, true, true>), grid, dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, false, true>), grid, dim3(256), lds, st, P);
+    } else {
+        if (pro) hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, true, false>), grid, dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, false, false>), grid, dim3(256), lds, st, P);
+    }
+    SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = name;
+    sg_prof_end(st, g_sgan_last_kernel);
+    return SGAN_OK;
+}
+
 int sg_launch_igemm3(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes) {
+    const Sg3pPlan pl = sg3p_plan(P);
+    if (sg3p_wanted(pl)) {
+        if (pl.a_it == 2) return sg3p_launch<64, 2>(P, st, "sg_igemm3p_kernel<64>");
+        return sg3p_launch<64, 4>(P, st, "sg_igemm3p_kernel<64>");
+    }
     const Sg3Tile t = sg3_pick_tile(P);
     if (t.BN == 32) return sg3_launch<128, 32, 4, 1>(P, st, ws, ws_bytes, "sg_igemm3_kernel<128,32,4,1>");
     if (t.BM == 128 && t.BN == 128) return sg3_launch<128, 128, 2, 4>(P, st, ws, ws_bytes, "sg_igemm3_kernel<128,128,2,4>");
@@ -561,6 +998,8 @@ int sg_launch_igemm3(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_byt
 }
 
 int64_t sg_igemm3_workspace_need(const SgIgemmParams& P) {
+    SgIgemmParams Q = P;
+    if (sg3p_wanted(sg3p_plan(Q))) return 0;
     const Sg3Tile t = sg3_pick_tile(P);
     const int ks = sg_plan_ksplit(P, t.BM, t.BN);
     return ks > 1 ? (int64_t)ks * P.q[0].Hout * P.q[0].Wout * P.N * 4 : 0;

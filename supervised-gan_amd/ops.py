@@ -322,6 +322,23 @@ def image_prep(img_u8, x0, y0, n, flip, rot, out=None):
     return out
 
 
+RESAMPLE = {"bilinear": 2, "bicubic": 3}      # Pillow's Image.BILINEAR / Image.BICUBIC
+
+
+def image_resize(img_u8, wo, ho, resample):
+    """img_u8 [H, W, C] uint8 device tensor -> [ho, wo, C] uint8: Image.resize((wo, ho), resample) bit for bit, on the device."""
+    require_gpu(img_u8, "image_resize")
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.is_contiguous(), (img_u8.shape, img_u8.dtype)
+    H, W, Cc = img_u8.shape
+    f = RESAMPLE[resample] if isinstance(resample, str) else int(resample)
+    lib = L.lib()
+    need = int(lib.sgan_image_resize_workspace(H, W, Cc, int(ho), int(wo), f))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=img_u8.device)
+    out = torch.empty((int(ho), int(wo), Cc), dtype=torch.uint8, device=img_u8.device)
+    L.check(lib.sgan_image_resize(_ptr(img_u8), H, W, Cc, _ptr(out), int(ho), int(wo), f, _ptr(ws), need, _stream()), "sgan_image_resize")
+    return out
+
+
 def gauss_down_fwd(x, Creal, g, g_chan_stride, k, pad, s, out):
     H, W, Cs = x.shape
     Ho, Wo, _ = out.shape

@@ -20,6 +20,7 @@ def ops():
     yield ops
     ops.set_math(prev)
     os.environ.pop("SGAN_TILE3", None)
+    os.environ.pop("SGAN_IGEMM3P", None)
 
 
 def _bf16_rne_bits(x):
@@ -76,20 +77,30 @@ SHAPES = [
     ("convT", 4, 2, 1, 256, 128, 16, 12, "bn", 1),
     ("convT", 4, 2, 1, 64, 32, 31, 33, "bn", 1),
     ("conv", 4, 2, 1, 24, 40, 30, 30, "in", 2),        # channel counts that are multiples of 8 but not of 32
+    ("conv", 7, 1, 3, 32, 64, 30, 41, "in", 1),        # 49 taps (resnet stem shape): a 14 x 14 patch
 ]
-TILES = ["auto", "64x64", "128x64", "128x128"]
+TILES = ["auto", "64x64", "128x64", "128x128", "patch"]
+
+
+def _select_tile(tile):
+    """SGAN_TILE3 forces a tile of sg_igemm3_kernel; "patch" forces the patch-stationary kernel wherever it is eligible."""
+    os.environ.pop("SGAN_TILE3", None)
+    os.environ.pop("SGAN_IGEMM3P", None)
+    if tile == "patch":
+        os.environ["SGAN_IGEMM3P"] = "1"
+    elif tile != "auto":
+        os.environ["SGAN_TILE3"] = tile
+        os.environ["SGAN_IGEMM3P"] = "0"
 
 
 @pytest.mark.parametrize("tile", TILES)
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"{c[0]}_k{c[1]}s{c[2]}_{c[4]}to{c[5]}_{c[6]}x{c[7]}" for c in SHAPES])
 def test_igemm3_vs_fp32_kernel_and_fp64(ops, shape, tile):
     from hip_utils import from_buf, master_weight, pad_vec, rel, stats_of, to_buf
+    from supervised_gan_amd import _lib
     kind, k, s, p, cin, cout, H, W, norm, act = shape
     tr = kind == "convT"
-    if tile == "auto":
-        os.environ.pop("SGAN_TILE3", None)
-    else:
-        os.environ["SGAN_TILE3"] = tile
+    _select_tile(tile)
     g = torch.Generator().manual_seed(99)
     x = (torch.randn(1, cin, H, W, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
     wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
@@ -118,9 +129,15 @@ def test_igemm3_vs_fp32_kernel_and_fp64(ops, shape, tile):
         ob = torch.full((Ho, Wo, cout), float("nan"), device="cuda")
         ost = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
         ops.conv_fwd(desc, xb, in_norm, wm, bb, ob, 0, ost)
+        kf = _lib.lib().sgan_last_kernel().decode()
         din = torch.full((H, W, cin), float("nan"), device="cuda")
         sums = torch.zeros(2 * cin, dtype=torch.float64, device="cuda") if norm else None
         ops.conv_dgrad(desc, Rb, wm._sgan_wt, din, xb, in_norm, sums, w_transposed=True)
+        kd = _lib.lib().sgan_last_kernel().decode()
+        if mode == "bf16x3" and tile == "patch" and cin % 32 == 0 and cout % 32 == 0 and H * W >= 256:
+            # unit-stride gathers: the forward of a stride-1 Conv2d / of any ConvTranspose2d, the backward-data of any Conv2d
+            # (result channels > 32: narrower layers keep the 128 x 32 tile of sg_igemm3_kernel)
+            assert ("igemm3p" in kf) == ((tr or s == 1) and cout > 32) and ("igemm3p" in kd) == ((not tr or s == 1) and cin > 32), (kf, kd)
         if norm:
             ops.norm_bwd_apply(din, xb, in_norm, sums)
         dw, db = torch.zeros_like(wm), torch.zeros_like(bb)
@@ -144,11 +161,12 @@ def test_igemm3_vs_fp32_kernel_and_fp64(ops, shape, tile):
     assert rel(res["bf16x3"][0], res["f32"][0]) < 3e-6
 
 
-def test_igemm3_grouped_and_splitk(ops):
+@pytest.mark.parametrize("tile", ["auto", "patch"])
+def test_igemm3_grouped_and_splitk(ops, tile):
     """Three problems of one layer type and different sizes in one grouped launch, and a deep reduction on a tiny map (split-K
     through the slab epilogue), both in split-bf16 against the exact-fp32 kernels."""
     from hip_utils import master_weight, pad_vec, rel, stats_of, to_buf
-    os.environ.pop("SGAN_TILE3", None)
+    _select_tile(tile)
     g = torch.Generator().manual_seed(3)
     cin, cout = 128, 256
     w = torch.randn(cout, cin, 4, 4, generator=g) * 0.03

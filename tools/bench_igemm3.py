@@ -103,17 +103,21 @@ def main():
             for m in a.modes.split(","):
                 ops.set_math(m)
                 for t in (tiles if m == "bf16x3" else ["-"]):
-                    if t in ("auto", "-"):
-                        os.environ.pop("SGAN_TILE3", None)
-                    else:
+                    os.environ.pop("SGAN_TILE3", None)
+                    os.environ.pop("SGAN_IGEMM3P", None)
+                    if t == "patch":
+                        os.environ["SGAN_IGEMM3P"] = "1"
+                    elif t not in ("auto", "-"):
                         os.environ["SGAN_TILE3"] = t
+                        os.environ["SGAN_IGEMM3P"] = "0"
                     us = graph_time(fns[op])
                     kn = lib.sgan_last_kernel().decode().replace("sg_", "").replace("_kernel", "")
                     cells.append(f"{us:7.1f} {gf / us * 1e3:5.0f}TF")
-                    if t in ("auto", "-"):
+                    if t in ("auto", "-", "patch"):
                         cells[-1] += f" {kn[-14:]}"
             print(f"{name:6s} {op:5s} {gf:7.3f} | " + " | ".join(cells), flush=True)
     os.environ.pop("SGAN_TILE3", None)
+    os.environ.pop("SGAN_IGEMM3P", None)
 
 
 main()

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Re-runs only the bench lines (profiles/r01_pmc_traffic.json from collect_profiles.sh + summarize_profiles.py must exist,
+# Re-runs only the bench lines (profiles/<round>_pmc_traffic.json from collect_profiles.sh + summarize_profiles.py must exist,
 # bench.py reads the dominant kernel's HBM traffic from it).
 set -o pipefail
-OUT=gpurun_out/r01
+R=${ROUND:-r02}
+OUT=gpurun_out/$R
 mkdir -p $OUT
 echo "== bench (default flags)"; timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
 echo "== bench --skip_wasted_D_wgrad"; timeout -k 10 300 python bench.py --skip_wasted_D_wgrad --no_cpu_baseline > $OUT/bench_skip.json 2>> $OUT/bench.err; echo "exit $?"

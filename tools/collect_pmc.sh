@@ -1,6 +1,7 @@
 #!/bin/bash
 set -o pipefail
-OUT=gpurun_out/r01
+R=${ROUND:-r02}
+OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 echo "== eager single-stream bench under rocprofv3 (regime of the live per-kernel measurement)"

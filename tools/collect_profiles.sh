@@ -1,8 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): the bench lines and the rocprofv3 evidence for them.  Everything lands in
-# gpurun_out/r01/ ; tools/summarize_profiles.py copies the summaries to keep into profiles/.
+# gpurun_out/<round>/ ; tools/summarize_profiles.py copies the summaries to keep into profiles/.
 set -o pipefail
-OUT=gpurun_out/r01
+R=${ROUND:-r02}
+OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 echo "== bench (default flags)"; timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"

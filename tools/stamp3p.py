@@ -1,0 +1,66 @@
+"""Diagnostics: per-workgroup phase times of sg_igemm3p_kernel from a -DSG3P_STAMP build of the library (tools/stamp3p.sh)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from supervised_gan_amd import _lib, ops  # noqa: E402
+from hip_utils import derived_copies  # noqa: E402
+
+op, nprob = sys.argv[1], int(sys.argv[2])
+k, s, p, cin, cout = 4, 1, 2, 128, 256
+sizes = [65, 33, 17] * (nprob // 3)
+os.environ["SGAN_IGEMM3P"] = "1"
+ops.set_math("bf16x3")
+w = torch.randn(k * k * cout * cin, device="cuda") * 0.05
+wm, wt = derived_copies(w, k, cout, cin)
+b = torch.randn(cout, device="cuda")
+jf, jd, keep = [], [], []
+for H in sizes:
+    Ho = H + 1
+    x = torch.randn(H, H, cin, device="cuda"); y = torch.empty(Ho, Ho, cout, device="cuda"); r = torch.randn(Ho, Ho, cout, device="cuda")
+    dx = torch.empty(H, H, cin, device="cuda")
+    st_in = torch.zeros(2 * cin, dtype=torch.float64, device="cuda"); st_in[cin:] = H * H
+    st_out = torch.zeros(2 * cout, dtype=torch.float64, device="cuda"); sums = torch.zeros(2 * cin, dtype=torch.float64, device="cuda")
+    nrm = ops.norm_desc(st_in, None, None, H * H, 1e-5, 2, 0.2)
+    desc = ops.conv_desc(0, k, s, p, H, H, cin, Ho, Ho, cout)
+    jf.append((desc, x, nrm, wm, b, y, st_out)); jd.append((desc, r, wt, dx, x, nrm, sums, 0, False, True))
+    keep.append((x, y, r, dx, st_in, st_out, sums, nrm, desc))
+fn = (lambda: ops.conv_fwd_grouped(jf)) if op == "fwd" else (lambda: ops.conv_dgrad_grouped(jd))
+for _ in range(5):
+    fn()
+torch.cuda.synchronize()
+buf = np.zeros(8 * 4096, dtype=np.uint64)
+lib = _lib.lib()
+lib.sgan_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+assert lib.sgan_debug_stamps(buf.ctypes.data, buf.size) == 0
+st = buf.reshape(4096, 8)
+st = st[st[:, 0] > 0].astype(np.int64)
+print(op, "workgroups stamped:", len(st))
+d = np.diff(st[:, :5], axis=1)
+names = ["setup (tap table, scale/shift, barrier)", "first patch + weight tile", "tap loop", "epilogue"]
+for i, n in enumerate(names):
+    print(f"  {n:42s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f} cycles")
+tot = st[:, 4] - st[:, 0]
+print(f"  workgroup total median {np.median(tot):.0f} cycles")
+rt0 = st[:, 6].min()
+start = (st[:, 6] - rt0) / 100.0
+end = (st[:, 7] - rt0) / 100.0
+print(f"  start times (us): p50 {np.median(start):.1f} p90 {np.percentile(start, 90):.1f} max {start.max():.1f};  end max {end.max():.1f};  WG duration us median {np.median(end - start):.1f}")
+late = start > 3.0
+print(f"  workgroups starting later than 3 us after the first: {late.sum()} (second round)")
+
+if hasattr(lib, "sgan_debug_phases"):
+    lib.sgan_debug_phases.argtypes = [C.c_void_p, C.c_int]
+    pb = np.zeros(8 * 4096, dtype=np.uint64)
+    assert lib.sgan_debug_phases(pb.ctypes.data, pb.size) == 0
+    ph = pb.reshape(4096, 8).astype(np.float64)
+    ph = ph[ph[:, 5] > 0]
+    per = ph[:, :5] / ph[:, 5:6]
+    for i, n in enumerate(["frag reads issued+returned", "vmcnt wait + weight-tile LDS stores", "6 MFMAs issued", "next weight addresses", "boundary + barrier"]):
+        print(f"  loop phase {n:38s} median {np.median(per[:, i]):7.0f} cycles / unit (stamp cost ~40 included)")

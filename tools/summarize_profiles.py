@@ -1,7 +1,7 @@
-"""gpurun_out/r01/* (bench lines + rocprofv3 CSVs) -> profiles/r01_* (small, committed)."""
+"""gpurun_out/<round>/* (bench lines + rocprofv3 CSVs) -> profiles/<round>_* (small, committed).   python tools/summarize_profiles.py r02"""
 import collections, csv, glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -16,6 +16,12 @@ def short(name):
     merged: the prologue flag of sg_igemm / sg_wgrad, the layout flag of sg_conv_small_n)."""
     n = name.split("(")[0].replace("void ", "").replace(" ", "")
     m = re.match(r"(sg_igemm_kernel)<(\d+,\d+,\d+,\d+,(?:true|false)),(?:true|false)(?:,\d+)?>$", n)   # prologue flag, wave groups
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"(sg_igemm3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false),(?:true|false)>$", n)   # prologue flag, fp16 / bf16 planes
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"(sg_wgrad3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false)>$", n)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
     m = re.match(r"(sg_wgrad_kernel)<(.*),(true|false)>$", n)

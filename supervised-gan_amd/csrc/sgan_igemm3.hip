@@ -507,13 +507,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
 //    16-byte slots at any tap offset;
 //  * per tap the A fragments are read straight out of the patch at a per-tap byte offset (no copy); only the weight tile
 //    [BN][32 k] of (tap, channel block) is staged per step, a plain 16-byte copy of the packed rows through a register ring;
-//  * one barrier per tap; at a channel-block boundary one more around the patch store (its loads were issued a block ahead).
+//  * one barrier per tap, the LDS reads of the next tap issued between the two MFMA halves of the current one; at a channel-
+//    block boundary one more barrier behind the patch store (its loads were issued a block ahead).
 // Same prologue / epilogue / packed weights / problem grouping as sg_igemm3_kernel; rectangular tiles waste the ragged edge
 // (66 x 66 result: 81 tiles for 68 tiles' worth of pixels), which the dispatcher prices in.
 // ------------------------------------------------------------------------------------------
 #define SG3P_PS 144
 #ifndef SG3P_ABL
-#define SG3P_ABL 0   // diagnostics builds only (wrong results): 1 no weight loads, 2 no weight LDS stores, 4 no fragment reads, 8 no MFMA, 16 no per-tap barrier
+#define SG3P_ABL 0   // diagnostics builds only (wrong results, tools/abl3p.sh): 1 no weight loads, 2 no weight LDS stores
 #endif
 __host__ __device__ __forceinline__ int sg3p_row_stride(int ppw) { return ((ppw * SG3P_PS + 127) & ~255) + 128; }
 
@@ -534,16 +535,6 @@ extern "C" int sgan_debug_stamps(void* dst, int n) {
 }
 #else
 #define SG3P_MARK(i)
-#endif
-#ifdef SG3P_STAMP2     // diagnostics build: cycles per phase of the tap loop, summed over the units of a workgroup (wave 0)
-__device__ unsigned long long sg3p_phase[8 * 4096];
-#define SG3P_T(var)                                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                     \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                            \
-    __builtin_amdgcn_sched_barrier(0);
-extern "C" int sgan_debug_phases(void* dst, int n) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sg3p_phase), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
-}
 #endif
 
 template <int BN, int A_IT, bool PRO, bool F16>
@@ -612,27 +603,24 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
         }
     }
 
-    // ---- patch staging: item e = 4 * patch pixel + k-group (8 channels = two 16-byte loads -> one hi and one lo chunk).  Runs once
-    // per channel block, so the per-item addresses are recomputed there instead of living in registers across the tap loop. ----
+    // ---- patch staging: item e = 4 * patch pixel + k-group (8 channels = two 16-byte loads -> one hi and one lo chunk) ----
     const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
     const int kg = tid & 3;
-    auto a_item = [&](int it, int& goff, int& dst, bool& ok, bool& use) {
+    int a_goff[A_IT], a_dst[A_IT];     // a_goff == OOB: outside the input (zero after the transform); a_dst < 0: no such patch pixel
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
         const int p = (tid + it * NT) >> 2;
         const int pr = p / PW, pc = p - pr * PW;
         const int iy = (ty0 + pr) * P.is + dy0, ix = (tx0 + pc) * P.is + dx0;
-        use = p < npix;
-        ok = use & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
-        goff = ((iy * P.Win + ix) * P.in_ld + kg * 8) << 2;
-        dst = pr * RS + pc * SG3P_PS + kg * 32;
-    };
+        const bool ok = (p < npix) & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
+        a_goff[it] = ok ? ((iy * P.Win + ix) * P.in_ld + kg * 8) << 2 : OOB;
+        a_dst[it] = p < npix ? pr * RS + pc * SG3P_PS + kg * 32 : -1;
+    }
     f32x4 a_reg[A_IT][2];
     auto issue_a = [&](int cb) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            int goff, dst;
-            bool ok, use;
-            a_item(it, goff, dst, ok, use);
-            const int o = (ok & (cb < ncb)) ? goff + cb * 128 : OOB;     // past the last block: zeros, never used
+            const int o = ((a_goff[it] != OOB) & (cb < ncb)) ? a_goff[it] + cb * 128 : OOB;     // past the last block: zeros, never used
             a_reg[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o, 0, 0));
             a_reg[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o + 16, 0, 0));
         }
@@ -640,15 +628,12 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
     auto store_a = [&](int cb) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            int goff, dst;
-            bool ok, use;
-            a_item(it, goff, dst, ok, use);
             f32x4 v0 = a_reg[it][0], v1 = a_reg[it][1];
             if constexpr (PRO) {   // zero padding applies AFTER norm + activation (see sg_igemm3_kernel)
                 const int c = cb * 32 + kg * 8;
                 const f32x4 sc0 = *reinterpret_cast<const f32x4*>(pscale + c), sc1 = *reinterpret_cast<const f32x4*>(pscale + c + 4);
                 const f32x4 sh0 = *reinterpret_cast<const f32x4*>(pshift + c), sh1 = *reinterpret_cast<const f32x4*>(pshift + c + 4);
-                const float okf = ok ? 1.f : 0.f;
+                const float okf = a_goff[it] != OOB ? 1.f : 0.f;
                 const float okn = okf * pro_neg;
                 const f32x4 y0 = v0 * sc0 + sh0, y1 = v1 * sc1 + sh1;
                 const f32x4 p0 = y0 * okf, q0 = y0 * okn, p1 = y1 * okf, q1 = y1 * okn;
@@ -657,9 +642,9 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
             }
             u32x4 hi, lo;
             sg_split8<F16>(v0, v1, hi, lo);
-            if (use) {
-                *reinterpret_cast<u32x4*>(Ap + dst) = hi;
-                *reinterpret_cast<u32x4*>(Ap + dst + 16) = lo;
+            if (a_dst[it] >= 0) {
+                *reinterpret_cast<u32x4*>(Ap + a_dst[it]) = hi;
+                *reinterpret_cast<u32x4*>(Ap + a_dst[it] + 16) = lo;
             }
         }
     };
@@ -722,78 +707,60 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
     __syncthreads();   // tap table, scale / shift visible
     SG3P_MARK(1);
 
+    // Step u = (channel block cur_cb, tap cur_tap); its weight tile lives in LDS buffer u & 1 and register slot u % 4.  Order
+    // inside a step (a wave issues in order; pinned with sched_barrier), software-pipelined by k16 halves so that the LDS reads of
+    // step u + 1 run under the MFMAs of step u and the first MFMA after the barrier never waits:
+    //   MFMA half 0 of u | [last tap of a block: store the next patch, barrier] | fragment reads half 0 of u + 1 |
+    //   MFMA half 1 of u | fragment reads half 1 of u + 1 | weight tile of u + 2: registers -> LDS buffer u & 1 (step u's fragments
+    //   left it one step ago) | global loads of the tile of u + 6 into the slot just stored | barrier.
+    // In-kernel stamps of the unpipelined order (reads, then MFMAs, per step): ~370 cycles of fragment reads, ~190 of MFMA
+    // issue and ~350 at the barrier per 64x64x32 step, whether the workgroup shares its CU or not.
     int cur_tap = 0, cur_cb = 0;
-    int tapoff = ttab[0].x;
-#ifdef SG3P_STAMP2
-    unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0};
-#endif
+    u32x4 ah[2], al[2], bh[2][NB], bl[2][NB];
+    auto read_half = [&](auto H_, const char* Ab, const char* Bb) {
+        constexpr int s = decltype(H_)::value;
+        ah[s] = *reinterpret_cast<const u32x4*>(Ab + s * 64);
+        al[s] = *reinterpret_cast<const u32x4*>(Ab + s * 64 + 16);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            bh[s][j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * 128 + f_off[s][0]);
+            bl[s][j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * 128 + f_off[s][1]);
+        }
+    };
+    auto mfma_half = [&](auto H_) {
+        constexpr int s = decltype(H_)::value;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            acc[0][j] = sg3_mfma<F16>(al[s], bh[s][j], acc[0][j]);
+            acc[0][j] = sg3_mfma<F16>(ah[s], bl[s][j], acc[0][j]);
+            acc[0][j] = sg3_mfma<F16>(ah[s], bh[s][j], acc[0][j]);
+        }
+    };
     auto iteration = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
-#ifdef SG3P_STAMP2
-        unsigned long long q0, q1, q2, q3, q4, q5;
-        SG3P_T(q0)
-#endif
-        const char* Ab = Ap + fa_base + tapoff;
-        const char* Bb = Bs + (S & 1) * BN * 128 + fb_row;
-        issue_b(std::integral_constant<int, S>{});
-        u32x4 ah[2], al[2], bh[2][NB], bl[2][NB];
-        if constexpr (SG3P_ABL & 4) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                ah[s] = b_reg[0][0]; al[s] = b_reg[1][0];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) { bh[s][j] = b_reg[2][0]; bl[s][j] = b_reg[3][0]; }
-            }
-        } else
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            ah[s] = *reinterpret_cast<const u32x4*>(Ab + s * 64);
-            al[s] = *reinterpret_cast<const u32x4*>(Ab + s * 64 + 16);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                bh[s][j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * 128 + f_off[s][0]);
-                bl[s][j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * 128 + f_off[s][1]);
-            }
-        }
+        mfma_half(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
         ++cur_tap;
-        const bool wrap = cur_tap == ntaps;
-        if (wrap) { cur_tap = 0; ++cur_cb; }
-        tapoff = ttab[cur_tap].x;
-#ifdef SG3P_STAMP2
-        SG3P_T(q1)      // fragment reads issued AND returned (the stamp drains lgkmcnt)
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        store_b(std::integral_constant<int, (S + 1) % NSET>{});
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef SG3P_STAMP2
-        SG3P_T(q2)      // weight tile of the next step in LDS (vmcnt wait + 2 stores)
-#endif
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if constexpr (SG3P_ABL & 8) { acc[0][j][0] += __builtin_bit_cast(f32x4, al[s])[0] + __builtin_bit_cast(f32x4, ah[s])[1] + __builtin_bit_cast(f32x4, bl[s][j])[2] + __builtin_bit_cast(f32x4, bh[s][j])[3]; continue; }
-                acc[0][j] = sg3_mfma<F16>(al[s], bh[s][j], acc[0][j]);
-                acc[0][j] = sg3_mfma<F16>(ah[s], bl[s][j], acc[0][j]);
-                acc[0][j] = sg3_mfma<F16>(ah[s], bh[s][j], acc[0][j]);
+        if (cur_tap == ntaps) {
+            cur_tap = 0;
+            ++cur_cb;
+            if (cur_cb < ncb) {       // nobody reads the old patch any more (the reads of this step were issued a step ago)
+                store_a(cur_cb);
+                issue_a(cur_cb + 1);
+                __syncthreads();
             }
-#ifdef SG3P_STAMP2
-        SG3P_T(q3)      // MFMAs issued
-#endif
-        next_b_addrs();
-#ifdef SG3P_STAMP2
-        SG3P_T(q4)
-#endif
-        if (wrap && cur_cb < ncb) {       // channel-block boundary: every wave is done with the patch -> replace it
-            __syncthreads();
-            store_a(cur_cb);
-            issue_a(cur_cb + 1);
         }
-        if constexpr (!(SG3P_ABL & 16)) __syncthreads();
-#ifdef SG3P_STAMP2
-        SG3P_T(q5)
-        ph_acc[0] += q1 - q0; ph_acc[1] += q2 - q1; ph_acc[2] += q3 - q2; ph_acc[3] += q4 - q3; ph_acc[4] += q5 - q4; ph_acc[5] += 1;
-#endif
+        const char* Ab = Ap + fa_base + ttab[cur_tap].x;
+        const char* Bb = Bs + ((S + 1) & 1) * BN * 128 + fb_row;
+        read_half(std::integral_constant<int, 0>{}, Ab, Bb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(std::integral_constant<int, 1>{}, Ab, Bb);
+        store_b(std::integral_constant<int, (S + 2) % NSET>{});
+        issue_b(std::integral_constant<int, (S + 2) % NSET>{});
+        next_b_addrs();
+        __syncthreads();
     };
     auto prefetch = [&](auto K_) { next_b_addrs(); issue_b(K_); };
     auto maybe = [&](auto K_, int u) { if (u + decltype(K_)::value < nunits) iteration(K_); };
@@ -801,11 +768,19 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
     issue_a(0);
     prefetch(std::integral_constant<int, 0>{}); prefetch(std::integral_constant<int, 1>{});
     prefetch(std::integral_constant<int, 2>{}); prefetch(std::integral_constant<int, 3>{});
-    next_b_addrs();
     store_a(0);
     issue_a(1);
-    store_b(std::integral_constant<int, 0>{});
+    store_b(std::integral_constant<int, 0>{});      // step 0 -> buffer 0, step 1 -> buffer 1; their slots take steps 4 and 5
+    prefetch(std::integral_constant<int, 0>{});
+    store_b(std::integral_constant<int, 1>{});
+    prefetch(std::integral_constant<int, 1>{});
+    next_b_addrs();
     __syncthreads();
+    {
+        const char* Ab = Ap + fa_base + ttab[0].x;
+        read_half(std::integral_constant<int, 0>{}, Ab, Bs + fb_row);
+        read_half(std::integral_constant<int, 1>{}, Ab, Bs + fb_row);
+    }
     SG3P_MARK(2);
     {
         int u = 0;
@@ -817,10 +792,6 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
         maybe(std::integral_constant<int, 2>{}, u);
     }
     SG3P_MARK(3);
-#ifdef SG3P_STAMP2
-    if (threadIdx.x == 0 && blockIdx.x < 4096)
-        for (int i = 0; i < 6; ++i) sg3p_phase[blockIdx.x * 8 + i] = ph_acc[i];
-#endif
 
     sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, 0, n0, wm, wn, tid, [&](int row) -> int64_t {
         const int py = ty0 + (row >> 3), px = tx0 + (row & 7);

@@ -8,8 +8,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 name, op, mode, tile = sys.argv[1:5]
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 5
-if tile != "auto":
+if tile == "patch":
+    os.environ["SGAN_IGEMM3P"] = "1"
+elif tile != "auto":
     os.environ["SGAN_TILE3"] = tile
+    os.environ["SGAN_IGEMM3P"] = "0"
 import torch  # noqa: E402
 
 from supervised_gan_amd import ops  # noqa: E402

@@ -55,12 +55,3 @@ print(f"  start times (us): p50 {np.median(start):.1f} p90 {np.percentile(start,
 late = start > 3.0
 print(f"  workgroups starting later than 3 us after the first: {late.sum()} (second round)")
 
-if hasattr(lib, "sgan_debug_phases"):
-    lib.sgan_debug_phases.argtypes = [C.c_void_p, C.c_int]
-    pb = np.zeros(8 * 4096, dtype=np.uint64)
-    assert lib.sgan_debug_phases(pb.ctypes.data, pb.size) == 0
-    ph = pb.reshape(4096, 8).astype(np.float64)
-    ph = ph[ph[:, 5] > 0]
-    per = ph[:, :5] / ph[:, 5:6]
-    for i, n in enumerate(["frag reads issued+returned", "vmcnt wait + weight-tile LDS stores", "6 MFMAs issued", "next weight addresses", "boundary + barrier"]):
-        print(f"  loop phase {n:38s} median {np.median(per[:, i]):7.0f} cycles / unit (stamp cost ~40 included)")

@@ -273,17 +273,20 @@ int sgan_gan_loss_bwd(const float* logits, int32_t ld, int32_t npix, float targe
 
 /* ---- every GAN-loss term of one backward pass at once ----------------------------------------------
  * total = sum_i weight_i * loss_i over up to 8 logits maps, loss_i as sgan_gan_loss_fwd computes it;
- * each_out[i] = loss_i (for logging).  The backward writes dlogits_i = gout * weight_i * dloss_i/dx.
+ * each_out[i] = loss_i (for logging).  A forward job with a `dlogits` buffer also gets dlogits_i = weight_i * dloss_i/dx, the
+ * gradient for an upstream gradient of 1 (the trainers call backward() on `total` itself); the backward entry point writes
+ * dlogits_i = gout * weight_i * dloss_i/dx for any other upstream gradient.
  * Replaces the per-discriminator GANLoss calls plus the scalar arithmetic the trainers wrap around them:
  * (loss_D_fake + loss_D_real) * 0.5 and sum_i lambda_i * loss_i (models/fcgan_model.py:150-176). */
 typedef struct sgan_gan_loss_job {
     const float* logits; int32_t ld; int32_t npix;
     float target; float weight;
-    float* dlogits; int32_t dld;   /* backward only */
+    float* dlogits; int32_t dld;   /* forward: optional (unit-gradient result); backward: required */
 } sgan_gan_loss_job;
-/* `workspace`: SGAN_GAN_LOSS_WS_BYTES of 8-byte aligned device scratch (uninitialised is fine): the terms are reduced by
- * several workgroups each and finished by a second kernel. */
-#define SGAN_GAN_LOSS_WS_BYTES 1024
+/* `workspace`: SGAN_GAN_LOSS_WS_BYTES of 8-byte aligned device scratch, ZERO on first use and owned by one stream at a time: the
+ * terms are reduced by several workgroups each, the last one to arrive (a ticket counter at the end of the scratch) finishes
+ * and leaves the counter at zero again -- one launch, no fill per call. */
+#define SGAN_GAN_LOSS_WS_BYTES 2048
 int sgan_gan_loss_multi_fwd(const sgan_gan_loss_job* jobs, int32_t n, int32_t mode, float* each_out, float* total_out,
                             void* workspace, int64_t workspace_bytes, void* stream);
 int sgan_gan_loss_multi_bwd(const sgan_gan_loss_job* jobs, int32_t n, int32_t mode, const float* gout, void* stream);
@@ -415,6 +418,10 @@ int sgan_sgd_multi(const sgan_adam_seg* segs, int32_t nseg, const float* lr_dev,
  * seeds are independent streams, so a net that draws several tensors per forward pass reads one offset (advance = 0) and
  * moves it once with sgan_rng_advance. */
 int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, int32_t advance, void* stream);
+/* The same values as sgan_normal_fill on a contiguous [C][H][W] tensor, written where the generator reads them: element (c, h, w)
+ * at dst[(h * W + w) * Cs + c] of a padded NHWC buffer (channels C .. Cs-1 are not touched: zero them once). */
+int sgan_normal_fill_nhwc(float* dst, int32_t C, int32_t H, int32_t W, int32_t Cs, uint64_t seed, uint64_t* offset_dev,
+                          int32_t advance, void* stream);
 int sgan_rng_advance(uint64_t* offset_dev, uint64_t by, void* stream);
 
 #ifdef __cplusplus

@@ -116,6 +116,7 @@ SIGNATURES = {
     "sgan_adam_multi": [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _P, _P],
     "sgan_sgd_multi": [C.POINTER(AdamSeg), _I, _P, _F, _P],
     "sgan_normal_fill": [_P, _L, C.c_uint64, _P, _I, _P],
+    "sgan_normal_fill_nhwc": [_P, _I, _I, _I, _I, C.c_uint64, _P, _I, _P],
     "sgan_profile_enable": [_I],
     "sgan_profile_count": [],
     "sgan_profile_mark": [_P],

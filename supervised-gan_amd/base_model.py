@@ -8,6 +8,8 @@ from collections import OrderedDict
 
 import torch
 
+from . import ops
+
 
 class BaseModel:
     def name(self):
@@ -29,6 +31,7 @@ class BaseModel:
         one = getattr(self, '_grad_one', None)
         if one is None or one.device != loss.device or one.shape != loss.shape:
             one = self._grad_one = torch.ones_like(loss)
+            ops.UNIT_GRADS.add(one.data_ptr())      # fused loss nodes skip the rescaling of their gradients for this tensor
         loss.backward(one)
 
     def set_input(self, input):

@@ -1375,7 +1375,7 @@ extern "C" int sgan_gan_loss_bwd(const float* logits, int32_t ld, int32_t npix, 
 }
 
 // ------------------------------------------------------------------------------------------
-// All GAN-loss terms of one backward pass in two launches: total = sum_i weight_i * loss_i over up to 8
+// All GAN-loss terms of one backward pass in one launch: total = sum_i weight_i * loss_i over up to 8
 // logits maps (the three discriminators on the fake and the real batch), each term as in sg_gan_loss_*.
 // Replaces the per-term Sigmoid+BCELoss modules AND the scalar adds/muls the trainers build around them
 // ((fake + real) * 0.5, * lambda_D: models/fcgan_model.py:150-176).
@@ -1389,16 +1389,21 @@ struct SgLossMulti {
 };
 
 // The log / exp arithmetic of a few 67x67 maps keeps a single CU busy for ~20 us, so the terms are spread over
-// SG_LOSS_BLOCKS workgroups each: block (b, j) leaves the fp64 partial sum of its slice of term j in `part`, and a second,
-// one-wave kernel turns the partials into each[] and the weighted total (a kernel boundary is the cheapest device-wide
-// release/acquire there is; no atomics, no zero-initialised scratch).
+// SG_LOSS_BLOCKS workgroups each: block (b, j) leaves the fp64 partial sum of its slice of term j in `part` and, where the
+// job carries a gradient buffer, writes d total / d logits of its slice (for an upstream gradient of 1: the total is the scalar
+// the trainers call backward() on).  The workgroup that arrives last at the counter behind `part` turns the partials into
+// each[] and the weighted total and leaves the counter at zero for the next call: one launch, no zero fill per call.
 #define SG_LOSS_BLOCKS 16
-__global__ __launch_bounds__(256) void sg_gan_loss_multi_fwd_kernel(SgLossMulti J, double* part) {
+__global__ __launch_bounds__(256) void sg_gan_loss_multi_fwd_kernel(SgLossMulti J, double* part, unsigned* counter, float* each, float* total) {
     __shared__ double wsum[4];
+    __shared__ int last;
     const int j = blockIdx.y, b = blockIdx.x;
     const float tg = J.target[j];
     const int np = J.npix[j], ld = J.ld[j];
     const float* lg = J.logits[j];
+    float* dl = J.dlogits[j];
+    const int dld = J.dld[j];
+    const float go = J.weight[j] / (float)np;
     double acc = 0.0;
     for (int i0 = b * 256 + threadIdx.x; i0 < np; i0 += SG_LOSS_BLOCKS * 256 * 4) {
         float xs[4];
@@ -1409,39 +1414,55 @@ __global__ __launch_bounds__(256) void sg_gan_loss_multi_fwd_kernel(SgLossMulti 
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i0 + u * SG_LOSS_BLOCKS * 256 >= np) break;
+            const int i = i0 + u * SG_LOSS_BLOCKS * 256;
+            if (i >= np) break;
             const float x = xs[u];
-            float l;
+            float l, d;
             if (J.mode == 0) {
                 const float p = sg_sigmoid(x);
                 const float lp = fmaxf(logf(p), -100.f);
                 const float lq = fmaxf(log1pf(-p), -100.f);
                 l = -(tg * lp + (1.f - tg) * lq);
+                const float pq = (1.f - p) * p;
+                d = (p - tg) / fmaxf(pq, 1e-12f) * go * pq;     // the same expression as sg_gan_loss_multi_bwd_kernel
             } else {
-                const float d = x - tg;
-                l = d * d;
+                const float df = x - tg;
+                l = df * df;
+                d = 2.f * df * go;
             }
             acc += (double)l;
+            if (dl) {
+                float* o = dl + (int64_t)i * dld;
+                o[0] = d;
+                for (int c = 1; c < dld; ++c) o[c] = 0.f;
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) part[j * SG_LOSS_BLOCKS + b] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-}
-
-__global__ __launch_bounds__(64) void sg_gan_loss_multi_fin_kernel(SgLossMulti J, const double* part, float* each, float* total) {
+    if (threadIdx.x == 0) {
+        part[j * SG_LOSS_BLOCKS + b] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        __threadfence();                                     // the partial is out before the ticket is taken
+        last = atomicAdd(counter, 1u) == (unsigned)(SG_LOSS_BLOCKS * J.n - 1);
+    }
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    __threadfence();                                         // every other workgroup's partial is visible from here on
     const int t = threadIdx.x;
     double w = 0.0;
     if (t < J.n) {
         double sum = 0.0;
-        for (int b = 0; b < SG_LOSS_BLOCKS; ++b) sum += part[t * SG_LOSS_BLOCKS + b];
+        for (int bb = 0; bb < SG_LOSS_BLOCKS; ++bb) sum += __builtin_nontemporal_load(&part[t * SG_LOSS_BLOCKS + bb]);
         const float m = (float)(sum / (double)J.npix[t]);
         each[t] = m;
         w = (double)J.weight[t] * (double)m;
     }
     for (int off = 4; off > 0; off >>= 1) w += __shfl_xor(w, off);   // n <= 8 terms sit in lanes 0..7
-    if (t == 0) total[0] = (float)w;
+    if (t == 0) {
+        total[0] = (float)w;
+        counter[0] = 0u;
+    }
 }
 
 __global__ __launch_bounds__(256) void sg_gan_loss_multi_bwd_kernel(SgLossMulti J, const float* gout) {
@@ -1482,14 +1503,15 @@ extern "C" int sgan_gan_loss_multi_fwd(const sgan_gan_loss_job* jobs, int32_t n,
     SgLossMulti J;
     int rc = sg_fill_loss(J, jobs, n, mode, false);
     if (rc) return rc;
+    for (int i = 0; i < n; ++i) SGAN_CHECK(!jobs[i].dlogits || jobs[i].dld >= 1, "bad gradient leading dimension of loss job %d", i);
     SGAN_CHECK(each_out && total_out, "null output");
     SGAN_CHECK(workspace && workspace_bytes >= SGAN_GAN_LOSS_WS_BYTES && ((uintptr_t)workspace & 7) == 0,
                "workspace of SGAN_GAN_LOSS_WS_BYTES (8-byte aligned) required");
-    static_assert(8 * SG_LOSS_BLOCKS * sizeof(double) <= SGAN_GAN_LOSS_WS_BYTES, "workspace size");
+    static_assert((8 * SG_LOSS_BLOCKS + 1) * sizeof(double) <= SGAN_GAN_LOSS_WS_BYTES, "workspace size");
     double* part = static_cast<double*>(workspace);
-    hipLaunchKernelGGL(sg_gan_loss_multi_fwd_kernel, dim3(SG_LOSS_BLOCKS, n), dim3(256), 0, (hipStream_t)stream, J, part);
-    SGAN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sg_gan_loss_multi_fin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, J, part, each_out, total_out);
+    unsigned* counter = reinterpret_cast<unsigned*>(part + 8 * SG_LOSS_BLOCKS);
+    hipLaunchKernelGGL(sg_gan_loss_multi_fwd_kernel, dim3(SG_LOSS_BLOCKS, n), dim3(256), 0, (hipStream_t)stream, J, part, counter, each_out,
+                       total_out);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
 }
@@ -1745,7 +1767,9 @@ __device__ __forceinline__ void sg_philox(uint32_t c0, uint32_t c1, uint32_t c2,
 }
 
 // advance_by != 0 (single-block launches only): the block moves the stream offset itself once every thread has read it
-__global__ __launch_bounds__(256) void sg_normal_fill_kernel(float* dst, int64_t n, uint64_t seed, uint64_t* offset, uint64_t advance_by) {
+// cs != 0: element i of the logical [C][H][W] tensor goes to the NHWC buffer position (i % hw) * cs + i / hw
+__global__ __launch_bounds__(256) void sg_normal_fill_kernel(float* dst, int64_t n, uint64_t seed, uint64_t* offset, uint64_t advance_by,
+                                                             int hw, int cs) {
     const uint64_t off = offset ? offset[0] : 0;
     if (advance_by) {
         __syncthreads();
@@ -1767,8 +1791,10 @@ __global__ __launch_bounds__(256) void sg_normal_fill_kernel(float* dst, int64_t
             z[2 * h] = rad * cs;
             z[2 * h + 1] = rad * sn;
         }
-        for (int j = 0; j < 4; ++j)
-            if (q * 4 + j < n) dst[q * 4 + j] = z[j];
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = q * 4 + j;
+            if (i < n) dst[cs ? (i % hw) * cs + i / hw : i] = z[j];
+        }
     }
 }
 
@@ -1809,23 +1835,33 @@ extern "C" int sgan_dropout_mask(float* mask, int64_t n, float p, uint64_t seed,
     return SGAN_OK;
 }
 
-extern "C" int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, int32_t advance, void* stream) {
-    SGAN_CHECK(dst && n > 0, "bad argument");
+static int sg_normal_fill_launch(float* dst, int64_t n, int hw, int cs, uint64_t seed, uint64_t* offset_dev, int32_t advance, void* stream) {
     const int64_t nq = (n + 3) >> 2;
     int blocks = ew_cdiv(nq, 256);
     if (blocks > 1024) blocks = 1024;
     hipStream_t st = (hipStream_t)stream;
     if (!advance) {
-        hipLaunchKernelGGL(sg_normal_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, n, seed, offset_dev, (uint64_t)0);
+        hipLaunchKernelGGL(sg_normal_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, n, seed, offset_dev, (uint64_t)0, hw, cs);
         SGAN_LAUNCH_CHECK();
         return SGAN_OK;
     }
     const bool self_advance = offset_dev && blocks == 1;
-    hipLaunchKernelGGL(sg_normal_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, n, seed, offset_dev, self_advance ? (uint64_t)nq : 0);
+    hipLaunchKernelGGL(sg_normal_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, n, seed, offset_dev, self_advance ? (uint64_t)nq : 0, hw, cs);
     SGAN_LAUNCH_CHECK();
     if (offset_dev && !self_advance) {
         hipLaunchKernelGGL(sg_rng_advance_kernel, dim3(1), dim3(1), 0, st, offset_dev, (uint64_t)nq);
         SGAN_LAUNCH_CHECK();
     }
     return SGAN_OK;
+}
+
+extern "C" int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, int32_t advance, void* stream) {
+    SGAN_CHECK(dst && n > 0, "bad argument");
+    return sg_normal_fill_launch(dst, n, 1, 0, seed, offset_dev, advance, stream);
+}
+
+extern "C" int sgan_normal_fill_nhwc(float* dst, int32_t C, int32_t H, int32_t W, int32_t Cs, uint64_t seed, uint64_t* offset_dev,
+                                     int32_t advance, void* stream) {
+    SGAN_CHECK(dst && C > 0 && H > 0 && W > 0 && Cs >= C, "bad argument");
+    return sg_normal_fill_launch(dst, (int64_t)C * H * W, H * W, Cs, seed, offset_dev, advance, stream);
 }

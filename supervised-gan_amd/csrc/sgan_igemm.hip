@@ -410,6 +410,26 @@ __global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams 
         return;
     }
     const bool dact = P.xref != nullptr;
+    // the forward tensor at the result positions, every load in flight before the first store (which may alias it as far as the
+    // compiler knows: element by element each load would wait out a memory round trip behind the previous store)
+    float xv[NB][MB][4];
+    if (dact) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * WTM + i * 16 + fq * 4 + r;
+                    const int n = n0 + wn * WTN + j * 16 + fr;
+                    float x = 0.f;
+                    if (m < M && n < N) {
+                        const int py = m / Wp, px = m - py * Wp;
+                        x = P.xref[((int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob)) * P.xref_ld + n];
+                    }
+                    xv[j][i][r] = x;
+                }
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int nl = wn * WTN + j * 16 + fr;
@@ -435,7 +455,7 @@ __global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams 
                     const int64_t pix = (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);
                     float v = acc[i][j][r] + bias_v;
                     if (dact) {
-                        const float x = P.xref[pix * P.xref_ld + n];
+                        const float x = xv[j][i][r];
                         const float xhat = (x - x_mean) * x_rstd;
                         const float y = xnorm ? (x_g * xhat + x_b) : x;
                         v *= (y > 0.f ? 1.f : xn_neg);

@@ -127,6 +127,20 @@ __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB]
         s1[j] = 0.0;
         s2[j] = 0.0;
     }
+    // the forward tensor at the result positions, all loads in flight before the first store (the stores below may alias them as far
+    // as the compiler knows: read row by row they would each wait out a full memory round trip)
+    float xv[MB][16][NB];
+    if (dact) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t pix = rowpix(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh);
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    xv[i][r][j] = (pix >= 0 && nvalid[j]) ? P.xref[pix * P.xref_ld + n0 + wn * WTN + j * 32 + fr] : 0.f;
+            }
+    }
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
 #pragma unroll
@@ -139,7 +153,7 @@ __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB]
                     if (nvalid[j]) {
                         float v = acc[i][j][r] + bias_v[j];
                         if (dact) {
-                            const float x = P.xref[pix * P.xref_ld + n];
+                            const float x = xv[i][r][j];
                             const float xhat = (x - x_mean[j]) * x_rstd[j];
                             const float y = xnorm ? (x_g[j] * xhat + x_b[j]) : x;
                             v *= (y > 0.f ? 1.f : xn_neg);
@@ -541,7 +555,10 @@ template <int BN, int A_IT, bool PRO, bool F16>
 __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) {
     constexpr int NT = 256, WGN = 2, WTM = 32, WTN = BN / WGN, MB = 1, NB = WTN / 32;
     constexpr int B_IT = BN * 8 / NT;
-    constexpr int NSET = 4;          // weight-tile register ring (even: the LDS buffer of a step is its slot's parity)
+    // weight-tile register ring (even: the LDS buffer of a step is its slot's parity).  BN = 128 (wave tile 32 x 64, ring of 2)
+    // compiles but measured slower on every layer tried (D 128 -> 256 @65^2 x 6: dgrad 73 us against 63.5): the halved workgroup
+    // count costs more than the better MFMA : LDS ratio returns, so the dispatcher only uses BN = 64.
+    constexpr int NSET = BN == 64 ? 4 : 2;
     static_assert(BN % 64 == 0 && B_IT >= 1, "N tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -767,10 +784,10 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
 
     issue_a(0);
     prefetch(std::integral_constant<int, 0>{}); prefetch(std::integral_constant<int, 1>{});
-    prefetch(std::integral_constant<int, 2>{}); prefetch(std::integral_constant<int, 3>{});
+    if constexpr (NSET == 4) { prefetch(std::integral_constant<int, 2>{}); prefetch(std::integral_constant<int, 3>{}); }
     store_a(0);
     issue_a(1);
-    store_b(std::integral_constant<int, 0>{});      // step 0 -> buffer 0, step 1 -> buffer 1; their slots take steps 4 and 5
+    store_b(std::integral_constant<int, 0>{});      // step 0 -> buffer 0, step 1 -> buffer 1; their slots take steps NSET, NSET + 1
     prefetch(std::integral_constant<int, 0>{});
     store_b(std::integral_constant<int, 1>{});
     prefetch(std::integral_constant<int, 1>{});
@@ -786,10 +803,10 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
         int u = 0;
         for (; u + NSET - 1 < nunits; u += NSET) {
             iteration(std::integral_constant<int, 0>{}); iteration(std::integral_constant<int, 1>{});
-            iteration(std::integral_constant<int, 2>{}); iteration(std::integral_constant<int, 3>{});
+            if constexpr (NSET == 4) { iteration(std::integral_constant<int, 2>{}); iteration(std::integral_constant<int, 3>{}); }
         }
-        maybe(std::integral_constant<int, 0>{}, u); maybe(std::integral_constant<int, 1>{}, u);
-        maybe(std::integral_constant<int, 2>{}, u);
+        maybe(std::integral_constant<int, 0>{}, u);
+        if constexpr (NSET == 4) { maybe(std::integral_constant<int, 1>{}, u); maybe(std::integral_constant<int, 2>{}, u); }
     }
     SG3P_MARK(3);
 
@@ -922,7 +939,7 @@ static bool sg3p_wanted(const Sg3pPlan& pl) {
 }
 
 template <int BN, int A_IT>
-static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {
+static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {   // BN: 64, or 128 (wave tile 32 x 64) for wide results
     int t = 0, maxlds = 0;
     for (int g = 0; g < P.nprob; ++g)
         for (int ph = 0; ph < P.nphase; ++ph) {

@@ -38,7 +38,13 @@ class FCGANModel(BaseModel):
         zshape = (opt.batchSize, opt.noise_nc, opt.noiseSize, opt.noiseSize)
         self.input = self.Tensor(opt.batchSize, opt.input_nc, opt.fineSize, opt.fineSize)
         self.noise = None
-        self.noise_ = self.Tensor(*zshape)
+        if self.device.type == 'cuda' and opt.batchSize == 1:
+            # the latent lives in the padded NHWC buffer the generator reads; `noise_` is its logical [1, C, H, W] view
+            self._noise_buf = torch.zeros((opt.noiseSize, opt.noiseSize, ops.pad4(opt.noise_nc)), dtype=torch.float32, device=self.device)
+            self.noise_ = ops.logical_view(self._noise_buf, opt.noise_nc)
+        else:
+            self._noise_buf = None
+            self.noise_ = self.Tensor(*zshape)
         self._rng_seed = 0 if opt.manualSeed is None else int(opt.manualSeed)
         self._rng_offset = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.noise_source = None    # optional callable() -> z tensor (tests inject latents)
@@ -93,6 +99,8 @@ class FCGANModel(BaseModel):
         if self.noise_source is not None:
             z = self.noise_source()
             self.noise_.copy_(z)
+        elif self._noise_buf is not None:
+            ops.normal_fill_nhwc(self._noise_buf, self.opt.noise_nc, self._rng_seed, self._rng_offset)
         else:
             ops.normal_fill(self.noise_, self._rng_seed, self._rng_offset)
         return self.noise_

@@ -375,17 +375,47 @@ class ChainNet(nn.Module):
         key = self._derived_key()
         if getattr(self, "_wt_key", None) == key:
             return
+        mates = getattr(self, "_arena_mates", None)
+        if mates is not None and self._refresh_arena(mates):
+            return
         if getattr(self, "_flat_t", None) is None or self._flat_t.shape != self._flat.shape or self._flat_t.device != self._flat.device:
             self._flat_t = torch.zeros_like(self._flat)
             self._pk_f = torch.zeros_like(self._flat)
             self._pk_b = torch.zeros_like(self._flat)
+        ops.pack_weights(self._flat, self._flat_t, self._pk_f, self._pk_b, self._conv_segments())
+        self._wt_key = key
+
+    def _conv_segments(self, base=0):
         segs, seen = [], set()
         for Lx in self.layers:
             if Lx.w_off not in seen:
                 seen.add(Lx.w_off)
-                segs.append((Lx.w_off, Lx.k * Lx.k, Lx.cout_s, Lx.cin_s))
-        ops.pack_weights(self._flat, self._flat_t, self._pk_f, self._pk_b, segs)
-        self._wt_key = key
+                segs.append((base + Lx.w_off, Lx.k * Lx.k, Lx.cout_s, Lx.cin_s))
+        return segs
+
+    def _refresh_arena(self, mates) -> bool:
+        """Networks that share one parameter arena (pack_flat) and one optimizer go stale together: refresh the derived copies of
+        all of them that are stale in ONE launch over the arena.  False: the arena was re-homed since; take the per-net path."""
+        arena_p = self._arena[0]
+        if any(getattr(n, "_arena", (None,))[0] is not arena_p or n._flat.data_ptr() != arena_p.data_ptr() + 4 * n._arena[2] for n in mates):
+            return False
+        der = getattr(arena_p, "_sgan_derived", None)
+        if der is None or der[0].shape != arena_p.shape or der[0].device != arena_p.device:
+            der = arena_p._sgan_derived = tuple(torch.zeros_like(arena_p) for _ in range(3))
+        segs, stale = [], []
+        for n in mates:
+            off = n._arena[2]
+            if getattr(n, "_flat_t", None) is None or n._flat_t.data_ptr() != der[0].data_ptr() + 4 * off:
+                n._flat_t, n._pk_f, n._pk_b = (d[off: off + n._nflat] for d in der)
+                n._wt_key = None
+            key = n._derived_key()
+            if n._wt_key != key:
+                segs += n._conv_segments(off)
+                stale.append((n, key))
+        ops.pack_weights(arena_p, der[0], der[1], der[2], segs)
+        for n, key in stale:
+            n._wt_key = key
+        return True
 
     def _gwb(self, L: LayerSpec):
         w = self._gflat[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s]
@@ -510,6 +540,10 @@ def pack_flat(nets):
         n._arena = (arena_p, arena_g, off)
         n._rebind()
         off += n._nflat
+    for n in nets:
+        if isinstance(n, ChainNet) and all(isinstance(m, ChainNet) for m in nets):
+            n._arena_mates = nets
+            n._flat_t = None      # derived copies move into arena-wide buffers on the next refresh
     return arena_p, arena_g
 
 
@@ -2016,7 +2050,9 @@ class _GanLossFn(torch.autograd.Function):
 
 
 class _GanLossMultiFn(torch.autograd.Function):
-    """total = sum_i w_i * GANLoss(pred_i, target_i) -- one forward and one backward kernel for all terms."""
+    """total = sum_i w_i * GANLoss(pred_i, target_i) -- ONE kernel for all terms, their finish and (when a gradient will be asked
+    for) d total / d pred_i for an upstream gradient of 1.  backward() hands those out as they are when the upstream gradient is
+    the trainers' cached unit gradient (ops.UNIT_GRADS), and rescales them with one more kernel per term otherwise."""
 
     @staticmethod
     def forward(ctx, targets, weights, mode, *logits):
@@ -2024,15 +2060,21 @@ class _GanLossMultiFn(torch.autograd.Function):
         dev = logits[0].device
         each = torch.empty(len(lbs), dtype=torch.float32, device=dev)
         total = torch.empty((), dtype=torch.float32, device=dev)
-        ops.gan_loss_multi_fwd(lbs, targets, weights, mode, each, total)
-        ctx.lbs, ctx.targets, ctx.weights, ctx.mode = lbs, targets, weights, mode
+        ds = [torch.empty_like(lb) for lb in lbs] if any(ctx.needs_input_grad[3:]) else None
+        ops.gan_loss_multi_fwd(lbs, targets, weights, mode, each, total, ds)
+        ctx.ds = ds
         ctx.mark_non_differentiable(each)
         return total, each
 
     @staticmethod
     def backward(ctx, gtotal, _geach):
-        ds = [torch.empty_like(lb) for lb in ctx.lbs]
-        ops.gan_loss_multi_bwd(ctx.lbs, ctx.targets, ctx.weights, ctx.mode, gtotal.contiguous(), ds)
+        ds = ctx.ds
+        if gtotal.data_ptr() not in ops.UNIT_GRADS:
+            scaled = [torch.empty_like(d) for d in ds]
+            g = gtotal.contiguous()
+            for d, o in zip(ds, scaled):
+                ops.scale(g, d, o)
+            ds = scaled
         return (None, None, None) + tuple(ops.logical_view(d, 1) for d in ds)
 
 

@@ -391,14 +391,29 @@ def gan_loss_bwd(logits, target, mode, gout, dlogits):
                                       _ptr(_act(dlogits)), dlogits.stride(1), _stream()), "sgan_gan_loss_bwd")
 
 
-GAN_LOSS_WS_BYTES = 1024   # SGAN_GAN_LOSS_WS_BYTES
+GAN_LOSS_WS_BYTES = 2048   # SGAN_GAN_LOSS_WS_BYTES
+_loss_ws = {}
+UNIT_GRADS = set()         # data_ptr() of gradient tensors known to hold 1.0 (BaseModel._backward's cached root gradient)
 
 
-def gan_loss_multi_fwd(logits, targets, weights, mode, each_out, total_out):
+def _gan_loss_workspace(device):
+    """Zero-initialised once per device; the kernel leaves its ticket counter at zero.  The fused loss runs on the trainer's main
+    stream only (side-stream chains use the per-term loss)."""
+    key = device.index
+    ws = _loss_ws.get(key)
+    if ws is None:
+        ws = _loss_ws[key] = torch.zeros(GAN_LOSS_WS_BYTES // 8, dtype=torch.float64, device=device)
+    return ws
+
+
+def gan_loss_multi_fwd(logits, targets, weights, mode, each_out, total_out, dlogits=None):
+    """dlogits (optional list of NHWC buffers): also receives d total / d logits_i for an upstream gradient of 1."""
     arr = (L.GanLossJob * len(logits))()
     for i, (lb, t, w) in enumerate(zip(logits, targets, weights)):
-        arr[i] = L.GanLossJob(_ptr(_act(lb)).value, lb.stride(1), lb.shape[0] * lb.shape[1], float(t), float(w), None, 0)
-    ws = torch.empty(GAN_LOSS_WS_BYTES // 8, dtype=torch.float64, device=each_out.device)
+        d = dlogits[i] if dlogits is not None else None
+        arr[i] = L.GanLossJob(_ptr(_act(lb)).value, lb.stride(1), lb.shape[0] * lb.shape[1], float(t), float(w),
+                              _ptr(_act(d)).value if d is not None else None, d.stride(1) if d is not None else 0)
+    ws = _gan_loss_workspace(each_out.device)
     L.check(L.lib().sgan_gan_loss_multi_fwd(arr, len(logits), mode, _ptr(each_out), _ptr(total_out), _ptr(ws), GAN_LOSS_WS_BYTES,
                                             _stream()), "sgan_gan_loss_multi_fwd")
 
@@ -447,6 +462,15 @@ def normal_fill(dst, seed, offset_dev=None, advance=True):
     assert dst.is_contiguous() and dst.dtype == torch.float32
     L.check(L.lib().sgan_normal_fill(_ptr(dst), dst.numel(), C.c_uint64(seed & (2 ** 64 - 1)), _ptr(offset_dev), int(bool(advance)),
                                      _stream()), "sgan_normal_fill")
+
+
+def normal_fill_nhwc(buf, C_real, seed, offset_dev=None, advance=True):
+    """N(0, 1) values of a logical [1, C_real, H, W] tensor (the same values normal_fill gives its contiguous form), written into
+    the padded NHWC buffer `buf` [H, W, Cs] the networks read: no layout kernel between the draw and the generator."""
+    H, W, Cs = buf.shape
+    assert buf.is_contiguous() and buf.dtype == torch.float32
+    L.check(L.lib().sgan_normal_fill_nhwc(_ptr(buf), int(C_real), H, W, Cs, C.c_uint64(seed & (2 ** 64 - 1)), _ptr(offset_dev),
+                                          int(bool(advance)), _stream()), "sgan_normal_fill_nhwc")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -421,6 +421,59 @@ def test_normal_fill_moments_and_counter(hip):
     assert torch.equal(a, c)                           # counter-based: same (seed, offset) -> same numbers
 
 
+def test_normal_fill_nhwc_is_the_flat_fill_in_place(hip):
+    """The latent drawn straight into the generator's padded NHWC buffer holds the values normal_fill gives the contiguous
+    [C, H, W] tensor, at (h, w, c); the padding channels are left alone; the offset moves the same way."""
+    ops = hip
+    Cr, H, W = 6, 8, 5
+    flat = torch.empty(Cr * H * W, device="cuda")
+    buf = torch.full((H, W, 8), 7.0, device="cuda")
+    o1 = torch.tensor([11], dtype=torch.int64, device="cuda")
+    o2 = o1.clone()
+    ops.normal_fill(flat, 99, o1)
+    ops.normal_fill_nhwc(buf, Cr, 99, o2)
+    torch.cuda.synchronize()
+    assert torch.equal(buf[..., :Cr].permute(2, 0, 1).contiguous().view(-1), flat)
+    assert float(buf[..., Cr:].min()) == 7.0 and float(buf[..., Cr:].max()) == 7.0
+    assert int(o1) == int(o2) == 11 + (Cr * H * W + 3) // 4
+
+
+def test_fused_gan_loss_one_kernel(hip):
+    """_GanLossMultiFn: the forward kernel finishes the terms itself (ticket counter, left at zero) and writes the unit-gradient
+    d total / d logits; backward() returns them for a registered unit gradient and rescales them for any other upstream gradient.
+    Both against torch autograd on the same formula, BCE-with-sigmoid and LSGAN."""
+    ops = hip
+    from supervised_gan_amd import networks as N
+    g = torch.Generator().manual_seed(12)
+    sizes, targets, weights = [(67, 67), (35, 35), (19, 21)], [1.0, 0.0, 1.0], [0.5, 0.25, 2.0]
+    for mode in (0, 1):
+        raw = [(torch.randn(1, 1, h, w, generator=g) * 3).cuda() for h, w in sizes]
+        for gscale in (None, 0.37):
+            xs = [r.clone().requires_grad_(True) for r in raw]
+            ref_x = [r.clone().double().requires_grad_(True) for r in raw]
+            terms = []
+            for x, t in zip(ref_x, targets):
+                tt = torch.full_like(x, t)
+                terms.append(torch.nn.functional.binary_cross_entropy_with_logits(x, tt) if mode == 0 else ((x - tt) ** 2).mean())
+            ref_total = sum(w * l for w, l in zip(weights, terms))
+            total, each = N._GanLossMultiFn.apply(targets, weights, mode, *xs)
+            if gscale is None:
+                one = torch.ones_like(total)
+                ops.UNIT_GRADS.add(one.data_ptr())
+                total.backward(one)
+                ref_total.backward()
+            else:
+                (total * gscale).backward()
+                (ref_total * gscale).backward()
+            torch.cuda.synchronize()
+            assert abs(float(total) - float(ref_total)) < 1e-5 * max(1.0, abs(float(ref_total)))
+            assert torch.allclose(each.double().cpu(), torch.stack([l.detach() for l in terms]).cpu(), rtol=1e-5, atol=1e-6)
+            for x, rx in zip(xs, ref_x):
+                assert torch.allclose(x.grad.double(), rx.grad, rtol=2e-5, atol=1e-9), (mode, gscale)
+    ws = ops._gan_loss_workspace(torch.device("cuda", 0))
+    assert int(ws.view(torch.int32)[-4]) == 0 and int(ws.view(torch.int64)[8 * 16]) == 0      # the ticket counter is back at zero
+
+
 # BASELINE configs[1] layer shapes (fcgan: deconv G ngf 32 on an 8x8x8 latent, PatchGAN D ndf 32 on 2x512x512)
 FULL_LAYERS = [
     ("convT", 4, 2, 1, 8, 256, 8), ("convT", 4, 2, 1, 256, 256, 16), ("convT", 4, 2, 1, 256, 128, 32),

@@ -644,6 +644,168 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
 }
 
 
+// ------------------------------------------------------------------------------------------
+// One-channel head of a stride-1 Conv2d (PatchGAN logits: 256 -> 1, k4 s1 p2 on 66 x 66): every output pixel is a 4096-term dot
+// product, and the gather kernel above re-fetches each input element once per tap (16x) from L1/L2.  Here a workgroup owns an
+// 8 x 8 block of output pixels: per 32-channel block the (8 + span - 1)^2 input patch is loaded once, normalised / activated and
+// kept in LDS; lane (pixel, channel octet) walks the taps reading its 8 channels of the shifted pixel and the matching 8 weights
+// (all weights of the layer sit in LDS, read as broadcasts), and a 4-lane shuffle adds the octets.  Exact fp32 (VALU FMA), the
+// same norm-on-load prologue and bias / tanh epilogue as the other forward kernels; no output statistics (heads have no norm).
+// ------------------------------------------------------------------------------------------
+#define SGH_PS 144     // bytes per patch pixel (32 fp32 channels + 16 pad: the four octets of neighbouring pixels spread over the banks)
+__global__ __launch_bounds__(256) void sg_conv_head_kernel(const SgIgemmParams G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    int g, phz, mtile;
+    sg_decode_tile(G, blockIdx.x, g, phz, mtile);
+    const SgLocal P = sg_local(G, g);
+    const int Hp = G.q[g].Hp[phz], Wp = G.q[g].Wp[phz];
+    const int tiles_x = (Wp + 7) >> 3;
+    const int ty0 = (mtile / tiles_x) * 8, tx0 = (mtile % tiles_x) * 8;
+    const int ntaps = G.ntaps[phz], Ck = P.Ck, ncb = Ck >> 5;
+    const int PH = G.pph[phz], PW = G.ppw[phz], dy0 = G.pdy0[phz], dx0 = G.pdx0[phz];
+    const int RS = PW * SGH_PS;
+    const int npix = PH * PW;
+    char* Ap = smem;                                                                  // [PH][PW] pixels x 32 channels
+    float* Ws = reinterpret_cast<float*>(smem + ((PH * RS + 255) & ~255));            // [ntaps][Ck]
+    int* toff = reinterpret_cast<int*>(Ws + ntaps * Ck);                              // [ntaps] patch byte offset of the tap
+    float* pscale = reinterpret_cast<float*>(toff + SGAN_MAX_TAPS);                   // [Ck]
+    float* pshift = pscale + Ck;
+    const bool has_pro = (P.pro.stats != nullptr) || (P.pro.act != SGAN_ACT_NONE);
+    const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
+    if (tid < ntaps) {
+        const SgTap tp = G.taps[G.tap0[phz] + tid];
+        toff[tid] = ((int)tp.dy - dy0) * RS + ((int)tp.dx - dx0) * SGH_PS;
+    }
+    for (int i = tid * 4; i < ntaps * Ck; i += 1024) {     // W[tap][n = 0][k]: one contiguous Ck row per tap
+        const int t = i / Ck, k = i - t * Ck;
+        *reinterpret_cast<f32x4*>(Ws + i) = *reinterpret_cast<const f32x4*>(P.w + G.taps[G.tap0[phz] + t].w_off + k);
+    }
+    for (int c = tid; c < Ck; c += 256) {
+        float sc = 1.f, sh = 0.f;
+        if (P.pro.stats) {
+            float mean, rstd;
+            sg_mean_rstd(P.pro, Ck, c, mean, rstd);
+            const float gm = P.pro.gamma ? P.pro.gamma[c] : 1.f;
+            const float bt = P.pro.beta ? P.pro.beta[c] : 0.f;
+            sc = gm * rstd;
+            sh = bt - mean * sc;
+        }
+        pscale[c] = sc;
+        pshift[c] = sh;
+    }
+    // staging: item e = 8 * patch pixel + channel quad; four items per thread cover up to 128 pixels, eight up to 256
+    constexpr int S_IT = 8;
+    const int cq = tid & 7;
+    int s_goff[S_IT], s_dst[S_IT];
+#pragma unroll
+    for (int it = 0; it < S_IT; ++it) {
+        const int p = (tid + it * 256) >> 3;
+        const int pr = p / PW, pc = p - pr * PW;
+        const int iy = ty0 + pr + dy0, ix = tx0 + pc + dx0;
+        const bool ok = (p < npix) & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
+        s_goff[it] = ok ? (iy * P.Win + ix) * P.in_ld + cq * 4 : -1;
+        s_dst[it] = p < npix ? pr * RS + pc * SGH_PS + cq * 16 : -1;
+    }
+    f32x4 s_reg[S_IT];
+    auto issue = [&](int cb) {
+#pragma unroll
+        for (int it = 0; it < S_IT; ++it)
+            if (s_goff[it] >= 0 && cb < ncb) s_reg[it] = *reinterpret_cast<const f32x4*>(P.in + s_goff[it] + cb * 32);
+    };
+    auto store = [&](int cb) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + cb * 32 + cq * 4), sh = *reinterpret_cast<const f32x4*>(pshift + cb * 32 + cq * 4);
+#pragma unroll
+        for (int it = 0; it < S_IT; ++it) {
+            if (s_dst[it] < 0) continue;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};      // zero padding applies AFTER norm + activation
+            if (s_goff[it] >= 0) {
+                v = s_reg[it];
+                if (has_pro) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float y = v[j] * sc[j] + sh[j];
+                        v[j] = y > 0.f ? y : y * pro_neg;
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4*>(Ap + s_dst[it]) = v;
+        }
+    };
+    const int px = tid >> 2, co = tid & 3;      // output pixel of the tile, channel octet of the block
+    const int f_base = ((px >> 3) * RS + (px & 7) * SGH_PS) + co * 32;
+    float acc = 0.f;
+    issue(0);
+    __syncthreads();      // tap offsets, weights, scale / shift visible
+    for (int cb = 0; cb < ncb; ++cb) {
+        store(cb);
+        issue(cb + 1);
+        __syncthreads();
+        const float* wrow = Ws + cb * 32 + co * 8;
+#pragma unroll 4
+        for (int t = 0; t < ntaps; ++t) {
+            const char* a = Ap + f_base + toff[t];
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 16);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + t * Ck), w1 = *reinterpret_cast<const f32x4*>(wrow + t * Ck + 4);
+            acc += (a0[0] * w0[0] + a0[1] * w0[1]) + (a0[2] * w0[2] + a0[3] * w0[3]) + (a1[0] * w1[0] + a1[1] * w1[1]) + (a1[2] * w1[2] + a1[3] * w1[3]);
+        }
+        __syncthreads();   // everyone is done with the patch before the next block overwrites it
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    const int py = ty0 + (px >> 3), pxx = tx0 + (px & 7);
+    if (co == 0 && py < Hp && pxx < Wp) {
+        const int64_t pix = (int64_t)(py * P.os + G.oa[phz]) * P.Wout + (pxx * P.os + G.ob[phz]);
+        float v = acc + (P.bias ? P.bias[0] : 0.f);
+        if (P.out_act == SGAN_ACT_TANH) v = tanhf(v);
+        f32x4 o4 = (f32x4){v, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 1; n < 4; ++n) {       // padding channels carry the bias like the generic kernel (zero in practice)
+            float b = P.bias ? P.bias[n] : 0.f;
+            if (P.out_act == SGAN_ACT_TANH) b = tanhf(b);
+            o4[n] = b;
+        }
+        *reinterpret_cast<f32x4*>(P.out + pix * P.out_ld) = o4;
+    }
+}
+
+// eligibility + patch extents (shared fields with the split patch kernel); 8 x 8 tiles, one phase, unit stride, one real channel
+static bool sg_head_plan(SgIgemmParams& P) {
+    if (P.is != 1 || P.os != 1 || P.nphase != 1 || P.n_real > 1 || P.w_ks != 1 || (P.Ck & 31) || P.Ck > 1024) return false;
+    if (getenv("SGAN_NO_HEAD_KERNEL")) return false;
+    for (int g = 0; g < P.nprob; ++g)
+        if (P.q[g].stats || P.q[g].xref || P.q[g].accum || (P.q[g].out_ld & 3) || P.q[g].out_ld < 4) return false;
+    int dy0 = 1 << 30, dy1 = -(1 << 30), dx0 = 1 << 30, dx1 = -(1 << 30);
+    if (P.ntaps[0] < 4 || P.ntaps[0] > SGAN_MAX_TAPS) return false;
+    for (int t = 0; t < P.ntaps[0]; ++t) {
+        const SgTap& tp = P.taps[P.tap0[0] + t];
+        dy0 = min(dy0, (int)tp.dy); dy1 = max(dy1, (int)tp.dy);
+        dx0 = min(dx0, (int)tp.dx); dx1 = max(dx1, (int)tp.dx);
+    }
+    P.pdy0[0] = dy0; P.pdx0[0] = dx0;
+    P.pph[0] = 8 + dy1 - dy0; P.ppw[0] = 8 + dx1 - dx0;
+    if (P.pph[0] * P.ppw[0] > 256) return false;
+    const size_t lds = (size_t)((P.pph[0] * P.ppw[0] * SGH_PS + 255) & ~255) + (size_t)P.ntaps[0] * P.Ck * 4 + SGAN_MAX_TAPS * 4 + (size_t)2 * P.Ck * 4;
+    return lds <= 64 * 1024;
+}
+
+static int sg_launch_head(SgIgemmParams& P, hipStream_t st) {
+    int t = 0;
+    for (int g = 0; g < P.nprob; ++g) {
+        P.q[g].tile0[0] = t;
+        t += ((P.q[g].Hp[0] + 7) / 8) * ((P.q[g].Wp[0] + 7) / 8);
+        for (int ph = 1; ph < SGAN_MAX_PHASES; ++ph) P.q[g].tile0[ph] = 1 << 30;
+    }
+    if (t == 0) return SGAN_OK;
+    const size_t lds = (size_t)((P.pph[0] * P.ppw[0] * SGH_PS + 255) & ~255) + (size_t)P.ntaps[0] * P.Ck * 4 + SGAN_MAX_TAPS * 4 + (size_t)2 * P.Ck * 4;
+    sg_prof_begin(st);
+    hipLaunchKernelGGL(sg_conv_head_kernel, dim3(t), dim3(256), lds, st, P);
+    SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = "sg_conv_head_kernel";
+    sg_prof_end(st, g_sgan_last_kernel);
+    return SGAN_OK;
+}
+
 template <int LPP, int R, int U, int NR>
 static int sg_launch_small_n_nr(SgIgemmParams& P, hipStream_t st) {
     constexpr int PPB = 256 / LPP;
@@ -1142,6 +1304,7 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
     P.slab_stride = 0;
     if (sg_use_small_n(P)) {   // skinny result: direct kernels
         if (sg_use_scatter4(P)) return sg_launch_scatter4(P, st);
+        if (sg_head_plan(P)) return sg_launch_head(P, st);
         const int ktot = sg_max_k(P);
         if (ktot >= 2048) return sg_launch_small_n<64, 1, 8>(P, st);
         if (ktot >= 256) return sg_launch_small_n<16, 2, 4>(P, st);

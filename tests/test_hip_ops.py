@@ -59,6 +59,7 @@ CASES = [
     ("conv", 4, 2, 2, 3, 64, 64, 64, None, 0),      # cgan D first layer (3 channels)
     ("conv", 4, 2, 2, 64, 128, 129, 129, "in", 2),  # > 1 split, odd
     ("conv", 3, 1, 1, 8, 1, 20, 22, "in", 1),       # CRN output conv: k3, Cout = 1 (K = 9 taps x 4: a partial k-tile in dgrad)
+    ("conv", 3, 1, 1, 64, 1, 21, 19, "bn", 1),      # one-channel head, k3, BN + ReLU on load, ragged 8 x 8 tiles (sg_conv_head_kernel)
     ("conv", 3, 1, 1, 16, 8, 12, 12, "in", 0),      # CRN stage conv: norm without activation on load
     ("conv", 3, 1, 1, 2, 8, 16, 16, None, 0),       # CRN label conv
     ("convT", 4, 2, 1, 16, 8, 6, 6, "in", 0),       # CRN ConvT upsampling, norm without activation on load

@@ -101,6 +101,7 @@ SIGNATURES = {
     "sgan_bn_running_update": [C.POINTER(BnRunningDesc), _I, _F, _P],
     "sgan_image_prep": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "sgan_image_resize": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _L, _P],
+    "sgan_image_resize_workspace": [_I, _I, _I, _I, _I, _I],
     "sgan_gauss_down_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "sgan_gauss_down_multi_fwd": [C.POINTER(GaussJob), _I, _I, _I, _P],
     "sgan_gauss_down_multi_bwd": [C.POINTER(GaussJob), _I, _I, _I, _I, _P],
@@ -123,6 +124,7 @@ SIGNATURES = {
     "sgan_profile_read": [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_float)],
 }
 
+RESTYPES = {"sgan_image_resize_workspace": C.c_int64}      # everything else returns an int status
 _lib = None
 
 
@@ -146,9 +148,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args
-            fn.restype = C.c_int
-        l.sgan_image_resize_workspace.argtypes = [_I, _I, _I, _I, _I, _I]
-        l.sgan_image_resize_workspace.restype = C.c_int64
+            fn.restype = RESTYPES.get(name, C.c_int)
         l.sgan_version.restype = C.c_char_p
         l.sgan_last_error.restype = C.c_char_p
         l.sgan_last_kernel.restype = C.c_char_p

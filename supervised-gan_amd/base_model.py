@@ -31,7 +31,7 @@ class BaseModel:
         one = getattr(self, '_grad_one', None)
         if one is None or one.device != loss.device or one.shape != loss.shape:
             one = self._grad_one = torch.ones_like(loss)
-            ops.UNIT_GRADS.add(one.data_ptr())      # fused loss nodes skip the rescaling of their gradients for this tensor
+            ops.register_unit_grad(one)      # fused loss nodes skip the rescaling of their gradients for this tensor
         loss.backward(one)
 
     def set_input(self, input):

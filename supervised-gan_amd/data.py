@@ -1,7 +1,8 @@
 """Image-folder feeders with the reference's transforms (data/single_dataset.py, data/aligned_dataset.py, data/base_dataset.py:17-55,
-data/image_folder.py): file listing and PIL decode / resize on the host, then ONE kernel per image on the device for
-crop -> flip -> rot90 -> ToTensor -> Normalize (`sgan_image_prep`), so the float image never exists in host memory and the
-trainers' set_input reads a device tensor.
+data/image_folder.py): file listing and PIL decode on the host; the decoded uint8 image is uploaded once and everything after it
+runs on the device -- Image.resize (`sgan_image_resize`, bit-exact with Pillow's two-pass resampler) and ONE kernel for
+crop -> flip -> rot90 -> ToTensor -> Normalize (`sgan_image_prep`) -- so neither the resized nor the float image ever exists in
+host memory and the trainers' set_input reads a device tensor.
 
 Yields what the reference's DataLoader yields at batchSize 1: {'A': [1, 3, H, W] in [-1, 1], 'A_paths': [path]} (single) or
 {'A', 'B', 'A_paths', 'B_paths'} (aligned, unaligned).  Random draws use Python's `random` like the reference; the aligned feeder makes them
@@ -29,12 +30,11 @@ def make_dataset(dir):
     return images
 
 
-def _scale_width(img, target_width):
-    from PIL import Image
-    ow, oh = img.size
+def _scale_width_size(ow, oh, target_width):
+    """(w, h) after __scale_width (base_dataset.py:43-50)."""
     if ow == target_width:
-        return img
-    return img.resize((target_width, int(target_width * oh / ow)), Image.BILINEAR)      # base_dataset.py:43-50
+        return ow, oh
+    return target_width, int(target_width * oh / ow)
 
 
 class _FolderDataset:
@@ -96,23 +96,26 @@ class SingleFolderDataset(_FolderDataset):
 
     def _decode(self, path):
         from PIL import Image
-        opt = self.opt
         img = Image.open(path).convert('RGB')
-        if opt.resize_or_crop == 'resize_and_crop':
-            img = img.resize((opt.loadSize, opt.loadSize), Image.BILINEAR)      # transforms.Scale([loadSize, loadSize], BILINEAR)
-        elif opt.resize_or_crop == 'scale_width':
-            img = _scale_width(img, opt.fineSize)
-        elif opt.resize_or_crop == 'scale_width_and_crop':
-            img = _scale_width(img, opt.loadSize)
-        elif opt.resize_or_crop != 'crop':
-            raise ValueError('--resize_or_crop %s' % opt.resize_or_crop)
         img.load()
         return img
+
+    def _resized_size(self, ow, oh):
+        opt = self.opt
+        if opt.resize_or_crop == 'resize_and_crop':
+            return opt.loadSize, opt.loadSize                  # transforms.Scale([loadSize, loadSize], BILINEAR)
+        if opt.resize_or_crop == 'scale_width':
+            return _scale_width_size(ow, oh, opt.fineSize)
+        if opt.resize_or_crop == 'scale_width_and_crop':
+            return _scale_width_size(ow, oh, opt.loadSize)
+        if opt.resize_or_crop != 'crop':
+            raise ValueError('--resize_or_crop %s' % opt.resize_or_crop)
+        return ow, oh
 
     def _draw_and_prep(self, img, path):
         opt, n = self.opt, self.opt.fineSize
         crop = opt.resize_or_crop != 'scale_width'
-        w, h = img.size
+        w, h = self._resized_size(*img.size)
         if crop:
             if w < n or h < n:
                 raise ValueError('image %s is %dx%d after resizing, smaller than --fineSize %d' % (path, w, h, n))
@@ -123,7 +126,10 @@ class SingleFolderDataset(_FolderDataset):
             x0 = y0 = 0
         flip = opt.isTrain and not opt.no_flip and random.random() < 0.5
         rot = random.randint(0, 3) if (opt.isTrain and not opt.no_rotate) else 0
-        return ops.image_prep(self._to_device(img), x0, y0, n, flip, rot)
+        dev = self._to_device(img)
+        if (w, h) != img.size:
+            dev = ops.image_resize(dev, w, h, "bilinear")      # Image.resize((w, h), BILINEAR), on the device
+        return ops.image_prep(dev, x0, y0, n, flip, rot)
 
 
 class UnalignedFolderDataset(SingleFolderDataset):
@@ -161,8 +167,9 @@ class AlignedFolderDataset(_FolderDataset):
 
     def _host(self, index):
         from PIL import Image
-        opt = self.opt
-        return Image.open(self.paths[index]).convert('RGB').resize((opt.loadSize * 2, opt.loadSize), Image.BICUBIC)
+        img = Image.open(self.paths[index]).convert('RGB')
+        img.load()
+        return img
 
     def _device(self, index, AB):
         opt, path = self.opt, self.paths[index]
@@ -171,6 +178,8 @@ class AlignedFolderDataset(_FolderDataset):
         h_offset = random.randint(0, max(0, h - n - 1))
         flip = (not opt.no_flip) and random.random() < 0.5
         dev = self._to_device(AB)
+        if AB.size != (2 * w, h):
+            dev = ops.image_resize(dev, 2 * w, h, "bicubic")   # AB.resize((loadSize * 2, loadSize), Image.BICUBIC), on the device
         A = ops.image_prep(dev, w_offset, h_offset, n, flip, 0)
         B = ops.image_prep(dev, w + w_offset, h_offset, n, flip, 0)
         return {'A': ops.logical_view(A, 3), 'B': ops.logical_view(B, 3), 'A_paths': [path], 'B_paths': [path]}

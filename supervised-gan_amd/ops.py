@@ -23,6 +23,9 @@ _MATH_NAMES = {"f32": L.MATH_F32, "fp32": L.MATH_F32, "bf16x3": L.MATH_BF16X3}
 _math = _MATH_NAMES[__import__("os").environ.get("SGAN_MATH", "bf16x3").lower()]
 
 
+_DGRAD_MATH = _MATH_NAMES.get(__import__("os").environ.get("SGAN_DGRAD_MATH", "").lower())      # diagnostics: backward-data only
+
+
 def set_math(name: str):
     global _math
     _math = _MATH_NAMES[name.lower()]
@@ -146,7 +149,7 @@ def conv_dgrad_grouped(jobs):
     arr = (L.ConvDgradJob * len(jobs))()
     for i, job in enumerate(jobs):
         desc, dout, w, din, x, x_norm, sums = job[:7]
-        desc.math = _math
+        desc.math = _DGRAD_MATH if _DGRAD_MATH is not None else _math
         arr[i] = L.ConvDgradJob(C.pointer(desc), _ptr(_act(dout)).value, dout.stride(1), _ptr(w).value, _ptr(_act(din)).value,
                                 din.stride(1), _ptr(x).value, x.stride(1) if x is not None else 0, _pn(x_norm), _ptr(sums).value,
                                 int(job[7]) if len(job) > 7 else 0, int(bool(job[8])) if len(job) > 8 else 0,
@@ -393,7 +396,18 @@ def gan_loss_bwd(logits, target, mode, gout, dlogits):
 
 GAN_LOSS_WS_BYTES = 2048   # SGAN_GAN_LOSS_WS_BYTES
 _loss_ws = {}
-UNIT_GRADS = set()         # data_ptr() of gradient tensors known to hold 1.0 (BaseModel._backward's cached root gradient)
+_unit_grads = []           # weak references to gradient tensors known to hold 1.0 (BaseModel._backward's cached root gradient)
+
+
+def register_unit_grad(t):
+    """`t` holds 1.0 and is never written: a fused loss node that receives this very tensor object as its upstream gradient hands
+    out its precomputed unit-gradient result without a rescaling kernel."""
+    _unit_grads[:] = [r for r in _unit_grads if r() is not None]
+    _unit_grads.append(weakref.ref(t))
+
+
+def is_unit_grad(t) -> bool:
+    return any(r() is t for r in _unit_grads)
 
 
 def _gan_loss_workspace(device):

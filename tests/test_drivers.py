@@ -232,6 +232,20 @@ def test_train_and_test_from_image_folders(tmp_path):
     assert tuple(item["A"].shape) == (1, 3, 128, 128) and item["A"].is_cuda and float(item["A"].abs().max()) <= 1.0
     assert os.path.dirname(item["A_paths"][0]) == str(root / "single" / "train")
 
+    # the device pipeline (upload uint8 -> sgan_image_resize -> sgan_image_prep) against Pillow's on the same draws, bit for bit
+    import random
+    import image_prep as IP
+    from PIL import Image
+    opt.serial_batches, opt.nThreads = True, 0
+    ds = SingleFolderDataset(opt)
+    random.seed(21)
+    got = ds[2]["A"][0].cpu().numpy()
+    random.seed(21)
+    x0, y0 = random.randint(0, 143 - 128), random.randint(0, 143 - 128)
+    flip, rot = random.random() < 0.5, random.randint(0, 3)
+    ref_img = np.asarray(Image.open(ds.paths[2]).convert("RGB").resize((143, 143), Image.BILINEAR), dtype=np.uint8)
+    assert np.array_equal(got, IP.prep_pil(ref_img, x0, y0, 128, flip, rot))
+
     def epoch(threads):            # host decodes on worker threads must not change what an epoch yields
         import random
         opt.nThreads = threads
@@ -248,6 +262,18 @@ def test_train_and_test_from_image_folders(tmp_path):
     m = train_driver.main(cnet + common + ["--which_model_netD", "n_layers", "--n_layers_D", "3", "--ndf", "8", "--scale_factor", "1",
                                           "--lambda_D", "1.0", "--no_lsgan", "--max_steps", "3"])
     assert all(np.isfinite(v) for v in m.get_current_errors().values())
+    from supervised_gan_amd.data import AlignedFolderDataset
+    copt = TrainOptions().parse(cnet + common + ["--which_model_netD", "n_layers", "--n_layers_D", "3", "--ndf", "8", "--scale_factor", "1",
+                                                 "--lambda_D", "1.0", "--no_lsgan"], save=False)
+    ads = AlignedFolderDataset(copt)
+    random.seed(5)
+    pair = ads[1]
+    random.seed(5)
+    wo, ho = random.randint(0, 140 - 128 - 1), random.randint(0, 140 - 128 - 1)
+    aflip = random.random() < 0.5
+    AB = np.asarray(Image.open(ads.paths[1]).convert("RGB").resize((280, 140), Image.BICUBIC), dtype=np.uint8)    # aligned_dataset.py:25
+    assert np.array_equal(pair["A"][0].cpu().numpy(), IP.prep_pil(AB, wo, ho, 128, aflip, 0))
+    assert np.array_equal(pair["B"][0].cpu().numpy(), IP.prep_pil(AB, 140 + wo, ho, 128, aflip, 0))
     out = test_driver.main(cnet + ["--gpu_ids", "0", "--checkpoints_dir", str(tmp_path / "ckpt"), "--norm", "instance",
                                    "--results_dir", str(tmp_path / "res"), "--how_many", "2"])
     assert len(out) == 4 and all(os.path.exists(p) and os.path.dirname(p).startswith(str(tmp_path / "res")) for p in out)

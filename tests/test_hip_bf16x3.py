@@ -78,6 +78,8 @@ SHAPES = [
     ("convT", 4, 2, 1, 64, 32, 31, 33, "bn", 1),
     ("conv", 4, 2, 1, 24, 40, 30, 30, "in", 2),        # channel counts that are multiples of 8 but not of 32
     ("conv", 7, 1, 3, 32, 64, 30, 41, "in", 1),        # 49 taps (resnet stem shape): a 14 x 14 patch
+    ("conv", 4, 2, 2, 64, 128, 65, 67, "in", 2),       # backward-data = 4 phases of 2 x 2 taps, 64 result channels (patch kernel)
+    ("convT", 4, 2, 1, 128, 64, 21, 19, "bn", 1),      # forward = 4 phases of 2 x 2 taps on odd sizes
 ]
 TILES = ["auto", "64x64", "128x64", "128x128", "patch"]
 

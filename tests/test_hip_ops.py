@@ -422,6 +422,25 @@ def test_normal_fill_moments_and_counter(hip):
     assert torch.equal(a, c)                           # counter-based: same (seed, offset) -> same numbers
 
 
+def test_image_resize_bit_exact_vs_pillow(hip):
+    """sgan_image_resize against Image.resize of the Pillow in this image: bilinear and bicubic, up- and down-scaling (the filter
+    support grows with the down-scale factor), one axis unchanged, a 1-pixel-wide result, the aligned dataset's 2:1 shape."""
+    import image_prep as IP
+    ops = hip
+    rng = np.random.RandomState(16)
+    for (h, w, ho, wo) in [(70, 131, 48, 48), (64, 64, 143, 143), (100, 37, 37, 100), (150, 300, 140, 280), (33, 50, 33, 25),
+                           (600, 400, 286, 286), (17, 19, 200, 3), (256, 256, 256, 256), (1024, 1024, 286, 572)]:
+        img = rng.randint(0, 256, size=(h, w, 3), dtype=np.uint8)
+        dev = torch.from_numpy(img).cuda()
+        for f in ("bilinear", "bicubic"):
+            out = ops.image_resize(dev, wo, ho, f)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), IP.resize_pil(img, wo, ho, f)), (h, w, ho, wo, f)
+    from supervised_gan_amd._lib import SganError
+    with pytest.raises(SganError, match="filter"):
+        ops.image_resize(dev, 10, 10, 1)
+
+
 def test_normal_fill_nhwc_is_the_flat_fill_in_place(hip):
     """The latent drawn straight into the generator's padded NHWC buffer holds the values normal_fill gives the contiguous
     [C, H, W] tensor, at (h, w, c); the padding channels are left alone; the offset moves the same way."""
@@ -460,7 +479,7 @@ def test_fused_gan_loss_one_kernel(hip):
             total, each = N._GanLossMultiFn.apply(targets, weights, mode, *xs)
             if gscale is None:
                 one = torch.ones_like(total)
-                ops.UNIT_GRADS.add(one.data_ptr())
+                ops.register_unit_grad(one)
                 total.backward(one)
                 ref_total.backward()
             else:

@@ -682,3 +682,15 @@ def test_segm_cycle_step(golden_dir):
             assert rel(m.fake_A[:, :, :64, :64], g["step1/fake_A_crop"]) < 1e-4 and rel(m.recon_A[:, :, :64, :64], g["step1/recon_A_crop"]) < 1e-4
         losses.append(m.losses())
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
+
+
+def test_resize_restatement_matches_pillow():
+    """oracle/image_prep.py: resize_numpy (precompute_coeffs + normalize_coeffs_8bpc + the two 8-bit passes of Pillow's Resample.c,
+    restated) equals Image.resize of the Pillow in this image bit for bit -- it is what tells a reader of sgan_image_resize what
+    the kernel must compute; the GPU test compares the kernel with Pillow itself."""
+    import image_prep as IP
+    rng = np.random.RandomState(4)
+    for (h, w, ho, wo) in [(70, 131, 48, 48), (40, 40, 91, 91), (100, 37, 37, 100), (33, 50, 33, 25), (300, 200, 143, 143), (17, 19, 120, 3)]:
+        img = rng.randint(0, 256, size=(h, w, 3), dtype=np.uint8)
+        for f in ("bilinear", "bicubic"):
+            assert np.array_equal(IP.resize_pil(img, wo, ho, f), IP.resize_numpy(img, wo, ho, f)), (h, w, ho, wo, f)

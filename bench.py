@@ -334,6 +334,36 @@ def cpu_baseline(n_update_G, budget_s=20.0):
             "cpu_model": _cpu_model(), "value_1thread": 1.0 / dt1}
 
 
+def committed_profile_of(kernel):
+    """(HBM bytes per launch from the newest profiles/r*_pmc_traffic.json, average launch us and file name from the newest
+    profiles/r*_bench_kernel_stats.csv) of `kernel`, template variants merged the way sgan_last_kernel() names them."""
+    import csv
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from kernel_names import short
+    except Exception:      # noqa: BLE001
+        return None, None, None
+    traffic = us = src = None
+    try:
+        pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))["kernels"]
+        traffic = pm[kernel]["hbm_bytes_per_launch"] if kernel in pm else None
+    except Exception:      # noqa: BLE001
+        pass
+    try:
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))[-1]
+        calls = tot = 0
+        for r in csv.DictReader(open(f)):
+            if short(r["Name"]) == kernel:
+                calls += int(r["Calls"])
+                tot += float(r["TotalDurationNs"])
+        if calls:
+            us, src = tot / calls / 1e3, os.path.basename(f)
+    except Exception:      # noqa: BLE001
+        pass
+    return traffic, us, src
+
+
 def main():
     if os.environ.get("SGAN_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit
         import faulthandler
@@ -471,19 +501,19 @@ def main():
             split = "igemm3" in dom or "wgrad3" in dom      # split-bf16 kernel: 3 bf16 MFMA flops issued per useful flop
             # MI355X_MICROARCH.md: fp32 matrix peak 157.3 TFLOP/s; bf16 dense MFMA peak 2500 TFLOP/s (never the 2:1-sparsity figure)
             peak = 2500.0 if split else 157.3
-            traffic = None     # HBM bytes per launch from the committed PMC passes (profiles/), same kernel
-            try:      # the committed counter passes were taken on the fcgan step: only that workload's launch mix matches them
-                import glob
-                pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))["kernels"]
-                traffic = pm[dom]["hbm_bytes_per_launch"] if (dom in pm and args.workload == "fcgan") else None
-            except Exception:
-                traffic = None
+            traffic, rp_us, rp_src = None, None, None
+            if args.workload == "fcgan":      # the committed passes were taken on the fcgan step: only its launch mix matches them
+                traffic, rp_us, rp_src = committed_profile_of(dom)
             issued = kern[dom]["tflops"] * (3.0 if split else 1.0)
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": issued, "peak": peak,
                                "unit": "TFLOP/s", "frac": issued / peak, "traffic": traffic,
                                "achieved_useful": kern[dom]["tflops"], "mfma_flops_issued_per_useful_flop": 3 if split else 1,
                                "frac_of_fp32_matrix_peak": kern[dom]["tflops"] / 157.3,
                                "avg_launch_us": kern[dom]["avg_us"], "gflop_per_launch": kern[dom]["gflop_per_launch"],
+                               # the same kernel in the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/):
+                               # average launch duration there, and the fraction it gives
+                               "rocprof_avg_launch_us": rp_us, "rocprof_source": rp_src,
+                               "rocprof_frac": (kern[dom]["gflop_per_launch"] / rp_us * 1e-3 * (3.0 if split else 1.0) / peak) if rp_us else None,
                                "launches_per_step": kern[dom]["launches_per_step"],
                                "measured": "every conv call of one step captured 8x back to back into a hipGraph and replayed: device time "
                                            "per call (HIP events on the replay stream), launch boundary and any second kernel of the call included"}

@@ -75,11 +75,14 @@ typedef struct sgan_conv_desc {
     int32_t Cin_logical, Cout_logical;
     /* Arithmetic of the MFMA kernels (the dtype enum of the boundary).  Storage is fp32 in every mode.
      *   SGAN_MATH_F32    : v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 fma chain (the parity mode);
-     *   SGAN_MATH_BF16X3 : split-bf16 -- every fp32 operand x is cut into hi = bf16(x), lo = bf16(x - hi) and a product is
-     *                      a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-16
-     *                      relative error per product (an fp32-equivalent result, inside the 1e-3 contract) at 16/3 of the
-     *                      fp32 matrix rate.  Needs the job's `w_packed` copy of the weights (sgan_pack_weights); layers the
-     *                      split kernels do not cover (stored channels not a multiple of 8, 4-channel heads) run the fp32
+     *   SGAN_MATH_BF16X3 : split 16-bit planes -- every fp32 operand x is cut into hi = rne16(x), lo = rne16(x - hi) and a
+     *                      product is a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulation,
+     *                      at 16/3 of the fp32 matrix rate.  The forward pass uses fp16 planes (11 + 11 bits; the packed
+     *                      weights hold w * 2^10): measured 2e-7 .. 1e-6 per layer against fp64, the same as SGAN_MATH_F32.
+     *                      Backward-data and backward-weight use bf16 planes (8 + 8 bits, the fp32 exponent range of
+     *                      gradients): ~5e-6 per layer, inside the 1e-3 contract.  Needs the job's `w_packed` copy of the
+     *                      weights (sgan_pack_weights) and fails without it; layers the split kernels do not cover (stored
+     *                      channels not a multiple of 8 or under 16, maps under 256 pixels, 4-channel heads) run the fp32
      *                      kernels whatever this field says. */
     int32_t math;
 } sgan_conv_desc;

@@ -1,0 +1,30 @@
+"""rocprofv3 kernel name -> the name libsgan_hip reports through sgan_last_kernel() (shared by bench.py and the profile tools)."""
+import re
+
+
+def short(name):
+    """rocprofv3 kernel name -> the name libsgan_hip reports through sgan_last_kernel() (template variants of one kernel
+    merged: the prologue flag of sg_igemm / sg_wgrad, the layout flag of sg_conv_small_n)."""
+    n = name.split("(")[0].replace("void ", "").replace(" ", "")
+    m = re.match(r"(sg_igemm_kernel)<(\d+,\d+,\d+,\d+,(?:true|false)),(?:true|false)(?:,\d+)?>$", n)   # prologue flag, wave groups
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"(sg_igemm3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false),(?:true|false)>$", n)   # prologue flag, fp16 / bf16 planes
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"(sg_igemm3p_kernel)<(\d+),.*>$", n)      # patch-tile count, prologue flag, plane type
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"(sg_wgrad3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false)>$", n)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"(sg_wgrad_kernel)<(.*),(true|false)>$", n)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"sg_conv_small_n_kernel<(\d+),(?:\d+,)*(true|false)>$", n)
+    if m:
+        return f"sg_conv_small_n_kernel<{m.group(1)}>"
+    m = re.match(r"sg_wgrad_thin_kernel<(\d+),(true|false),(true|false)>$", n)
+    if m:
+        return f"sg_wgrad_thin_kernel<{m.group(1)},{'cout4' if m.group(3) == 'true' else 'cin4'}>"
+    return n

@@ -11,29 +11,8 @@ def newest(pat):
     return fs[-1] if fs else None
 
 
-def short(name):
-    """rocprofv3 kernel name -> the name libsgan_hip reports through sgan_last_kernel() (template variants of one kernel
-    merged: the prologue flag of sg_igemm / sg_wgrad, the layout flag of sg_conv_small_n)."""
-    n = name.split("(")[0].replace("void ", "").replace(" ", "")
-    m = re.match(r"(sg_igemm_kernel)<(\d+,\d+,\d+,\d+,(?:true|false)),(?:true|false)(?:,\d+)?>$", n)   # prologue flag, wave groups
-    if m:
-        return f"{m.group(1)}<{m.group(2)}>"
-    m = re.match(r"(sg_igemm3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false),(?:true|false)>$", n)   # prologue flag, fp16 / bf16 planes
-    if m:
-        return f"{m.group(1)}<{m.group(2)}>"
-    m = re.match(r"(sg_wgrad3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false)>$", n)
-    if m:
-        return f"{m.group(1)}<{m.group(2)}>"
-    m = re.match(r"(sg_wgrad_kernel)<(.*),(true|false)>$", n)
-    if m:
-        return f"{m.group(1)}<{m.group(2)}>"
-    m = re.match(r"sg_conv_small_n_kernel<(\d+),(?:\d+,)*(true|false)>$", n)
-    if m:
-        return f"sg_conv_small_n_kernel<{m.group(1)}>"
-    m = re.match(r"sg_wgrad_thin_kernel<(\d+),(true|false),(true|false)>$", n)
-    if m:
-        return f"sg_wgrad_thin_kernel<{m.group(1)},{'cout4' if m.group(3) == 'true' else 'cin4'}>"
-    return n
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import short  # noqa: E402
 
 
 for tag, sub in (("bench", "stats"), ("bench_eager_1stream", "stats_eager"), ("bench_cgan_eager_1stream", "stats_cgan_eager"),

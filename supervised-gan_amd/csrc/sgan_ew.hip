@@ -111,16 +111,34 @@ __global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(const SgNormBwdT
     const int64_t total = (int64_t)J.npix * CQ;
     float* dy = J.dy;
     const float* x = J.x;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)J.blocks * 256) {
-        const int p = (int)(e / CQ), c = (int)(e - (int64_t)p * CQ) * 4;
-        f32x4 d = *reinterpret_cast<const f32x4*>(dy + (int64_t)p * J.dy_ld + c);
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)p * J.x_ld + c);
+    // four chunks per trip, all eight loads in flight before the first store: dy is updated in place, so the compiler keeps every
+    // load behind the previous trip's store and a one-chunk loop waits out a memory round trip per chunk
+    const int64_t stride = (int64_t)J.blocks * 256;
+    for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += 4 * stride) {
+        f32x4 d[4], xv[4];
+        int64_t od[4];
+        int cc[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float xhat = (xv[j] - cMean[c + j]) * cRstd[c + j];
-            d[j] = cA[c + j] * (d[j] - cS1[c + j] - xhat * cS2[c + j]);
+        for (int u = 0; u < 4; ++u) {
+            const int64_t e = e0 + u * stride;
+            const bool ok = e < total;
+            const int p = ok ? (int)(e / CQ) : 0;
+            cc[u] = ok ? (int)(e - (int64_t)p * CQ) * 4 : 0;
+            od[u] = ok ? (int64_t)p * J.dy_ld + cc[u] : -1;
+            d[u] = *reinterpret_cast<const f32x4*>(dy + (ok ? od[u] : 0));
+            xv[u] = *reinterpret_cast<const f32x4*>(x + (ok ? (int64_t)p * J.x_ld + cc[u] : 0));
         }
-        *reinterpret_cast<f32x4*>(dy + (int64_t)p * J.dy_ld + c) = d;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (od[u] < 0) continue;
+            const int c = cc[u];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xhat = (xv[u][j] - cMean[c + j]) * cRstd[c + j];
+                d[u][j] = cA[c + j] * (d[u][j] - cS1[c + j] - xhat * cS2[c + j]);
+            }
+            *reinterpret_cast<f32x4*>(dy + od[u]) = d[u];
+        }
     }
 }
 

@@ -77,9 +77,34 @@ __device__ __forceinline__ int sg3_off(int row, int slot) { return row * 128 + (
 // Bias, fp64 statistics of the result (forward) or act'(norm(x)) and the two norm-backward sums (backward-data), tanh, accumulate;
 // or the raw partial tile to the split-K slab.  `red` is [2 BN] fp64 of LDS, zeroed before the main loop.
 // ------------------------------------------------------------------------------------------
+// Per-column constants of the epilogue (bias; mean / rstd / affine of the norm the forward consumer applied), fetched BEFORE the
+// main loop: read in the epilogue itself they put two dependent memory round trips in front of the first store.
+template <int NB>
+struct Sg3EpiConst { float bias_v[NB], x_mean[NB], x_rstd[NB], x_g[NB], x_b[NB]; };
+
+template <int WTN, int NB>
+__device__ __forceinline__ Sg3EpiConst<NB> sg3_epilogue_constants(const SgLocal& P, int n0, int wn, int tid) {
+    Sg3EpiConst<NB> E;
+    const int fr = tid & 31;
+    const bool xnorm = P.xref != nullptr && P.xn.stats != nullptr;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + fr;
+        const bool nv = n < P.N;
+        E.bias_v[j] = (P.bias && nv) ? P.bias[n] : 0.f;
+        E.x_mean[j] = 0.f; E.x_rstd[j] = 1.f; E.x_g[j] = 1.f; E.x_b[j] = 0.f;
+        if (xnorm && nv) {
+            sg_mean_rstd(P.xn, P.N, n, E.x_mean[j], E.x_rstd[j]);
+            E.x_g[j] = P.xn.gamma ? P.xn.gamma[n] : 1.f;
+            E.x_b[j] = P.xn.beta ? P.xn.beta[n] : 0.f;
+        }
+    }
+    return E;
+}
+
 template <int BN, int WTM, int WTN, int MB, int NB, bool F16, typename RowPix>
 __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB][NB], double* red, int split, int n0, int wm, int wn,
-                                             int tid, RowPix rowpix) {
+                                             int tid, const Sg3EpiConst<NB>& EC, RowPix rowpix) {
     const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
     const int N = P.N;
     if constexpr (F16) {     // the fp16 weight planes hold w * 2^SGAN_F16_WEIGHT_SHIFT (an exact power of two)
@@ -110,20 +135,12 @@ __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB]
     const bool dact = P.xref != nullptr;
     const bool xnorm = dact && P.xn.stats != nullptr;
     const float xn_neg = P.xn.act == SGAN_ACT_NONE ? 1.f : (P.xn.act == SGAN_ACT_RELU ? 0.f : P.xn.slope);
-    float bias_v[NB], x_mean[NB], x_rstd[NB], x_g[NB], x_b[NB];
+    const float (&bias_v)[NB] = EC.bias_v, (&x_mean)[NB] = EC.x_mean, (&x_rstd)[NB] = EC.x_rstd, (&x_g)[NB] = EC.x_g, (&x_b)[NB] = EC.x_b;
     bool nvalid[NB];
     double s1[NB], s2[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + fr;
-        nvalid[j] = n < N;
-        bias_v[j] = (P.bias && nvalid[j]) ? P.bias[n] : 0.f;
-        x_mean[j] = 0.f; x_rstd[j] = 1.f; x_g[j] = 1.f; x_b[j] = 0.f;
-        if (xnorm && nvalid[j]) {
-            sg_mean_rstd(P.xn, N, n, x_mean[j], x_rstd[j]);
-            x_g[j] = P.xn.gamma ? P.xn.gamma[n] : 1.f;
-            x_b[j] = P.xn.beta ? P.xn.beta[n] : 0.f;
-        }
+        nvalid[j] = n0 + wn * WTN + j * 32 + fr < N;
         s1[j] = 0.0;
         s2[j] = 0.0;
     }
@@ -314,6 +331,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     __syncthreads();  // tap table visible
+    const Sg3EpiConst<NB> epi_const = sg3_epilogue_constants<WTN, NB>(P, n0, wn, tid);
 
     int ld_left = nkt;
     auto next_addrs = [&]() {
@@ -501,7 +519,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     }
 #undef SG3_FOR_SETS
 
-    sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, split, n0, wm, wn, tid, [&](int row) -> int64_t {
+    sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, split, n0, wm, wn, tid, epi_const, [&](int row) -> int64_t {
         const int m = m0 + row;
         if (m >= M) return -1;
         const int py = m / Wp, px = m - py * Wp;
@@ -722,6 +740,7 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
     const int fb_row = (wn * WTN + fr) * 128;
 
     __syncthreads();   // tap table, scale / shift visible
+    const Sg3EpiConst<NB> epi_const = sg3_epilogue_constants<WTN, NB>(P, n0, wn, tid);
     SG3P_MARK(1);
 
     // Step u = (channel block cur_cb, tap cur_tap); its weight tile lives in LDS buffer u & 1 and register slot u % 4.  Order
@@ -810,7 +829,7 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
     }
     SG3P_MARK(3);
 
-    sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, 0, n0, wm, wn, tid, [&](int row) -> int64_t {
+    sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, 0, n0, wm, wn, tid, epi_const, [&](int row) -> int64_t {
         const int py = ty0 + (row >> 3), px = tx0 + (row & 7);
         if (py >= Hp || px >= Wp) return -1;
         return (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);

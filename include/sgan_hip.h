@@ -372,6 +372,15 @@ int sgan_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* s
 int sgan_to_nhwc(const float* src, int64_t sc, int64_t sh, int64_t sw, int32_t H, int32_t W, int32_t Creal,
                  float* dst, int32_t dst_ld, int32_t Cstore, void* stream);
 
+/* ---- the (label, image) pair of the conditional discriminators -------------------------------------
+ * torch.cat((real_A, fake_B), 1) (models/cgan_model.py:162,172,187; twostage_cycle_model.py) of two NHWC buffers, written as the
+ * padded NHWC buffer the discriminator reads (channels Ca + Cb .. Cstore-1 zero), and its backward: channels [c0, c0 + C) of the
+ * pair's gradient as a padded NHWC buffer of their own. */
+int sgan_concat_nhwc(const float* a, int32_t a_ld, int32_t Ca, const float* b, int32_t b_ld, int32_t Cb, int64_t npix,
+                     float* dst, int32_t dst_ld, int32_t Cstore, void* stream);
+int sgan_slice_nhwc(const float* src, int32_t src_ld, int32_t c0, int32_t C, int64_t npix, float* dst, int32_t dst_ld,
+                    int32_t Cstore, void* stream);
+
 /* ---- input pipeline tail (data/base_dataset.py:17-55, data/aligned_dataset.py:31-42) ------------
  * From a decoded (and, if asked, resized: sgan_image_resize) RGB image `img` [H0][W0][3] uint8 already in device memory: crop the n x n window at
  * (x0, y0) (transforms.RandomCrop / the aligned dataset's offsets) -> horizontal flip (RandomHorizontalFlip) -> rotate by

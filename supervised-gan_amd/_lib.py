@@ -114,6 +114,8 @@ SIGNATURES = {
     "sgan_sigmoid_bwd": [_P, _I, _P, _I, _I, _P, _I, _P],
     "sgan_tanh_bwd": [_P, _P, _P, _L, _P],
     "sgan_to_nhwc": [_P, _L, _L, _L, _I, _I, _I, _P, _I, _I, _P],
+    "sgan_concat_nhwc": [_P, _I, _I, _P, _I, _I, _L, _P, _I, _I, _P],
+    "sgan_slice_nhwc": [_P, _I, _I, _I, _L, _P, _I, _I, _P],
     "sgan_adam_multi": [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _P, _P],
     "sgan_sgd_multi": [C.POINTER(AdamSeg), _I, _P, _F, _P],
     "sgan_normal_fill": [_P, _L, C.c_uint64, _P, _I, _P],

@@ -8,6 +8,7 @@ from collections import OrderedDict
 
 import torch
 
+from . import networks
 from .cgan_model import CGANModel
 from .image_pool import ImagePool
 
@@ -54,7 +55,7 @@ class CGAN2Model(CGANModel):
 
     def _pool_source(self):
         a, b = self._pair(self.opt.train_D_on_fake_fake_pair)
-        return b if self.opt.no_cgan else torch.cat((a, b), 1)
+        return b if self.opt.no_cgan else networks.cat_pair(a, b)
 
     def backward_G(self):
         """loss_G = sum_i lambda_i * GAN(D_i(pair), 1) + lambda_A * L1_w(G(real_A), real_B) [paired label only]"""
@@ -63,7 +64,7 @@ class CGAN2Model(CGANModel):
         for netD in self.netD:
             netD.compute_param_grads = not skip
         a, b = self._pair(self.opt.train_G_on_fake_fake_pair)
-        fake = b if self.opt.no_cgan else torch.cat((a, b), 1)
+        fake = b if self.opt.no_cgan else networks.cat_pair(a, b)
         trick = not self.opt.no_logD_trick
         self.loss_G_GAN, self._each_G = self._d_losses([(d, fake, trick) for d in self.netD],
                                                        [l if trick else -l for l in self.opt.lambda_D])

@@ -94,7 +94,7 @@ class CGANCycleModel(BaseModel):
 
     # ---- hipGraph hooks (graph_step.GraphedStep) --------------------------------------------------
     def _pair(self, a, b):
-        return b if self.opt.no_cgan else torch.cat((a, b), 1)
+        return b if self.opt.no_cgan else networks.cat_pair(a, b)
 
     def graph_spec(self):
         o = self.opt

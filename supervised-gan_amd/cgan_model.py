@@ -97,11 +97,30 @@ class CGANModel(BaseModel):
             a = b = input['A']
         else:
             raise NotImplementedError('Dataset mode [%s] is not recognized' % self.opt.dataset_mode)
-        a = a.to(self.device, non_blocking=True).index_select(1, self._chnl_dev[0])
-        b = b.to(self.device, non_blocking=True).index_select(1, self._chnl_dev[1])
-        self.input_A.resize_(a.size()).copy_(a)
-        self.input_B.resize_(b.size()).copy_(b)
+        if not (self._gather_input(a, 0, 'input_A') and self._gather_input(b, 1, 'input_B')):
+            a = a.to(self.device, non_blocking=True).index_select(1, self._chnl_dev[0])
+            b = b.to(self.device, non_blocking=True).index_select(1, self._chnl_dev[1])
+            self.input_A.resize_(a.size()).copy_(a)
+            self.input_B.resize_(b.size()).copy_(b)
         self.image_paths = input.get('A_paths' if AtoB else 'B_paths')
+
+    def _gather_input(self, data, which, name):
+        """One gather kernel per image: reads the batch where it lies (pinned host memory: the kernel is the H2D copy), picks the
+        contiguous channel range of --which_channel and writes the padded NHWC buffer behind `self.<name>`.  False: not a case
+        the kernel covers (the caller takes the index_select path)."""
+        idx = self.chnl_idx_input[which]
+        run = idx == list(range(idx[0], idx[0] + len(idx)))
+        if not (self.device.type == 'cuda' and run and len(idx) <= 4 and data.dim() == 4 and data.shape[0] == 1
+                and data.dtype == torch.float32 and data.stride(3) == 1 and (data.is_cuda or data.is_pinned())):
+            return False
+        _, _, H, W = data.shape
+        buf = getattr(self, '_buf_' + name, None)
+        if buf is None or buf.shape[:2] != (H, W):
+            buf = torch.zeros((H, W, 4), dtype=torch.float32, device=self.device)
+            setattr(self, '_buf_' + name, buf)
+            setattr(self, name, ops.logical_view(buf, len(idx)))
+        ops.host_batch_to_nhwc(data[:, idx[0]: idx[0] + len(idx)], buf)
+        return True
 
     def _draw_noise(self):
         """z ~ N(0, 1) [1, noise_nc, noiseSize, noiseSize] (cgan_model.py:137-138); only the CRN generator reads it."""
@@ -123,7 +142,7 @@ class CGANModel(BaseModel):
 
     def _pool_source(self):
         """What the reference hands to ImagePool.query (cgan_model.py:160-163)."""
-        return self.fake_B if self.opt.no_cgan else torch.cat((self.real_A, self.fake_B), 1)
+        return self.fake_B if self.opt.no_cgan else networks.cat_pair(self.real_A, self.fake_B)
 
     def test(self):
         with torch.no_grad():
@@ -143,7 +162,7 @@ class CGANModel(BaseModel):
         """loss_D = 0.5 * (sum_i GAN(D_i(fake), 0) + sum_i GAN(D_i(real), 1))   (cgan_model.py:158-182)"""
         fake = self._pool_override if self._pool_override is not None else self.fake_pool.query(self._pool_source())
         fake = fake.detach()
-        real = self.real_B if self.opt.no_cgan else torch.cat((self.real_A, self.real_B), 1)
+        real = self.real_B if self.opt.no_cgan else networks.cat_pair(self.real_A, self.real_B)
         n = self.n_netD
         self.loss_D, self._each_D = self._d_losses([(d, fake, False) for d in self.netD] + [(d, real, True) for d in self.netD],
                                                    [0.5] * (2 * n))
@@ -154,7 +173,7 @@ class CGANModel(BaseModel):
         skip = getattr(self.opt, 'skip_wasted_D_wgrad', False)
         for netD in self.netD:
             netD.compute_param_grads = not skip
-        fake = self.fake_B if self.opt.no_cgan else torch.cat((self.real_A, self.fake_B), 1)
+        fake = self.fake_B if self.opt.no_cgan else networks.cat_pair(self.real_A, self.fake_B)
         trick = not self.opt.no_logD_trick
         gan, self._each_G = self._d_losses([(d, fake, trick) for d in self.netD],
                                            [l if trick else -l for l in self.opt.lambda_D])

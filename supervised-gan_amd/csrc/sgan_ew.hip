@@ -1658,6 +1658,50 @@ extern "C" int sgan_to_nhwc(const float* src, int64_t sc, int64_t sh, int64_t sw
 }
 
 // ------------------------------------------------------------------------------------------
+// (label, image) pair of the conditional discriminators: torch.cat((A, B), 1) of two NHWC buffers as ONE pass that writes the
+// padded NHWC buffer the discriminator reads, and its backward (the channel slice of the pair's gradient that belongs to one
+// member).  One thread per pixel, whole padded pixels in and out.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sg_concat_nhwc_kernel(const float* a, int a_ld, int Ca, const float* b, int b_ld, int Cb,
+                                                             int64_t npix, float* dst, int dst_ld, int Cstore) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+        const float* pa = a + p * a_ld;
+        const float* pb = b + p * b_ld;
+        float* o = dst + p * dst_ld;
+        for (int c = 0; c < Cstore; ++c) o[c] = c < Ca ? pa[c] : (c < Ca + Cb ? pb[c - Ca] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_slice_nhwc_kernel(const float* src, int src_ld, int c0, int C, int64_t npix, float* dst,
+                                                            int dst_ld, int Cstore) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+        const float* ps = src + p * src_ld + c0;
+        float* o = dst + p * dst_ld;
+        for (int c = 0; c < Cstore; ++c) o[c] = c < C ? ps[c] : 0.f;
+    }
+}
+
+extern "C" int sgan_concat_nhwc(const float* a, int32_t a_ld, int32_t Ca, const float* b, int32_t b_ld, int32_t Cb, int64_t npix,
+                                float* dst, int32_t dst_ld, int32_t Cstore, void* stream) {
+    SGAN_CHECK(a && b && dst && npix > 0 && Ca > 0 && Cb > 0 && a_ld >= Ca && b_ld >= Cb && Cstore >= Ca + Cb && dst_ld >= Cstore, "bad argument");
+    int blocks = ew_cdiv(npix, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sg_concat_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, a_ld, Ca, b, b_ld, Cb, npix, dst, dst_ld, Cstore);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_slice_nhwc(const float* src, int32_t src_ld, int32_t c0, int32_t C, int64_t npix, float* dst, int32_t dst_ld,
+                               int32_t Cstore, void* stream) {
+    SGAN_CHECK(src && dst && npix > 0 && c0 >= 0 && C > 0 && src_ld >= c0 + C && Cstore >= C && dst_ld >= Cstore, "bad argument");
+    int blocks = ew_cdiv(npix, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sg_slice_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, src_ld, c0, C, npix, dst, dst_ld, Cstore);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Adam: one prep launch (step counter + bias corrections, fp64) and one streaming launch
 // ------------------------------------------------------------------------------------------
 struct SgAdamTable {

@@ -2061,6 +2061,32 @@ class _GanLossFn(torch.autograd.Function):
         return ops.logical_view(d, 1), None, None
 
 
+class _CatPairFn(torch.autograd.Function):
+    """torch.cat((a, b), 1) of two logical [1, C, H, W] tensors as ONE kernel that writes the padded NHWC buffer the discriminators
+    read (no CatArrayBatchedCopy + layout pass), and one slice kernel per member that needs a gradient in backward."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.Ca, ctx.Cb = a.shape[1], b.shape[1]
+        out = ops.concat_nhwc(ops.as_nhwc(a), ctx.Ca, ops.as_nhwc(b), ctx.Cb)
+        return ops.logical_view(out, ctx.Ca + ctx.Cb)
+
+    @staticmethod
+    def backward(ctx, g):
+        gb = ops.as_nhwc(g)
+        ga = ops.logical_view(ops.slice_nhwc(gb, 0, ctx.Ca), ctx.Ca) if ctx.needs_input_grad[0] else None
+        gbb = ops.logical_view(ops.slice_nhwc(gb, ctx.Ca, ctx.Cb), ctx.Cb) if ctx.needs_input_grad[1] else None
+        return ga, gbb
+
+
+def cat_pair(a, b):
+    """The conditional discriminators' input cat((label, image), 1) (models/cgan_model.py:162,172,187) on the HIP path; anything
+    that is not a batch-1 fp32 device pair goes to torch.cat."""
+    if a.is_cuda and b.is_cuda and a.dim() == 4 and a.shape[0] == 1 and a.shape[2:] == b.shape[2:] and a.dtype == b.dtype == torch.float32:
+        return _CatPairFn.apply(a, b)
+    return torch.cat((a, b), 1)
+
+
 class _GanLossMultiFn(torch.autograd.Function):
     """total = sum_i w_i * GANLoss(pred_i, target_i) -- ONE kernel for all terms, their finish and (when a gradient will be asked
     for) d total / d pred_i for an upstream gradient of 1.  backward() hands those out as they are when the upstream gradient is

@@ -529,6 +529,25 @@ def host_batch_to_nhwc(t: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def concat_nhwc(a, Ca, b, Cb):
+    """Padded NHWC buffers a [H, W, >= Ca], b [H, W, >= Cb] -> [H, W, pad4(Ca + Cb)]: torch.cat of the logical tensors, one pass."""
+    H, W, _ = a.shape
+    assert b.shape[:2] == (H, W)
+    out = torch.empty((H, W, pad4(Ca + Cb)), dtype=torch.float32, device=a.device)
+    L.check(L.lib().sgan_concat_nhwc(_ptr(_act(a)), a.stride(1), int(Ca), _ptr(_act(b)), b.stride(1), int(Cb), H * W, _ptr(out), out.stride(1),
+                                     out.shape[2], _stream()), "sgan_concat_nhwc")
+    return out
+
+
+def slice_nhwc(src, c0, Cn):
+    """Channels [c0, c0 + Cn) of a padded NHWC buffer as a padded NHWC buffer of their own."""
+    H, W, _ = src.shape
+    out = torch.empty((H, W, pad4(Cn)), dtype=torch.float32, device=src.device)
+    L.check(L.lib().sgan_slice_nhwc(_ptr(_act(src)), src.stride(1), int(c0), int(Cn), H * W, _ptr(out), out.stride(1), out.shape[2], _stream()),
+            "sgan_slice_nhwc")
+    return out
+
+
 def as_nhwc(t: torch.Tensor) -> torch.Tensor:
     """Logical [1, C, H, W] tensor (any strides) -> padded NHWC buffer [H, W, pad4(C)]."""
     require_gpu(t, "as_nhwc")

@@ -123,13 +123,13 @@ class SegmentationCycleModel(CGANCycleModel):
 
     # ---- losses -----------------------------------------------------------------------------------
     def _d_fake_source(self):
-        return self.fake_A if self.opt.no_cgan else torch.cat((self.real_B, self.fake_A), 1)
+        return self.fake_A if self.opt.no_cgan else networks.cat_pair(self.real_B, self.fake_A)
 
     def backward_D2(self):
         """(:201-222)"""
         fake = self._pool_overrides[0] if self._pool_overrides is not None else self.fake_pool2.query(self._d_fake_source())
         fake = fake.detach()
-        real = self.real_A if self.opt.no_cgan else torch.cat((self.real_B, self.real_A), 1)
+        real = self.real_A if self.opt.no_cgan else networks.cat_pair(self.real_B, self.real_A)
         n = self.n_netD2
         self.loss_D2, each = self._gan([(d, fake, False) for d in self.netD2] + [(d, real, True) for d in self.netD2], [0.5] * (2 * n))
         self.loss_D2_fake, self.loss_D2_real = each[:n].sum(), each[n:].sum()

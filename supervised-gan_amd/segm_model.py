@@ -88,7 +88,7 @@ class SegmentationModel(CGANModel):
         skip = getattr(self.opt, 'skip_wasted_D_wgrad', False)
         for netD in self.netD:
             netD.compute_param_grads = not skip
-        fake = self.fake_B if self.opt.no_cgan else torch.cat((self.real_A, self.fake_B), 1)
+        fake = self.fake_B if self.opt.no_cgan else networks.cat_pair(self.real_A, self.fake_B)
         self.loss_G_GAN, self._each_G = self._d_losses([(d, fake, True) for d in self.netD], list(self.opt.lambda_D))
         for netD in self.netD:
             netD.compute_param_grads = True

@@ -244,7 +244,7 @@ class TwoStageCycleModel(BaseModel):
         self._backward(self.loss_D1)
 
     def _pair(self, a, b):
-        return b if self.opt.no_cgan else torch.cat([a, b], 1)
+        return b if self.opt.no_cgan else networks.cat_pair(a, b)
 
     def backward_D2_binary(self):
         """(:264-299) -- one ImagePool serves both fake pairs, queried in the reference's order."""

@@ -422,6 +422,29 @@ def test_normal_fill_moments_and_counter(hip):
     assert torch.equal(a, c)                           # counter-based: same (seed, offset) -> same numbers
 
 
+def test_cat_pair_forward_backward(hip):
+    """networks.cat_pair == torch.cat((a, b), 1) (one kernel, padded NHWC result registered as a zero-copy view) and its gradient
+    slices; channel counts that fill, underfill and exceed one 4-channel group."""
+    from supervised_gan_amd import networks as N
+    g = torch.Generator().manual_seed(8)
+    for Ca, Cb in ((2, 1), (1, 1), (3, 3), (4, 2)):
+        a = torch.randn(1, Ca, 13, 9, generator=g).cuda().requires_grad_(True)
+        b = torch.randn(1, Cb, 13, 9, generator=g).cuda().requires_grad_(True)
+        r = torch.randn(1, Ca + Cb, 13, 9, generator=g).cuda()
+        out = N.cat_pair(a, b)
+        assert torch.equal(out, torch.cat((a, b), 1))
+        buf = hip.as_nhwc(out)
+        assert buf.data_ptr() == out.data_ptr() and float(buf[..., Ca + Cb:].abs().sum()) == 0.0      # zero-copy, zero padding
+        (out * r).sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(a.grad, r[:, :Ca]) and torch.equal(b.grad, r[:, Ca:])
+    a = torch.randn(1, 2, 8, 8).cuda()
+    b = torch.randn(1, 1, 8, 8).cuda().requires_grad_(True)
+    out = N.cat_pair(a, b)
+    out.sum().backward()
+    assert a.grad is None and torch.equal(b.grad, torch.ones_like(b))
+
+
 def test_image_resize_bit_exact_vs_pillow(hip):
     """sgan_image_resize against Image.resize of the Pillow in this image: bilinear and bicubic, up- and down-scaling (the filter
     support grows with the down-scale factor), one axis unchanged, a 1-pixel-wide result, the aligned dataset's 2:1 shape."""

@@ -404,8 +404,8 @@ class SeqDropoutInjector:
         inj = self
 
         def dropout(x, p=0.5, training=True, inplace=False):
-            assert p == 0.5 and training
-            m = O.dropout_mask_np(inj.seed + inj.n, x.shape)
+            assert training
+            m = O.dropout_mask_np(inj.seed + inj.n, x.shape, p)
             inj.n += 1
             return x * m
         torch.nn.functional.dropout = dropout
@@ -449,6 +449,26 @@ def golden_autoencoder_small():
     for k, p in g.named_parameters():
         arrs["grad/" + k] = p.grad.numpy()
     save("autoencoder_small.npz", **arrs)
+
+
+def golden_autoencoder_dropout():
+    """The autoencoder with use_dropout (Dropout(0.2) in the encoder, Dropout(0.5) in the decoder, between norm and ReLU;
+    models/networks.py:441-447,468-474), masks injected in call order."""
+    in_nc, out_nc, nl, ngf, hw = 2, 1, 3, 8, 128
+    sd = O.init_autoencoder(62, in_nc, out_nc, nl, ngf, True)
+    g = RN.define_G(in_nc, out_nc, ngf, "autoencoder", "instance", True, n_layers_G=nl, gpu_ids=[])
+    assert list(g.state_dict().keys()) == list(sd.keys()), (list(g.state_dict().keys()), list(sd.keys()))
+    load_sd(g, sd)
+    x = O.np_uniform(611, (1, in_nc, hw, hw)).requires_grad_(True)
+    r = O.np_normal(612, (1, out_nc, hw, hw))
+    with SeqDropoutInjector(70):
+        y = g.forward(x)
+    loss = (y * r).sum()
+    loss.backward()
+    arrs = {"y": y.detach().numpy(), "dx": x.grad.numpy(), "loss": np.float64(loss.item())}
+    for k, p in g.named_parameters():
+        arrs["grad/" + k] = p.grad.numpy()
+    save("autoencoder_dropout.npz", **arrs)
 
 
 def golden_g_nofcn_small():
@@ -1052,6 +1072,7 @@ def main():
         golden_resnet_small()
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
+        golden_autoencoder_dropout()
     if not only or "dcgan" in only:
         golden_dcgan_small()
         golden_g_nofcn_small()

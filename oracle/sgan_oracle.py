@@ -524,11 +524,11 @@ def resnet_forward(sd, x, n_blocks: int, use_dropout: bool = False, mask_seed: i
     return torch.tanh(torch.tanh(y)) if tanh else y
 
 
-def dropout_mask_np(seed: int, shape) -> torch.Tensor:
-    """Deterministic Dropout(0.5) keep-mask (0 or 2), keyed on the tensor shape (make_golden.py injects
-    the same masks into the reference)."""
+def dropout_mask_np(seed: int, shape, p: float = 0.5) -> torch.Tensor:
+    """Deterministic Dropout(p) keep-mask (0 or 1 / (1 - p); 0 or 2 for the default 0.5), keyed on the tensor shape
+    (make_golden.py injects the same masks into the reference)."""
     rs = np.random.RandomState(seed + int(shape[1]) * 7 + int(shape[2]))
-    return torch.from_numpy((rs.uniform(size=tuple(shape)) >= 0.5).astype(np.float32) * 2.0)
+    return torch.from_numpy((rs.uniform(size=tuple(shape)) >= p).astype(np.float32) * np.float32(1.0 / (1.0 - p)))
 
 
 def gauss_noise_np(seed: int, shape) -> torch.Tensor:
@@ -579,34 +579,36 @@ def norm_cancelled_keys_unet(num_downs: int, ngf: int = 64, num_skips: int = -1)
 
 
 # ----------------------------------------------------------------------------------
-# AutoEncoder generator (models/networks.py:421-490), no dropout
+# AutoEncoder generator (models/networks.py:421-490)
 # ----------------------------------------------------------------------------------
-def autoencoder_plan(input_nc: int, output_nc: int, n_layers: int, ngf: int):
-    """[(sequential index, kind, cin, cout, bias, normed)]"""
+def autoencoder_plan(input_nc: int, output_nc: int, n_layers: int, ngf: int, use_dropout: bool = False):
+    """[(sequential index, kind, cin, cout, bias, normed, dropout p)]; with use_dropout every block but the first of each half is
+    conv, norm, Dropout, ReLU (four modules: networks.py:441-447 p = 0.2, :468-474 p = 0.5)."""
+    step = 4 if use_dropout else 3
     plan, idx, nf = [], 0, 1
-    plan.append((idx, "conv", input_nc, ngf, True, True))
+    plan.append((idx, "conv", input_nc, ngf, True, True, 0.0))
     idx += 3
     for n in range(1, n_layers):
         nf_prev, nf = nf, min(2 ** n, 8)
-        plan.append((idx, "conv", nf_prev * ngf, ngf * nf, True, True))
-        idx += 3
+        plan.append((idx, "conv", nf_prev * ngf, ngf * nf, True, True, 0.2 if use_dropout else 0.0))
+        idx += step
     latent = min(2 ** n_layers, 8)
-    plan.append((idx, "conv", nf * ngf, latent, False, False))
+    plan.append((idx, "conv", nf * ngf, latent, False, False, 0.0))
     idx += 1
     nf = min(2 ** (n_layers - 1), 8)
-    plan.append((idx, "convt", latent, ngf * nf, False, True))
+    plan.append((idx, "convt", latent, ngf * nf, False, True, 0.0))
     idx += 3
     for n in range(1, n_layers):
         nf_prev, nf = nf, min(2 ** (n_layers - n - 1), 8)
-        plan.append((idx, "convt", ngf * nf_prev, ngf * nf, True, True))
-        idx += 3
-    plan.append((idx, "convt", ngf, output_nc, False, False))
+        plan.append((idx, "convt", ngf * nf_prev, ngf * nf, True, True, 0.5 if use_dropout else 0.0))
+        idx += step
+    plan.append((idx, "convt", ngf, output_nc, False, False, 0.0))
     return plan
 
 
-def init_autoencoder(seed: int, input_nc: int, output_nc: int, n_layers: int = 3, ngf: int = 64):
+def init_autoencoder(seed: int, input_nc: int, output_nc: int, n_layers: int = 3, ngf: int = 64, use_dropout: bool = False):
     sd = OrderedDict()
-    for k, (idx, kind, ci, co, bias, _n) in enumerate(autoencoder_plan(input_nc, output_nc, n_layers, ngf)):
+    for k, (idx, kind, ci, co, bias, _n, _p) in enumerate(autoencoder_plan(input_nc, output_nc, n_layers, ngf, use_dropout)):
         shape = (co, ci, 4, 4) if kind == "conv" else (ci, co, 4, 4)
         sd[f"model.{idx}.weight"] = np_normal(seed * 1000 + 2 * k, shape, 0.0, 0.02)
         if bias:
@@ -615,16 +617,22 @@ def init_autoencoder(seed: int, input_nc: int, output_nc: int, n_layers: int = 3
     return sd
 
 
-def autoencoder_forward(sd, x, n_layers: int, ngf: int):
+def autoencoder_forward(sd, x, n_layers: int, ngf: int, use_dropout: bool = False, mask_seed=None):
+    """mask_seed: the i-th dropout layer (in forward order) multiplies by dropout_mask_np(mask_seed + i, shape, p) -- training
+    mode with injected masks; None: no dropout (eval mode, or a net built without it)."""
     input_nc, output_nc = sd["model.0.weight"].shape[1], None
     last = max(int(k.split(".")[1]) for k in sd)
     output_nc = sd[f"model.{last}.weight"].shape[1]
-    h = x
-    for idx, kind, ci, co, bias, normed in autoencoder_plan(input_nc, output_nc, n_layers, ngf):
+    h, nd = x, 0
+    for idx, kind, ci, co, bias, normed, p in autoencoder_plan(input_nc, output_nc, n_layers, ngf, use_dropout):
         w, b = sd[f"model.{idx}.weight"], sd.get(f"model.{idx}.bias")
         h = F.conv2d(h, w, b, stride=2, padding=1) if kind == "conv" else F.conv_transpose2d(h, w, b, stride=2, padding=1)
         if normed:
-            h = F.relu(F.instance_norm(h, eps=IN_EPS))
+            h = F.instance_norm(h, eps=IN_EPS)
+            if p > 0 and mask_seed is not None:
+                h = h * dropout_mask_np(mask_seed + nd, h.shape, p)
+                nd += 1
+            h = F.relu(h)
     return torch.tanh(h)
 
 

@@ -91,6 +91,7 @@ class LayerSpec:
     norm: Optional[str]      # None | "in" | "bn" : normalisation of THIS layer's output
     act: int                 # activation after the norm (applied by the consumer on load)
     slope: float = 0.0
+    drop: float = 0.0        # nn.Dropout(p) between this layer's norm and its activation (training mode only)
     # filled by the net
     w_off: int = 0
     b_off: int = -1
@@ -434,6 +435,13 @@ class ChainNet(nn.Module):
             return ops.norm_desc(st, g, be, count, BN_EPS, L.act, L.slope)
         return ops.norm_desc(st, None, None, count, IN_EPS, L.act, L.slope)
 
+    def _norm_in(self, li, stats, count, drop):
+        """_norm_of for a consumer that may read the materialised dropout tensor of layer li: only the activation is left to apply."""
+        if li in drop:
+            L = self.layers[li]
+            return ops.norm_desc(None, None, None, count, 0.0, L.act, L.slope)
+        return self._norm_of(li, stats, count)
+
     # ---- forward / backward programs ----------------------------------------------------------
     def run_forward(self, x: torch.Tensor, update_running=True):
         """x: [H, W, Cs] NHWC buffer.  Returns (outs, stats): raw conv outputs and per-layer stats."""
@@ -458,15 +466,37 @@ class ChainNet(nn.Module):
         stats[-1].final_act = final_act
         outs = []
         cur = x
+        # Dropout layers (norm -> Dropout(p) -> ReLU, the AutoEncoder's): the mask commutes with the ReLU, so the masked normalised
+        # tensor t = norm(y) * mask is materialised by one pass (sgan_norm_apply_fwd) and the consumer reads ReLU(t) with no norm.
+        drop = {}
+        if self.training and any(L.drop > 0 for L in self.layers):
+            if getattr(self, "_rng_offset", None) is None or self._rng_offset.device != x.device:
+                self._rng_offset = torch.zeros(1, dtype=torch.int64, device=x.device)
+            drawn = 0
         for li, L in enumerate(self.layers):
             desc, h, w, ho, wo = geo[li]
             out = torch.empty((ho, wo, L.cout_s), dtype=torch.float32, device=x.device)
-            in_norm = self._norm_of(li - 1, stats, h * w) if li > 0 else None
+            in_norm = self._norm_in(li - 1, stats, h * w, drop) if li > 0 else None
             wt, b = self._wb(L)
             last = li == len(self.layers) - 1
             ops.conv_fwd(desc, cur, in_norm, wt, b, out, final_act if last else ACT_NONE, stats[li])
             outs.append(out)
             cur = out
+            if self.training and L.drop > 0:
+                mask = torch.empty((ho, wo, L.cout_s), dtype=torch.float32, device=x.device)
+                src = getattr(self, "mask_source", None)        # tests inject the reference's masks
+                if src is not None:
+                    mask.copy_(src(li, (ho, wo, L.cout_s)))
+                else:
+                    ops.dropout_mask(mask, L.drop, getattr(self, "_rng_seed", 0) + li, self._rng_offset, advance=False)
+                    drawn = max(drawn, (mask.numel() + 3) // 4)
+                t = torch.empty_like(out)
+                ops.norm_apply_fwd(out, ops.norm_desc(stats[li], None, None, ho * wo, IN_EPS, ACT_NONE, 0.0), t, mask)
+                drop[li] = (t, mask)
+                cur = t
+        if drop and getattr(self, "mask_source", None) is None:
+            ops.rng_advance(self._rng_offset, drawn)
+        stats[-1].drop = drop
         if update_running and self._bn_boxes:
             rl = []
             for li, L in enumerate(self.layers):
@@ -499,11 +529,13 @@ class ChainNet(nn.Module):
             else:
                 sums.append(None)
         dx = None
+        drop = getattr(stats[-1], "drop", {})
         for li in range(nL - 1, -1, -1):
             L = self.layers[li]
             desc, h, w, ho, wo = geo[li]
-            src = outs[li - 1] if li > 0 else x
-            in_norm = self._norm_of(li - 1, stats, h * w) if li > 0 else None
+            dropped = (li - 1) in drop
+            src = (drop[li - 1][0] if dropped else outs[li - 1]) if li > 0 else x
+            in_norm = self._norm_in(li - 1, stats, h * w, drop) if li > 0 else None
             wt, _ = self._wb(L)
             if want_wgrad:
                 gw, gb = self._gwb(L)
@@ -512,8 +544,12 @@ class ChainNet(nn.Module):
                 P = self.layers[li - 1]
                 din = torch.empty((h, w, P.cout_s), dtype=torch.float32, device=dev)
                 with ops.math_scope(_dgrad_math(P)):
-                    ops.conv_dgrad(desc, dcur, self._wt(L), din, src, in_norm, sums[li - 1], w_transposed=True)
-                if P.norm:
+                    ops.conv_dgrad(desc, dcur, self._wt(L), din, src, in_norm, None if dropped else sums[li - 1], w_transposed=True)
+                if dropped:      # din = d t * ReLU'(t); through the mask, with the two norm-backward sums of the masked gradient
+                    raw_norm = self._norm_of(li - 1, stats, h * w)
+                    ops.norm_apply_bwd_sums(din, outs[li - 1], raw_norm, sums[li - 1], drop[li - 1][1])
+                    ops.norm_bwd_apply(din, outs[li - 1], raw_norm, sums[li - 1])
+                elif P.norm:
                     dg = self._gflat[P.g_off: P.g_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
                     db = self._gflat[P.be_off: P.be_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
                     ops.norm_bwd_apply(din, src, in_norm, sums[li - 1], dg, db)
@@ -1081,22 +1117,25 @@ class DCGANDiscriminator(ChainNet):
 
 
 class AutoEncoder(ChainNet):
-    """AutoEncoder (models/networks.py:421-490) without dropout: Conv(k4,s2,p1)+norm+ReLU x n_layers, a bias-free latent Conv
-    with nothing after it, then ConvT(k4,s2,p1)+norm+ReLU x n_layers and a bias-free ConvT -> Tanh."""
+    """AutoEncoder (models/networks.py:421-490): Conv(k4,s2,p1)+norm+ReLU x n_layers, a bias-free latent Conv with nothing after
+    it, then ConvT(k4,s2,p1)+norm+ReLU x n_layers and a bias-free ConvT -> Tanh; with `use_dropout` every block but the first of
+    each half has nn.Dropout(0.2) (encoder) / nn.Dropout(0.5) (decoder) between its norm and its ReLU (ChainNet's `drop`)."""
     final_act = ACT_TANH
 
     def __init__(self, input_nc, output_nc, n_layers=3, ngf=64, norm="batch", use_dropout=False, gpu_ids=[]):
-        if use_dropout:
-            raise NotImplementedError("AutoEncoder dropout (0.2 / 0.5 between norm and ReLU) is not on the MI355X path")
         nrm = {"instance": "in", "batch": "bn"}[norm]
+        if use_dropout and nrm != "in":
+            raise NotImplementedError("AutoEncoder dropout on the MI355X path implements --norm instance (the masked tensor is "
+                                      "materialised without an affine)")
+        step = 4 if use_dropout else 3      # modules per block in the reference's nn.Sequential
         layers, idx = [], 0
         nf = 1
         layers.append(LayerSpec(str(idx), CONV, 4, 2, 1, input_nc, ngf, True, nrm, ACT_RELU))
         idx += 3
         for n in range(1, n_layers):
             nf_prev, nf = nf, min(2 ** n, 8)
-            layers.append(LayerSpec(str(idx), CONV, 4, 2, 1, nf_prev * ngf, ngf * nf, True, nrm, ACT_RELU))
-            idx += 3
+            layers.append(LayerSpec(str(idx), CONV, 4, 2, 1, nf_prev * ngf, ngf * nf, True, nrm, ACT_RELU, drop=0.2 if use_dropout else 0.0))
+            idx += step
         latent_nc = min(2 ** n_layers, 8)
         layers.append(LayerSpec(str(idx), CONV, 4, 2, 1, nf * ngf, latent_nc, False, None, ACT_NONE))
         idx += 1
@@ -1105,8 +1144,8 @@ class AutoEncoder(ChainNet):
         idx += 3
         for n in range(1, n_layers):
             nf_prev, nf = nf, min(2 ** (n_layers - n - 1), 8)
-            layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, ngf * nf_prev, ngf * nf, True, nrm, ACT_RELU))
-            idx += 3
+            layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, ngf * nf_prev, ngf * nf, True, nrm, ACT_RELU, drop=0.5 if use_dropout else 0.0))
+            idx += step
         layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, ngf, output_nc, False, None, ACT_NONE))
         super().__init__(layers)
         self.gpu_ids = gpu_ids

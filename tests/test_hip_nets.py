@@ -341,6 +341,40 @@ def test_autoencoder_small(N, golden_dir):
             assert rel(params[k[5:]].grad, g[k]) < TOL, k
 
 
+def test_autoencoder_dropout(N, golden_dir):
+    """`--which_model_netG autoencoder` with dropout: the masked normalised tensor is materialised (sgan_norm_apply_fwd) and its
+    backward runs mask -> sums -> norm backward (sgan_norm_apply_bwd_sums, sgan_norm_bwd_apply); the reference's masks are injected.
+    Eval mode drops nothing."""
+    g = load(golden_dir, "autoencoder_dropout.npz")
+    G = N.define_G(2, 1, 8, "autoencoder", "instance", True, n_layers_G=3, gpu_ids=[0])
+    sd = O.init_autoencoder(62, 2, 1, 3, 8, True)
+    assert list(G.state_dict().keys()) == list(sd.keys())
+    G.load_state_dict(sd)
+    order = [li for li, L in enumerate(G.layers) if L.drop > 0]
+    ps = {li: G.layers[li].drop for li in order}
+    assert [ps[li] for li in order] == [0.2, 0.2, 0.5, 0.5]
+    G.mask_source = lambda li, shape: O.dropout_mask_np(70 + order.index(li), (1, shape[2], shape[0], shape[1]), ps[li])[0].permute(1, 2, 0).contiguous().cuda()
+    x = O.np_uniform(611, (1, 2, 128, 128)).cuda().requires_grad_(True)
+    r = O.np_normal(612, (1, 1, 128, 128)).cuda()
+    y = G.forward(x)
+    (y * r).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, g["y"]) < TOL and rel(x.grad, g["dx"]) < TOL
+    params = dict(G.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith(".weight"):
+            assert rel(params[k[5:]].grad, g[k]) < TOL, k
+    G.mask_source = None
+    y1 = G.forward(x.detach())          # own Philox masks: a different draw every call, same statistics
+    y2 = G.forward(x.detach())
+    assert float((y1 - y2).abs().max()) > 0
+    G.eval()
+    with torch.no_grad():
+        ye = G.forward(x.detach())
+    ref = O.autoencoder_forward({k: v for k, v in sd.items()}, x.detach().cpu(), 3, 8, True, mask_seed=None)
+    assert rel(ye, ref) < TOL
+
+
 def test_dcgan_small(N, golden_dir):
     """`--which_model_netG dcgan` / `--which_model_netD dcgan` (models/networks.py:1015-1129): k4 s1 p0 ConvT on a 1x1 latent, BatchNorm
     chains without biases, a k4 s1 p0 logits conv on a 4x4 map."""

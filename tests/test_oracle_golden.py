@@ -684,6 +684,24 @@ def test_segm_cycle_step(golden_dir):
     assert np.abs(np.asarray(losses) - g["losses"]).max() < 2e-3 * max(1.0, np.abs(g["losses"]).max()), (losses, g["losses"])
 
 
+def test_autoencoder_dropout(golden_dir):
+    """The autoencoder with use_dropout against the reference run with injected masks (Dropout(0.2) / Dropout(0.5) between norm
+    and ReLU; the Sequential indices move by one per dropout block)."""
+    g = load(golden_dir, "autoencoder_dropout.npz")
+    sd = O.init_autoencoder(62, 2, 1, 3, 8, True)
+    assert [int(k.split(".")[1]) for k in sd if k.endswith(".weight")] == [0, 3, 7, 11, 12, 15, 19, 23]
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = O.np_uniform(611, (1, 2, 128, 128)).requires_grad_(True)
+    r = O.np_normal(612, (1, 1, 128, 128))
+    y = O.autoencoder_forward(sd, x, 3, 8, True, mask_seed=70)
+    (y * r).sum().backward()
+    assert rel(y, g["y"]) < TIGHT * 5 and rel(x.grad, g["dx"]) < 1e-4
+    for k, v in sd.items():
+        if k.endswith(".weight"):
+            assert rel(v.grad, g["grad/" + k]) < 1e-4, k
+
+
 def test_resize_restatement_matches_pillow():
     """oracle/image_prep.py: resize_numpy (precompute_coeffs + normalize_coeffs_8bpc + the two 8-bit passes of Pillow's Resample.c,
     restated) equals Image.resize of the Pillow in this image bit for bit -- it is what tells a reader of sgan_image_resize what

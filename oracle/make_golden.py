@@ -561,6 +561,27 @@ def golden_crn_small():
         save(f"crn_small_{tag}.npz", **arrs)
 
 
+def golden_crn_noise():
+    """crn with --add_gaussian_noise (sigma 0.1 on the normalised output of upsample blocks 5..1), ConvTranspose upsampling,
+    2-layer blocks; the noise tensors injected from numpy."""
+    in_nc, out_nc, nz, ngf, hw, mode, nlb = 2, 1, 8, 8, 128, "convt", 2
+    sd = O.init_crn(43, in_nc, out_nc, nz, ngf, mode, nlb, True)
+    g = RN.define_G(in_nc, out_nc, ngf, "crn", "instance", False, n_layers_G=5, noise_nc=nz, upsample_mode=mode,
+                    n_layers_CRN_block=nlb, share_label_weights=True, add_gaussian_noise=True, gaussian_sigma=0.1, gpu_ids=[])
+    load_sd(g, sd)
+    label = O.np_uniform(411, (1, in_nc, hw, hw)).requires_grad_(True)
+    z = O.np_normal(412, (1, nz, hw // 64, hw // 64)).requires_grad_(True)
+    r = O.np_normal(413, (1, out_nc, hw, hw))
+    with UnetRandomInjector(0, 80):
+        y = g.forward(label, z)
+    loss = (y * r).sum()
+    loss.backward()
+    arrs = {"y": y.detach().numpy(), "dlabel": label.grad.numpy(), "dz": z.grad.numpy(), "loss": np.float64(loss.item())}
+    for k, p in g.named_parameters():
+        arrs["grad/" + k] = p.grad.numpy()
+    save("crn_small_noise.npz", **arrs)
+
+
 def build_ref_cgan(cfg: "O.CGANConfig", seed: int, tmpdir: str):
     from options.train_options import TrainOptions
     if cfg.variant == "cgan2":
@@ -1094,6 +1115,7 @@ def main():
                          O.CGANConfig(**dict(small, train_D_on_fake_fake_pair=True, train_G_on_fake_fake_pair=True)), 0, 2)
     if not only or "crn" in only:
         golden_crn_small()
+        golden_crn_noise()
     if not only or "multiclass" in only:
         golden_twostage("twostage_multiclass_small.npz",
                         O.TwoStageConfig(fineSize=256, ngf1=8, noiseSize1=2, ndf1=8, ngf2=8, noiseSize2=4, nff2=8, ndf2=8,

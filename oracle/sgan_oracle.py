@@ -801,9 +801,10 @@ def init_crn(seed: int, input_nc: int, output_nc: int, noise_nc: int, ngf: int =
 
 
 def crn_forward(sd, label, noise, ngf: int, upsample_mode: str = "convt", n_layers_block: int = 1,
-                share_label_weights: bool = True, tanh: bool = True):
+                share_label_weights: bool = True, tanh: bool = True, gauss_seed=None, gauss_sigma: float = 0.1):
     """CascadedRefinementNetwork.forward (:708-733) with CrnUpsampleBlock (:737-757) and CrnInterBlock (:760-787)
-    inlined; InstanceNorm2d(affine=False), no Gaussian noise."""
+    inlined; InstanceNorm2d(affine=False).  gauss_seed: --add_gaussian_noise, every upsample block but blockh0 adds
+    gauss_sigma * gauss_noise_np(gauss_seed, shape) to its normalised output (:655-680,757-760)."""
     def conv3(x, key):
         return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=1, padding=1)
 
@@ -814,6 +815,8 @@ def crn_forward(sd, label, noise, ngf: int, upsample_mode: str = "convt", n_laye
         else:
             h = F.interpolate(conv3(x, k0), scale_factor=2, mode="bilinear", align_corners=False)
         h = F.instance_norm(h, eps=IN_EPS)
+        if gauss_seed is not None and s > 0:
+            h = h + gauss_sigma * gauss_noise_np(gauss_seed, h.shape)
         for i in range(n_layers_block):
             h = conv3(F.relu(h), f"blockh{s}.1.model.{3 * i + 1}")
             if not (s == 0 and i == n_layers_block - 1):

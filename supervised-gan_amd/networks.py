@@ -1718,14 +1718,16 @@ class CascadedRefinementNetwork(ChainNet):
         assert n_layers == 5
         if norm != "instance":
             raise NotImplementedError("CascadedRefinementNetwork on the MI355X path implements --norm instance")
-        if add_gaussian_noise:
-            raise NotImplementedError("CascadedRefinementNetwork --add_gaussian_noise is not on the MI355X path")
         if upsample_mode not in ('convt', 'bilinear'):
             raise NotImplementedError('UpsampleBlock mode [%s] is not recognized' % upsample_mode)
         if input_nc > 4:
             raise NotImplementedError("label images with more than 4 channels are not on the MI355X path")
         self.input_nc, self.output_nc, self.noise_nc, self.ngf = input_nc, output_nc, noise_nc, ngf
         self.mode, self.nlb, self.share = upsample_mode, n_layers_block, share_label_weights
+        # --add_gaussian_noise: sigma * N(0, 1) on the normalised output of every upsample block but the last (networks.py:655-680,757-760)
+        self.add_gauss, self.gauss_sigma = bool(add_gaussian_noise), float(gaussian_sigma)
+        self.noise_override = None      # tests: {stage: [2h, 2w, ngf] NHWC tensor}
+        self._rng_seed, self._rng_offset = 0, None
         self.up, self.inter, self.lab = {}, {}, {}
         layers = []
         for s in range(5, -1, -1):
@@ -1804,8 +1806,9 @@ class CascadedRefinementNetwork(ChainNet):
             wt, b = self._wb(L)
             ops.conv_fwd(self._desc(L, *res[s]), lv[s], None, wt, b, cat[s][:, :, :ngf], ACT_NONE, st(("cat", s), 2 * C2), C2)
         final_act = self._take_call_act()
-        saved = dict(final_act=final_act, label=label, first=x["first"], lv=lv, cat=cat, c={}, u={}, t={}, arena=arena, lay=lay, off=off, res=res)
+        saved = dict(final_act=final_act, label=label, first=x["first"], lv=lv, cat=cat, c={}, u={}, un={}, t={}, arena=arena, lay=lay, off=off, res=res)
         out = None
+        drawn = 0
         for s in range(5, -1, -1):
             h, w = res[s]
             U = self.up[s]
@@ -1823,6 +1826,19 @@ class CascadedRefinementNetwork(ChainNet):
                 saved["c"][s] = c
             saved["u"][s] = u
             cur, cur_stat = u, ustat
+            if self.add_gauss and s > 0:      # t = norm(u) + sigma * noise, materialised; the inter block reads ReLU(t) with no norm
+                if self.noise_override is not None:
+                    nz = self.noise_override[s]
+                else:
+                    if self._rng_offset is None or self._rng_offset.device != dev:
+                        self._rng_offset = torch.zeros(1, dtype=torch.int64, device=dev)
+                    nz = torch.empty_like(u)
+                    ops.normal_fill(nz, self._rng_seed + s, self._rng_offset, advance=False)
+                    drawn = max(drawn, (nz.numel() + 3) // 4)
+                tn = torch.empty_like(u)
+                ops.norm_apply_fwd(u, ops.norm_desc(ustat, None, None, 4 * h * w, IN_EPS, ACT_NONE, 0.0), tn, None, nz, self.gauss_sigma)
+                saved["un"][s] = tn
+                cur, cur_stat = tn, None
             for i, L in enumerate(self.inter[s]):
                 wt, b = self._wb(L)
                 nrm = ops.norm_desc(cur_stat, None, None, 4 * h * w, IN_EPS, ACT_RELU, 0.0)
@@ -1839,6 +1855,8 @@ class CascadedRefinementNetwork(ChainNet):
                     ops.conv_fwd(self._desc(L, 2 * h, 2 * w), cur, nrm, wt, b, t, ACT_NONE, tstat)
                     saved["t"][(s, i)] = t
                     cur, cur_stat = t, tstat
+        if drawn:
+            ops.rng_advance(self._rng_offset, drawn)      # every stage read the same offset with its own seed
         saved["out"] = out
         return [out], saved
 
@@ -1872,15 +1890,21 @@ class CascadedRefinementNetwork(ChainNet):
             # inter block, last conv first: `d` is the gradient w.r.t. the raw output of inter[s][-1]
             for i in range(nlb - 1, -1, -1):
                 L = self.inter[s][i]
-                src = u if i == 0 else S["t"][(s, i - 1)]
-                sstat = ustat if i == 0 else st(("t", s, i - 1), 2 * ngf)
+                noisy = i == 0 and s in S["un"]
+                src = (S["un"][s] if noisy else u) if i == 0 else S["t"][(s, i - 1)]
+                sstat = (None if noisy else ustat) if i == 0 else st(("t", s, i - 1), 2 * ngf)
                 ssum = sm(("u", s), 2 * ngf) if i == 0 else sm(("t", s, i - 1), 2 * ngf)
                 nrm = ops.norm_desc(sstat, None, None, 4 * h * w, IN_EPS, ACT_RELU, 0.0)
                 desc = self._desc(L, 2 * h, 2 * w)
                 wgrad(L, desc, src, nrm, d)
                 din = torch.empty((2 * h, 2 * w, ngf), dtype=torch.float32, device=dev)
-                ops.conv_dgrad(desc, d, self._wt(L), din, src, nrm, ssum, w_transposed=True)
-                ops.norm_bwd_apply(din, src, nrm, ssum)
+                ops.conv_dgrad(desc, d, self._wt(L), din, src, nrm, None if noisy else ssum, w_transposed=True)
+                if noisy:      # din = d t (the noise has no gradient): sums of the norm backward, then the norm backward itself
+                    unrm = ops.norm_desc(ustat, None, None, 4 * h * w, IN_EPS, ACT_NONE, 0.0)
+                    ops.norm_apply_bwd_sums(din, u, unrm, ssum, None)
+                    ops.norm_bwd_apply(din, u, unrm, ssum)
+                else:
+                    ops.norm_bwd_apply(din, src, nrm, ssum)
                 d = din
             # d = gradient w.r.t. u_s (raw, before its InstanceNorm)
             U = self.up[s]

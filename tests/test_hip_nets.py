@@ -322,6 +322,32 @@ def test_crn_small(N, golden_dir, tag):
             assert rel(params[name].grad, g[k]) < TOL, name
 
 
+def test_crn_small_noise(N, golden_dir):
+    """`--add_gaussian_noise` of the CRN: norm(u) + sigma * noise is materialised (sgan_norm_apply_fwd) in front of the inter block of
+    stages 5..1; the reference's noise tensors are injected.  Without injection two calls differ (own Philox draws)."""
+    g = load(golden_dir, "crn_small_noise.npz")
+    G = N.define_G(2, 1, 8, "crn", "instance", False, n_layers_G=5, noise_nc=8, upsample_mode="convt", n_layers_CRN_block=2,
+                   share_label_weights=True, add_gaussian_noise=True, gaussian_sigma=0.1, gpu_ids=[0])
+    G.load_state_dict(O.init_crn(43, 2, 1, 8, 8, "convt", 2, True))
+    G.noise_override = {s: O.gauss_noise_np(80, (1, 8, 128 >> s, 128 >> s))[0].permute(1, 2, 0).contiguous().cuda() for s in range(1, 6)}
+    label = O.np_uniform(411, (1, 2, 128, 128)).cuda().requires_grad_(True)
+    z = O.np_normal(412, (1, 8, 2, 2)).cuda().requires_grad_(True)
+    r = O.np_normal(413, (1, 1, 128, 128)).cuda()
+    y = G.forward(label, z)
+    (y * r).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, g["y"]) < TOL and rel(label.grad, g["dlabel"]) < TOL and rel(z.grad, g["dz"]) < TOL
+    params = dict(G.named_parameters())
+    undet = O.norm_cancelled_keys_crn(2, 1, 8, 8, "convt", 2, True)
+    for k in g.files:
+        if k.startswith("grad/") and k[5:] not in undet:
+            assert rel(params[k[5:]].grad, g[k]) < TOL, k
+    G.noise_override = None
+    with torch.no_grad():
+        y1, y2 = G.forward(label.detach(), z.detach()), G.forward(label.detach(), z.detach())
+    assert float((y1 - y2).abs().max()) > 0
+
+
 def test_autoencoder_small(N, golden_dir):
     """`--which_model_netG autoencoder` (models/networks.py:421-490), a plain chain on the same kernels."""
     g = load(golden_dir, "autoencoder_small.npz")

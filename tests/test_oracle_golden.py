@@ -391,6 +391,28 @@ def test_crn_small(golden_dir, tag):
             assert rel(v.grad, g["grad/" + k]) < 1e-4, k
 
 
+def test_crn_small_noise(golden_dir):
+    """--add_gaussian_noise of the CRN (sigma * N(0, 1) on the normalised output of upsample blocks 5..1) against the reference run
+    with the same injected noise tensors."""
+    g = load(golden_dir, "crn_small_noise.npz")
+    sd = O.init_crn(43, 2, 1, 8, 8, "convt", 2, True)
+    for v in sd.values():
+        v.requires_grad_(True)
+    label = O.np_uniform(411, (1, 2, 128, 128)).requires_grad_(True)
+    z = O.np_normal(412, (1, 8, 2, 2)).requires_grad_(True)
+    r = O.np_normal(413, (1, 1, 128, 128))
+    y = O.crn_forward(sd, label, z, 8, "convt", 2, True, gauss_seed=80, gauss_sigma=0.1)
+    (y * r).sum().backward()
+    assert rel(y, g["y"]) < TIGHT * 5
+    assert rel(label.grad, g["dlabel"]) < 1e-4 and rel(z.grad, g["dz"]) < 1e-4
+    undet = O.norm_cancelled_keys_crn(2, 1, 8, 8, "convt", 2, True)
+    for k, v in sd.items():
+        if k not in undet:
+            assert rel(v.grad, g["grad/" + k]) < 1e-4, k
+    y0 = O.crn_forward(sd, label, z, 8, "convt", 2, True)
+    assert rel(y0, g["y"]) > 1e-3        # the noise is really in the golden
+
+
 # ------------------------------------------------------------------------------------------------
 # twostage_cycle (BASELINE configs[4]): G1 fcgan + G2 crn + F2 unet_128 + 2 x D1 + 4 x D2
 # ------------------------------------------------------------------------------------------------

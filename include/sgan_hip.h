@@ -60,7 +60,11 @@ typedef struct sgan_norm_desc {
     float slope;         /* LeakyReLU slope */
     int32_t sq_stride;   /* distance (in doubles) from sum[c] to sumsq[c]; 0 = C.  Lets `stats` point into the
                           * statistics of a wider concat buffer (U-Net skip: [up half | skip half]) */
+    int32_t rep_stride;  /* 0: one copy of the statistics.  > 0: SGAN_STAT_REPLICAS copies, `rep_stride` doubles apart, whose SUM
+                          * is the statistic: the producers spread their same-address fp64 atomics over the copies (workgroup b adds
+                          * to copy b % SGAN_STAT_REPLICAS), every reader adds the copies up.  All copies start at zero. */
 } sgan_norm_desc;
+#define SGAN_STAT_REPLICAS 8
 
 /* Geometry of one Conv2d / ConvTranspose2d layer (square kernel, symmetric stride/pad). */
 typedef struct sgan_conv_desc {
@@ -147,6 +151,7 @@ typedef struct sgan_conv_fwd_job {
     double* out_stats;
     int32_t out_stats_sq_stride;  /* distance from sum[n] to sumsq[n] in out_stats; 0 = Cout */
     const void* w_packed;         /* SGAN_MATH_BF16X3: the `packed_fwd` copy of `w` (sgan_pack_weights), same element offset; else NULL */
+    int32_t out_stats_rep_stride; /* > 0: out_stats is the first of SGAN_STAT_REPLICAS copies this far apart (sgan_norm_desc.rep_stride) */
 } sgan_conv_fwd_job;
 typedef struct sgan_conv_dgrad_job {
     const sgan_conv_desc* d;
@@ -161,6 +166,7 @@ typedef struct sgan_conv_dgrad_job {
                                    * reduction channel (Cout) is then contiguous and backward-data stages its weights with
                                    * 16-byte LDS stores like the forward pass */
     const void* w_packed;         /* SGAN_MATH_BF16X3: the `packed_bwd` copy of the weights (sgan_pack_weights); else NULL */
+    int32_t bwd_sums_rep_stride;  /* > 0: bwd_sums is the first of SGAN_STAT_REPLICAS copies this far apart */
 } sgan_conv_dgrad_job;
 typedef struct sgan_conv_wgrad_job {
     const sgan_conv_desc* d;
@@ -220,6 +226,7 @@ typedef struct sgan_norm_bwd_job {
     const sgan_norm_desc* x_norm;
     const double* bwd_sums; int32_t bwd_sums_sq_stride;
     float* dgamma; float* dbeta;
+    int32_t bwd_sums_rep_stride;   /* > 0: bwd_sums is the first of SGAN_STAT_REPLICAS copies this far apart (summed on read) */
 } sgan_norm_bwd_job;
 int sgan_norm_bwd_apply_multi(const sgan_norm_bwd_job* jobs, int32_t n /* 1..8 */, void* stream);
 
@@ -234,6 +241,7 @@ typedef struct sgan_bn_running_desc {
     int32_t count;     /* H*W */
     int32_t sq_stride; /* distance from a channel's sum to its sum of squares inside `stats`; 0 = C (wider when `stats`
                           is a slice of a concatenated tensor's statistics, or C is not a multiple of 4) */
+    int32_t rep_stride; /* > 0: `stats` is the first of SGAN_STAT_REPLICAS copies this far apart (summed on read) */
 } sgan_bn_running_desc;
 int sgan_bn_running_update(const sgan_bn_running_desc* layers, int32_t n, float momentum, void* stream);
 

@@ -14,7 +14,8 @@ CONV, CONVT = 0, 1
 
 class NormDesc(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-                ("count", C.c_int32), ("eps", C.c_float), ("act", C.c_int32), ("slope", C.c_float), ("sq_stride", C.c_int32)]
+                ("count", C.c_int32), ("eps", C.c_float), ("act", C.c_int32), ("slope", C.c_float), ("sq_stride", C.c_int32),
+                ("rep_stride", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -33,14 +34,14 @@ class GaussJob(C.Structure):
 class ConvFwdJob(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("inp", C.c_void_p), ("in_ld", C.c_int32), ("in_norm", C.POINTER(NormDesc)),
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("out_ld", C.c_int32), ("out_stats", C.c_void_p),
-                ("out_stats_sq_stride", C.c_int32), ("w_packed", C.c_void_p)]
+                ("out_stats_sq_stride", C.c_int32), ("w_packed", C.c_void_p), ("out_stats_rep_stride", C.c_int32)]
 
 
 class ConvDgradJob(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("w", C.c_void_p),
                 ("din", C.c_void_p), ("din_ld", C.c_int32), ("x", C.c_void_p), ("x_ld", C.c_int32),
                 ("x_norm", C.POINTER(NormDesc)), ("bwd_sums", C.c_void_p), ("bwd_sums_sq_stride", C.c_int32),
-                ("accumulate", C.c_int32), ("w_transposed", C.c_int32), ("w_packed", C.c_void_p)]
+                ("accumulate", C.c_int32), ("w_transposed", C.c_int32), ("w_packed", C.c_void_p), ("bwd_sums_rep_stride", C.c_int32)]
 
 
 class WtSeg(C.Structure):
@@ -55,7 +56,7 @@ class ConvWgradJob(C.Structure):
 class NormBwdJob(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("dy_ld", C.c_int32), ("x", C.c_void_p), ("x_ld", C.c_int32), ("npix", C.c_int32),
                 ("C", C.c_int32), ("x_norm", C.POINTER(NormDesc)), ("bwd_sums", C.c_void_p), ("bwd_sums_sq_stride", C.c_int32),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("bwd_sums_rep_stride", C.c_int32)]
 
 
 class GanLossJob(C.Structure):
@@ -65,7 +66,8 @@ class GanLossJob(C.Structure):
 
 class BnRunningDesc(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
-                ("num_batches_tracked", C.c_void_p), ("C", C.c_int32), ("count", C.c_int32), ("sq_stride", C.c_int32)]
+                ("num_batches_tracked", C.c_void_p), ("C", C.c_int32), ("count", C.c_int32), ("sq_stride", C.c_int32),
+                ("rep_stride", C.c_int32)]
 
 
 class AdamSeg(C.Structure):

@@ -76,13 +76,18 @@ class _BwdArena:
     """Zeroed fp64 scratch for the backward sums, carved from the same fill as the forward statistics.  A second
     backward through the same forward (retain_graph) gets a fresh zeroed buffer."""
 
-    def __init__(self, buf):
+    def __init__(self, buf, rep=0):
         self.buf, self.dev = buf, buf.device
+        self.rep = rep           # replica stride of the forward statistics AND of `buf` (they share one ops.stat_arena)
+        self.rep_bwd = rep       # replica stride of what take() handed out last
 
     def take(self, n):
         buf, self.buf = self.buf, None
         if buf is None or buf.numel() < n:
-            return torch.zeros(n, dtype=torch.float64, device=self.dev)
+            fresh = ops.stat_arena(n, self.dev)
+            self.rep_bwd = ops.stat_rep(fresh)
+            return fresh
+        self.rep_bwd = self.rep
         return buf[:n]
 
 
@@ -377,11 +382,12 @@ class ChainNet(nn.Module):
         if L.norm is None:
             return ops.norm_desc(None, None, None, count, 0.0, L.act, L.slope)
         st = stats[li]
+        rep = getattr(stats[-1], "rep", 0)      # the statistics live in an ops.stat_arena (replicated sums)
         if L.norm == "bn":
             g = self._flat[L.g_off: L.g_off + L.cout_s]
             be = self._flat[L.be_off: L.be_off + L.cout_s]
-            return ops.norm_desc(st, g, be, count, BN_EPS, L.act, L.slope)
-        return ops.norm_desc(st, None, None, count, IN_EPS, L.act, L.slope)
+            return ops.norm_desc(st, g, be, count, BN_EPS, L.act, L.slope, 0, rep)
+        return ops.norm_desc(st, None, None, count, IN_EPS, L.act, L.slope, 0, rep)
 
     def _norm_in(self, li, stats, count, drop):
         """_norm_of for a consumer that may read the materialised dropout tensor of layer li: only the activation is left to apply."""
@@ -402,7 +408,8 @@ class ChainNet(nn.Module):
         final_act = self._take_call_act()
         n_stats = sum(2 * L.cout_s for L in self.layers if L.norm)
         # one zero-fill serves the forward statistics and the backward sums (second half, consumed by run_backward)
-        arena = torch.zeros(max(2 * n_stats, 1), dtype=torch.float64, device=x.device)
+        arena = ops.stat_arena(2 * n_stats, x.device)
+        rep = ops.stat_rep(arena)
         stats, o = [], 0
         for L in self.layers:
             if L.norm:
@@ -410,7 +417,7 @@ class ChainNet(nn.Module):
                 o += 2 * L.cout_s
             else:
                 stats.append(None)
-        stats.append(_BwdArena(arena[n_stats:]))
+        stats.append(_BwdArena(arena[n_stats:], rep))
         stats[-1].final_act = final_act
         outs = []
         cur = x
@@ -427,7 +434,7 @@ class ChainNet(nn.Module):
             in_norm = self._norm_in(li - 1, stats, h * w, drop) if li > 0 else None
             wt, b = self._wb(L)
             last = li == len(self.layers) - 1
-            ops.conv_fwd(desc, cur, in_norm, wt, b, out, final_act if last else ACT_NONE, stats[li])
+            ops.conv_fwd(desc, cur, in_norm, wt, b, out, final_act if last else ACT_NONE, stats[li], 0, rep)
             outs.append(out)
             cur = out
             if self.training and L.drop > 0:
@@ -439,7 +446,7 @@ class ChainNet(nn.Module):
                     ops.dropout_mask(mask, L.drop, getattr(self, "_rng_seed", 0) + li, self._rng_offset, advance=False)
                     drawn = max(drawn, (mask.numel() + 3) // 4)
                 t = torch.empty_like(out)
-                ops.norm_apply_fwd(out, ops.norm_desc(stats[li], None, None, ho * wo, IN_EPS, ACT_NONE, 0.0), t, mask)
+                ops.norm_apply_fwd(out, ops.norm_desc(stats[li], None, None, ho * wo, IN_EPS, ACT_NONE, 0.0, 0, rep), t, mask)
                 drop[li] = (t, mask)
                 cur = t
         if drop and getattr(self, "mask_source", None) is None:
@@ -451,7 +458,7 @@ class ChainNet(nn.Module):
                 if L.norm == "bn":
                     nb = self._bn_boxes[L.key]
                     _, _, _, ho, wo = geo[li]
-                    rl.append((stats[li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo, L.cout_s))
+                    rl.append((stats[li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo, L.cout_s, rep))
             ops.bn_running_update(rl, BN_MOMENTUM)
         return outs, stats
 
@@ -469,6 +476,7 @@ class ChainNet(nn.Module):
             dcur = d2
         n_sums = sum(2 * L.cout_s for L in self.layers if L.norm)
         arena = stats[-1].take(max(n_sums, 1))
+        brep = stats[-1].rep_bwd
         sums, o = [], 0
         for L in self.layers:
             if L.norm:
@@ -492,15 +500,16 @@ class ChainNet(nn.Module):
                 P = self.layers[li - 1]
                 din = torch.empty((h, w, P.cout_s), dtype=torch.float32, device=dev)
                 with ops.math_scope(_dgrad_math(P)):
-                    ops.conv_dgrad(desc, dcur, self._wt(L), din, src, in_norm, None if dropped else sums[li - 1], w_transposed=True)
+                    ops.conv_dgrad(desc, dcur, self._wt(L), din, src, in_norm, None if dropped else sums[li - 1], w_transposed=True,
+                                   sums_rep=brep)
                 if dropped:      # din = d t * ReLU'(t); through the mask, with the two norm-backward sums of the masked gradient
                     raw_norm = self._norm_of(li - 1, stats, h * w)
-                    ops.norm_apply_bwd_sums(din, outs[li - 1], raw_norm, sums[li - 1], drop[li - 1][1])
-                    ops.norm_bwd_apply(din, outs[li - 1], raw_norm, sums[li - 1])
+                    ops.norm_apply_bwd_sums(din, outs[li - 1], raw_norm, sums[li - 1], drop[li - 1][1])      # adds to the first copy only
+                    ops.norm_bwd_apply(din, outs[li - 1], raw_norm, sums[li - 1], None, None, 0, brep)
                 elif P.norm:
                     dg = self._gflat[P.g_off: P.g_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
                     db = self._gflat[P.be_off: P.be_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
-                    ops.norm_bwd_apply(din, src, in_norm, sums[li - 1], dg, db)
+                    ops.norm_bwd_apply(din, src, in_norm, sums[li - 1], dg, db, 0, brep)
                 dcur = din
             elif need_dx:
                 dx = torch.empty((h, w, L.cin_s), dtype=torch.float32, device=dev)
@@ -584,8 +593,9 @@ def _grouped_forward(nets, xs):
     J = len(nets)
     geos = [n._geometry(x.shape[0], x.shape[1]) for n, x in zip(nets, xs)]
     per_job = sum(2 * L.cout_s for L in nets[0].layers if L.norm)
-    arena = torch.zeros(max(2 * per_job * J, 1), dtype=torch.float64, device=dev)   # forward statistics | backward sums
-    bwd = _BwdArena(arena[per_job * J:])
+    arena = ops.stat_arena(2 * per_job * J, dev)   # forward statistics | backward sums, in replicated copies
+    rep = ops.stat_rep(arena)
+    bwd = _BwdArena(arena[per_job * J:], rep)
     stats = []
     for j in range(J):
         st, o = [], j * per_job
@@ -608,7 +618,7 @@ def _grouped_forward(nets, xs):
             out = torch.empty((ho, wo, L.cout_s), dtype=torch.float32, device=dev)
             in_norm = net._norm_of(li - 1, stats[j], h * w) if li > 0 else None
             wt, b = net._wb(L)
-            jobs.append((desc, cur[j], in_norm, wt, b, out, stats[j][li]))
+            jobs.append((desc, cur[j], in_norm, wt, b, out, stats[j][li], 0, rep))
             outs[j].append(out)
             cur[j] = out
         ops.conv_fwd_grouped(jobs, nets[0].final_act if li == nL - 1 else ACT_NONE)
@@ -619,7 +629,7 @@ def _grouped_forward(nets, xs):
                 if L.norm == "bn":
                     nb = net._bn_boxes[L.key]
                     _, _, _, ho, wo = geos[j][li]
-                    rl.append((stats[j][li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo, L.cout_s))
+                    rl.append((stats[j][li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo, L.cout_s, rep))
             ops.bn_running_update(rl, BN_MOMENTUM)
     return outs, stats
 
@@ -640,6 +650,7 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
             dcur[j] = d2
     per_job = sum(2 * L.cout_s for L in nets[0].layers if L.norm)
     arena = stats[0][-1].take(max(per_job * J, 1))
+    brep = stats[0][-1].rep_bwd
     sums = []
     for j in range(J):
         sm, o = [], j * per_job
@@ -664,7 +675,7 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
                 desc, h, w, ho, wo = geos[j][li]
                 din = torch.empty((h, w, Pv.cout_s), dtype=torch.float32, device=dev)
                 dins.append(din)
-                jobs.append((desc, dcur[j], net._wt(net.layers[li]), din, srcs[j], norms[j], sums[j][li - 1], 0, False, True))
+                jobs.append((desc, dcur[j], net._wt(net.layers[li]), din, srcs[j], norms[j], sums[j][li - 1], 0, False, True, brep))
             with ops.math_scope(_dgrad_math(nets[0].layers[li - 1])):
                 ops.conv_dgrad_grouped(jobs)
             nb = []
@@ -674,7 +685,7 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
                     bn = Pv.norm == "bn" and want_wgrad[j]
                     dg = net._gflat[Pv.g_off: Pv.g_off + Pv.cout_s] if bn else None
                     db = net._gflat[Pv.be_off: Pv.be_off + Pv.cout_s] if bn else None
-                    nb.append((dins[j], srcs[j], norms[j], sums[j][li - 1], dg, db))
+                    nb.append((dins[j], srcs[j], norms[j], sums[j][li - 1], dg, db, 0, brep))
                 dcur[j] = dins[j]
             if nb:
                 ops.norm_bwd_apply_multi(nb)

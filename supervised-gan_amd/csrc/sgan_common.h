@@ -69,6 +69,7 @@ struct SgNorm {  // device-side copy of sgan_norm_desc
     int32_t act;
     float slope;
     int32_t sq_stride;  // 0 = C
+    int32_t rep_stride; // 0 = one copy; else SGAN_STAT_REPLICAS copies this many doubles apart, summed on read
 };
 
 static inline SgNorm sg_norm_from(const sgan_norm_desc* d) {
@@ -76,9 +77,10 @@ static inline SgNorm sg_norm_from(const sgan_norm_desc* d) {
     if (d) {
         n.stats = d->stats; n.gamma = d->gamma; n.beta = d->beta;
         n.count = d->count; n.eps = d->eps; n.act = d->act; n.slope = d->slope; n.sq_stride = d->sq_stride;
+        n.rep_stride = d->rep_stride;
     } else {
         n.stats = nullptr; n.gamma = nullptr; n.beta = nullptr;
-        n.count = 1; n.eps = 0.f; n.act = SGAN_ACT_NONE; n.slope = 0.f; n.sq_stride = 0;
+        n.count = 1; n.eps = 0.f; n.act = SGAN_ACT_NONE; n.slope = 0.f; n.sq_stride = 0; n.rep_stride = 0;
     }
     return n;
 }
@@ -89,8 +91,23 @@ static inline SgNorm sg_norm_from(const sgan_norm_desc* d) {
 int sg_build_phases(const sgan_conv_desc* d, bool dgrad, SgPhase* ph, int* nphase, int* is, int* os);
 
 // mean / rstd of channel c from accumulated (sum, sumsq) statistics (biased variance)
+// a statistic kept in SGAN_STAT_REPLICAS copies `rep` doubles apart (0: one copy): the copies summed
+__device__ __forceinline__ double sg_stat_sum(const double* base, int idx, int rep) {
+    double v = base[idx];
+    if (rep) {
+#pragma unroll
+        for (int r = 1; r < SGAN_STAT_REPLICAS; ++r) v += base[idx + (int64_t)r * rep];
+    }
+    return v;
+}
+
+// the copy workgroup `b` adds its partial statistics to
+__device__ __forceinline__ double* sg_stat_replica(double* base, int rep, unsigned b) {
+    return base + (int64_t)(rep ? (b & (SGAN_STAT_REPLICAS - 1)) : 0) * rep;
+}
+
 __device__ __forceinline__ void sg_mean_rstd(const SgNorm& n, int C, int c, float& mean, float& rstd) {
-    double s = n.stats[c], q = n.stats[(n.sq_stride ? n.sq_stride : C) + c];
+    double s = sg_stat_sum(n.stats, c, n.rep_stride), q = sg_stat_sum(n.stats, (n.sq_stride ? n.sq_stride : C) + c, n.rep_stride);
     double inv = 1.0 / (double)n.count;
     double m = s * inv;
     double var = q * inv - m * m;

@@ -76,7 +76,7 @@ static inline int ew_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b);
 struct SgNormBwdJob {
     float* dy; const float* x; const double* sums; float* dgamma; float* dbeta;
     SgNorm xn;
-    int32_t dy_ld, x_ld, npix, C, sums_sq, blocks;
+    int32_t dy_ld, x_ld, npix, C, sums_sq, sums_rep, blocks;
 };
 struct SgNormBwdTable { SgNormBwdJob j[8]; };
 
@@ -99,11 +99,12 @@ __global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(const SgNormBwdT
         cA[c] = g * rstd;
         cMean[c] = mean;
         cRstd[c] = rstd;
-        cS1[c] = (float)(J.sums[c] * invM);
-        cS2[c] = (float)(J.sums[J.sums_sq + c] * invM);
+        const double s1 = sg_stat_sum(J.sums, c, J.sums_rep), s2 = sg_stat_sum(J.sums, J.sums_sq + c, J.sums_rep);
+        cS1[c] = (float)(s1 * invM);
+        cS2[c] = (float)(s2 * invM);
         if (blockIdx.x == 0) {
-            if (J.dgamma) atomicAdd(&J.dgamma[c], (float)J.sums[J.sums_sq + c]);   // concurrent chains may share the buffer
-            if (J.dbeta) atomicAdd(&J.dbeta[c], (float)J.sums[c]);
+            if (J.dgamma) atomicAdd(&J.dgamma[c], (float)s2);   // concurrent chains may share the buffer
+            if (J.dbeta) atomicAdd(&J.dbeta[c], (float)s1);
         }
     }
     __syncthreads();
@@ -156,6 +157,7 @@ extern "C" int sgan_norm_bwd_apply_multi(const sgan_norm_bwd_job* jobs, int32_t 
         J.xn = sg_norm_from(S.x_norm);
         J.dy_ld = S.dy_ld; J.x_ld = S.x_ld; J.npix = S.npix; J.C = S.C;
         J.sums_sq = S.bwd_sums_sq_stride ? S.bwd_sums_sq_stride : S.C;
+        J.sums_rep = S.bwd_sums_rep_stride;
         const int64_t total = (int64_t)S.npix * (S.C >> 2);
         int blocks = ew_cdiv(total, 256 * 4);
         if (blocks > 2048) blocks = 2048;
@@ -172,7 +174,7 @@ extern "C" int sgan_norm_bwd_apply_multi(const sgan_norm_bwd_job* jobs, int32_t 
 extern "C" int sgan_norm_bwd_apply(float* dy, int32_t dy_ld, const float* x, int32_t x_ld, int32_t npix, int32_t C,
                                    const sgan_norm_desc* x_norm, const double* bwd_sums, int32_t bwd_sums_sq_stride,
                                    float* dgamma, float* dbeta, void* stream) {
-    sgan_norm_bwd_job j = {dy, dy_ld, x, x_ld, npix, C, x_norm, bwd_sums, bwd_sums_sq_stride, dgamma, dbeta};
+    sgan_norm_bwd_job j = {dy, dy_ld, x, x_ld, npix, C, x_norm, bwd_sums, bwd_sums_sq_stride, dgamma, dbeta, 0};
     return sgan_norm_bwd_apply_multi(&j, 1, stream);
 }
 
@@ -720,8 +722,8 @@ __global__ __launch_bounds__(256) void sg_bn_running_kernel(SgBnRunTable T) {
     const double unb = L.count > 1 ? (double)L.count / (double)(L.count - 1) : 1.0;
     if (threadIdx.x == 0 && L.num_batches_tracked) L.num_batches_tracked[0] += 1;
     for (int c = threadIdx.x; c < L.C; c += 256) {
-        const double m = L.stats[c] * inv;
-        double var = L.stats[(L.sq_stride ? L.sq_stride : L.C) + c] * inv - m * m;
+        const double m = sg_stat_sum(L.stats, c, L.rep_stride) * inv;
+        double var = sg_stat_sum(L.stats, (L.sq_stride ? L.sq_stride : L.C) + c, L.rep_stride) * inv - m * m;
         if (var < 0.0) var = 0.0;
         L.running_mean[c] = (1.f - T.momentum) * L.running_mean[c] + T.momentum * (float)m;
         L.running_var[c] = (1.f - T.momentum) * L.running_var[c] + T.momentum * (float)(var * unb);

@@ -28,6 +28,7 @@ struct SgProb {
     int32_t xref_ld, pro_count, xn_count;
     int32_t pro_sq, xn_sq;   // sum -> sumsq distance of the two norm statistics (0 = channel count)
     int32_t stats_sq;        // same for the statistics this launch accumulates (0 = N)
+    int32_t pro_rep, xn_rep, stats_rep;   // replica strides (sgan_norm_desc.rep_stride) of the two norms read / the statistics written
     int32_t accum;           // out += result (backward-data into a tensor with two forward consumers)
     int32_t Hp[SGAN_MAX_PHASES], Wp[SGAN_MAX_PHASES];
     int32_t tile0[SGAN_MAX_PHASES];  // first blockIdx.x of (this problem, phase)
@@ -61,7 +62,7 @@ struct SgLocal {
     const float* in; float* out; const float* w; const float* bias; const float* xref; double* stats;
     int32_t Hin, Win, Ck, in_ld, Hout, Wout, N, out_ld, xref_ld, is, os, w_ns, w_ks, out_act, ksplit;
     float* slab; int64_t slab_stride;
-    int32_t stats_sq, accum;
+    int32_t stats_sq, accum, stats_rep;
     SgNorm pro, xn;
 };
 
@@ -73,10 +74,10 @@ __device__ __forceinline__ SgLocal sg_local(const SgIgemmParams& G, int g) {
     P.out_ld = Q.out_ld; P.xref_ld = Q.xref_ld; P.is = G.is; P.os = G.os; P.w_ns = G.w_ns; P.w_ks = G.w_ks;
     P.out_act = G.out_act; P.ksplit = G.ksplit; P.slab = G.slab; P.slab_stride = G.slab_stride;
     P.pro.stats = Q.pro_stats; P.pro.gamma = Q.pro_gamma; P.pro.beta = Q.pro_beta; P.pro.count = Q.pro_count;
-    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope; P.pro.sq_stride = Q.pro_sq;
-    P.stats_sq = Q.stats_sq ? Q.stats_sq : G.N; P.accum = Q.accum;
+    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope; P.pro.sq_stride = Q.pro_sq; P.pro.rep_stride = Q.pro_rep;
+    P.stats_sq = Q.stats_sq ? Q.stats_sq : G.N; P.accum = Q.accum; P.stats_rep = Q.stats_rep;
     P.xn.stats = Q.xn_stats; P.xn.gamma = Q.xn_gamma; P.xn.beta = Q.xn_beta; P.xn.count = Q.xn_count;
-    P.xn.eps = G.xn_eps; P.xn.act = G.xn_act; P.xn.slope = G.xn_slope; P.xn.sq_stride = Q.xn_sq;
+    P.xn.eps = G.xn_eps; P.xn.act = G.xn_act; P.xn.slope = G.xn_slope; P.xn.sq_stride = Q.xn_sq; P.xn.rep_stride = Q.xn_rep;
     return P;
 }
 

@@ -485,8 +485,11 @@ __global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams 
     if (want_stats) {
         __syncthreads();
         if (tid < BN && n0 + tid < N) {
-            atomicAdd(&P.stats[n0 + tid], red[tid]);
-            atomicAdd(&P.stats[P.stats_sq + n0 + tid], red[BN + tid]);
+#ifndef SG_NO_STAT_ATOMICS      // diagnostics build: what the same-address fp64 atomics cost
+            double* st = sg_stat_replica(P.stats, P.stats_rep, blockIdx.x);
+            atomicAdd(&st[n0 + tid], red[tid]);
+            atomicAdd(&st[P.stats_sq + n0 + tid], red[BN + tid]);
+#endif
         }
     }
 }
@@ -1064,8 +1067,11 @@ __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmPa
         }
         __syncthreads();
         for (int c = threadIdx.x; c < N; c += 256) {
-            atomicAdd(&P.stats[c], red[c]);
-            atomicAdd(&P.stats[P.stats_sq + c], red[N + c]);
+#ifndef SG_NO_STAT_ATOMICS      // diagnostics build: what the same-address fp64 atomics cost
+            double* st = sg_stat_replica(P.stats, P.stats_rep, blockIdx.x);
+            atomicAdd(&st[c], red[c]);
+            atomicAdd(&st[P.stats_sq + c], red[N + c]);
+#endif
         }
     }
 }
@@ -1390,12 +1396,13 @@ static int sg_group_geometry(SgIgemmParams& P, const sgan_conv_desc* const* desc
 }
 
 static void sg_set_norm(const sgan_norm_desc* d, const double** stats, const float** gamma, const float** beta, int32_t* count,
-                        int32_t* sq) {
+                        int32_t* sq, int32_t* rep) {
     *stats = d ? d->stats : nullptr;
     *gamma = d ? d->gamma : nullptr;
     *beta = d ? d->beta : nullptr;
     *count = d ? d->count : 1;
     *sq = d ? d->sq_stride : 0;
+    *rep = d ? d->rep_stride : 0;
 }
 
 extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, int32_t out_act, void* workspace,
@@ -1426,9 +1433,10 @@ extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, i
         SGAN_CHECK(J.d->math == d0->math, "grouped jobs must share the math mode");
         Q.in = J.in; Q.out = J.out; Q.w = J.w; Q.wp = J.w_packed; Q.bias = J.bias; Q.xref = nullptr; Q.stats = J.out_stats;
         Q.Hin = J.d->Hin; Q.Win = J.d->Win; Q.in_ld = J.in_ld; Q.Hout = J.d->Hout; Q.Wout = J.d->Wout; Q.out_ld = J.out_ld;
-        sg_set_norm(J.in_norm, &Q.pro_stats, &Q.pro_gamma, &Q.pro_beta, &Q.pro_count, &Q.pro_sq);
+        sg_set_norm(J.in_norm, &Q.pro_stats, &Q.pro_gamma, &Q.pro_beta, &Q.pro_count, &Q.pro_sq, &Q.pro_rep);
         Q.xn_count = 1;
         Q.stats_sq = J.out_stats_sq_stride;
+        Q.stats_rep = J.out_stats_rep_stride;
     }
     if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)
     return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
@@ -1467,8 +1475,9 @@ extern "C" int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t 
         Q.Hin = J.d->Hout; Q.Win = J.d->Wout; Q.in_ld = J.dout_ld; Q.Hout = J.d->Hin; Q.Wout = J.d->Win; Q.out_ld = J.din_ld;
         Q.xref_ld = J.x_ld;
         Q.pro_count = 1;
-        sg_set_norm(xn, &Q.xn_stats, &Q.xn_gamma, &Q.xn_beta, &Q.xn_count, &Q.xn_sq);
+        sg_set_norm(xn, &Q.xn_stats, &Q.xn_gamma, &Q.xn_beta, &Q.xn_count, &Q.xn_sq, &Q.xn_rep);
         Q.stats_sq = J.bwd_sums_sq_stride;
+        Q.stats_rep = J.bwd_sums_rep_stride;
         Q.accum = J.accumulate;
     }
     if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)

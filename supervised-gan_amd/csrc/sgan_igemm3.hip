@@ -202,8 +202,11 @@ __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB]
         }
         __syncthreads();
         if (tid < BN && n0 + tid < N) {
-            atomicAdd(&P.stats[n0 + tid], red[tid]);
-            atomicAdd(&P.stats[P.stats_sq + n0 + tid], red[BN + tid]);
+#ifndef SG_NO_STAT_ATOMICS      // diagnostics build: what the same-address fp64 atomics cost
+            double* st = sg_stat_replica(P.stats, P.stats_rep, blockIdx.x);
+            atomicAdd(&st[n0 + tid], red[tid]);
+            atomicAdd(&st[P.stats_sq + n0 + tid], red[BN + tid]);
+#endif
         }
     }
 }

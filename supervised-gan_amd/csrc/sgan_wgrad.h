@@ -14,7 +14,7 @@ struct SgWgradProb {
     const float* pro_beta;
     int32_t Hin, Win, in_ld;
     int32_t Hout, Wout, dout_ld;
-    int32_t pro_count, pro_sq;
+    int32_t pro_count, pro_sq, pro_rep;
     int32_t nsplit;  // pixel-range splits of this problem
     int32_t z0;      // first blockIdx.z of this problem (z = z0 + phase * nsplit + split)
     int32_t Hp[SGAN_MAX_PHASES], Wp[SGAN_MAX_PHASES];

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     P.Hin = Q.Hin; P.Win = Q.Win; P.Cin = G.Cin; P.in_ld = Q.in_ld; P.Hout = Q.Hout; P.Wout = Q.Wout; P.Cout = G.Cout;
     P.dout_ld = Q.dout_ld; P.is = G.is; P.os = G.os; P.w_ns = G.w_ns; P.nsplit = Q.nsplit;
     P.pro.stats = Q.pro_stats; P.pro.gamma = Q.pro_gamma; P.pro.beta = Q.pro_beta; P.pro.count = Q.pro_count;
-    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope; P.pro.sq_stride = Q.pro_sq;
+    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope; P.pro.sq_stride = Q.pro_sq; P.pro.rep_stride = Q.pro_rep;
     const int zl = blockIdx.z - Q.z0;
     const int phz = zl / P.nsplit, split = zl % P.nsplit;
     const int Hp = Q.Hp[phz], Wp = Q.Wp[phz], M = Hp * Wp, ktot = G.ktot[phz];
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
         // per-channel scale / shift once per workgroup (fp64 divide + sqrt per channel), then each lane picks its own
         SgNorm pn;
         pn.stats = Q.pro_stats; pn.gamma = Q.pro_gamma; pn.beta = Q.pro_beta; pn.count = Q.pro_count;
-        pn.eps = G.pro_eps; pn.act = G.pro_act; pn.slope = G.pro_slope; pn.sq_stride = Q.pro_sq;
+        pn.eps = G.pro_eps; pn.act = G.pro_act; pn.slope = G.pro_slope; pn.sq_stride = Q.pro_sq; pn.rep_stride = Q.pro_rep;
         pro_neg = G.pro_act == SGAN_ACT_NONE ? 1.f : (G.pro_act == SGAN_ACT_RELU ? 0.f : G.pro_slope);
         for (int c = tid; c < G.Cin; c += 256) {
             float sc = 1.f, sh = 0.f;
@@ -764,6 +764,7 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
         Q.pro_beta = J.in_norm ? J.in_norm->beta : nullptr;
         Q.pro_count = J.in_norm ? J.in_norm->count : 1;
         Q.pro_sq = J.in_norm ? J.in_norm->sq_stride : 0;
+        Q.pro_rep = J.in_norm ? J.in_norm->rep_stride : 0;
     }
     P.Cin = d0->Cin; P.Cout = d0->Cout; P.w_ns = d0->Cin;
     hipStream_t st = (hipStream_t)stream;

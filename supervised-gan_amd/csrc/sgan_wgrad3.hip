@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
     P.Hin = Q.Hin; P.Win = Q.Win; P.Cin = G.Cin; P.in_ld = Q.in_ld; P.Hout = Q.Hout; P.Wout = Q.Wout; P.Cout = G.Cout;
     P.dout_ld = Q.dout_ld; P.is = G.is; P.os = G.os; P.w_ns = G.w_ns; P.nsplit = Q.nsplit;
     P.pro.stats = Q.pro_stats; P.pro.gamma = Q.pro_gamma; P.pro.beta = Q.pro_beta; P.pro.count = Q.pro_count;
-    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope; P.pro.sq_stride = Q.pro_sq;
+    P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope; P.pro.sq_stride = Q.pro_sq; P.pro.rep_stride = Q.pro_rep;
     const int zl = blockIdx.z - Q.z0;
     const int phz = zl / P.nsplit, split = zl % P.nsplit;
     const int Hp = Q.Hp[phz], Wp = Q.Wp[phz], M = Hp * Wp, ktot = G.ktot[phz];
@@ -377,8 +377,8 @@ static int sgw3_launch(SgWgradParams& P, hipStream_t st, const char* name) {
         chunks_total += (long)sgw3_cdiv(maxM, 32) * P.nphase;
     }
     if (chunks_total == 0) return 1;
-    // pixel-range split per problem: ~768 workgroups over the launch with the same number of 32-pixel chunks each (>= 4)
-    const double want = getenv("SGAN_WGRAD3_WANT") ? atof(getenv("SGAN_WGRAD3_WANT")) : 768.0;
+    // pixel-range split per problem: ~512 workgroups over the launch (sweep 96 .. 2304 on the fcgan launches: 512 is best or within 3 % of best everywhere; 768 cost the small generator layers 10-25 %) with the same number of 32-pixel chunks each (>= 4)
+    const double want = getenv("SGAN_WGRAD3_WANT") ? atof(getenv("SGAN_WGRAD3_WANT")) : 512.0;
     int per = (int)((double)chunks_total * tiles / want + 0.999);
     if (per < 4) per = 4;
     int z = 0;

@@ -88,13 +88,33 @@ def conv_desc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin=0, 
     return L.ConvDesc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin, Cout, _math)
 
 
-def norm_desc(stats=None, gamma=None, beta=None, count=1, eps=1e-5, act=ACT_NONE, slope=0.0, sq_stride=0):
+STAT_REPLICAS = 8      # SGAN_STAT_REPLICAS
+
+
+_STAT_REPLICATED = __import__("os").environ.get("SGAN_NO_STAT_REPLICAS", "0") in ("", "0")      # diagnostics switch
+
+
+def stat_arena(n, device):
+    """Zeroed fp64 statistics arena of `n` doubles kept in STAT_REPLICAS copies `n` apart (returns the first copy; pass
+    rep_stride = stat_rep(arena) wherever a slice of it is written or read): the conv epilogues spread their same-address atomics
+    over the copies."""
+    n = max(n, 1)
+    return torch.zeros((STAT_REPLICAS if _STAT_REPLICATED else 1) * n, dtype=torch.float64, device=device)[:n]
+
+
+def stat_rep(arena):
+    """Replica stride of a stat_arena (0 when replication is switched off: one copy)."""
+    return arena.numel() if _STAT_REPLICATED else 0
+
+
+def norm_desc(stats=None, gamma=None, beta=None, count=1, eps=1e-5, act=ACT_NONE, slope=0.0, sq_stride=0, rep_stride=0):
     """None when the read is a plain one (no norm, no activation).  `sq_stride`: distance from a channel's sum to its
-    sum of squares inside `stats` (0 = the channel count of the tensor being read; wider when `stats` is a slice)."""
+    sum of squares inside `stats` (0 = the channel count of the tensor being read; wider when `stats` is a slice);
+    `rep_stride`: `stats` is a slice of a stat_arena of that length (0: a plain array)."""
     if stats is None and act == ACT_NONE:
         return None
     d = L.NormDesc(_ptr(stats).value, _ptr(gamma).value, _ptr(beta).value, int(count), float(eps), int(act), float(slope),
-                   int(sq_stride))
+                   int(sq_stride), int(rep_stride) if stats is not None else 0)
     d._keep = (stats, gamma, beta)
     return d
 
@@ -110,14 +130,14 @@ def _workspace(kib, device):
     return torch.empty(kib * 256, dtype=torch.float32, device=device) if kib > 0 else None
 
 
-def conv_fwd(desc, x, in_norm, w, bias, out, out_act=ACT_NONE, out_stats=None, stats_sq=0):
-    return conv_fwd_grouped([(desc, x, in_norm, w, bias, out, out_stats, stats_sq)], out_act)
+def conv_fwd(desc, x, in_norm, w, bias, out, out_act=ACT_NONE, out_stats=None, stats_sq=0, stats_rep=0):
+    return conv_fwd_grouped([(desc, x, in_norm, w, bias, out, out_stats, stats_sq, stats_rep)], out_act)
 
 
-def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None, sums_sq=0, accumulate=False, w_transposed=False):
+def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None, sums_sq=0, accumulate=False, w_transposed=False, sums_rep=0):
     """accumulate: din += result (a tensor with two consumers); sums_sq: see norm_desc; w_transposed: `w` is the
     [tap][Cin][Cout] copy made by pack_weights."""
-    return conv_dgrad_grouped([(desc, dout, w, din, x, x_norm, bwd_sums, sums_sq, accumulate, w_transposed)])
+    return conv_dgrad_grouped([(desc, dout, w, din, x, x_norm, bwd_sums, sums_sq, accumulate, w_transposed, sums_rep)])
 
 
 def conv_wgrad(desc, x, in_norm, dout, dw, dbias):
@@ -132,20 +152,21 @@ def _pn(d):
 
 
 def conv_fwd_grouped(jobs, out_act=ACT_NONE):
-    """jobs: list of (desc, x, in_norm, w, bias, out, out_stats[, stats_sq]) of the same layer type -> one launch."""
+    """jobs: list of (desc, x, in_norm, w, bias, out, out_stats[, stats_sq, stats_rep]) of the same layer type -> one launch."""
     arr = (L.ConvFwdJob * len(jobs))()
     for i, job in enumerate(jobs):
         desc, x, in_norm, w, bias, out, st = job[:7]
         desc.math = _math
         arr[i] = L.ConvFwdJob(C.pointer(desc), _ptr(_act(x)).value, x.stride(1), _pn(in_norm), _ptr(w).value, _ptr(bias).value,
-                              _ptr(_act(out)).value, out.stride(1), _ptr(st).value, int(job[7]) if len(job) > 7 else 0, _pk(w))
+                              _ptr(_act(out)).value, out.stride(1), _ptr(st).value, int(job[7]) if len(job) > 7 else 0, _pk(w),
+                              int(job[8]) if (len(job) > 8 and st is not None) else 0)
     ws = _workspace(L.lib().sgan_conv_fwd_grouped(arr, len(jobs), out_act, None, -1, None), jobs[0][1].device)
     L.check(L.lib().sgan_conv_fwd_grouped(arr, len(jobs), out_act, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_fwd_grouped")
 
 
 def conv_dgrad_grouped(jobs):
-    """jobs: list of (desc, dout, w, din, x, x_norm, bwd_sums[, sums_sq, accumulate, w_transposed])."""
+    """jobs: list of (desc, dout, w, din, x, x_norm, bwd_sums[, sums_sq, accumulate, w_transposed, sums_rep])."""
     arr = (L.ConvDgradJob * len(jobs))()
     for i, job in enumerate(jobs):
         desc, dout, w, din, x, x_norm, sums = job[:7]
@@ -153,7 +174,8 @@ def conv_dgrad_grouped(jobs):
         arr[i] = L.ConvDgradJob(C.pointer(desc), _ptr(_act(dout)).value, dout.stride(1), _ptr(w).value, _ptr(_act(din)).value,
                                 din.stride(1), _ptr(x).value, x.stride(1) if x is not None else 0, _pn(x_norm), _ptr(sums).value,
                                 int(job[7]) if len(job) > 7 else 0, int(bool(job[8])) if len(job) > 8 else 0,
-                                int(bool(job[9])) if len(job) > 9 else 0, _pk(w))
+                                int(bool(job[9])) if len(job) > 9 else 0, _pk(w),
+                                int(job[10]) if (len(job) > 10 and sums is not None) else 0)
     ws = _workspace(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device)
     L.check(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_dgrad_grouped")
@@ -190,14 +212,16 @@ def pack_weights(flat, flat_t, pk_fwd, pk_bwd, segs):
                 "sgan_pack_weights")
 
 
-def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None, sums_sq=0):
+def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None, sums_sq=0, sums_rep=0):
+    if sums_rep:
+        return norm_bwd_apply_multi([(dy, x, x_norm, bwd_sums, dgamma, dbeta, sums_sq, sums_rep)])
     H, W, Cs = dy.shape
     L.check(L.lib().sgan_norm_bwd_apply(_ptr(_act(dy)), dy.stride(1), _ptr(_act(x)), x.stride(1), H * W, Cs, _nd(x_norm),
                                         _ptr(bwd_sums), int(sums_sq), _ptr(dgamma), _ptr(dbeta), _stream()), "sgan_norm_bwd_apply")
 
 
 def norm_bwd_apply_multi(jobs):
-    """jobs: list of (dy, x, x_norm, bwd_sums, dgamma, dbeta[, sums_sq]) -> one launch (<= 8 per launch)."""
+    """jobs: list of (dy, x, x_norm, bwd_sums, dgamma, dbeta[, sums_sq, sums_rep]) -> one launch (<= 8 per launch)."""
     for i0 in range(0, len(jobs), 8):
         part = jobs[i0:i0 + 8]
         arr = (L.NormBwdJob * len(part))()
@@ -205,7 +229,8 @@ def norm_bwd_apply_multi(jobs):
             dy, x, x_norm, sums, dg, db = job[:6]
             H, W, Cs = dy.shape
             arr[i] = L.NormBwdJob(_ptr(_act(dy)).value, dy.stride(1), _ptr(_act(x)).value, x.stride(1), H * W, Cs, C.pointer(x_norm),
-                                  _ptr(sums).value, int(job[6]) if len(job) > 6 else 0, _ptr(dg).value, _ptr(db).value)
+                                  _ptr(sums).value, int(job[6]) if len(job) > 6 else 0, _ptr(dg).value, _ptr(db).value,
+                                  int(job[7]) if len(job) > 7 else 0)
         L.check(L.lib().sgan_norm_bwd_apply_multi(arr, len(part), _stream()), "sgan_norm_bwd_apply_multi")
 
 
@@ -305,12 +330,12 @@ def scale(gout, g, dx):
 
 
 def bn_running_update(layers, momentum=0.1):
-    """layers: list of (stats, running_mean, running_var, num_batches_tracked, C, count[, sq_stride])."""
+    """layers: list of (stats, running_mean, running_var, num_batches_tracked, C, count[, sq_stride, rep_stride])."""
     arr = (L.BnRunningDesc * len(layers))()
     for i, job in enumerate(layers):
         st, rm, rv, nbt, c, cnt = job[:6]
         arr[i] = L.BnRunningDesc(st.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr() if nbt is not None else 0, c, cnt,
-                                 int(job[6]) if len(job) > 6 else 0)
+                                 int(job[6]) if len(job) > 6 else 0, int(job[7]) if len(job) > 7 else 0)
     L.check(L.lib().sgan_bn_running_update(arr, len(layers), momentum, _stream()), "sgan_bn_running_update")
 
 

@@ -513,7 +513,7 @@ def main():
                                # the same kernel in the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/):
                                # average launch duration there, and the fraction it gives
                                "rocprof_avg_launch_us": rp_us, "rocprof_source": rp_src,
-                               "rocprof_frac": (kern[dom]["gflop_per_launch"] / rp_us * 1e-3 * (3.0 if split else 1.0) / peak) if rp_us else None,
+                               "rocprof_frac": (kern[dom]["gflop_per_launch"] / rp_us * 1e3 * (3.0 if split else 1.0) / peak) if rp_us else None,      # GFLOP / us = PFLOP/s
                                "launches_per_step": kern[dom]["launches_per_step"],
                                "measured": "every conv call of one step captured 8x back to back into a hipGraph and replayed: device time "
                                            "per call (HIP events on the replay stream), launch boundary and any second kernel of the call included"}

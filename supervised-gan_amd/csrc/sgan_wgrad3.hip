@@ -339,7 +339,11 @@ __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wc * WTC + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+#ifndef SGW3_NO_ATOMICS      // diagnostics build: what the gradient atomics cost
                 if (co < Cout) atomicAdd(base + (int64_t)co * P.w_ns, acc[i][j][r]);
+#else
+                if (co < Cout && acc[i][j][r] == 12345.678f) base[(int64_t)co * P.w_ns] = 0.f;
+#endif
             }
         }
     }

@@ -212,7 +212,9 @@ __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB]
 }
 
 // F16: operand planes are fp16 (forward pass: fp32-equivalent products) instead of bf16 (backward-data)
-template <int BM, int BN, int WGM, int WGN, bool PRO, bool F16>
+// KB2: two k-tiles per barrier (four LDS buffers): with 16-bit MFMAs a 32-deep k-tile is only 192 MFMA cycles per wave, less than
+// what a barrier interval costs in waits and bookkeeping; two tiles per interval halve that overhead per flop.
+template <int BM, int BN, int WGM, int WGN, bool PRO, bool F16, bool KB2 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemmParams G) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MB = WTM / 32, NB = WTN / 32;
@@ -222,9 +224,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                         // [2][BM * 128]
-    char* Bs = smem + 2 * BM * 128;          // [2][BN * 128]
-    double* red = reinterpret_cast<double*>(smem + 2 * (BM + BN) * 128);   // [2 * BN]
+    constexpr int NBUF = KB2 ? 4 : 2;
+    char* As = smem;                            // [NBUF][BM * 128]
+    char* Bs = smem + NBUF * BM * 128;          // [NBUF][BN * 128]
+    double* red = reinterpret_cast<double*>(smem + NBUF * (BM + BN) * 128);   // [2 * BN]
     int4* ttab = reinterpret_cast<int4*>(red + 2 * BN);                     // [16] {dy, dx, gather offset, weight slab offset}
     float* pscale = reinterpret_cast<float*>(ttab + SGAN_MAX_TAPS);         // [Ck]
     float* pshift = pscale + G.Ck;
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
 #ifndef SG3_NSET
 #define SG3_NSET 0
 #endif
-    constexpr int NSET = SG3_NSET ? SG3_NSET : ((2 * A_IT + B_IT <= 4) ? 6 : 4);
+    constexpr int NSET = KB2 ? 4 : (SG3_NSET ? SG3_NSET : ((2 * A_IT + B_IT <= 4) ? 6 : 4));      // KB2: the LDS buffer of a tile is its slot
     f32x4 a_reg[NSET][A_IT][2];
     bool a_ok[NSET][A_IT];
     int a_cs[NSET];
@@ -397,8 +400,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     };
     auto store_tile = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
-        char* Ab = As + (S & 1) * BM * 128;
-        char* Bb = Bs + (S & 1) * BN * 128;
+        char* Ab = As + (S & (NBUF - 1)) * BM * 128;
+        char* Bb = Bs + (S & (NBUF - 1)) * BN * 128;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             f32x4 v0 = a_reg[S][it][0], v1 = a_reg[S][it][1];
@@ -449,10 +452,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     // chip-wide (TCC_HIT * 128 B / time), which is 190 TFLOP/s at 0.125 B per MAC -- see DESIGN.md for what lifts that.
     auto iteration = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
-        const char* Ab = As + (S & 1) * BM * 128 + fa_row;
-        const char* Bb = Bs + (S & 1) * BN * 128 + fb_row;
+        constexpr int SN = (S + (KB2 ? 2 : 1)) % NSET;      // the tile this iteration moves from registers to LDS
+        const char* Ab = As + (S & (NBUF - 1)) * BM * 128 + fa_row;
+        const char* Bb = Bs + (S & (NBUF - 1)) * BN * 128 + fb_row;
         issue_loads(std::integral_constant<int, S>{});
-        load_scales(std::integral_constant<int, (S + 1) % NSET>{});
+        load_scales(std::integral_constant<int, SN>{});
         u32x4 ah[2][MB], al[2][MB], bh[2][NB], bl[2][NB];
         if constexpr (SG3_ABL & 32) {
 #pragma unroll
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        store_tile(std::integral_constant<int, (S + 1) % NSET>{});
+        store_tile(std::integral_constant<int, SN>{});
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x006, PER, 0);    // VALU / SALU in its shadow
         }
-        __syncthreads();
+        if constexpr (!KB2 || (S & 1)) __syncthreads();
     };
     auto prefetch = [&](auto K_) { next_addrs(); issue_loads(K_); };
     auto maybe = [&](auto K_, int kt) { if (kt + decltype(K_)::value < nkt) iteration(K_); };
@@ -514,6 +518,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     next_addrs();
     load_scales(std::integral_constant<int, 0>{});
     store_tile(std::integral_constant<int, 0>{});
+    if constexpr (KB2) {
+        load_scales(std::integral_constant<int, 1>{});
+        store_tile(std::integral_constant<int, 1>{});
+    }
     __syncthreads();
     {
         int kt = 0;
@@ -883,7 +891,7 @@ static Sg3Tile sg3_pick_tile(const SgIgemmParams& P) {
     return {64, 64};
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool KB2 = false>
 static int sg3_launch(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes, const char* name) {
     constexpr int NT = 64 * WGM * WGN;
     const int tiles = sg_fill_tiles(P, BM);
@@ -895,17 +903,17 @@ static int sg3_launch(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_by
     P.slab = ks > 1 ? ws : nullptr;
     P.slab_stride = slab;
     dim3 grid(tiles * sg3_cdiv(P.N, BN), 1, ks);
-    const size_t lds = (size_t)2 * (BM + BN) * 128 + (size_t)4 * BN * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
+    const size_t lds = (size_t)(KB2 ? 4 : 2) * (BM + BN) * 128 + (size_t)4 * BN * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
     if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
     bool pro = P.pro_act != SGAN_ACT_NONE;
     for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
     sg_prof_begin(st);
     if (P.planes_f16) {
-        if (pro) hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, true, true>), grid, dim3(NT), lds, st, P);
-        else hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, false, true>), grid, dim3(NT), lds, st, P);
+        if (pro) hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, true, true, KB2>), grid, dim3(NT), lds, st, P);
+        else hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, false, true, KB2>), grid, dim3(NT), lds, st, P);
     } else {
-        if (pro) hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, true, false>), grid, dim3(NT), lds, st, P);
-        else hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(NT), lds, st, P);
+        if (pro) hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, true, false, KB2>), grid, dim3(NT), lds, st, P);
+        else hipLaunchKernelGGL((sg_igemm3_kernel<BM, BN, WGM, WGN, false, false, KB2>), grid, dim3(NT), lds, st, P);
     }
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = name;
@@ -1004,6 +1012,8 @@ int sg_launch_igemm3(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_byt
     if (t.BN == 32) return sg3_launch<128, 32, 4, 1>(P, st, ws, ws_bytes, "sg_igemm3_kernel<128,32,4,1>");
     if (t.BM == 128 && t.BN == 128) return sg3_launch<128, 128, 2, 4>(P, st, ws, ws_bytes, "sg_igemm3_kernel<128,128,2,4>");
     if (t.BM == 128) return sg3_launch<128, 64, 2, 2>(P, st, ws, ws_bytes, "sg_igemm3_kernel<128,64,2,2>");
+    static const int kb2 = getenv("SGAN_KB2") ? atoi(getenv("SGAN_KB2")) : 1;      // tuning knob
+    if (kb2) return sg3_launch<64, 64, 2, 2, true>(P, st, ws, ws_bytes, "sg_igemm3_kernel<64,64,2,2>");
     return sg3_launch<64, 64, 2, 2>(P, st, ws, ws_bytes, "sg_igemm3_kernel<64,64,2,2>");
 }
 

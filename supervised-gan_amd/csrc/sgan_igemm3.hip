@@ -709,13 +709,17 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
     u32x4 b_reg[NSET][B_IT];
     int b_off_n[B_IT];
     int ld_tap = 0, ld_cb = 0;
+    // The tap-table entries (LDS) are fetched ONE CALL AHEAD of their use: read and used in the same step, each lookup puts an LDS
+    // round trip into the in-order instruction stream of every wave (two per step: this one and the fragment offset below).
+    int w_pref = 0;            // set behind the barrier that publishes the tap table
     auto next_b_addrs = [&]() {
         const bool in_range = ld_cb < ncb;
-        const int woff = ttab[in_range ? ld_tap : 0].w + ld_cb * 32;
+        const int woff = w_pref + ld_cb * 32;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) b_off_n[it] = (b_rowok[it] & in_range) ? (b_base[it] + woff) << 2 : OOB;
         ++ld_tap;
         if (ld_tap == ntaps) { ld_tap = 0; ++ld_cb; }
+        w_pref = ttab[ld_tap].w;
     };
     auto issue_b = [&](auto S_) {
         constexpr int S = decltype(S_)::value;
@@ -763,6 +767,8 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
     // In-kernel stamps of the unpipelined order (reads, then MFMAs, per step): ~370 cycles of fragment reads, ~190 of MFMA
     // issue and ~350 at the barrier per 64x64x32 step, whether the workgroup shares its CU or not.
     int cur_tap = 0, cur_cb = 0;
+    w_pref = ttab[0].w;
+    int tapx_pref = ttab[ntaps > 1 ? 1 : 0].x;      // patch offset of the NEXT step's tap, fetched a step ahead
     u32x4 ah[2], al[2], bh[2][NB], bl[2][NB];
     auto read_half = [&](auto H_, const char* Ab, const char* Bb) {
         constexpr int s = decltype(H_)::value;
@@ -797,7 +803,8 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
                 __syncthreads();
             }
         }
-        const char* Ab = Ap + fa_base + ttab[cur_tap].x;
+        const char* Ab = Ap + fa_base + tapx_pref;
+        tapx_pref = ttab[cur_tap + 1 == ntaps ? 0 : cur_tap + 1].x;
         const char* Bb = Bs + ((S + 1) & 1) * BN * 128 + fb_row;
         read_half(std::integral_constant<int, 0>{}, Ab, Bb);
         __builtin_amdgcn_sched_barrier(0);

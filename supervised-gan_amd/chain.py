@@ -493,15 +493,18 @@ class ChainNet(nn.Module):
             src = (drop[li - 1][0] if dropped else outs[li - 1]) if li > 0 else x
             in_norm = self._norm_in(li - 1, stats, h * w, drop) if li > 0 else None
             wt, _ = self._wb(L)
-            if want_wgrad:
-                gw, gb = self._gwb(L)
-                ops.conv_wgrad(desc, src, in_norm, dcur, gw, gb)
+            wjob = [(desc, src, in_norm, dcur) + self._gwb(L)] if want_wgrad else None
             if li > 0:
                 P = self.layers[li - 1]
                 din = torch.empty((h, w, P.cout_s), dtype=torch.float32, device=dev)
-                with ops.math_scope(_dgrad_math(P)):
-                    ops.conv_dgrad(desc, dcur, self._wt(L), din, src, in_norm, None if dropped else sums[li - 1], w_transposed=True,
-                                   sums_rep=brep)
+                djob = [(desc, dcur, self._wt(L), din, src, in_norm, None if dropped else sums[li - 1], 0, False, True, brep)]
+                if wjob and _dgrad_math(P) is None:
+                    ops.conv_bwd_grouped(djob, wjob)      # both halves in one launch where the fused kernel covers the layer
+                else:
+                    if wjob:
+                        ops.conv_wgrad_grouped(wjob)
+                    with ops.math_scope(_dgrad_math(P)):
+                        ops.conv_dgrad_grouped(djob)
                 if dropped:      # din = d t * ReLU'(t); through the mask, with the two norm-backward sums of the masked gradient
                     raw_norm = self._norm_of(li - 1, stats, h * w)
                     ops.norm_apply_bwd_sums(din, outs[li - 1], raw_norm, sums[li - 1], drop[li - 1][1])      # adds to the first copy only
@@ -511,7 +514,10 @@ class ChainNet(nn.Module):
                     db = self._gflat[P.be_off: P.be_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
                     ops.norm_bwd_apply(din, src, in_norm, sums[li - 1], dg, db, 0, brep)
                 dcur = din
-            elif need_dx:
+                continue
+            if wjob:
+                ops.conv_wgrad_grouped(wjob)
+            if need_dx:
                 dx = torch.empty((h, w, L.cin_s), dtype=torch.float32, device=dev)
                 ops.conv_dgrad(desc, dcur, self._wt(L), dx, None, None, None, w_transposed=True)
         return dx
@@ -666,8 +672,9 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
         srcs = [outs[j][li - 1] if li > 0 else xs[j] for j in range(J)]
         norms = [nets[j]._norm_of(li - 1, stats[j], geos[j][li][1] * geos[j][li][2]) if li > 0 else None for j in range(J)]
         wj = [j for j in range(J) if want_wgrad[j]]
-        if wj:
-            ops.conv_wgrad_grouped([(geos[j][li][0], srcs[j], norms[j], dcur[j]) + nets[j]._gwb(nets[j].layers[li]) for j in wj])
+        wjobs = [(geos[j][li][0], srcs[j], norms[j], dcur[j]) + nets[j]._gwb(nets[j].layers[li]) for j in wj]
+        if wjobs and li == 0:
+            ops.conv_wgrad_grouped(wjobs)
         if li > 0:
             jobs, dins = [], []
             for j, net in enumerate(nets):
@@ -676,8 +683,14 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
                 din = torch.empty((h, w, Pv.cout_s), dtype=torch.float32, device=dev)
                 dins.append(din)
                 jobs.append((desc, dcur[j], net._wt(net.layers[li]), din, srcs[j], norms[j], sums[j][li - 1], 0, False, True, brep))
-            with ops.math_scope(_dgrad_math(nets[0].layers[li - 1])):
-                ops.conv_dgrad_grouped(jobs)
+            dm = _dgrad_math(nets[0].layers[li - 1])
+            if wjobs and dm is None:
+                ops.conv_bwd_grouped(jobs, wjobs)
+            else:
+                if wjobs:
+                    ops.conv_wgrad_grouped(wjobs)
+                with ops.math_scope(dm):
+                    ops.conv_dgrad_grouped(jobs)
             nb = []
             for j, net in enumerate(nets):
                 Pv = net.layers[li - 1]

@@ -60,6 +60,9 @@ struct SgPhase {
     SgTap taps[SGAN_MAX_TAPS];
 };
 
+// what one half of a fused backward launch needs to know about the other (sgan_fused.hip)
+struct SgFusePlan { int variant; int nblocks; int gx, gy, gz; size_t lds; bool pro; const char* name; };
+
 struct SgNorm {  // device-side copy of sgan_norm_desc
     const double* stats;
     const float* gamma;

@@ -1,0 +1,74 @@
+// One launch for a layer's backward-data and backward-weight (split-bf16 mode).
+//
+// Both read the layer's output gradient and neither feeds the other; apart they are two latency-bound launches that each leave most
+// of the chip idle (a few hundred workgroups whose serial k-loops set the launch time: DESIGN.md R2.5), and a hipGraph replays
+// kernel nodes strictly one after the other, so the only way to run them side by side is to make them ONE grid: the first
+// `ndg` workgroups run the backward-data body (sg_igemm3p_body / sg_igemm3_body), the rest the backward-weight body
+// (sg_wgrad3_body), each with the workgroup coordinates it would have had in its own launch.  Nothing else changes: same
+// parameter blocks, same results (the two bodies write disjoint tensors).
+#define SG_KERNELS_ONLY
+#include "sgan_igemm3.hip"
+#include "sgan_wgrad.h"
+#include "sgan_wgrad3.hip"
+
+// DV: 1 = patch kernel with <= 128 patch pixels, 2 = patch kernel up to 256, 3 = sg_igemm3 64 x 64 (two k-tiles per barrier);
+// WV: 1 = backward-weight 64 x 64 tiles, 2 = 32 x 128
+template <int DV, int WV, bool WPRO>
+__global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G, const SgWgradParams W, int ndg, int wx, int wy) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    if (b < ndg) {
+        if constexpr (DV == 1) sg_igemm3p_body<64, 2, false, false>(G, smem, b, ndg);
+        else if constexpr (DV == 2) sg_igemm3p_body<64, 4, false, false>(G, smem, b, ndg);
+        else sg_igemm3_body<64, 64, 2, 2, false, false, true>(G, smem, b, ndg, 0);
+    } else {
+        const int w = b - ndg;
+        const int bx = w % wx, by = (w / wx) % wy, bz = w / (wx * wy);
+        if constexpr (WV == 1) sg_wgrad3_body<64, 64, 2, 2, WPRO>(W, smem, bx, by, bz);
+        else sg_wgrad3_body<32, 128, 1, 4, WPRO>(W, smem, bx, by, bz);
+    }
+}
+
+template <int DV, int WV>
+static void sg_fused_launch(const SgIgemmParams& P, const SgWgradParams& W, const SgFusePlan& pd, const SgFusePlan& pw, hipStream_t st) {
+    const dim3 grid(pd.nblocks + pw.nblocks);
+    const size_t lds = pd.lds > pw.lds ? pd.lds : pw.lds;
+    if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
+    else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
+}
+
+// 0: launched; 1: this pair is not covered (launch sgan_conv_dgrad_grouped and sgan_conv_wgrad_grouped instead); < 0: error
+extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw, void* stream) {
+    static const int off = getenv("SGAN_NO_BWD_FUSION") ? 1 : 0;
+    if (off) return 1;
+    SgIgemmParams P;
+    SgWgradParams W;
+    int rc = sg_build_dgrad_params(djobs, nd, P);
+    if (rc) return rc;
+    rc = sg_build_wgrad_params(wjobs, nw, W);
+    if (rc) return rc;
+    if (wjobs[0].d->math != SGAN_MATH_BF16X3 || sg_dgrad_is_skinny(P)) return 1;
+    const int e3 = sg_igemm3_eligible(P);
+    if (e3 < 0) return e3;
+    if (e3 == 0) return 1;
+    SgFusePlan pd, pw;
+    sg_igemm3_fuse_plan(P, &pd);
+    if (pd.variant == 0 || pd.nblocks == 0) return 1;
+    sg_wgrad3_fuse_plan(W, &pw);
+    if (pw.variant == 0 || pw.nblocks == 0) return 1;
+    if ((pd.lds > pw.lds ? pd.lds : pw.lds) > 64 * 1024) return 1;      // beyond the default dynamic-LDS limit: leave to the separate launches
+    hipStream_t st = (hipStream_t)stream;
+    sg_prof_begin(st);
+    switch (pd.variant * 10 + pw.variant) {
+        case 11: sg_fused_launch<1, 1>(P, W, pd, pw, st); break;
+        case 12: sg_fused_launch<1, 2>(P, W, pd, pw, st); break;
+        case 21: sg_fused_launch<2, 1>(P, W, pd, pw, st); break;
+        case 22: sg_fused_launch<2, 2>(P, W, pd, pw, st); break;
+        case 31: sg_fused_launch<3, 1>(P, W, pd, pw, st); break;
+        default: sg_fused_launch<3, 2>(P, W, pd, pw, st); break;
+    }
+    SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = "sg_bwd_fused_kernel";
+    sg_prof_end(st, g_sgan_last_kernel);
+    return SGAN_OK;
+}

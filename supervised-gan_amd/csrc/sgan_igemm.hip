@@ -1442,12 +1442,12 @@ extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, i
     return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
 }
 
-extern "C" int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t n, void* workspace, int64_t workspace_bytes,
-                                       void* stream) {
+bool sg_dgrad_is_skinny(const SgIgemmParams& P) { return sg_use_small_n(P); }
+
+int sg_build_dgrad_params(const sgan_conv_dgrad_job* jobs, int32_t n, SgIgemmParams& P) {
     SGAN_CHECK(jobs && n >= 1 && n <= SG_MAX_PROB, "1..%d jobs", SG_MAX_PROB);
     const sgan_conv_desc* descs[SG_MAX_PROB];
     for (int g = 0; g < n; ++g) descs[g] = jobs[g].d;
-    SgIgemmParams P;
     int rc = sg_group_geometry(P, descs, n, true);
     if (rc) return rc;
     const sgan_conv_desc* d0 = jobs[0].d;
@@ -1480,6 +1480,14 @@ extern "C" int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t 
         Q.stats_rep = J.bwd_sums_rep_stride;
         Q.accum = J.accumulate;
     }
+    return SGAN_OK;
+}
+
+extern "C" int sgan_conv_dgrad_grouped(const sgan_conv_dgrad_job* jobs, int32_t n, void* workspace, int64_t workspace_bytes,
+                                       void* stream) {
+    SgIgemmParams P;
+    int rc = sg_build_dgrad_params(jobs, n, P);
+    if (rc) return rc;
     if (workspace_bytes == -1) return (int)(sg_workspace_need(P) >> 10) + (sg_workspace_need(P) ? 1 : 0);   // query (KiB)
     return sg_dispatch_igemm(P, (hipStream_t)stream, (float*)workspace, workspace_bytes);
 }

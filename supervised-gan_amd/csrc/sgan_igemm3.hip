@@ -104,7 +104,7 @@ __device__ __forceinline__ Sg3EpiConst<NB> sg3_epilogue_constants(const SgLocal&
 
 template <int BN, int WTM, int WTN, int MB, int NB, bool F16, typename RowPix>
 __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB][NB], double* red, int split, int n0, int wm, int wn,
-                                             int tid, const Sg3EpiConst<NB>& EC, RowPix rowpix) {
+                                             int tid, unsigned bid, const Sg3EpiConst<NB>& EC, RowPix rowpix) {
     const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
     const int N = P.N;
     if constexpr (F16) {     // the fp16 weight planes hold w * 2^SGAN_F16_WEIGHT_SHIFT (an exact power of two)
@@ -203,7 +203,7 @@ __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB]
         __syncthreads();
         if (tid < BN && n0 + tid < N) {
 #ifndef SG_NO_STAT_ATOMICS      // diagnostics build: what the same-address fp64 atomics cost
-            double* st = sg_stat_replica(P.stats, P.stats_rep, blockIdx.x);
+            double* st = sg_stat_replica(P.stats, P.stats_rep, bid);
             atomicAdd(&st[n0 + tid], red[tid]);
             atomicAdd(&st[P.stats_sq + n0 + tid], red[BN + tid]);
 #endif
@@ -214,8 +214,10 @@ __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB]
 // F16: operand planes are fp16 (forward pass: fp32-equivalent products) instead of bf16 (backward-data)
 // KB2: two k-tiles per barrier (four LDS buffers): with 16-bit MFMAs a 32-deep k-tile is only 192 MFMA cycles per wave, less than
 // what a barrier interval costs in waits and bookkeeping; two tiles per interval halve that overhead per flop.
-template <int BM, int BN, int WGM, int WGN, bool PRO, bool F16, bool KB2 = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemmParams G) {
+// The kernel body takes its workgroup id, grid size and split index as arguments so that sg_bwd_fused_kernel (sgan_fused.hip) can run
+// it on a slice of a launch it shares with the backward-weight body.
+template <int BM, int BN, int WGM, int WGN, bool PRO, bool F16, bool KB2>
+__device__ __forceinline__ void sg_igemm3_body(const SgIgemmParams& G, char* smem, const int bid, const int nblocks, const int split) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MB = WTM / 32, NB = WTN / 32;
     constexpr int A_IT = BM * 4 / NT;              // tasks of 8 consecutive k of one row (two 16-byte loads) per thread
@@ -223,7 +225,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     static_assert(BM * 4 % NT == 0 && A_IT >= 1, "A tile");
     static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NBUF = KB2 ? 4 : 2;
     char* As = smem;                            // [NBUF][BM * 128]
     char* Bs = smem + NBUF * BM * 128;          // [NBUF][BN * 128]
@@ -235,11 +236,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
     const int ntn = (G.N + BN - 1) / BN;
-    const int item = sg_xcd_remap(blockIdx.x, gridDim.x);
+    const int item = sg_xcd_remap(bid, nblocks);
     int g, phz, mtile;
     sg_decode_tile(G, item / ntn, g, phz, mtile);
     const SgLocal P = sg_local(G, g);
-    const int split = blockIdx.z;
     const int Hp = G.q[g].Hp[phz], Wp = G.q[g].Wp[phz];
     const int M = Hp * Wp;
     const int m0 = mtile * BM, n0 = (item % ntn) * BN;
@@ -530,12 +530,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
     }
 #undef SG3_FOR_SETS
 
-    sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, split, n0, wm, wn, tid, epi_const, [&](int row) -> int64_t {
+    sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, split, n0, wm, wn, tid, (unsigned)bid, epi_const, [&](int row) -> int64_t {
         const int m = m0 + row;
         if (m >= M) return -1;
         const int py = m / Wp, px = m - py * Wp;
         return (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);
     });
+}
+
+template <int BM, int BN, int WGM, int WGN, bool PRO, bool F16, bool KB2 = false>
+__global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemmParams G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sg_igemm3_body<BM, BN, WGM, WGN, PRO, F16, KB2>(G, smem, blockIdx.x, gridDim.x, blockIdx.z);
 }
 
 
@@ -581,7 +587,7 @@ extern "C" int sgan_debug_stamps(void* dst, int n) {
 #endif
 
 template <int BN, int A_IT, bool PRO, bool F16>
-__global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) {
+__device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* smem, const int bid, const int nblocks) {
     constexpr int NT = 256, WGN = 2, WTM = 32, WTN = BN / WGN, MB = 1, NB = WTN / 32;
     constexpr int B_IT = BN * 8 / NT;
     // weight-tile register ring (even: the LDS buffer of a step is its slot's parity).  BN = 128 (wave tile 32 x 64, ring of 2)
@@ -590,7 +596,6 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
     constexpr int NSET = BN == 64 ? 4 : 2;
     static_assert(BN % 64 == 0 && B_IT >= 1, "N tile");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     SG3P_MARK(0);
 #ifdef SG3P_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) sg3p_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
     const int ntn = (G.N + BN - 1) / BN;
-    const int item = sg_xcd_remap(blockIdx.x, gridDim.x);
+    const int item = sg_xcd_remap(bid, nblocks);
     int g, phz, mtile;
     sg_decode_tile(G, item / ntn, g, phz, mtile);
     const SgLocal P = sg_local(G, g);
@@ -847,7 +852,7 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
     }
     SG3P_MARK(3);
 
-    sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, 0, n0, wm, wn, tid, epi_const, [&](int row) -> int64_t {
+    sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, 0, n0, wm, wn, tid, (unsigned)bid, epi_const, [&](int row) -> int64_t {
         const int py = ty0 + (row >> 3), px = tx0 + (row & 7);
         if (py >= Hp || px >= Wp) return -1;
         return (int64_t)(py * P.os + oa) * P.Wout + (px * P.os + ob);
@@ -858,6 +863,13 @@ __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) 
 #endif
 }
 
+template <int BN, int A_IT, bool PRO, bool F16>
+__global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sg_igemm3p_body<BN, A_IT, PRO, F16>(G, smem, blockIdx.x, gridDim.x);
+}
+
+#ifndef SG_KERNELS_ONLY      // sgan_fused.hip includes this file for the kernel bodies only
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1009,6 +1021,43 @@ static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {   /
     return SGAN_OK;
 }
 
+// Plan of a backward-data launch for sg_bwd_fused_kernel (sgan_fused.hip): fills the tile tables of P exactly as the launchers
+// below do and says which body runs it.  variant 0: not one of the bodies the fused kernel carries (the caller launches separately).
+int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out) {
+    out->variant = 0;
+    if (P.planes_f16 || P.pro_act != SGAN_ACT_NONE) return 0;
+    for (int g = 0; g < P.nprob; ++g)
+        if (P.q[g].pro_stats) return 0;
+    P.ksplit = 1;
+    P.slab = nullptr;
+    P.slab_stride = 0;
+    const Sg3pPlan pl = sg3p_plan(P);
+    if (sg3p_wanted(pl)) {
+        int t = 0, maxlds = 0;
+        for (int g = 0; g < P.nprob; ++g)
+            for (int ph = 0; ph < P.nphase; ++ph) {
+                P.q[g].tile0[ph] = t;
+                t += sg3_cdiv(P.q[g].Hp[ph], 8) * sg3_cdiv(P.q[g].Wp[ph], 8);
+            }
+        for (int g = 0; g < P.nprob; ++g)
+            for (int ph = P.nphase; ph < SGAN_MAX_PHASES; ++ph) P.q[g].tile0[ph] = 1 << 30;
+        for (int ph = 0; ph < P.nphase; ++ph) maxlds = max(maxlds, (P.pph[ph] * sg3p_row_stride(P.ppw[ph]) + 255) & ~255);
+        out->variant = pl.a_it == 2 ? 1 : 2;
+        out->nblocks = t * sg3_cdiv(P.N, 64);
+        out->lds = (size_t)maxlds + (size_t)2 * 64 * 128 + (size_t)4 * 64 * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
+        out->name = "sg_igemm3p_kernel<64>";
+        return 0;
+    }
+    const Sg3Tile tl = sg3_pick_tile(P);
+    if (tl.BM != 64 || tl.BN != 64 || sg_plan_ksplit(P, 64, 64) != 1) return 0;
+    const int tiles = sg_fill_tiles(P, 64);
+    out->variant = 3;
+    out->nblocks = tiles * sg3_cdiv(P.N, 64);
+    out->lds = (size_t)4 * (64 + 64) * 128 + (size_t)4 * 64 * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
+    out->name = "sg_igemm3_kernel<64,64,2,2>";
+    return 0;
+}
+
 int sg_launch_igemm3(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes) {
     const Sg3pPlan pl = sg3p_plan(P);
     if (sg3p_wanted(pl)) {
@@ -1031,3 +1080,4 @@ int64_t sg_igemm3_workspace_need(const SgIgemmParams& P) {
     const int ks = sg_plan_ksplit(P, t.BM, t.BN);
     return ks > 1 ? (int64_t)ks * P.q[0].Hout * P.q[0].Wout * P.N * 4 : 0;
 }
+#endif      // SG_KERNELS_ONLY

@@ -42,3 +42,7 @@ struct SgWgradLocal {
 
 // split-bf16 tiled kernel (sgan_wgrad3.hip): 1 = launched, 0 = layer not covered (caller runs the fp32 kernel), < 0 = error
 int sg_launch_wgrad3(SgWgradParams& P, hipStream_t st);
+
+// ---- one launch for a layer's backward-data and backward-weight (sgan_fused.hip) ----
+int sg_wgrad3_fuse_plan(SgWgradParams& P, SgFusePlan* out);
+int sg_build_wgrad_params(const sgan_conv_wgrad_job* jobs, int32_t n, SgWgradParams& P);   // sgan_wgrad.hip: checks + parameter block of sgan_conv_wgrad_grouped

@@ -722,10 +722,8 @@ static void sg_thin_swap_geometry(SgWgradParams& P, const sgan_conv_desc* d0, co
     }
 }
 
-extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* workspace, int64_t workspace_bytes,
-                                       void* stream) {
+int sg_build_wgrad_params(const sgan_conv_wgrad_job* jobs, int32_t n, SgWgradParams& P) {
     SGAN_CHECK(jobs && n >= 1 && n <= SGW_MAX_PROB, "1..%d jobs", SGW_MAX_PROB);
-    SgWgradParams P;
     memset(&P, 0, sizeof(P));
     P.nprob = n;
     const sgan_conv_desc* d0 = jobs[0].d;
@@ -767,6 +765,15 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
         Q.pro_rep = J.in_norm ? J.in_norm->rep_stride : 0;
     }
     P.Cin = d0->Cin; P.Cout = d0->Cout; P.w_ns = d0->Cin;
+    return SGAN_OK;
+}
+
+extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* workspace, int64_t workspace_bytes,
+                                       void* stream) {
+    SgWgradParams P;
+    int rcb = sg_build_wgrad_params(jobs, n, P);
+    if (rcb) return rcb;
+    const sgan_conv_desc* d0 = jobs[0].d;
     hipStream_t st = (hipStream_t)stream;
     if (!getenv("SGAN_NO_THIN_WGRAD") && d0->k * d0->k <= 16) {
         if (d0->Cin == 4 && P.nphase == 1) {      // conv-form gather of a 4-channel image

@@ -50,8 +50,9 @@ __device__ __forceinline__ sg_bf16x8 sgw_tr8(const char* p) {
 }
 
 // BCO x BKC tile of dW per workgroup, WGC x WGK waves of (BCO / WGC) x (BKC / WGK) each (multiples of 32)
+// body with explicit workgroup coordinates: sg_bwd_fused_kernel (sgan_fused.hip) runs it beside the backward-data body in one launch
 template <int BCO, int BKC, int WGC, int WGK, bool PRO>
-__global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
+__device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* smem, const int bx, const int by, const int bz) {
     constexpr int BP = 32;
     constexpr int WTC = BCO / WGC, WTK = BKC / WGK, MB = WTC / 32, NB = WTK / 32;
     // staging tasks (8 channels of one pixel) per thread: the 256 threads cover two 32-channel blocks of the 32 pixel rows per pass
@@ -59,7 +60,6 @@ __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
     constexpr int D_PLANE = BCO / 32 * 2048, A_PLANE = BKC / 32 * 2048;     // bytes of one plane of one operand
     static_assert(WGC * WGK == 4 && WTC % 32 == 0 && WTK % 32 == 0, "4 waves of 32 x 32 blocks");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ds = smem;                                    // [2 buffers][2 planes][D_PLANE]
     char* As = smem + 4 * D_PLANE;                      // [2 buffers][2 planes][A_PLANE]
     float* pscale = reinterpret_cast<float*>(smem + 4 * D_PLANE + 4 * A_PLANE);   // [Cin]
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
     const int wc = wid / WGK, wk = wid % WGK;
     int g = 0;
     for (int gi = 1; gi < G.nprob; ++gi)
-        if ((int)blockIdx.z >= G.q[gi].z0) g = gi;
+        if (bz >= G.q[gi].z0) g = gi;
     const SgWgradProb& Q = G.q[g];
     SgWgradLocal P;
     P.in = Q.in; P.dout = Q.dout; P.dw = Q.dw; P.dbias = Q.dbias;
@@ -77,11 +77,11 @@ __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
     P.dout_ld = Q.dout_ld; P.is = G.is; P.os = G.os; P.w_ns = G.w_ns; P.nsplit = Q.nsplit;
     P.pro.stats = Q.pro_stats; P.pro.gamma = Q.pro_gamma; P.pro.beta = Q.pro_beta; P.pro.count = Q.pro_count;
     P.pro.eps = G.pro_eps; P.pro.act = G.pro_act; P.pro.slope = G.pro_slope; P.pro.sq_stride = Q.pro_sq; P.pro.rep_stride = Q.pro_rep;
-    const int zl = blockIdx.z - Q.z0;
+    const int zl = bz - Q.z0;
     const int phz = zl / P.nsplit, split = zl % P.nsplit;
     const int Hp = Q.Hp[phz], Wp = Q.Wp[phz], M = Hp * Wp, ktot = G.ktot[phz];
     const int ph_oa = G.oa[phz], ph_ob = G.ob[phz];
-    const int kc0 = blockIdx.x * BKC, co0 = blockIdx.y * BCO;
+    const int kc0 = bx * BKC, co0 = by * BCO;
     if (kc0 >= ktot || M == 0) return;
     const int nchunk_total = (M + BP - 1) / BP;
     const int per = (nchunk_total + P.nsplit - 1) / P.nsplit;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const bool do_bias = (P.dbias != nullptr) && (blockIdx.x == 0);
+    const bool do_bias = (P.dbias != nullptr) && (bx == 0);
 
     // transposed fragment reads: lane L = 16 G + 4 q + p4 supplies the address of pixel row 8 (G >> 1) + q (+ 4 for the second
     // read, + 16 for the second k16 step), columns 16 (G & 1) + 4 p4 .. + 3 of its 32-channel block
@@ -367,10 +367,17 @@ __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
     }
 }
 
+template <int BCO, int BKC, int WGC, int WGK, bool PRO>
+__global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sg_wgrad3_body<BCO, BKC, WGC, WGK, PRO>(G, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+#ifndef SG_KERNELS_ONLY      // sgan_fused.hip includes this file for the kernel bodies only
 static inline int sgw3_cdiv(int a, int b) { return (a + b - 1) / b; }
 
-template <int BCO, int BKC, int WGC, int WGK>
-static int sgw3_launch(SgWgradParams& P, hipStream_t st, const char* name) {
+// pixel splits, z offsets, grid and LDS bytes of a launch with BCO x BKC tiles; false: nothing to do
+static bool sgw3_prepare(SgWgradParams& P, int BCO, int BKC, dim3* grid_out, size_t* lds_out, bool* pro_out) {
     int maxK = 0;
     for (int i = 0; i < P.nphase; ++i) maxK = max(maxK, P.ktot[i]);
     const int tiles = sgw3_cdiv(maxK, BKC) * sgw3_cdiv(P.Cout, BCO);
@@ -380,7 +387,7 @@ static int sgw3_launch(SgWgradParams& P, hipStream_t st, const char* name) {
         for (int i = 0; i < P.nphase; ++i) maxM = max(maxM, P.q[g].Hp[i] * P.q[g].Wp[i]);
         chunks_total += (long)sgw3_cdiv(maxM, 32) * P.nphase;
     }
-    if (chunks_total == 0) return 1;
+    if (chunks_total == 0) return false;
     // pixel-range split per problem: ~512 workgroups over the launch (sweep 96 .. 2304 on the fcgan launches: 512 is best or within 3 % of best everywhere; 768 cost the small generator layers 10-25 %) with the same number of 32-pixel chunks each (>= 4)
     const double want = getenv("SGAN_WGRAD3_WANT") ? atof(getenv("SGAN_WGRAD3_WANT")) : 512.0;
     int per = (int)((double)chunks_total * tiles / want + 0.999);
@@ -397,10 +404,20 @@ static int sgw3_launch(SgWgradParams& P, hipStream_t st, const char* name) {
         P.q[g].z0 = z;
         z += P.nphase * nsplit;
     }
-    dim3 grid(sgw3_cdiv(maxK, BKC), sgw3_cdiv(P.Cout, BCO), z);
-    const size_t lds = (size_t)4 * (BCO / 32 * 2048) + (size_t)4 * (BKC / 32 * 2048) + (size_t)2 * P.Cin * 4;
+    *grid_out = dim3(sgw3_cdiv(maxK, BKC), sgw3_cdiv(P.Cout, BCO), z);
+    *lds_out = (size_t)4 * (BCO / 32 * 2048) + (size_t)4 * (BKC / 32 * 2048) + (size_t)2 * P.Cin * 4;
     bool pro = P.pro_act != SGAN_ACT_NONE;
     for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
+    *pro_out = pro;
+    return true;
+}
+
+template <int BCO, int BKC, int WGC, int WGK>
+static int sgw3_launch(SgWgradParams& P, hipStream_t st, const char* name) {
+    dim3 grid;
+    size_t lds;
+    bool pro;
+    if (!sgw3_prepare(P, BCO, BKC, &grid, &lds, &pro)) return 1;
     sg_prof_begin(st);
     if (pro) hipLaunchKernelGGL((sg_wgrad3_kernel<BCO, BKC, WGC, WGK, true>), grid, dim3(256), lds, st, P);
     else hipLaunchKernelGGL((sg_wgrad3_kernel<BCO, BKC, WGC, WGK, false>), grid, dim3(256), lds, st, P);
@@ -411,10 +428,30 @@ static int sgw3_launch(SgWgradParams& P, hipStream_t st, const char* name) {
     return 1;
 }
 
-int sg_launch_wgrad3(SgWgradParams& P, hipStream_t st) {
-    if ((P.Cin & 7) || (P.Cout & 7) || P.Cin < 16 || P.Cout < 32) return 0;
+static bool sgw3_covers(const SgWgradParams& P) {
+    if ((P.Cin & 7) || (P.Cout & 7) || P.Cin < 16 || P.Cout < 32) return false;
     for (int g = 0; g < P.nprob; ++g)     // tiny maps stay exact fp32 (see sg_igemm3_eligible)
-        if (P.q[g].Hin * P.q[g].Win < SGAN_BF16X3_MIN_PIXELS || P.q[g].Hout * P.q[g].Wout < SGAN_BF16X3_MIN_PIXELS) return 0;
+        if (P.q[g].Hin * P.q[g].Win < SGAN_BF16X3_MIN_PIXELS || P.q[g].Hout * P.q[g].Wout < SGAN_BF16X3_MIN_PIXELS) return false;
+    return true;
+}
+
+// Plan of a backward-weight launch for sg_bwd_fused_kernel: variant 1 = 64 x 64 tiles, 2 = 32 x 128, 0 = not covered / nothing to do
+int sg_wgrad3_fuse_plan(SgWgradParams& P, SgFusePlan* out) {
+    out->variant = 0;
+    if (!sgw3_covers(P)) return 0;
+    dim3 grid;
+    const bool narrow = P.Cout < 64;
+    if (!sgw3_prepare(P, narrow ? 32 : 64, narrow ? 128 : 64, &grid, &out->lds, &out->pro)) return 0;
+    out->variant = narrow ? 2 : 1;
+    out->gx = grid.x; out->gy = grid.y; out->gz = grid.z;
+    out->nblocks = grid.x * grid.y * grid.z;
+    out->name = narrow ? "sg_wgrad3_kernel<32,128,1,4>" : "sg_wgrad3_kernel<64,64,2,2>";
+    return 0;
+}
+
+int sg_launch_wgrad3(SgWgradParams& P, hipStream_t st) {
+    if (!sgw3_covers(P)) return 0;
     if (P.Cout < 64) return sgw3_launch<32, 128, 1, 4>(P, st, "sg_wgrad3_kernel<32,128,1,4>");
     return sgw3_launch<64, 64, 2, 2>(P, st, "sg_wgrad3_kernel<64,64,2,2>");
 }
+#endif      // SG_KERNELS_ONLY

@@ -165,8 +165,7 @@ def conv_fwd_grouped(jobs, out_act=ACT_NONE):
             "sgan_conv_fwd_grouped")
 
 
-def conv_dgrad_grouped(jobs):
-    """jobs: list of (desc, dout, w, din, x, x_norm, bwd_sums[, sums_sq, accumulate, w_transposed, sums_rep])."""
+def _dgrad_array(jobs):
     arr = (L.ConvDgradJob * len(jobs))()
     for i, job in enumerate(jobs):
         desc, dout, w, din, x, x_norm, sums = job[:7]
@@ -176,6 +175,21 @@ def conv_dgrad_grouped(jobs):
                                 int(job[7]) if len(job) > 7 else 0, int(bool(job[8])) if len(job) > 8 else 0,
                                 int(bool(job[9])) if len(job) > 9 else 0, _pk(w),
                                 int(job[10]) if (len(job) > 10 and sums is not None) else 0)
+    return arr
+
+
+def _wgrad_array(jobs):
+    arr = (L.ConvWgradJob * len(jobs))()
+    for i, (desc, x, in_norm, dout, dw, dbias) in enumerate(jobs):
+        desc.math = _math
+        arr[i] = L.ConvWgradJob(C.pointer(desc), _ptr(_act(x)).value, x.stride(1), _pn(in_norm), _ptr(_act(dout)).value,
+                                dout.stride(1), _ptr(dw).value, _ptr(dbias).value)
+    return arr
+
+
+def conv_dgrad_grouped(jobs):
+    """jobs: list of (desc, dout, w, din, x, x_norm, bwd_sums[, sums_sq, accumulate, w_transposed, sums_rep])."""
+    arr = _dgrad_array(jobs)
     ws = _workspace(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device)
     L.check(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_dgrad_grouped")
@@ -183,15 +197,25 @@ def conv_dgrad_grouped(jobs):
 
 def conv_wgrad_grouped(jobs):
     """jobs: list of (desc, x, in_norm, dout, dw, dbias)."""
-    arr = (L.ConvWgradJob * len(jobs))()
-    for i, (desc, x, in_norm, dout, dw, dbias) in enumerate(jobs):
-        desc.math = _math
-        arr[i] = L.ConvWgradJob(C.pointer(desc), _ptr(_act(x)).value, x.stride(1), _pn(in_norm), _ptr(_act(dout)).value,
-                                dout.stride(1), _ptr(dw).value, _ptr(dbias).value)
+    arr = _wgrad_array(jobs)
     d0 = jobs[0][0]
     ws = _workspace(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device) if min(d0.Cin, d0.Cout) <= 4 else None
     L.check(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_wgrad_grouped")
+
+
+def conv_bwd_grouped(djobs, wjobs):
+    """A layer's backward-weight and backward-data (job lists as for the two calls above): one fused launch where
+    sgan_conv_bwd_fused covers the layer, the two grouped launches otherwise."""
+    if _math == L.MATH_BF16X3 and _DGRAD_MATH is None:
+        rc = L.lib().sgan_conv_bwd_fused(_dgrad_array(djobs), len(djobs), _wgrad_array(wjobs), len(wjobs), _stream())
+        if rc == 0:
+            return True
+        if rc < 0:
+            L.check(rc, "sgan_conv_bwd_fused")
+    conv_wgrad_grouped(wjobs)
+    conv_dgrad_grouped(djobs)
+    return False
 
 
 def transpose_weights(flat, flat_t, segs):

@@ -82,6 +82,7 @@ SHAPES = [
     ("convT", 4, 2, 1, 128, 64, 21, 19, "bn", 1),      # forward = 4 phases of 2 x 2 taps on odd sizes
 ]
 TILES = ["auto", "64x64", "128x64", "128x128", "patch"]
+_FUSED_SEEN = {}
 
 
 def _select_tile(tile):
@@ -208,6 +209,63 @@ def test_igemm3_grouped_and_splitk(ops, tile):
         got[mode] = (ob, ost)
     ops.set_math("bf16x3")
     assert rel(got["bf16x3"][0], got["f32"][0]) < 3e-5 and rel(got["bf16x3"][1], got["f32"][1]) < 1e-5
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"{c[0]}_k{c[1]}s{c[2]}_{c[4]}to{c[5]}_{c[6]}x{c[7]}" for c in SHAPES])
+def test_fused_backward_equals_the_two_launches(ops, shape):
+    """sgan_conv_bwd_fused (one grid for a layer's backward-data and backward-weight) against sgan_conv_dgrad_grouped +
+    sgan_conv_wgrad_grouped on the same two-problem job lists: the input gradients bit for bit (same body, same tile order), the
+    weight / bias gradients and the norm-backward sums up to the order of their atomic adds."""
+    from hip_utils import master_weight, pad_vec, rel, stats_of, to_buf
+    from supervised_gan_amd import _lib
+    kind, k, s, p, cin, cout, H, W, norm, act = shape
+    tr = kind == "convT"
+    _select_tile("auto")
+    ops.set_math("bf16x3")
+    g = torch.Generator().manual_seed(17)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    wm = master_weight(torch.randn(*wshape, generator=g) * 0.05, tr)
+    sizes = [(H, W), (H + 3, W + 2)]
+    probs = []
+    for h, w_ in sizes:
+        x = torch.randn(1, cin, h, w_, generator=g) * 1.5 + 0.3
+        ho, wo = ((h - 1) * s - 2 * p + k, (w_ - 1) * s - 2 * p + k) if tr else ((h + 2 * p - k) // s + 1, (w_ + 2 * p - k) // s + 1)
+        desc = ops.conv_desc(1 if tr else 0, k, s, p, h, w_, cin, ho, wo, cout, cin, cout)
+        nd = ops.norm_desc(stats_of(x), None, None, h * w_, 1e-5, act, 0.2) if norm else None
+        probs.append((desc, to_buf(x), nd, to_buf(torch.randn(1, cout, ho, wo, generator=g)), h, w_))
+    res = {}
+    for mode in ("apart", "fused"):
+        dw, db = torch.zeros_like(wm), torch.zeros(pad_vec(torch.zeros(cout)).numel(), device="cuda")
+        djobs, wjobs, keep = [], [], []
+        for desc, xb, nd, dy, h, w_ in probs:
+            din = torch.full((h, w_, cin), float("nan"), device="cuda")
+            sums = torch.zeros(2 * cin, dtype=torch.float64, device="cuda") if norm else None
+            djobs.append((desc, dy, wm._sgan_wt, din, xb, nd, sums, 0, False, True, 0))
+            wjobs.append((desc, xb, nd, dy, dw, db))
+            keep.append((din, sums))
+        if mode == "apart":
+            ops.conv_wgrad_grouped(wjobs)
+            ops.conv_dgrad_grouped(djobs)
+        else:
+            fused = ops.conv_bwd_grouped(djobs, wjobs)
+            if fused:
+                assert _lib.lib().sgan_last_kernel().decode() == "sg_bwd_fused_kernel"
+        torch.cuda.synchronize()
+        res[mode] = (keep, dw, db)
+    print("fused launch:", fused)
+    _FUSED_SEEN[shape] = fused
+    for (da, sa), (df, sf) in zip(res["apart"][0], res["fused"][0]):
+        assert torch.equal(da, df)
+        if sa is not None:
+            assert rel(sf, sa) < 1e-12
+    assert rel(res["fused"][1], res["apart"][1]) < 2e-6 and rel(res["fused"][2], res["apart"][2]) < 2e-6
+
+
+def test_fused_backward_is_taken(ops):
+    """The comparison above is vacuous where the fused entry point declines: of the listed shapes, those with >= 64 channels on
+    both sides and maps of >= 256 pixels must have gone through sg_bwd_fused_kernel."""
+    want = [c for c in SHAPES if c[4] >= 64 and c[5] >= 64 and c[6] * c[7] >= 256]
+    assert want and all(_FUSED_SEEN.get(c) for c in want), {c: _FUSED_SEEN.get(c) for c in want}
 
 
 def test_bf16x3_needs_packed_weights(ops):

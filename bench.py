@@ -444,11 +444,16 @@ def main():
     barrier()
     if getattr(model, "grad_sync", None) is not None and hasattr(model.grad_sync, "bytes"):
         model.grad_sync.bytes = model.grad_sync.calls = 0      # count the timed steps only
+    host_busy = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
+        th = time.perf_counter()
         step(args.warmup + i)
+        host_busy += time.perf_counter() - th
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("SGAN_BENCH_HOST"):      # diagnostic: is the host (graph launches, pool policy) or the device the longer leg?
+        print(f"[bench] host enqueue {host_busy / args.steps * 1e3:.3f} ms/step of {dt / args.steps * 1e3:.3f} ms/step", file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

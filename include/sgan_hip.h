@@ -383,6 +383,10 @@ int sgan_scale(const float* gout, const float* g, float* dx, int64_t n, void* st
  * be PINNED (page-locked, device-mapped) HOST memory: the gather kernel is then the host-to-device copy of the batch
  * (the transforms.ToTensor() -> .cuda() step of the reference's loop, train.py:25-29), queued with the step's kernels. */
 int sgan_tanh_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* out = act(a + b) over n contiguous floats (n % 4 == 0), act = SGAN_ACT_TANH or SGAN_ACT_NONE: `nn.Tanh()(x + y)`, the
+ * --use_residual tail of ResnetGenerator.forward / UnetGenerator.forward (models/networks.py:268, :367).  Backward:
+ * sgan_tanh_bwd(dout, out) is the gradient of both addends. */
+int sgan_add_act_fwd(const float* a, const float* b, float* out, int64_t n, int32_t act, void* stream);
 int sgan_to_nhwc(const float* src, int64_t sc, int64_t sh, int64_t sw, int32_t H, int32_t W, int32_t Creal,
                  float* dst, int32_t dst_ld, int32_t Cstore, void* stream);
 

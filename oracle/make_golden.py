@@ -372,14 +372,17 @@ class UnetRandomInjector:
         torch.Tensor.normal_ = self._orig_normal
 
 
-def golden_unet_small():
-    """unet_128 (7 downs) at 256x256, ngf=8: all skips + dropout; and 4 skips + Gaussian noise, no dropout."""
+def golden_unet_small(only=()):
+    """unet_128 (7 downs) at 256x256, ngf=8: all skips + dropout; 4 skips + Gaussian noise, no dropout; --use_residual (2 -> 2 channels)."""
     for tag, kw in (("skipall_dropout", dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False)),
-                    ("skip4_noise", dict(use_dropout=False, num_skips=4, add_gaussian_noise=True))):
-        ngf, in_nc, out_nc, hw = 8, 2, 1, 256
+                    ("skip4_noise", dict(use_dropout=False, num_skips=4, add_gaussian_noise=True)),
+                    ("residual", dict(use_dropout=False, num_skips=-1, add_gaussian_noise=False, use_residual=True, out_nc=2))):
+        if only and tag not in only:
+            continue
+        ngf, in_nc, out_nc, hw = 8, 2, kw.get("out_nc", 1), 256
         sd = O.init_unet(31, 7, in_nc, out_nc, ngf, kw["num_skips"])
         g = RN.define_G(in_nc, out_nc, ngf, "unet_128", "instance", kw["use_dropout"], n_layers_G_skip=kw["num_skips"],
-                        add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, gpu_ids=[])
+                        add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, use_residual=kw.get("use_residual", False), gpu_ids=[])
         load_sd(g, sd)
         x = O.np_uniform(301, (1, in_nc, hw, hw)).requires_grad_(True)
         r = O.np_normal(302, (1, out_nc, hw, hw))
@@ -415,12 +418,15 @@ class SeqDropoutInjector:
         torch.nn.functional.dropout = self._orig
 
 
-def golden_resnet_small():
+def golden_resnet_small(only=()):
     """resnet_6blocks without dropout and resnet_9blocks with dropout at 64x64, ngf 8, 2 -> 1 channels (models/networks.py:221-311)."""
-    for tag, which, nb, drop in (("6", "resnet_6blocks", 6, False), ("9_dropout", "resnet_9blocks", 9, True)):
-        ngf, in_nc, out_nc, hw = 8, 2, 1, 64
+    for tag, which, nb, drop, res in (("6", "resnet_6blocks", 6, False, False), ("9_dropout", "resnet_9blocks", 9, True, False),
+                                      ("6_residual", "resnet_6blocks", 6, False, True)):
+        if only and tag not in only:
+            continue
+        ngf, in_nc, out_nc, hw = 8, 2, 2 if res else 1, 64
         sd = O.init_resnet(41, in_nc, out_nc, ngf, nb, drop)
-        g = RN.define_G(in_nc, out_nc, ngf, which, "instance", drop, gpu_ids=[])
+        g = RN.define_G(in_nc, out_nc, ngf, which, "instance", drop, use_residual=res, gpu_ids=[])
         load_sd(g, sd)
         x = O.np_uniform(311, (1, in_nc, hw, hw)).requires_grad_(True)
         r = O.np_normal(312, (1, out_nc, hw, hw))
@@ -1091,6 +1097,9 @@ def main():
         golden_fcgan_star_small()
     if not only or "resnet" in only:
         golden_resnet_small()
+    if "residual" in only:       # only the --use_residual vectors (added after the others; same generators)
+        golden_resnet_small(("6_residual",))
+        golden_unet_small(("residual",))
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
         golden_autoencoder_dropout()

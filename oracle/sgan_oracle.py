@@ -500,7 +500,7 @@ def init_resnet(seed: int, input_nc: int, output_nc: int, ngf: int, n_blocks: in
     return sd
 
 
-def resnet_forward(sd, x, n_blocks: int, use_dropout: bool = False, mask_seed: int = 0, tanh: bool = True):
+def resnet_forward(sd, x, n_blocks: int, use_dropout: bool = False, mask_seed: int = 0, tanh: bool = True, use_residual: bool = False):
     """ResnetGenerator.forward (models/networks.py:221-268) with ResnetBlock (:271-311), padding_type 'reflect', InstanceNorm:
     the i-th block's Dropout(0.5) mask is dropout_mask_np(mask_seed + i, shape)."""
     inorm = lambda t: F.instance_norm(t, eps=1e-5)      # noqa: E731
@@ -520,7 +520,9 @@ def resnet_forward(sd, x, n_blocks: int, use_dropout: bool = False, mask_seed: i
         h = F.relu(inorm(F.conv_transpose2d(h, sd[key + ".weight"], sd[key + ".bias"], stride=2, padding=1, output_padding=1)))
     y = F.conv2d(rpad(h, 3), sd[f"model.{nb + 7}.weight"], sd[f"model.{nb + 7}.bias"])
     # the reference applies Tanh TWICE without --use_residual: once as the last module of self.model (:261-262) and again in
-    # forward() (:268: `nn.Tanh()(y)`)
+    # forward() (:268: `nn.Tanh()(y)`); with --use_residual the Sequential ends in the conv (:258-259) and forward() is tanh(x + y)
+    if use_residual:
+        return torch.tanh(x + y) if tanh else x + y
     return torch.tanh(torch.tanh(y)) if tanh else y
 
 
@@ -536,8 +538,10 @@ def gauss_noise_np(seed: int, shape) -> torch.Tensor:
 
 
 def unet_forward(sd, x, num_downs: int, ngf: int, num_skips: int = -1, use_dropout: bool = False, mask_seed: int = 0,
-                 add_gaussian_noise: bool = False, gaussian_sigma: float = 0.1, noise_seed: int = 0, tanh: bool = True):
-    """UnetGenerator.forward (:362-367) with UnetSkipConnectionBlock.forward (:409-419) inlined."""
+                 add_gaussian_noise: bool = False, gaussian_sigma: float = 0.1, noise_seed: int = 0, tanh: bool = True,
+                 use_residual: bool = False):
+    """UnetGenerator.forward (:362-367: `activation(x + y) if self.use_residual else activation(y)`) with
+    UnetSkipConnectionBlock.forward (:409-419) inlined."""
     input_nc = sd["model.0.weight"].shape[1]
     output_nc = sd["model.3.weight"].shape[1]
     levels = unet_plan(num_downs, ngf, input_nc, output_nc, num_skips, use_dropout)
@@ -563,6 +567,8 @@ def unet_forward(sd, x, num_downs: int, ngf: int, num_skips: int = -1, use_dropo
     h = block(1, h)
     h = F.relu(h)
     h = F.conv_transpose2d(h, sd["model.3.weight"], sd["model.3.bias"], stride=2, padding=1)
+    if use_residual:
+        h = x + h
     return torch.tanh(h) if tanh else h
 
 

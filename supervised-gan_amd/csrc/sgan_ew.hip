@@ -1613,6 +1613,31 @@ extern "C" int sgan_tanh_bwd(const float* dy, const float* y, float* dx, int64_t
     return SGAN_OK;
 }
 
+// out = tanh(a + b) (or a + b): the `--use_residual` tail of ResnetGenerator / UnetGenerator (models/networks.py:268, :367); the
+// backward is sgan_tanh_bwd of `out`, one gradient for both addends
+template <bool TANH>
+__global__ __launch_bounds__(256) void sg_add_act_kernel(const float* a, const float* b, float* out, int64_t n4) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+        const f32x4 u = reinterpret_cast<const f32x4*>(a)[e];
+        const f32x4 v = reinterpret_cast<const f32x4*>(b)[e];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = TANH ? tanhf(u[j] + v[j]) : u[j] + v[j];
+        reinterpret_cast<f32x4*>(out)[e] = o;
+    }
+}
+
+extern "C" int sgan_add_act_fwd(const float* a, const float* b, float* out, int64_t n, int32_t act, void* stream) {
+    SGAN_CHECK(a && b && out && n > 0 && (n & 3) == 0, "bad argument");
+    SGAN_CHECK(act == SGAN_ACT_NONE || act == SGAN_ACT_TANH, "act must be SGAN_ACT_NONE or SGAN_ACT_TANH");
+    int blocks = ew_cdiv(n / 4, 256);
+    if (blocks > 2048) blocks = 2048;
+    if (act == SGAN_ACT_TANH) hipLaunchKernelGGL(sg_add_act_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4);
+    else hipLaunchKernelGGL(sg_add_act_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
 __global__ __launch_bounds__(256) void sg_to_nhwc_kernel(const float* src, int64_t sc, int64_t sh, int64_t sw, int H, int W,
                                                          int Creal, float* dst, int dst_ld, int Cstore) {
     const int64_t total = (int64_t)H * W * Cstore;

@@ -303,6 +303,40 @@ class AutoEncoder(ChainNet):
         return y
 
 
+class _ResidualActFn(torch.autograd.Function):
+    """act(x + y) of two logical images in one pass (`nn.Tanh()(x + y)`, models/networks.py:268, :367); one gradient serves both."""
+
+    @staticmethod
+    def forward(ctx, x, y, act):
+        a, b = ops.as_nhwc(x).contiguous(), ops.as_nhwc(y).contiguous()
+        out = torch.empty_like(a)
+        ops.add_act_fwd(a, b, out, act)
+        ctx.act, ctx.out, ctx.nc = act, out, x.shape[1]
+        return ops.logical_view(out, x.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.act == ACT_TANH:
+            d = torch.empty_like(ctx.out)
+            ops.tanh_bwd(ops.as_nhwc(g).contiguous(), ctx.out, d)
+            g = ops.logical_view(d, ctx.nc)
+        return g, g, None
+
+
+def _residual_forward(net, x, activation, run):
+    """`activation(x + net.model(x))` for a generator built with use_residual: the chain ends raw, the sum and a Tanh are one kernel."""
+    if x.shape[1] != net.output_nc:
+        raise ValueError(f"use_residual adds the input to the output: input_nc {x.shape[1]} != output_nc {net.output_nc}")
+    net._call_act = ACT_NONE
+    try:
+        y = run()
+    finally:
+        net._call_act = None
+    custom = activation is not None and not isinstance(activation, nn.Tanh)
+    s = _ResidualActFn.apply(x, y, ACT_NONE if custom else ACT_TANH)
+    return activation(s) if custom else s
+
+
 class ResnetGenerator(ChainNet):
     """ResnetGenerator + ResnetBlock (models/networks.py:221-311; `resnet_6blocks` / `resnet_9blocks`, padding_type 'reflect'):
         ReflectionPad(3) Conv(k7) IN ReLU -> 2 x [Conv(k3,s2,p1) IN ReLU] -> n x ResnetBlock -> 2 x [ConvT(k3,s2,p1,op1) IN ReLU]
@@ -317,8 +351,7 @@ class ResnetGenerator(ChainNet):
     def __init__(self, input_nc, output_nc, ngf=64, norm="instance", use_dropout=False, n_blocks=6, use_residual=False, gpu_ids=[]):
         if norm != "instance":
             raise NotImplementedError("ResnetGenerator on the MI355X path implements --norm instance")
-        if use_residual:
-            raise NotImplementedError("ResnetGenerator --use_residual (tanh(x + y)) is not on the MI355X path")
+        self.use_residual = bool(use_residual)      # the Sequential then ends without its nn.Tanh (:258-259); forward() adds the input
         self.n_blocks, self.use_dropout, self.input_nc, self.output_nc = int(n_blocks), bool(use_dropout), input_nc, output_nc
         C = 4 * ngf
         self.c0 = LayerSpec("1", CONV, 7, 1, 0, input_nc, ngf, True, "in", ACT_RELU)
@@ -346,6 +379,8 @@ class ResnetGenerator(ChainNet):
         # the reference's forward() applies nn.Tanh() to the output of self.model, which (without --use_residual) already ends in
         # nn.Tanh() (models/networks.py:261-262,268): tanh(tanh(conv)).  The first is the conv epilogue, the second one elementwise op
         # on the output image.
+        if self.use_residual:
+            return _residual_forward(self, x, None, lambda: _ChainFn.apply(self, x, *list(self.model.parameters())))
         return torch.tanh(_ChainFn.apply(self, x, *list(self.model.parameters())))
 
     def _wrap_output(self, y):
@@ -541,8 +576,7 @@ class UnetGenerator(ChainNet):
                  add_gaussian_noise=False, gaussian_sigma=0.1, num_skips=-1, gpu_ids=[]):
         if norm != "instance":
             raise NotImplementedError("UnetGenerator on the MI355X path implements --norm instance (the reference default)")
-        if use_residual:
-            raise NotImplementedError("UnetGenerator --use_residual is not on the MI355X path")
+        self.use_residual = bool(use_residual)
         if num_downs < 5:
             raise ValueError("UnetGenerator needs num_downs >= 5")
         n = num_downs
@@ -834,6 +868,8 @@ class UnetGenerator(ChainNet):
     def forward(self, x, noise=None, activation=None):
         """`noise` is accepted and ignored like in the reference (models/networks.py:362)."""
         params = list(self.model.parameters())
+        if self.use_residual:
+            return _residual_forward(self, x, activation, lambda: _ChainFn.apply(self, x, *params))
         return self._apply_with_activation(activation, lambda: _ChainFn.apply(self, x, *params))
 
     def _wrap_output(self, y):

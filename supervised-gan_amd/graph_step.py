@@ -110,7 +110,10 @@ class GraphedStep:
             m.set_input(data)
         self.gA.replay()
         for pool, src, buf in zip(self.pools, self._fakeA, self.fake_for_D):      # the reference's query order
-            buf.copy_(ops.as_nhwc(pool.query(src)))
+            # a copy KERNEL on the step's stream: Tensor.copy_ of a contiguous tensor is hipMemcpyAsync, which on this stack starts
+            # ~100 us after the work queued before it (measured: profiles/r02 timeline), a bubble in every step
+            q = ops.as_nhwc(pool.query(src))
+            ops.slice_nhwc(q, 0, q.shape[2], out=buf)
         for kind, obj in self.segs:
             if kind == "graph":
                 obj.replay()

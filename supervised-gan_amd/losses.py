@@ -76,11 +76,14 @@ class _GanLossMultiFn(torch.autograd.Function):
         ops.gan_loss_multi_fwd(lbs, targets, weights, mode, each, total, ds)
         ctx.ds = ds
         ctx.mark_non_differentiable(each)
+        ctx.set_materialize_grads(False)      # or autograd zero-fills a gradient for `each` on every backward (one more launch)
         return total, each
 
     @staticmethod
     def backward(ctx, gtotal, _geach):
         ds = ctx.ds
+        if gtotal is None:
+            return (None,) * (3 + len(ds))
         if not ops.is_unit_grad(gtotal):
             scaled = [torch.empty_like(d) for d in ds]
             g = gtotal.contiguous()

@@ -505,6 +505,12 @@ def tanh_bwd(dy, y, dx):
     L.check(L.lib().sgan_tanh_bwd(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream()), "sgan_tanh_bwd")
 
 
+def add_act_fwd(a, b, out, act=ACT_TANH):
+    """out = act(a + b) on contiguous padded NHWC buffers of one shape (the --use_residual tail of the generators)."""
+    assert a.shape == b.shape == out.shape and a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
+    L.check(L.lib().sgan_add_act_fwd(_ptr(a), _ptr(b), _ptr(out), a.numel(), int(act), _stream()), "sgan_add_act_fwd")
+
+
 def adam_multi(segs, lr_dev, beta1, beta2, eps, state_dev):
     """segs: list of (p, g, m, v, n) flat fp32 tensors (16-byte aligned)."""
     arr = (L.AdamSeg * len(segs))()
@@ -588,10 +594,12 @@ def concat_nhwc(a, Ca, b, Cb):
     return out
 
 
-def slice_nhwc(src, c0, Cn):
-    """Channels [c0, c0 + Cn) of a padded NHWC buffer as a padded NHWC buffer of their own."""
+def slice_nhwc(src, c0, Cn, out=None):
+    """Channels [c0, c0 + Cn) of a padded NHWC buffer as a padded NHWC buffer of their own (`out`: write into this one)."""
     H, W, _ = src.shape
-    out = torch.empty((H, W, pad4(Cn)), dtype=torch.float32, device=src.device)
+    if out is None:
+        out = torch.empty((H, W, pad4(Cn)), dtype=torch.float32, device=src.device)
+    assert out.shape[:2] == (H, W) and out.shape[2] >= pad4(Cn)
     L.check(L.lib().sgan_slice_nhwc(_ptr(_act(src)), src.stride(1), int(c0), int(Cn), H * W, _ptr(out), out.stride(1), out.shape[2], _stream()),
             "sgan_slice_nhwc")
     return out

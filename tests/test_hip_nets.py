@@ -178,7 +178,8 @@ def test_grouped_chains_equal_individual_chains(N):
 # U-Net generator (models/networks.py:318-419)
 # ------------------------------------------------------------------------------------------------
 UNET_SMALL = {"skipall_dropout": dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False),
-              "skip4_noise": dict(use_dropout=False, num_skips=4, add_gaussian_noise=True)}
+              "skip4_noise": dict(use_dropout=False, num_skips=4, add_gaussian_noise=True),
+              "residual": dict(use_dropout=False, num_skips=-1, add_gaussian_noise=False, use_residual=True, out_nc=2)}
 
 
 def inject_unet_random(G, H, mask_seed, noise_seed):
@@ -199,18 +200,19 @@ def inject_unet_random(G, H, mask_seed, noise_seed):
 def test_unet_small(N, golden_dir, tag):
     g = load(golden_dir, f"unet_small_{tag}.npz")
     kw = UNET_SMALL[tag]
-    G = N.define_G(2, 1, 8, "unet_128", "instance", kw["use_dropout"], n_layers_G_skip=kw["num_skips"],
-                   add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, gpu_ids=[0])
-    sd = O.init_unet(31, 7, 2, 1, 8, kw["num_skips"])
+    onc = kw.get("out_nc", 1)      # "residual": --use_residual, tanh(x + y) on 2 -> 2 channels (models/networks.py:367)
+    G = N.define_G(2, onc, 8, "unet_128", "instance", kw["use_dropout"], n_layers_G_skip=kw["num_skips"],
+                   add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, use_residual=kw.get("use_residual", False), gpu_ids=[0])
+    sd = O.init_unet(31, 7, 2, onc, 8, kw["num_skips"])
     assert set(G.state_dict().keys()) == set(sd.keys())
     assert list(G.state_dict().keys())[:3] == ['model.0.weight', 'model.0.bias', 'model.1.model.1.weight']     # nn.Sequential order
     assert list(G.state_dict().keys())[-2:] == ['model.3.weight', 'model.3.bias']
     G.load_state_dict(sd)
     inject_unet_random(G, 256, 40, 50)
     x = O.np_uniform(301, (1, 2, 256, 256)).cuda().requires_grad_(True)
-    r = O.np_normal(302, (1, 1, 256, 256)).cuda()
+    r = O.np_normal(302, (1, onc, 256, 256)).cuda()
     y = G.forward(x)
-    assert y.shape == (1, 1, 256, 256)
+    assert y.shape == (1, onc, 256, 256)
     (y * r).sum().backward()
     torch.cuda.synchronize()
     assert rel(y, g["y"]) < TOL
@@ -228,21 +230,23 @@ def test_unet_small(N, golden_dir, tag):
             assert rel(params[name].grad, g[k]) < TOL, name
 
 
-@pytest.mark.parametrize("tag,which,nb,drop", [("6", "resnet_6blocks", 6, False), ("9_dropout", "resnet_9blocks", 9, True)])
-def test_resnet_small(N, golden_dir, tag, which, nb, drop):
+@pytest.mark.parametrize("tag,which,nb,drop,res", [("6", "resnet_6blocks", 6, False, False), ("9_dropout", "resnet_9blocks", 9, True, False),
+                                                   ("6_residual", "resnet_6blocks", 6, False, True)])
+def test_resnet_small(N, golden_dir, tag, which, nb, drop, res):
     """--which_model_netG resnet_6blocks / resnet_9blocks (models/networks.py:221-311) on the HIP path against the reference golden:
     reflection padding (materialised gather), 49-tap k7 layers, stride-2 convs, residual blocks with dropout, ConvT k3 s2 with
     output padding; state_dict keys and order as the reference's nn.Sequential."""
     g = load(golden_dir, f"resnet_small_{tag}.npz")
-    G = N.define_G(2, 1, 8, which, "instance", drop, gpu_ids=[0])
-    sd = O.init_resnet(41, 2, 1, 8, nb, drop)
+    onc = 2 if res else 1      # --use_residual: no Tanh module at the end of the Sequential, forward() = tanh(x + y) (:258-268)
+    G = N.define_G(2, onc, 8, which, "instance", drop, use_residual=res, gpu_ids=[0])
+    sd = O.init_resnet(41, 2, onc, 8, nb, drop)
     assert list(G.state_dict().keys()) == list(sd.keys())
     G.load_state_dict(sd)
     G.mask_source = lambda i, shape: O.dropout_mask_np(60 + i, (1, shape[2], shape[0], shape[1]))[0].permute(1, 2, 0).contiguous().cuda()
     x = O.np_uniform(311, (1, 2, 64, 64)).cuda().requires_grad_(True)
-    r = O.np_normal(312, (1, 1, 64, 64)).cuda()
+    r = O.np_normal(312, (1, onc, 64, 64)).cuda()
     y = G.forward(x)
-    assert y.shape == (1, 1, 64, 64)
+    assert y.shape == (1, onc, 64, 64)
     (y * r).sum().backward()
     torch.cuda.synchronize()
     assert rel(y, g["y"]) < TOL

@@ -250,24 +250,26 @@ def test_fcgan_step(golden_dir, name, kw):
 # U-Net generator and the cgan step (BASELINE configs[2])
 # ------------------------------------------------------------------------------------------------
 UNET_SMALL = {"skipall_dropout": dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False),
-              "skip4_noise": dict(use_dropout=False, num_skips=4, add_gaussian_noise=True)}
+              "skip4_noise": dict(use_dropout=False, num_skips=4, add_gaussian_noise=True),
+              "residual": dict(use_dropout=False, num_skips=-1, add_gaussian_noise=False, use_residual=True, out_nc=2)}
 
 
-def unet_small_inputs():
-    return O.np_uniform(301, (1, 2, 256, 256)), O.np_normal(302, (1, 1, 256, 256))
+def unet_small_inputs(out_nc=1):
+    return O.np_uniform(301, (1, 2, 256, 256)), O.np_normal(302, (1, out_nc, 256, 256))
 
 
 @pytest.mark.parametrize("tag", list(UNET_SMALL))
 def test_unet_small(golden_dir, tag):
     g = load(golden_dir, f"unet_small_{tag}.npz")
     kw = UNET_SMALL[tag]
-    sd = O.init_unet(31, 7, 2, 1, 8, kw["num_skips"])
+    sd = O.init_unet(31, 7, 2, kw.get("out_nc", 1), 8, kw["num_skips"])
     for v in sd.values():
         v.requires_grad_(True)
-    x, r = unet_small_inputs()
+    x, r = unet_small_inputs(kw.get("out_nc", 1))
     x.requires_grad_(True)
     y = O.unet_forward(sd, x, 7, 8, kw["num_skips"], kw["use_dropout"], mask_seed=40,
-                       add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, noise_seed=50)
+                       add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, noise_seed=50,
+                       use_residual=kw.get("use_residual", False))
     (y * r).sum().backward()
     assert rel(y, g["y"]) < TIGHT * 5
     assert rel(x.grad, g["dx"]) < 1e-4
@@ -279,7 +281,8 @@ def test_unet_small(golden_dir, tag):
             assert rel(v.grad, g["grad/" + k]) < 1e-4, k
 
 
-RESNET_SMALL = {"6": dict(n_blocks=6, use_dropout=False), "9_dropout": dict(n_blocks=9, use_dropout=True)}
+RESNET_SMALL = {"6": dict(n_blocks=6, use_dropout=False), "9_dropout": dict(n_blocks=9, use_dropout=True),
+                "6_residual": dict(n_blocks=6, use_dropout=False, use_residual=True, out_nc=2)}
 
 
 @pytest.mark.parametrize("tag", list(RESNET_SMALL))
@@ -288,12 +291,13 @@ def test_resnet_small(golden_dir, tag):
     against the reference's own nets."""
     g = load(golden_dir, f"resnet_small_{tag}.npz")
     kw = RESNET_SMALL[tag]
-    sd = O.init_resnet(41, 2, 1, 8, kw["n_blocks"], kw["use_dropout"])
+    onc = kw.get("out_nc", 1)
+    sd = O.init_resnet(41, 2, onc, 8, kw["n_blocks"], kw["use_dropout"])
     assert {"grad/" + k for k in sd} == {k for k in g.files if k.startswith("grad/")}
     for v in sd.values():
         v.requires_grad_(True)
-    x, r = O.np_uniform(311, (1, 2, 64, 64)).requires_grad_(True), O.np_normal(312, (1, 1, 64, 64))
-    y = O.resnet_forward(sd, x, kw["n_blocks"], kw["use_dropout"], mask_seed=60)
+    x, r = O.np_uniform(311, (1, 2, 64, 64)).requires_grad_(True), O.np_normal(312, (1, onc, 64, 64))
+    y = O.resnet_forward(sd, x, kw["n_blocks"], kw["use_dropout"], mask_seed=60, use_residual=kw.get("use_residual", False))
     (y * r).sum().backward()
     assert rel(y, g["y"]) < TIGHT * 5
     assert rel(x.grad, g["dx"]) < 1e-4

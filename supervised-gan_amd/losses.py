@@ -43,6 +43,9 @@ class _CatPairFn(torch.autograd.Function):
     def forward(ctx, a, b):
         ctx.Ca, ctx.Cb = a.shape[1], b.shape[1]
         out = ops.concat_nhwc(ops.as_nhwc(a), ctx.Ca, ops.as_nhwc(b), ctx.Cb)
+        # autograd hands the caller a detached alias of a differentiable view output; the buffer object must outlive this call
+        # for that alias to map back to it without a copy (ops.as_nhwc looks the buffer up by address)
+        ctx.out = out
         return ops.logical_view(out, ctx.Ca + ctx.Cb)
 
     @staticmethod

@@ -553,9 +553,9 @@ _VIEW_REGISTRY = {}
 def logical_view(buf: torch.Tensor, C_real: int) -> torch.Tensor:
     """[H, W, Cs] buffer -> logical [1, C_real, H, W] view; registered for zero-copy round trips."""
     v = buf.permute(2, 0, 1)[:C_real].unsqueeze(0)
-    _VIEW_REGISTRY[buf.data_ptr()] = (weakref.ref(buf), C_real)
+    _VIEW_REGISTRY[buf.data_ptr()] = (weakref.ref(buf), C_real, buf.untyped_storage()._cdata, tuple(buf.shape))
     if len(_VIEW_REGISTRY) > 4096:
-        for k in [k for k, (r, _) in _VIEW_REGISTRY.items() if r() is None]:
+        for k in [k for k, e in _VIEW_REGISTRY.items() if e[0]() is None]:
             del _VIEW_REGISTRY[k]
     return v
 
@@ -616,6 +616,11 @@ def as_nhwc(t: torch.Tensor) -> torch.Tensor:
     ent = _VIEW_REGISTRY.get(t.data_ptr())
     if ent is not None:
         buf = ent[0]()
+        if (buf is None and ent[3] == (H, W, Cs) and t.untyped_storage()._cdata == ent[2] and t.stride(1) == 1
+                and t.stride(3) == Cs and t.stride(2) == W * Cs):
+            # the buffer's Python object is gone (autograd hands out detached aliases of view outputs, ImagePool.query detaches)
+            # but `t` still IS that buffer's storage at the registered address: the same memory under the buffer's shape
+            buf = t.as_strided((H, W, Cs), (W * Cs, Cs, 1))
         if (buf is not None and ent[1] == Cr and buf.shape == (H, W, Cs) and buf.data_ptr() == t.data_ptr()
                 and t.stride(1) == 1 and t.stride(2) == buf.stride(0) and t.stride(3) == buf.stride(1)):
             return buf

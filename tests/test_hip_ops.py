@@ -445,6 +445,27 @@ def test_cat_pair_forward_backward(hip):
     assert a.grad is None and torch.equal(b.grad, torch.ones_like(b))
 
 
+def test_cat_pair_output_with_a_gradient_stays_zero_copy(hip):
+    """The pair a conditional discriminator is fed with in the G step (the image half needs a gradient): autograd returns an alias
+    of the view made in forward(); it must still map back to the concat buffer -- no sg_to_nhwc launch in front of the discriminator."""
+    from supervised_gan_amd import _lib, networks as N
+    a, b = torch.randn(1, 2, 16, 12).cuda(), torch.randn(1, 1, 16, 12).cuda().requires_grad_(True)
+    pair = N.cat_pair(a, b)
+    hip.tanh_bwd(torch.zeros(4, device="cuda"), torch.zeros(4, device="cuda"), torch.zeros(4, device="cuda"))      # moves sgan_last_kernel on
+    before = _lib.lib().sgan_last_kernel()
+    buf = hip.as_nhwc(pair)
+    assert buf.data_ptr() == pair.data_ptr() and buf.shape == (16, 12, 4) and _lib.lib().sgan_last_kernel() == before
+    assert torch.equal(buf[..., :3].permute(2, 0, 1).unsqueeze(0), torch.cat((a, b), 1)) and float(buf[..., 3].abs().sum()) == 0.0
+    # ... and the pair neither member of which needs one, handed on detached (the D step; ImagePool.query detaches as well)
+    import gc
+    pair = N.cat_pair(a, b.detach()).detach()
+    gc.collect()
+    before = _lib.lib().sgan_last_kernel()
+    buf = hip.as_nhwc(pair)
+    assert buf.data_ptr() == pair.data_ptr() and buf.shape == (16, 12, 4) and _lib.lib().sgan_last_kernel() == before
+    assert torch.equal(buf[..., :3].permute(2, 0, 1).unsqueeze(0), torch.cat((a, b), 1)) and float(buf[..., 3].abs().sum()) == 0.0
+
+
 def test_image_resize_bit_exact_vs_pillow(hip):
     """sgan_image_resize against Image.resize of the Pillow in this image: bilinear and bicubic, up- and down-scaling (the filter
     support grows with the down-scale factor), one axis unchanged, a 1-pixel-wide result, the aligned dataset's 2:1 shape."""

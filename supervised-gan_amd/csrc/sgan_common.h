@@ -10,6 +10,7 @@
 #include "../../include/sgan_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // thread-local last-error string (sgan_last_error()).
 extern thread_local char g_sgan_err[512];

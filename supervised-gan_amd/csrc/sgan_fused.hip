@@ -56,7 +56,7 @@ extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd,
     if (pd.variant == 0 || pd.nblocks == 0) return 1;
     sg_wgrad3_fuse_plan(W, &pw);
     if (pw.variant == 0 || pw.nblocks == 0) return 1;
-    if ((pd.lds > pw.lds ? pd.lds : pw.lds) > 64 * 1024) return 1;      // beyond the default dynamic-LDS limit: leave to the separate launches
+    if ((pd.lds > pw.lds ? pd.lds : pw.lds) > 160 * 1024) return 1;     // the CU's LDS (the split kernels with two k-tiles per barrier take a little over 64 KB)
     hipStream_t st = (hipStream_t)stream;
     sg_prof_begin(st);
     switch (pd.variant * 10 + pw.variant) {

@@ -656,7 +656,12 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
 // same norm-on-load prologue and bias / tanh epilogue as the other forward kernels; no output statistics (heads have no norm).
 // ------------------------------------------------------------------------------------------
 #define SGH_PS 144     // bytes per patch pixel (32 fp32 channels + 16 pad: the four octets of neighbouring pixels spread over the banks)
+// TH x 8 result pixels per workgroup; the 256 threads are (pixel, channel group): 256 / (8 TH) groups of 32 / groups channels each.
+// Short tiles (TH 4, 2) give a small launch enough workgroups to overlap their load latencies (the kernel is latency-, not
+// bandwidth-bound: one 8 x 8 tile per CU leaves one wave per SIMD).
+template <int TH>
 __global__ __launch_bounds__(256) void sg_conv_head_kernel(const SgIgemmParams G) {
+    constexpr int NG = 256 / (8 * TH), CPG = 32 / NG;       // channel groups per pixel, channels per group: (4, 8) (8, 4) (16, 2)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     int g, phz, mtile;
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(256) void sg_conv_head_kernel(const SgIgemmParams G
     const SgLocal P = sg_local(G, g);
     const int Hp = G.q[g].Hp[phz], Wp = G.q[g].Wp[phz];
     const int tiles_x = (Wp + 7) >> 3;
-    const int ty0 = (mtile / tiles_x) * 8, tx0 = (mtile % tiles_x) * 8;
+    const int ty0 = (mtile / tiles_x) * TH, tx0 = (mtile % tiles_x) * 8;
     const int ntaps = G.ntaps[phz], Ck = P.Ck, ncb = Ck >> 5;
     const int PH = G.pph[phz], PW = G.ppw[phz], dy0 = G.pdy0[phz], dx0 = G.pdx0[phz];
     const int RS = PW * SGH_PS;
@@ -697,8 +702,10 @@ __global__ __launch_bounds__(256) void sg_conv_head_kernel(const SgIgemmParams G
         pscale[c] = sc;
         pshift[c] = sh;
     }
-    // staging: item e = 8 * patch pixel + channel quad; four items per thread cover up to 128 pixels, eight up to 256
-    constexpr int S_IT = 8;
+    // staging: item e = 8 * patch pixel + channel quad; S_IT items per thread cover 32 S_IT patch pixels.  The loads of D channel
+    // blocks are in flight at once (register ring with static slots: the block loop is unrolled by D).  Measured on the fcgan
+    // heads (256 channels, 230 tall tiles): D = 6..8 is no faster than D = 2 -- the launch is not bound by this latency
+    constexpr int S_IT = TH, D = 2;
     const int cq = tid & 7;
     int s_goff[S_IT], s_dst[S_IT];
 #pragma unroll
@@ -710,13 +717,13 @@ __global__ __launch_bounds__(256) void sg_conv_head_kernel(const SgIgemmParams G
         s_goff[it] = ok ? (iy * P.Win + ix) * P.in_ld + cq * 4 : -1;
         s_dst[it] = p < npix ? pr * RS + pc * SGH_PS + cq * 16 : -1;
     }
-    f32x4 s_reg[S_IT];
-    auto issue = [&](int cb) {
+    f32x4 s_regs[D][S_IT];
+    auto issue = [&](int cb, f32x4* s_reg) {
 #pragma unroll
         for (int it = 0; it < S_IT; ++it)
             if (s_goff[it] >= 0 && cb < ncb) s_reg[it] = *reinterpret_cast<const f32x4*>(P.in + s_goff[it] + cb * 32);
     };
-    auto store = [&](int cb) {
+    auto store = [&](int cb, const f32x4* s_reg) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(pscale + cb * 32 + cq * 4), sh = *reinterpret_cast<const f32x4*>(pshift + cb * 32 + cq * 4);
 #pragma unroll
         for (int it = 0; it < S_IT; ++it) {
@@ -735,27 +742,43 @@ __global__ __launch_bounds__(256) void sg_conv_head_kernel(const SgIgemmParams G
             *reinterpret_cast<f32x4*>(Ap + s_dst[it]) = v;
         }
     };
-    const int px = tid >> 2, co = tid & 3;      // output pixel of the tile, channel octet of the block
-    const int f_base = ((px >> 3) * RS + (px & 7) * SGH_PS) + co * 32;
+    const int px = tid / NG, co = tid % NG;      // output pixel of the tile, channel group of the block
+    const int f_base = ((px >> 3) * RS + (px & 7) * SGH_PS) + co * (CPG * 4);
     float acc = 0.f;
-    issue(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d, s_regs[d]);
     __syncthreads();      // tap offsets, weights, scale / shift visible
-    for (int cb = 0; cb < ncb; ++cb) {
-        store(cb);
-        issue(cb + 1);
+    for (int cb0 = 0; cb0 < ncb; cb0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int cb = cb0 + d;
+        if (cb >= ncb) break;
+        store(cb, s_regs[d]);
+        issue(cb + D, s_regs[d]);
         __syncthreads();
-        const float* wrow = Ws + cb * 32 + co * 8;
+        const float* wrow = Ws + cb * 32 + co * CPG;
 #pragma unroll 4
         for (int t = 0; t < ntaps; ++t) {
             const char* a = Ap + f_base + toff[t];
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 16);
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + t * Ck), w1 = *reinterpret_cast<const f32x4*>(wrow + t * Ck + 4);
-            acc += (a0[0] * w0[0] + a0[1] * w0[1]) + (a0[2] * w0[2] + a0[3] * w0[3]) + (a1[0] * w1[0] + a1[1] * w1[1]) + (a1[2] * w1[2] + a1[3] * w1[3]);
+            if constexpr (CPG == 8) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 16);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + t * Ck), w1 = *reinterpret_cast<const f32x4*>(wrow + t * Ck + 4);
+                acc += (a0[0] * w0[0] + a0[1] * w0[1]) + (a0[2] * w0[2] + a0[3] * w0[3]) + (a1[0] * w1[0] + a1[1] * w1[1]) + (a1[2] * w1[2] + a1[3] * w1[3]);
+            } else if constexpr (CPG == 4) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(a);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + t * Ck);
+                acc += (a0[0] * w0[0] + a0[1] * w0[1]) + (a0[2] * w0[2] + a0[3] * w0[3]);
+            } else {
+                const f32x2 a0 = *reinterpret_cast<const f32x2*>(a);
+                const f32x2 w0 = *reinterpret_cast<const f32x2*>(wrow + t * Ck);
+                acc += a0[0] * w0[0] + a0[1] * w0[1];
+            }
         }
         __syncthreads();   // everyone is done with the patch before the next block overwrites it
+      }
     }
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
+#pragma unroll
+    for (int o = 1; o < NG; o <<= 1) acc += __shfl_xor(acc, o);
     const int py = ty0 + (px >> 3), pxx = tx0 + (px & 7);
     if (co == 0 && py < Hp && pxx < Wp) {
         const int64_t pix = (int64_t)(py * P.os + G.oa[phz]) * P.Wout + (pxx * P.os + G.ob[phz]);
@@ -786,7 +809,19 @@ static bool sg_head_plan(SgIgemmParams& P) {
         dx0 = min(dx0, (int)tp.dx); dx1 = max(dx1, (int)tp.dx);
     }
     P.pdy0[0] = dy0; P.pdx0[0] = dx0;
-    P.pph[0] = 8 + dy1 - dy0; P.ppw[0] = 8 + dx1 - dx0;
+    // tile height: 8 rows when that alone gives every CU a few workgroups, else 4 (SGAN_HEAD_TH = 8 / 4 / 2 overrides: tuning knob)
+    long t8 = 0;
+    for (int g = 0; g < P.nprob; ++g) t8 += (long)((P.q[g].Hp[0] + 7) / 8) * ((P.q[g].Wp[0] + 7) / 8);
+    static const int th_env = getenv("SGAN_HEAD_TH") ? atoi(getenv("SGAN_HEAD_TH")) : 0;
+    int th = t8 >= 1024 ? 8 : 4;      // fcgan heads (230 tall tiles): 27.6 us with 8 rows, 21.6 with 4, 22.5 with 2
+    if (th_env == 8 || th_env == 4 || th_env == 2) th = th_env;
+    P.pph[0] = th + dy1 - dy0; P.ppw[0] = 8 + dx1 - dx0;
+    P.pph[1] = th;      // (phase 1 is unused by this kernel: carries the tile height to the launcher)
+    if (P.pph[0] * P.ppw[0] > 32 * th) {      // the staging of a TH tile covers 32 TH patch pixels: big kernels keep the tall tile
+        th = 8;
+        P.pph[0] = th + dy1 - dy0;
+        P.pph[1] = th;
+    }
     if (P.pph[0] * P.ppw[0] > 256) return false;
     const size_t lds = (size_t)((P.pph[0] * P.ppw[0] * SGH_PS + 255) & ~255) + (size_t)P.ntaps[0] * P.Ck * 4 + SGAN_MAX_TAPS * 4 + (size_t)2 * P.Ck * 4;
     return lds <= 64 * 1024;
@@ -794,15 +829,18 @@ static bool sg_head_plan(SgIgemmParams& P) {
 
 static int sg_launch_head(SgIgemmParams& P, hipStream_t st) {
     int t = 0;
+    const int th = P.pph[1];
     for (int g = 0; g < P.nprob; ++g) {
         P.q[g].tile0[0] = t;
-        t += ((P.q[g].Hp[0] + 7) / 8) * ((P.q[g].Wp[0] + 7) / 8);
+        t += ((P.q[g].Hp[0] + th - 1) / th) * ((P.q[g].Wp[0] + 7) / 8);
         for (int ph = 1; ph < SGAN_MAX_PHASES; ++ph) P.q[g].tile0[ph] = 1 << 30;
     }
     if (t == 0) return SGAN_OK;
     const size_t lds = (size_t)((P.pph[0] * P.ppw[0] * SGH_PS + 255) & ~255) + (size_t)P.ntaps[0] * P.Ck * 4 + SGAN_MAX_TAPS * 4 + (size_t)2 * P.Ck * 4;
     sg_prof_begin(st);
-    hipLaunchKernelGGL(sg_conv_head_kernel, dim3(t), dim3(256), lds, st, P);
+    if (th == 8) hipLaunchKernelGGL(sg_conv_head_kernel<8>, dim3(t), dim3(256), lds, st, P);
+    else if (th == 4) hipLaunchKernelGGL(sg_conv_head_kernel<4>, dim3(t), dim3(256), lds, st, P);
+    else hipLaunchKernelGGL(sg_conv_head_kernel<2>, dim3(t), dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = "sg_conv_head_kernel";
     sg_prof_end(st, g_sgan_last_kernel);

@@ -262,9 +262,11 @@ def test_fused_backward_equals_the_two_launches(ops, shape):
 
 
 def test_fused_backward_is_taken(ops):
-    """The comparison above is vacuous where the fused entry point declines: of the listed shapes, those with >= 64 channels on
-    both sides and maps of >= 256 pixels must have gone through sg_bwd_fused_kernel."""
-    want = [c for c in SHAPES if c[4] >= 64 and c[5] >= 64 and c[6] * c[7] >= 256]
+    """The comparison above is vacuous where the fused entry point declines (backward-data on a tile shape the fused kernel does not
+    carry, split-K): of the listed shapes, the stride-1 convs with >= 64 channels on both sides must have gone through
+    sg_bwd_fused_kernel, and at least one more."""
+    want = [c for c in SHAPES if c[0] == "conv" and c[2] == 1 and c[4] >= 64 and c[5] >= 64 and c[6] * c[7] >= 256]
+    assert sum(bool(v) for v in _FUSED_SEEN.values()) > len(want)
     assert want and all(_FUSED_SEEN.get(c) for c in want), {c: _FUSED_SEEN.get(c) for c in want}
 
 

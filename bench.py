@@ -186,6 +186,19 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
         setattr(ops, name, f)
         return orig
 
+    def wrap_pair(name):      # conv_bwd_grouped(djobs, wjobs): ONE record when it took the fused launch, else its two inner calls record themselves
+        orig = getattr(ops, name)
+
+        def f(djobs, wjobs, *a, **k):
+            if depth[0] > 0:
+                return orig(djobs, wjobs, *a, **k)
+            fused = orig(djobs, wjobs, *a, **k)
+            if fused:
+                calls.append((orig, (djobs, wjobs) + a, k, sum(flops(j[0]) for j in djobs) + sum(flops(j[0]) for j in wjobs)))
+            return fused
+        setattr(ops, name, f)
+        return orig
+
     names = {"conv_fwd": False, "conv_dgrad": False, "conv_wgrad": False,
              "conv_fwd_grouped": True, "conv_dgrad_grouped": True, "conv_wgrad_grouped": True}
     saved_streams, model._streams = getattr(model, "_streams", []), []     # one stream: kernels are timed one at a time
@@ -194,6 +207,7 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
             model.set_input(ring[i % len(ring)])
             model.optimize_parameters()
         origs = {n: wrap(n, gr) for n, gr in names.items()}
+        origs["conv_bwd_grouped"] = wrap_pair("conv_bwd_grouped")
         try:
             model.set_input(ring[2 % len(ring)])
             model.optimize_parameters()
@@ -503,7 +517,7 @@ def main():
             out["collective"] = rccl
         if kern:
             dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
-            split = "igemm3" in dom or "wgrad3" in dom      # split-bf16 kernel: 3 bf16 MFMA flops issued per useful flop
+            split = "igemm3" in dom or "wgrad3" in dom or dom == "sg_bwd_fused_kernel"      # split-bf16 kernel: 3 bf16 MFMA flops issued per useful flop
             # MI355X_MICROARCH.md: fp32 matrix peak 157.3 TFLOP/s; bf16 dense MFMA peak 2500 TFLOP/s (never the 2:1-sparsity figure)
             peak = 2500.0 if split else 157.3
             traffic, rp_us, rp_src = None, None, None

@@ -184,8 +184,12 @@ int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* wo
  * the reference's autograd runs for every conv in netD / netG backward (models/networks.py:502-529, 815-835 are the layers;
  * models/fcgan_model.py:131-152 the backward calls).  Same jobs as the two grouped entry points above, same results; the
  * workgroups of both share one grid so the chip is not left half idle twice.  Returns SGAN_OK when launched, 1 when this layer
- * is not covered by the fused kernel (the caller then issues the two grouped calls; nothing was written), < 0 on error. */
-int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw, void* stream);
+ * is not covered by the fused kernel (the caller then issues the two grouped calls; nothing was written), < 0 on error.
+ * dgrad_math: SGAN_MATH_* of the backward-data half, or -1 for the descriptors' own (the two job lists usually point at the
+ * same descriptors, and backward-data into a layer without a normalisation runs exact fp32 next to a split-bf16
+ * backward-weight: DESIGN.md R2.3); the backward-weight half must be SGAN_MATH_BF16X3. */
+int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw,
+                        int32_t dgrad_math, void* stream);
 
 /* ---- transposed weight copy for backward-data ---------------------------------------------------
  * flat_t[off + tap][ci][co] = flat[off + tap][co][ci] for every conv segment (bias / affine ranges of the flat

@@ -498,11 +498,9 @@ class ChainNet(nn.Module):
                 P = self.layers[li - 1]
                 din = torch.empty((h, w, P.cout_s), dtype=torch.float32, device=dev)
                 djob = [(desc, dcur, self._wt(L), din, src, in_norm, None if dropped else sums[li - 1], 0, False, True, brep)]
-                if wjob and _dgrad_math(P) is None:
-                    ops.conv_bwd_grouped(djob, wjob)      # both halves in one launch where the fused kernel covers the layer
+                if wjob:
+                    ops.conv_bwd_grouped(djob, wjob, _dgrad_math(P))      # both halves in one launch where the fused kernel covers the layer
                 else:
-                    if wjob:
-                        ops.conv_wgrad_grouped(wjob)
                     with ops.math_scope(_dgrad_math(P)):
                         ops.conv_dgrad_grouped(djob)
                 if dropped:      # din = d t * ReLU'(t); through the mask, with the two norm-backward sums of the masked gradient
@@ -684,8 +682,8 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
                 dins.append(din)
                 jobs.append((desc, dcur[j], net._wt(net.layers[li]), din, srcs[j], norms[j], sums[j][li - 1], 0, False, True, brep))
             dm = _dgrad_math(nets[0].layers[li - 1])
-            if wjobs and dm is None:
-                ops.conv_bwd_grouped(jobs, wjobs)
+            if wjobs:
+                ops.conv_bwd_grouped(jobs, wjobs, dm)
             else:
                 if wjobs:
                     ops.conv_wgrad_grouped(wjobs)

@@ -7,11 +7,13 @@
 // (sg_wgrad3_body), each with the workgroup coordinates it would have had in its own launch.  Nothing else changes: same
 // parameter blocks, same results (the two bodies write disjoint tensors).
 #define SG_KERNELS_ONLY
+#include "sgan_igemm.hip"
 #include "sgan_igemm3.hip"
 #include "sgan_wgrad.h"
 #include "sgan_wgrad3.hip"
 
-// DV: 1 = patch kernel with <= 128 patch pixels, 2 = patch kernel up to 256, 3 = sg_igemm3 64 x 64 (two k-tiles per barrier);
+// DV: 1 = patch kernel with <= 128 patch pixels, 2 = patch kernel up to 256, 3 = sg_igemm3 64 x 64 (two k-tiles per barrier),
+//     4 = exact-fp32 sg_igemm 128 x 32 (backward-data into a layer without a normalisation: chain._dgrad_math);
 // WV: 1 = backward-weight 64 x 64 tiles, 2 = 32 x 128
 template <int DV, int WV, bool WPRO>
 __global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G, const SgWgradParams W, int ndg, int wx, int wy) {
@@ -20,7 +22,8 @@ __global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G
     if (b < ndg) {
         if constexpr (DV == 1) sg_igemm3p_body<64, 2, false, false>(G, smem, b, ndg);
         else if constexpr (DV == 2) sg_igemm3p_body<64, 4, false, false>(G, smem, b, ndg);
-        else sg_igemm3_body<64, 64, 2, 2, false, false, true>(G, smem, b, ndg, 0);
+        else if constexpr (DV == 3) sg_igemm3_body<64, 64, 2, 2, false, false, true>(G, smem, b, ndg, 0);
+        else sg_igemm_body<128, 32, 4, 1, true, false, 1>(G, smem, b, ndg, 0);
     } else {
         const int w = b - ndg;
         const int bx = w % wx, by = (w / wx) % wy, bz = w / (wx * wy);
@@ -38,7 +41,8 @@ static void sg_fused_launch(const SgIgemmParams& P, const SgWgradParams& W, cons
 }
 
 // 0: launched; 1: this pair is not covered (launch sgan_conv_dgrad_grouped and sgan_conv_wgrad_grouped instead); < 0: error
-extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw, void* stream) {
+extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw,
+                                   int32_t dgrad_math, void* stream) {
     static const int off = getenv("SGAN_NO_BWD_FUSION") ? 1 : 0;
     if (off) return 1;
     SgIgemmParams P;
@@ -48,11 +52,14 @@ extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd,
     rc = sg_build_wgrad_params(wjobs, nw, W);
     if (rc) return rc;
     if (wjobs[0].d->math != SGAN_MATH_BF16X3 || sg_dgrad_is_skinny(P)) return 1;
+    if (dgrad_math >= 0) P.math = dgrad_math;      // the two job lists may share descriptors: the backward-data mode comes apart
     const int e3 = sg_igemm3_eligible(P);
     if (e3 < 0) return e3;
-    if (e3 == 0) return 1;
     SgFusePlan pd, pw;
-    sg_igemm3_fuse_plan(P, &pd);
+    static const int no_f32 = getenv("SGAN_NO_F32_FUSION") ? 1 : 0;      // tuning knob
+    if (e3 == 0 && no_f32) return 1;
+    if (e3 == 0) sg_igemm_fuse_plan_f32(P, &pd);
+    else sg_igemm3_fuse_plan(P, &pd);
     if (pd.variant == 0 || pd.nblocks == 0) return 1;
     sg_wgrad3_fuse_plan(W, &pw);
     if (pw.variant == 0 || pw.nblocks == 0) return 1;
@@ -65,10 +72,12 @@ extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd,
         case 21: sg_fused_launch<2, 1>(P, W, pd, pw, st); break;
         case 22: sg_fused_launch<2, 2>(P, W, pd, pw, st); break;
         case 31: sg_fused_launch<3, 1>(P, W, pd, pw, st); break;
-        default: sg_fused_launch<3, 2>(P, W, pd, pw, st); break;
+        case 32: sg_fused_launch<3, 2>(P, W, pd, pw, st); break;
+        case 41: sg_fused_launch<4, 1>(P, W, pd, pw, st); break;
+        default: sg_fused_launch<4, 2>(P, W, pd, pw, st); break;
     }
     SGAN_LAUNCH_CHECK();
-    g_sgan_last_kernel = "sg_bwd_fused_kernel";
+    g_sgan_last_kernel = pd.variant == 4 ? "sg_bwd_fused_kernel<f32 dgrad>" : "sg_bwd_fused_kernel";      // both halves split-bf16 unless said otherwise
     sg_prof_end(st, g_sgan_last_kernel);
     return SGAN_OK;
 }

@@ -116,5 +116,6 @@ int64_t sg_igemm3_workspace_need(const SgIgemmParams& P);
 
 // ---- one launch for a layer's backward-data and backward-weight (sgan_fused.hip) ----
 int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out);
+int sg_igemm_fuse_plan_f32(SgIgemmParams& P, SgFusePlan* out);                              // sgan_igemm.hip: exact-fp32 backward-data
 int sg_build_dgrad_params(const sgan_conv_dgrad_job* jobs, int32_t n, SgIgemmParams& P);   // sgan_igemm.hip: the argument checks + parameter block of sgan_conv_dgrad_grouped
 bool sg_dgrad_is_skinny(const SgIgemmParams& P);                                           // routed to the direct small-N kernels

@@ -39,14 +39,13 @@ __device__ __forceinline__ int sg_swz(int row, int kslot) { return (kslot ^ ((ro
 //      per SIMD waits out every barrier and LDS round trip alone -- and this doubles the waves without the slab round
 //      trip and second kernel of the global split-K.
 template <int BM, int BN, int WGM, int WGN, bool BKC, bool PRO, int KW = 1>
-__global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams G) {
+__device__ __forceinline__ void sg_igemm_body(const SgIgemmParams& G, char* smem, const int bid, const int nblocks, const int split) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MB = WTM / 16, NB = WTN / 16;
     constexpr int A_IT = BM * 8 / 256;
     constexpr int B_IT = (BN * 8 + 255) / 256;
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(BM * 8 % 256 == 0, "A tile");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int GROUP_FLOATS = 2 * BM * 32 + 2 * BN * 32;
     const int kg = KW == 1 ? 0 : (int)(threadIdx.x >> 8);   // wave group
     float* As = reinterpret_cast<float*>(smem) + kg * GROUP_FLOATS;  // [2][BM*32]
@@ -62,11 +61,10 @@ __global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams 
     const int wm = wid / WGN, wn = wid % WGN;
     // grid.x enumerates (M tile, N tile) pairs, N fastest, in XCD-contiguous order; grid.z = K split
     const int ntn = (G.N + BN - 1) / BN;
-    const int item = sg_xcd_remap(blockIdx.x, gridDim.x);
+    const int item = sg_xcd_remap(bid, nblocks);
     int g, phz, mtile;
     sg_decode_tile(G, item / ntn, g, phz, mtile);
     const SgLocal P = sg_local(G, g);
-    const int split = blockIdx.z;
     const int Hp = G.q[g].Hp[phz], Wp = G.q[g].Wp[phz];
     const int M = Hp * Wp;
     const int m0 = mtile * BM, n0 = (item % ntn) * BN;
@@ -486,7 +484,7 @@ __global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams 
         __syncthreads();
         if (tid < BN && n0 + tid < N) {
 #ifndef SG_NO_STAT_ATOMICS      // diagnostics build: what the same-address fp64 atomics cost
-            double* st = sg_stat_replica(P.stats, P.stats_rep, blockIdx.x);
+            double* st = sg_stat_replica(P.stats, P.stats_rep, bid);
             atomicAdd(&st[n0 + tid], red[tid]);
             atomicAdd(&st[P.stats_sq + n0 + tid], red[BN + tid]);
 #endif
@@ -494,6 +492,13 @@ __global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams 
     }
 }
 
+template <int BM, int BN, int WGM, int WGN, bool BKC, bool PRO, int KW = 1>
+__global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sg_igemm_body<BM, BN, WGM, WGN, BKC, PRO, KW>(G, smem, blockIdx.x, gridDim.x, blockIdx.z);
+}
+
+#ifndef SG_KERNELS_ONLY      // sgan_fused.hip includes this file for sg_igemm_body only
 // ------------------------------------------------------------------------------------------
 // Direct kernel for results with <= 4 stored channels (PatchGAN logits head Cout = 1, generator output
 // Cout = 2, image gradient of the first discriminator conv Cin = 2).  Such a GEMM has N = 4: an MFMA
@@ -1379,6 +1384,27 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
     return sg_launch_igemm<64, 64, 2, 2>(P, st, ws, ws_bytes);
 }
 
+// Plan of an exact-fp32 backward-data launch for sg_bwd_fused_kernel (sgan_fused.hip): variant 4 = the 128 x 32 tile, unsplit,
+// no prologue -- what backward-data into a layer without a normalisation runs on (the first PatchGAN layer); 0 = not covered
+int sg_igemm_fuse_plan_f32(SgIgemmParams& P, SgFusePlan* out) {
+    out->variant = 0;
+    P.ksplit = 1;
+    P.slab = nullptr;
+    P.slab_stride = 0;
+    if (sg_use_small_n(P) || P.w_ks != 1 || P.pro_act != SGAN_ACT_NONE) return 0;
+    for (int g = 0; g < P.nprob; ++g)
+        if (P.q[g].pro_stats) return 0;
+    int BM, BN;
+    sg_pick_tile(P, &BM, &BN);
+    if (BM != 128 || BN != 32 || sg_plan_ksplit(P, BM, BN) != 1) return 0;
+    const int tiles = sg_fill_tiles(P, BM);
+    out->variant = 4;
+    out->nblocks = tiles * sg_cdiv(P.N, BN);
+    out->lds = (size_t)((2 * BM * 32 + 2 * BN * 32) + 4 * BN) * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
+    out->name = "sg_igemm_kernel<128,32,4,1,true>";
+    return 0;
+}
+
 static int64_t sg_workspace_need(const SgIgemmParams& P) {
     if (sg_use_small_n(P)) return 0;
     if (sg_igemm3_eligible(P) > 0) return sg_igemm3_workspace_need(P);
@@ -1545,3 +1571,4 @@ extern "C" int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32
     sgan_conv_dgrad_job j = {d, dout, dout_ld, w, din, din_ld, x, x_ld, x_norm, bwd_sums, 0, 0, 0, nullptr};
     return sgan_conv_dgrad_grouped(&j, 1, workspace, workspace_bytes, stream);
 }
+#endif      // SG_KERNELS_ONLY

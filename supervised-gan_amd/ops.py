@@ -204,17 +204,20 @@ def conv_wgrad_grouped(jobs):
             "sgan_conv_wgrad_grouped")
 
 
-def conv_bwd_grouped(djobs, wjobs):
+def conv_bwd_grouped(djobs, wjobs, dgrad_math=None):
     """A layer's backward-weight and backward-data (job lists as for the two calls above): one fused launch where
-    sgan_conv_bwd_fused covers the layer, the two grouped launches otherwise."""
-    if _math == L.MATH_BF16X3 and _DGRAD_MATH is None:
-        rc = L.lib().sgan_conv_bwd_fused(_dgrad_array(djobs), len(djobs), _wgrad_array(wjobs), len(wjobs), _stream())
+    sgan_conv_bwd_fused covers the layer, the two grouped launches otherwise.  dgrad_math: arithmetic of the backward-data half
+    ("f32" / "bf16x3"; None = the current mode)."""
+    dm = _DGRAD_MATH if _DGRAD_MATH is not None else (_MATH_NAMES[dgrad_math] if dgrad_math else _math)
+    if _math == L.MATH_BF16X3:
+        rc = L.lib().sgan_conv_bwd_fused(_dgrad_array(djobs), len(djobs), _wgrad_array(wjobs), len(wjobs), dm, _stream())
         if rc == 0:
             return True
         if rc < 0:
             L.check(rc, "sgan_conv_bwd_fused")
     conv_wgrad_grouped(wjobs)
-    conv_dgrad_grouped(djobs)
+    with math_scope(dgrad_math):
+        conv_dgrad_grouped(djobs)
     return False
 
 

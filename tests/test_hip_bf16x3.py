@@ -211,8 +211,9 @@ def test_igemm3_grouped_and_splitk(ops, tile):
     assert rel(got["bf16x3"][0], got["f32"][0]) < 3e-5 and rel(got["bf16x3"][1], got["f32"][1]) < 1e-5
 
 
+@pytest.mark.parametrize("dmath", [None, "f32"])
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"{c[0]}_k{c[1]}s{c[2]}_{c[4]}to{c[5]}_{c[6]}x{c[7]}" for c in SHAPES])
-def test_fused_backward_equals_the_two_launches(ops, shape):
+def test_fused_backward_equals_the_two_launches(ops, shape, dmath):
     """sgan_conv_bwd_fused (one grid for a layer's backward-data and backward-weight) against sgan_conv_dgrad_grouped +
     sgan_conv_wgrad_grouped on the same two-problem job lists: the input gradients bit for bit (same body, same tile order), the
     weight / bias gradients and the norm-backward sums up to the order of their atomic adds."""
@@ -245,15 +246,16 @@ def test_fused_backward_equals_the_two_launches(ops, shape):
             keep.append((din, sums))
         if mode == "apart":
             ops.conv_wgrad_grouped(wjobs)
-            ops.conv_dgrad_grouped(djobs)
+            with ops.math_scope(dmath):      # "f32": exact-fp32 backward-data next to the split-bf16 backward-weight (chain._dgrad_math)
+                ops.conv_dgrad_grouped(djobs)
         else:
-            fused = ops.conv_bwd_grouped(djobs, wjobs)
+            fused = ops.conv_bwd_grouped(djobs, wjobs, dmath)
             if fused:
-                assert _lib.lib().sgan_last_kernel().decode() == "sg_bwd_fused_kernel"
+                assert _lib.lib().sgan_last_kernel().decode().startswith("sg_bwd_fused_kernel")
         torch.cuda.synchronize()
         res[mode] = (keep, dw, db)
     print("fused launch:", fused)
-    _FUSED_SEEN[shape] = fused
+    _FUSED_SEEN[(shape, dmath)] = fused
     for (da, sa), (df, sf) in zip(res["apart"][0], res["fused"][0]):
         assert torch.equal(da, df)
         if sa is not None:
@@ -266,8 +268,10 @@ def test_fused_backward_is_taken(ops):
     carry, split-K): of the listed shapes, the stride-1 convs with >= 64 channels on both sides must have gone through
     sg_bwd_fused_kernel, and at least one more."""
     want = [c for c in SHAPES if c[0] == "conv" and c[2] == 1 and c[4] >= 64 and c[5] >= 64 and c[6] * c[7] >= 256]
-    assert sum(bool(v) for v in _FUSED_SEEN.values()) > len(want)
-    assert want and all(_FUSED_SEEN.get(c) for c in want), {c: _FUSED_SEEN.get(c) for c in want}
+    assert sum(bool(v) for (c, m), v in _FUSED_SEEN.items() if m is None) > len(want)
+    assert want and all(_FUSED_SEEN.get((c, None)) for c in want), {c: _FUSED_SEEN.get((c, None)) for c in want}
+    # exact-fp32 backward-data with <= 32 result channels (the 128 x 32 tile): the second PatchGAN layer's launch
+    assert _FUSED_SEEN.get((SHAPES[0], "f32")), _FUSED_SEEN
 
 
 def test_bf16x3_needs_packed_weights(ops):

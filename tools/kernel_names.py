@@ -18,9 +18,15 @@ def short(name):
     m = re.match(r"(sg_wgrad3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false)>$", n)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"sg_bwd_fused_kernel<(\d+),\d+,(?:true|false)>$", n)      # backward-data variant, backward-weight tile, prologue flag
+    if m:
+        return "sg_bwd_fused_kernel<f32 dgrad>" if m.group(1) == "4" else "sg_bwd_fused_kernel"
     m = re.match(r"(sg_wgrad_kernel)<(.*),(true|false)>$", n)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"sg_conv_head_kernel<\d+>$", n)      # tile height
+    if m:
+        return "sg_conv_head_kernel"
     m = re.match(r"sg_conv_small_n_kernel<(\d+),(?:\d+,)*(true|false)>$", n)
     if m:
         return f"sg_conv_small_n_kernel<{m.group(1)}>"

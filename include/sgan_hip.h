@@ -98,6 +98,7 @@ const char* sgan_last_error(void);
 /* name of the kernel template instantiation the calling thread's last sgan_conv_* call launched
  * (matches the name rocprofv3 reports) -- lets a benchmark attribute time and flops per kernel */
 const char* sgan_last_kernel(void);
+int sgan_stat_replicas(void);     /* SGAN_STAT_REPLICAS of the built library: statistics arenas must hold this many copies */
 
 /* ---- optional per-launch timing (diagnostics; single-threaded; do not enable during graph capture) ----
  * While enabled, every main conv kernel launch (implicit-GEMM / small-N / backward-weight; not the split-K

@@ -18,6 +18,7 @@ int sgan_fail(int code, const char* fmt, ...) {
 extern "C" const char* sgan_version(void) { return "sgan_hip 0.2 (gfx950; fp32 MFMA 16x16x4 + split-bf16 MFMA 32x32x16)"; }
 extern "C" const char* sgan_last_error(void) { return g_sgan_err; }
 extern "C" const char* sgan_last_kernel(void) { return g_sgan_last_kernel; }
+extern "C" int sgan_stat_replicas(void) { return SGAN_STAT_REPLICAS; }      // what this build was compiled with (callers size their arenas by it)
 
 // ---- optional per-launch timing -------------------------------------------------------------
 #define SG_PROF_MAX 8192

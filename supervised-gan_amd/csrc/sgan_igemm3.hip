@@ -1049,7 +1049,10 @@ int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out) {
         return 0;
     }
     const Sg3Tile tl = sg3_pick_tile(P);
-    if (tl.BM != 64 || tl.BN != 64 || sg_plan_ksplit(P, 64, 64) != 1) return 0;
+    // a launch that would have been split-K on its own runs unsplit here when the split is shallow: the backward-weight
+    // workgroups of the same grid fill the CUs the split was there to fill (SGAN_FUSE_MAX_KS: tuning knob)
+    static const int max_ks = getenv("SGAN_FUSE_MAX_KS") ? atoi(getenv("SGAN_FUSE_MAX_KS")) : 1;
+    if (tl.BM != 64 || tl.BN != 64 || sg_plan_ksplit(P, 64, 64) > max_ks) return 0;
     const int tiles = sg_fill_tiles(P, 64);
     out->variant = 3;
     out->nblocks = tiles * sg3_cdiv(P.N, 64);

@@ -88,7 +88,10 @@ def conv_desc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin=0, 
     return L.ConvDesc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin, Cout, _math)
 
 
-STAT_REPLICAS = 8      # SGAN_STAT_REPLICAS
+def stat_replicas():
+    """SGAN_STAT_REPLICAS of the loaded library."""
+    return L.lib().sgan_stat_replicas()
+
 
 
 _STAT_REPLICATED = __import__("os").environ.get("SGAN_NO_STAT_REPLICAS", "0") in ("", "0")      # diagnostics switch
@@ -99,7 +102,7 @@ def stat_arena(n, device):
     rep_stride = stat_rep(arena) wherever a slice of it is written or read): the conv epilogues spread their same-address atomics
     over the copies."""
     n = max(n, 1)
-    return torch.zeros((STAT_REPLICAS if _STAT_REPLICATED else 1) * n, dtype=torch.float64, device=device)[:n]
+    return torch.zeros((stat_replicas() if _STAT_REPLICATED else 1) * n, dtype=torch.float64, device=device)[:n]
 
 
 def stat_rep(arena):

@@ -160,7 +160,10 @@ extern "C" int sgan_norm_bwd_apply_multi(const sgan_norm_bwd_job* jobs, int32_t 
         J.sums_sq = S.bwd_sums_sq_stride ? S.bwd_sums_sq_stride : S.C;
         J.sums_rep = S.bwd_sums_rep_stride;
         const int64_t total = (int64_t)S.npix * (S.C >> 2);
-        int blocks = ew_cdiv(total, 256 * 4);
+        // every workgroup first turns the replica sums of ALL channels into coefficients (32 fp64 loads + a divide and a root per
+        // channel): few, fat workgroups amortise that (SGAN_NBA_CHUNK 16-byte chunks per thread: tuning knob)
+        static const int chunk = getenv("SGAN_NBA_CHUNK") ? atoi(getenv("SGAN_NBA_CHUNK")) : 4;
+        int blocks = ew_cdiv(total, 256 * (chunk > 0 ? chunk : 4));
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
         J.blocks = blocks;

@@ -13,8 +13,9 @@ _TRAINERS = {                       # --model         module                    
     'twostage_factd': ('twostage_cycle_model', 'TwoStageFactDModel'),
     'segmentation':   ('segm_model',           'SegmentationModel'),
     'segmentation_cycle': ('segm_cycle_model', 'SegmentationCycleModel'),
+    'test':           ('test_model',           'TestModel'),
 }
-_NOT_ON_THIS_PATH = ('test',)
+_NOT_ON_THIS_PATH = ()
 
 
 def create_model(opt):
@@ -24,6 +25,8 @@ def create_model(opt):
                                   % (name, ', '.join(sorted(_TRAINERS))))
     if name not in _TRAINERS:
         raise ValueError("Model [%s] not recognized." % name)
+    if name == 'test':
+        assert opt.dataset_mode == 'single'      # models/models.py:31
     module, cls = _TRAINERS[name]
     model = getattr(importlib.import_module('.' + module, __package__), cls)()
     model.initialize(opt)

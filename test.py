@@ -25,7 +25,8 @@ def main(argv=None):
     def dump(visuals, stem):
         written.extend(visualizer.save_images(webpage, visuals, [stem + '.png']))
 
-    if opt.model.startswith(('cgan', 'segmentation')):       # models that read a label image (test.py:27-41)
+    if opt.model.startswith(('cgan', 'segmentation')) or opt.model == 'test':       # models that read an image (test.py:27-41; `test`: the
+        # reference's loop never feeds TestModel its input, test.py:43-52 -- here it gets the dataset like the cgan models)
         if opt.dataroot == 'synthetic':
             dataset = SyntheticDataset(opt, opt.how_many)
         else:

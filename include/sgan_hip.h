@@ -320,7 +320,8 @@ int sgan_sigmoid_bwd(const float* dp, int32_t dpld, const float* p, int32_t pld,
                      int32_t dxld, void* stream);
 
 /* ---- U-Net up path: normalise (+ dropout) (+ additive Gaussian noise) into a concat slice --------------
- * t[p][c] = (u[p][c] - mean_c) * rstd_c * (mask ? mask[p][c] : 1) + (noise ? sigma * noise[p][c] : 0)
+ * t[p][c] = ((u[p][c] - mean_c) * rstd_c * gamma_c + beta_c) * (mask ? mask[p][c] : 1) + (noise ? sigma * noise[p][c] : 0)
+ * (gamma = 1, beta = 0 without an affine: InstanceNorm; with one: norm_layer = BatchNorm2d -> nn.Dropout, networks.py:516-521)
  * mask holds 0 or 1/(1-p) (nn.Dropout(0.5) => 0 or 2).  Replaces norm_layer + nn.Dropout + the `y + noise` of
  * UnetSkipConnectionBlock (models/networks.py:387-403,414-419); `t` is written straight into the up half
  * of the concat buffer the next ConvTranspose2d reads (torch.cat, :417-419, never materialises).

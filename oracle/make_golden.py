@@ -159,6 +159,28 @@ def golden_g_small():
     save("fcgan_g_small.npz", **arrs)
 
 
+def golden_g_dropout_small():
+    """FCGANGenerator with use_dropout (ConvT -> BatchNorm -> Dropout(0.5) -> ReLU in the blocks above the first, networks.py:513-521):
+    the i-th dropout call of the pass gets O.dropout_mask_np(70 + i + 1, shape) (block i + 1)."""
+    ngf, nl, nz, out_nc, zs = 8, 5, 8, 2, 2
+    sd = O.init_fcgan_g(11, nz, out_nc, ngf, nl, use_dropout=True)
+    g = RN.define_G(out_nc, 0, ngf, "fcgan", "instance", True, n_layers_G=nl, use_fcn=True, noise_nc=nz, gpu_ids=[])
+    load_sd(g, sd)
+    z = O.np_normal(101, (1, nz, zs, zs)).requires_grad_(True)
+    r = O.np_normal(102, (1, out_nc, zs * 64, zs * 64))
+    with SeqDropoutInjector(71):
+        y = g.forward(z)
+    loss = (y * r).sum()
+    loss.backward()
+    arrs = {"y": y.detach().numpy(), "dz": z.grad.numpy(), "loss": np.float64(loss.item())}
+    for k, p in g.named_parameters():
+        arrs["grad/" + k] = p.grad.numpy()
+    for k, v in g.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            arrs["buf/" + k] = v.numpy()
+    save("fcgan_g_dropout_small.npz", **arrs)
+
+
 def golden_d_small():
     ndf, nl, nc, hw = 8, 3, 2, 128
     for s in (1, 2, 4):
@@ -1097,6 +1119,8 @@ def main():
         golden_fcgan_star_small()
     if not only or "resnet" in only:
         golden_resnet_small()
+    if "g_dropout" in only:
+        golden_g_dropout_small()
     if "residual" in only:       # only the --use_residual vectors (added after the others; same generators)
         golden_resnet_small(("6_residual",))
         golden_unet_small(("residual",))

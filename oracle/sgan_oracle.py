@@ -106,7 +106,8 @@ def fcgan_g_channels(ngf: int, n_layers: int):
     return [ngf * m for m in mults]
 
 
-def init_fcgan_g(seed: int, noise_nc: int, out_nc: int, ngf: int = 32, n_layers: int = 5) -> "OrderedDict[str, torch.Tensor]":
+def init_fcgan_g(seed: int, noise_nc: int, out_nc: int, ngf: int = 32, n_layers: int = 5,
+                 use_dropout: bool = False) -> "OrderedDict[str, torch.Tensor]":
     """state_dict of FCGANGenerator(use_fcn=True) with numpy-seeded values drawn from the
     reference's init distributions (weights_init: conv N(0,.02), BN gamma N(1,.02), beta 0;
     conv biases U(+-1/sqrt(fan_in)) = torch default for ConvTranspose2d: fan_in = Cout*k*k)."""
@@ -126,7 +127,7 @@ def init_fcgan_g(seed: int, noise_nc: int, out_nc: int, ngf: int = 32, n_layers:
         sd[f"model.{idx + 1}.running_var"] = torch.ones(cout)
         sd[f"model.{idx + 1}.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
         cin = cout
-        idx += 3
+        idx += 4 if (use_dropout and li > 0) else 3      # blocks above the first carry an nn.Dropout module (networks.py:513-521)
     sd[f"model.{idx}.weight"] = np_normal(s, (cin, out_nc, 4, 4), 0.0, 0.02)
     return sd
 
@@ -163,7 +164,7 @@ def init_nlayer_d(seed: int, input_nc: int, ndf: int = 32, n_layers: int = 3, sc
 # network forwards (functional; autograd gives the backward)
 # ----------------------------------------------------------------------------------
 def fcgan_g_forward(sd, z, n_layers: int = 5, update_running: bool = True, tanh: bool = True,
-                    taps: dict | None = None, use_fcn: bool = True):
+                    taps: dict | None = None, use_fcn: bool = True, use_dropout: bool = False, mask_seed: int = 0):
     """FCGANGenerator.forward (models/networks.py:535-540), BatchNorm always in train mode
     (the reference never calls .eval()).  `taps` (optional dict) receives raw conv outputs."""
     x = z
@@ -180,8 +181,10 @@ def fcgan_g_forward(sd, z, n_layers: int = 5, update_running: bool = True, tanh:
                          training=True, momentum=BN_MOMENTUM, eps=BN_EPS)
         if update_running and f"model.{idx + 1}.num_batches_tracked" in sd:
             sd[f"model.{idx + 1}.num_batches_tracked"] += 1
+        if use_dropout and li > 0:      # ConvT -> BatchNorm -> Dropout(0.5) -> ReLU (:513-521); the li-th mask of the pass
+            x = x * dropout_mask_np(mask_seed + li, x.shape)
         x = F.relu(x)
-        idx += 3
+        idx += 4 if (use_dropout and li > 0) else 3
     x = F.conv_transpose2d(x, sd[f"model.{idx}.weight"], None, stride=2, padding=1)
     if taps is not None:
         taps[f"conv{n_layers}"] = x

@@ -446,7 +446,12 @@ class ChainNet(nn.Module):
                     ops.dropout_mask(mask, L.drop, getattr(self, "_rng_seed", 0) + li, self._rng_offset, advance=False)
                     drawn = max(drawn, (mask.numel() + 3) // 4)
                 t = torch.empty_like(out)
-                ops.norm_apply_fwd(out, ops.norm_desc(stats[li], None, None, ho * wo, IN_EPS, ACT_NONE, 0.0, 0, rep), t, mask)
+                if L.norm == "bn":      # BatchNorm -> Dropout (the fcgan generator's blocks): the affine goes into the materialised tensor
+                    raw = ops.norm_desc(stats[li], self._flat[L.g_off: L.g_off + L.cout_s], self._flat[L.be_off: L.be_off + L.cout_s],
+                                        ho * wo, BN_EPS, ACT_NONE, 0.0, 0, rep)
+                else:
+                    raw = ops.norm_desc(stats[li], None, None, ho * wo, IN_EPS, ACT_NONE, 0.0, 0, rep)
+                ops.norm_apply_fwd(out, raw, t, mask)
                 drop[li] = (t, mask)
                 cur = t
         if drop and getattr(self, "mask_source", None) is None:
@@ -506,7 +511,9 @@ class ChainNet(nn.Module):
                 if dropped:      # din = d t * ReLU'(t); through the mask, with the two norm-backward sums of the masked gradient
                     raw_norm = self._norm_of(li - 1, stats, h * w)
                     ops.norm_apply_bwd_sums(din, outs[li - 1], raw_norm, sums[li - 1], drop[li - 1][1])      # adds to the first copy only
-                    ops.norm_bwd_apply(din, outs[li - 1], raw_norm, sums[li - 1], None, None, 0, brep)
+                    dg = self._gflat[P.g_off: P.g_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
+                    db = self._gflat[P.be_off: P.be_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
+                    ops.norm_bwd_apply(din, outs[li - 1], raw_norm, sums[li - 1], dg, db, 0, brep)
                 elif P.norm:
                     dg = self._gflat[P.g_off: P.g_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
                     db = self._gflat[P.be_off: P.be_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None

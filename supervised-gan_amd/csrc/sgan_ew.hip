@@ -190,12 +190,14 @@ __global__ __launch_bounds__(256) void sg_norm_apply_fwd_kernel(const float* u, 
                                                                 int C) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* cMean = reinterpret_cast<float*>(smem);
-    float* cRstd = cMean + C;
+    float* cA = cMean + C;         // gamma * rstd     (gamma, beta: the BatchNorm affine; absent for InstanceNorm)
+    float* cB = cA + C;            // beta
     for (int c = threadIdx.x; c < C; c += 256) {
         float mean = 0.f, rstd = 1.f;
         if (un.stats) sg_mean_rstd(un, C, c, mean, rstd);
         cMean[c] = mean;
-        cRstd[c] = rstd;
+        cA[c] = (un.gamma ? un.gamma[c] : 1.f) * rstd;
+        cB[c] = un.beta ? un.beta[c] : 0.f;
     }
     __syncthreads();
     const int CQ = C >> 2;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void sg_norm_apply_fwd_kernel(const float* u, 
         if (noise) nz = *reinterpret_cast<const f32x4*>(noise + (int64_t)p * C + c);
         f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (x[j] - cMean[c + j]) * cRstd[c + j] * m[j] + sigma * nz[j];
+        for (int j = 0; j < 4; ++j) o[j] = ((x[j] - cMean[c + j]) * cA[c + j] + cB[c + j]) * m[j] + sigma * nz[j];
         *reinterpret_cast<f32x4*>(t + (int64_t)p * t_ld + c) = o;
     }
 }
@@ -284,7 +286,7 @@ extern "C" int sgan_norm_apply_fwd(const float* u, int32_t u_ld, const sgan_norm
     int blocks = ew_cdiv(total, 256 * 2);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sg_norm_apply_fwd_kernel, dim3(blocks), dim3(256), (size_t)2 * C * 4, (hipStream_t)stream, u, u_ld,
+    hipLaunchKernelGGL(sg_norm_apply_fwd_kernel, dim3(blocks), dim3(256), (size_t)3 * C * 4, (hipStream_t)stream, u, u_ld,
                        sg_norm_from(u_norm), mask, noise, sigma, t, t_ld, npix, C);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;

@@ -25,8 +25,6 @@ class FCGANGenerator(ChainNet):
     final_act = ACT_TANH
 
     def __init__(self, noise_nc, input_nc, ngf=64, n_layers=3, use_dropout=False, use_fcn=False, gpu_ids=[]):
-        if use_dropout:
-            raise NotImplementedError("FCGANGenerator dropout is not on the MI355X path (README uses --no_dropout)")
         layers = []
         nf = min(2 ** (n_layers - 1), 8)
         # --noiseSize 1 (use_fcn False): the first ConvT is k4 s1 p0 and turns the 1x1 latent into a 4x4 map (:503-504)
@@ -34,8 +32,9 @@ class FCGANGenerator(ChainNet):
         idx = 3
         for n in range(1, n_layers):
             nf_prev, nf = nf, min(2 ** (n_layers - n - 1), 8)
-            layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, ngf * nf_prev, ngf * nf, True, "bn", ACT_RELU))
-            idx += 3
+            # with use_dropout every block above the first is ConvT -> BatchNorm -> Dropout(0.5) -> ReLU (:513-521): four modules
+            layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, ngf * nf_prev, ngf * nf, True, "bn", ACT_RELU, drop=0.5 if use_dropout else 0.0))
+            idx += 4 if use_dropout else 3
         layers.append(LayerSpec(str(idx), CONVT, 4, 2, 1, ngf, input_nc, False, None, ACT_NONE))
         super().__init__(layers)
         self.gpu_ids = gpu_ids
@@ -263,9 +262,6 @@ class AutoEncoder(ChainNet):
 
     def __init__(self, input_nc, output_nc, n_layers=3, ngf=64, norm="batch", use_dropout=False, gpu_ids=[]):
         nrm = {"instance": "in", "batch": "bn"}[norm]
-        if use_dropout and nrm != "in":
-            raise NotImplementedError("AutoEncoder dropout on the MI355X path implements --norm instance (the masked tensor is "
-                                      "materialised without an affine)")
         step = 4 if use_dropout else 3      # modules per block in the reference's nn.Sequential
         layers, idx = [], 0
         nf = 1

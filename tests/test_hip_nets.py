@@ -58,6 +58,40 @@ def test_fcgan_g_small(N, golden_dir):
             assert rel(G.state_dict()[k[4:]].double(), g[k].astype(np.float64)) < TOL, k
 
 
+def test_fcgan_g_dropout_small(N, golden_dir):
+    """--which_model_netG fcgan without --no_dropout (models/networks.py:513-521: ConvT -> BatchNorm -> Dropout(0.5) -> ReLU above the
+    first block) against the reference golden made with the same injected masks: the masked BatchNorm output (affine included) is
+    materialised by sgan_norm_apply_fwd, its backward runs mask -> sums -> norm backward with the affine's gradients."""
+    g = load(golden_dir, "fcgan_g_dropout_small.npz")
+    G = N.define_G(2, 0, 8, "fcgan", "instance", True, n_layers_G=5, use_fcn=True, noise_nc=8, gpu_ids=[0])
+    sd = O.init_fcgan_g(11, 8, 2, 8, 5, use_dropout=True)
+    assert list(G.state_dict().keys()) == list(sd.keys())       # nn.Sequential indices with the Dropout modules counted
+    G.load_state_dict(sd)
+    G.mask_source = lambda li, shape: O.dropout_mask_np(70 + li, (1, shape[2], shape[0], shape[1]))[0].permute(1, 2, 0).contiguous().cuda()
+    z = O.np_normal(101, (1, 8, 2, 2)).cuda().requires_grad_(True)
+    r = O.np_normal(102, (1, 2, 128, 128)).cuda()
+    y = G.forward(z)
+    (y * r).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(y, g["y"]) < TOL and rel(z.grad, g["dz"]) < TOL
+    params = dict(G.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/"):
+            name = k[5:]
+            wname = name.replace(".bias", ".weight")
+            if name.endswith(".bias") and params[wname].dim() == 4:      # conv bias in front of a BatchNorm: analytically zero
+                scale = np.abs(g["grad/" + wname]).max()
+                assert np.abs(params[name].grad.cpu().numpy() - g[k]).max() < TOL * scale, name
+            else:
+                assert rel(params[name].grad, g[k]) < TOL, name
+        if k.startswith("buf/") and not k.endswith("running_mean"):      # running_mean tracks the undetermined conv bias
+            assert rel(G.state_dict()[k[4:]].double(), g[k].astype(np.float64)) < TOL, k
+    G.mask_source = None      # own Philox masks: a fresh set per forward
+    y1, y2 = G.forward(z.detach()), G.forward(z.detach())
+    torch.cuda.synchronize()
+    assert float((y1 - y2).abs().max()) > 0 and float(y1.abs().max()) <= 1.0
+
+
 @pytest.mark.parametrize("s", [1, 2, 4])
 def test_nlayer_d_small(N, golden_dir, s):
     g = load(golden_dir, f"nlayer_d_small_s{s}.npz")

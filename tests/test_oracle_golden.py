@@ -65,6 +65,26 @@ def test_fcgan_g_small(golden_dir):
             assert rel(sd[name].double(), g[k].astype(np.float64)) < TIGHT, name
 
 
+def test_fcgan_g_dropout_small(golden_dir):
+    """FCGANGenerator with use_dropout (ConvT -> BatchNorm -> Dropout(0.5) -> ReLU above the first block, networks.py:513-521; the
+    Sequential indices shift by one per block) restated, against the reference with the same injected masks."""
+    g = load(golden_dir, "fcgan_g_dropout_small.npz")
+    sd = O.init_fcgan_g(11, 8, 2, 8, 5, use_dropout=True)
+    assert {"grad/" + k for k, v in sd.items() if v.is_floating_point() and "running" not in k} == {k for k in g.files if k.startswith("grad/")}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    z = O.np_normal(101, (1, 8, 2, 2)).requires_grad_(True)
+    y = O.fcgan_g_forward(sd, z, 5, use_dropout=True, mask_seed=70)
+    (y * O.np_normal(102, (1, 2, 128, 128))).sum().backward()
+    assert rel(y, g["y"]) < TIGHT and rel(z.grad, g["dz"]) < TIGHT
+    for k in g.files:
+        if k.startswith("grad/") and (sd[k[5:]].dim() == 4 or "model.1." in k or not k.endswith(".bias") or sd[k[5:].replace(".bias", ".weight")].dim() == 1):
+            assert rel(sd[k[5:]].grad, g[k]) < TIGHT * 10, k
+        if k.startswith("buf/"):
+            assert rel(sd[k[4:]].double(), g[k].astype(np.float64)) < TIGHT, k
+
+
 @pytest.mark.parametrize("s", [1, 2, 4])
 def test_nlayer_d_small(golden_dir, s):
     g = load(golden_dir, f"nlayer_d_small_s{s}.npz")

@@ -99,6 +99,12 @@ const char* sgan_last_error(void);
  * (matches the name rocprofv3 reports) -- lets a benchmark attribute time and flops per kernel */
 const char* sgan_last_kernel(void);
 int sgan_stat_replicas(void);     /* SGAN_STAT_REPLICAS of the built library: statistics arenas must hold this many copies */
+/* The explicit device of the boundary (SURVEY 8b "Threading": backward is called from autograd worker threads that did not
+ * choose a device).  Launches go to the device their stream belongs to and HIP wants the calling thread's current device to be
+ * that one: a host thread that has not set it calls sgan_set_device(sgan_stream_device(stream)) once before its first entry
+ * point.  (torch's autograd engine does this for its own workers; the Python binding therefore never calls these.) */
+int sgan_set_device(int32_t device_id);
+int sgan_stream_device(void* stream, int32_t* device_id);
 
 /* ---- optional per-launch timing (diagnostics; single-threaded; do not enable during graph capture) ----
  * While enabled, every main conv kernel launch (implicit-GEMM / small-N / backward-weight; not the split-K

@@ -117,6 +117,8 @@ SIGNATURES = {
     "sgan_sigmoid_bwd": [_P, _I, _P, _I, _I, _P, _I, _P],
     "sgan_tanh_bwd": [_P, _P, _P, _L, _P],
     "sgan_stat_replicas": [],
+    "sgan_set_device": [_I],
+    "sgan_stream_device": [_P, C.POINTER(C.c_int32)],
     "sgan_add_act_fwd": [_P, _P, _P, _L, _I, _P],
     "sgan_to_nhwc": [_P, _L, _L, _L, _I, _I, _I, _P, _I, _I, _P],
     "sgan_concat_nhwc": [_P, _I, _I, _P, _I, _I, _L, _P, _I, _I, _P],

@@ -19,6 +19,22 @@ extern "C" const char* sgan_version(void) { return "sgan_hip 0.2 (gfx950; fp32 M
 extern "C" const char* sgan_last_error(void) { return g_sgan_err; }
 extern "C" const char* sgan_last_kernel(void) { return g_sgan_last_kernel; }
 extern "C" int sgan_stat_replicas(void) { return SGAN_STAT_REPLICAS; }      // what this build was compiled with (callers size their arenas by it)
+// The explicit device of the boundary: kernels go to the device the stream belongs to, and HIP wants the calling thread's
+// current device to be that one.  A host thread that has not chosen a device itself (an autograd worker of a non-torch host, a
+// thread pool) calls this before its first entry point.
+extern "C" int sgan_set_device(int32_t device_id) {
+    hipError_t e = hipSetDevice(device_id);
+    if (e != hipSuccess) return sgan_fail(SGAN_ERR_HIP, "hipSetDevice(%d): %s", (int)device_id, hipGetErrorString(e));
+    return SGAN_OK;
+}
+extern "C" int sgan_stream_device(void* stream, int32_t* device_id) {      // which device a stream's launches will run on
+    if (!device_id) return sgan_fail(SGAN_ERR_INVALID, "null device_id");
+    hipDevice_t dev;
+    hipError_t e = hipStreamGetDevice((hipStream_t)stream, &dev);
+    if (e != hipSuccess) return sgan_fail(SGAN_ERR_HIP, "hipStreamGetDevice: %s", hipGetErrorString(e));
+    *device_id = (int32_t)dev;
+    return SGAN_OK;
+}
 
 // ---- optional per-launch timing -------------------------------------------------------------
 #define SG_PROF_MAX 8192

@@ -466,6 +466,19 @@ def test_cat_pair_output_with_a_gradient_stays_zero_copy(hip):
     assert torch.equal(buf[..., :3].permute(2, 0, 1).unsqueeze(0), torch.cat((a, b), 1)) and float(buf[..., 3].abs().sum()) == 0.0
 
 
+def test_explicit_device_of_the_boundary(hip):
+    """sgan_stream_device / sgan_set_device: what a host thread that never chose a device calls before its first entry point."""
+    import ctypes as C
+    from supervised_gan_amd import _lib
+    lib = _lib.lib()
+    dev = C.c_int32(-1)
+    assert lib.sgan_stream_device(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(dev)) == 0 and dev.value == torch.cuda.current_device()
+    assert lib.sgan_stream_device(None, C.byref(dev)) == 0 and dev.value == torch.cuda.current_device()      # the null stream: the current device
+    assert lib.sgan_set_device(dev.value) == 0
+    assert lib.sgan_set_device(4096) < 0 and b"hipSetDevice" in lib.sgan_last_error()
+    assert lib.sgan_stream_device(None, None) < 0
+
+
 def test_image_resize_bit_exact_vs_pillow(hip):
     """sgan_image_resize against Image.resize of the Pillow in this image: bilinear and bicubic, up- and down-scaling (the filter
     support grows with the down-scale factor), one axis unchanged, a 1-pixel-wide result, the aligned dataset's 2:1 shape."""

@@ -809,10 +809,17 @@ class UnetGenerator(ChainNet):
                 gw, gb = self._gwb(L)
                 ops.conv_wgrad(desc, src, nrm, dy, gw, gb)
 
+        def bwd(L, desc, src, nrm, dy, din, sums, sq=0, accumulate=False):
+            """Backward-weight and backward-data of one conv: one fused launch where sgan_conv_bwd_fused covers the layer."""
+            djob = [(desc, dy, self._wt(L), din, src, nrm, sums, sq, accumulate, True, 0)]
+            if want_wgrad:
+                ops.conv_bwd_grouped(djob, [(desc, src, nrm, dy) + self._gwb(L)])
+            else:
+                ops.conv_dgrad_grouped(djob)
+
         # final transposed conv: gradient of ReLU(cat_1)
         nrm = self._cat_norm(1, hw, catstat)
-        wgrad(self.up[0], upd[0], cat[1], nrm, d0)
-        ops.conv_dgrad(upd[0], d0, self._wt(self.up[0]), dcat[1], cat[1], nrm, None, w_transposed=True)
+        bwd(self.up[0], upd[0], cat[1], nrm, d0, dcat[1], None)
         # decoder, outermost block first
         d_inner = None
         for l in range(1, n):
@@ -828,22 +835,20 @@ class UnetGenerator(ChainNet):
                 src, nrm = cat[l + 1], self._cat_norm(l + 1, hw, catstat)
                 din = dcat[l + 1]
                 sums = csum[l + 1] if (skip[l + 1] and l + 1 > 1) else None
-            wgrad(self.up[l], upd[l], src, nrm, dy)
-            ops.conv_dgrad(upd[l], dy, self._wt(self.up[l]), din, src, nrm, sums, w_transposed=True)
+            bwd(self.up[l], upd[l], src, nrm, dy, din, sums)
         # encoder, innermost first: dr = gradient w.r.t. the raw output of down[l]
         dr = d_inner
         for l in range(n - 1, 0, -1):
             src = xr[l - 1]
             nrm = self._x_norm(l - 1, hw, xstat, ACT_LRELU, 0.2)
-            wgrad(self.down[l], dn[l], src, nrm, dr)
             normed = 1 <= l - 1 <= n - 2
             sums, sq = xsum[l - 1] if normed else (None, 0)
             if skip[l]:
                 din = dcat[l][:, :, c[l - 1]:]
-                ops.conv_dgrad(dn[l], dr, self._wt(self.down[l]), din, src, nrm, sums, sq, accumulate=True, w_transposed=True)
+                bwd(self.down[l], dn[l], src, nrm, dr, din, sums, sq, accumulate=True)
             else:
                 din = torch.empty(hw[l - 1] + (c[l - 1],), dtype=torch.float32, device=dev)
-                ops.conv_dgrad(dn[l], dr, self._wt(self.down[l]), din, src, nrm, sums, sq, w_transposed=True)
+                bwd(self.down[l], dn[l], src, nrm, dr, din, sums, sq)
             if normed:
                 ops.norm_bwd_apply(din, src, nrm, sums, None, None, sq)
             dr = din
@@ -1047,6 +1052,14 @@ class CascadedRefinementNetwork(ChainNet):
                 gw, gb = self._gwb(L)
                 ops.conv_wgrad(desc, src, nrm, dy, gw, gb)
 
+        def bwd(L, desc, src, nrm, dy, din, sums):
+            """Backward-weight and backward-data of one conv: one fused launch where sgan_conv_bwd_fused covers the layer."""
+            djob = [(desc, dy, self._wt(L), din, src, nrm, sums, 0, False, True, 0)]
+            if want_wgrad:
+                ops.conv_bwd_grouped(djob, [(desc, src, nrm, dy) + self._gwb(L)])
+            else:
+                ops.conv_dgrad_grouped(djob)
+
         if S["final_act"] == ACT_TANH:
             d = torch.empty_like(S["out"])
             ops.tanh_bwd(dout.contiguous(), S["out"], d)
@@ -1067,9 +1080,8 @@ class CascadedRefinementNetwork(ChainNet):
                 ssum = sm(("u", s), 2 * ngf) if i == 0 else sm(("t", s, i - 1), 2 * ngf)
                 nrm = ops.norm_desc(sstat, None, None, 4 * h * w, IN_EPS, ACT_RELU, 0.0)
                 desc = self._desc(L, 2 * h, 2 * w)
-                wgrad(L, desc, src, nrm, d)
                 din = torch.empty((2 * h, 2 * w, ngf), dtype=torch.float32, device=dev)
-                ops.conv_dgrad(desc, d, self._wt(L), din, src, nrm, None if noisy else ssum, w_transposed=True)
+                bwd(L, desc, src, nrm, d, din, None if noisy else ssum)
                 if noisy:      # din = d t (the noise has no gradient): sums of the norm backward, then the norm backward itself
                     unrm = ops.norm_desc(ustat, None, None, 4 * h * w, IN_EPS, ACT_NONE, 0.0)
                     ops.norm_apply_bwd_sums(din, u, unrm, ssum, None)
@@ -1086,15 +1098,15 @@ class CascadedRefinementNetwork(ChainNet):
                 d = dc
             src = S["first"] if s == 5 else cat[s]
             nrm = None if s == 5 else ops.norm_desc(st(("cat", s), 2 * C2), None, None, h * w, IN_EPS, ACT_NONE, 0.0)
-            wgrad(U, desc, src, nrm, d)
             if s == 5:
+                wgrad(U, desc, src, nrm, d)
                 if need_dx:
                     dfirst = torch.empty_like(S["first"])
                     ops.conv_dgrad(desc, d, self._wt(U), dfirst, None, None, None, w_transposed=True)
                 break
             dc_ = torch.empty_like(cat[s])
             csum = sm(("cat", s), 2 * C2)
-            ops.conv_dgrad(desc, d, self._wt(U), dc_, cat[s], nrm, csum, w_transposed=True)
+            bwd(U, desc, src, nrm, d, dc_, csum)
             ops.norm_bwd_apply(dc_, cat[s], nrm, csum)          # both halves at once: raw gradients of l_s and of h_{s+1}
             # label branch of this stage
             Ll = self.lab[s]

@@ -1001,6 +1001,136 @@ __global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmPara
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward of a conv whose gathered tensor has 4 stored channels (the first PatchGAN / U-Net conv on the 2- or 3-channel image):
+// K = 4 channels x <= 16 taps.  The generic kernel stages two 32-deep k-tiles through LDS for that, with its barriers, prologue
+// and ring set-up -- all fixed cost.  Here ONE v_mfma_f32_16x16x4_f32 is one tap: its k dimension is the pixel's four channels.
+// A wave keeps ALL weights of its N columns in registers (W[tap][n][k]: 16 taps x N/16 VGPRs), walks 16-pixel row blocks, loads
+// one float per lane and tap straight from the image (L1 serves the overlap of neighbouring taps and pixels) and stores the tile
+// from the accumulators.  No LDS, no barrier.  Exact fp32, same products and tap order as the generic kernel.
+// ------------------------------------------------------------------------------------------
+template <int NB, int RB>     // N / 16 column blocks; 16-pixel row blocks per wave (64 RB result pixels per workgroup)
+__global__ __launch_bounds__(256) void sg_conv_c4_kernel(const SgIgemmParams G) {
+    __shared__ int4 ttab[16];
+    __shared__ __attribute__((aligned(16))) float Ws[16 * NB * 16 * 4];      // [tap][n][4 channels], zero for taps / columns that do not exist
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    int g, phz, mtile;
+    sg_decode_tile(G, blockIdx.x, g, phz, mtile);
+    const SgLocal P = sg_local(G, g);
+    const int Hp = G.q[g].Hp[phz], Wp = G.q[g].Wp[phz];
+    const int M = Hp * Wp;
+    const int ntaps = G.ntaps[phz], t0 = G.tap0[phz];
+    const int oa = G.oa[phz], ob = G.ob[phz];
+    constexpr int OOB = (int)0x80000000u;
+    constexpr int NW = NB * 16;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in), 0, 0x7FFFFFFF, 0x00020000);
+    if (tid < 16) {
+        const SgTap tp = G.taps[t0 + (tid < ntaps ? tid : 0)];
+        ttab[tid] = make_int4((int)tp.dy, (int)tp.dx, tp.w_off, 0);
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * NW; e += 256) {      // one (tap, column) per item: its four channel weights
+        const int t = e / NW, n = e - t * NW;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t < ntaps && n < P.N) v = *reinterpret_cast<const f32x4*>(P.w + ttab[t].z + n * P.w_ns);
+        *reinterpret_cast<f32x4*>(Ws + e * 4) = v;
+    }
+    // The MFMA runs "transposed": rows = result channels (weights as the A operand), columns = the 16 pixels of a row block (the
+    // gathered image as B).  k of one MFMA = four TAPS of one channel: lane (fr, fq) loads the whole 16-byte pixel of tap 4 T + fq
+    // once and feeds its four channels to four MFMAs; the accumulator of lane (fr, fq) is then result pixel fr, channels
+    // 16 j + 4 fq .. + 3 -- one 16-byte store.  All gathers of the wave are in flight before the first MFMA.
+    const int m_wave = mtile * (64 * RB) + wid * (16 * RB);
+    f32x4 xv[RB][4];
+    int opix[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int m = m_wave + rb * 16 + fr;
+        const bool valid = m < M;
+        const int py = m / Wp, px = m - py * Wp;
+        opix[rb] = valid ? (py * P.os + oa) * P.Wout + (px * P.os + ob) : -1;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const int4 tp = ttab[4 * T + fq];
+            const int iy = py * P.is + tp.x, ix = px * P.is + tp.y;
+            const bool ok = valid & (4 * T + fq < ntaps) & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
+            xv[rb][T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? ((iy * P.Win + ix) * P.in_ld) << 2 : OOB, 0, 0));
+        }
+    }
+    __syncthreads();      // weights staged
+    f32x4 wreg[4][NB];    // [T][j]: the four channel weights of (tap 4 T + fq, column 16 j + fr)
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) wreg[T][j] = *reinterpret_cast<const f32x4*>(Ws + ((4 * T + fq) * NW + j * 16 + fr) * 4);
+    f32x4 bias4[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (P.bias)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[j][r] = (j * 16 + 4 * fq + r < P.N) ? P.bias[j * 16 + 4 * fq + r] : 0.f;
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        f32x4 acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[T][j][c], xv[rb][T][c], acc[j], 0, 0, 0);
+        if (opix[rb] < 0) continue;
+        float* o = P.out + (int64_t)opix[rb] * P.out_ld;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = j * 16 + 4 * fq;
+            if (n >= P.N) continue;      // N is a multiple of 4: whole 16-byte groups
+            f32x4 v = acc[j] + bias4[j];
+            if (P.out_act == SGAN_ACT_TANH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            }
+            *reinterpret_cast<f32x4*>(o + n) = v;
+        }
+    }
+}
+
+// 4 gathered channels, k-contiguous weights, <= 16 taps per phase, 16 < N <= 64, nothing but bias (+ tanh) in the epilogue
+static bool sg_use_c4(const SgIgemmParams& P) {
+    static const int off = getenv("SGAN_NO_C4") ? 1 : 0;
+    if (off || P.Ck != 4 || P.w_ks != 1 || (P.w_ns & 3) || P.N <= 16 || P.N > 64 || (P.N & 3) || P.pro_act != SGAN_ACT_NONE) return false;
+    for (int ph = 0; ph < P.nphase; ++ph)
+        if (P.ntaps[ph] > 16) return false;
+    for (int g = 0; g < P.nprob; ++g)
+        if (P.q[g].stats || P.q[g].xref || P.q[g].accum || P.q[g].pro_stats || (P.q[g].out_ld & 3) || (P.q[g].in_ld & 3)) return false;
+    return true;
+}
+
+template <int RB>
+static void sg_launch_c4_rb(SgIgemmParams& P, int tiles, hipStream_t st) {
+    if (P.N <= 32) hipLaunchKernelGGL((sg_conv_c4_kernel<2, RB>), dim3(tiles), dim3(256), 0, st, P);
+    else if (P.N <= 48) hipLaunchKernelGGL((sg_conv_c4_kernel<3, RB>), dim3(tiles), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((sg_conv_c4_kernel<4, RB>), dim3(tiles), dim3(256), 0, st, P);
+}
+
+static int sg_launch_c4(SgIgemmParams& P, hipStream_t st) {
+    static const int rb = getenv("SGAN_C4_RB") ? atoi(getenv("SGAN_C4_RB")) : 4;      // tuning knob: 1, 2 or 4 row blocks per wave
+    const int RB = (rb == 1 || rb == 2) ? rb : 4;
+    const int tiles = sg_fill_tiles(P, 64 * RB);
+    if (tiles == 0) return SGAN_OK;
+    sg_prof_begin(st);
+    if (RB == 1) sg_launch_c4_rb<1>(P, tiles, st);
+    else if (RB == 2) sg_launch_c4_rb<2>(P, tiles, st);
+    else sg_launch_c4_rb<4>(P, tiles, st);
+    SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = "sg_conv_c4_kernel";
+    sg_prof_end(st, g_sgan_last_kernel);
+    return SGAN_OK;
+}
+
 static bool sg_use_scatter4(const SgIgemmParams& P) {
     static const int off = getenv("SGAN_NO_SCATTER4") ? 1 : 0;
     if (off || P.N != 4 || P.nphase != 4 || P.os != 2 || P.is != 1 || P.w_ks != 1 || (P.Ck & 15) || P.Ck > 512 || P.Ck < 16) return false;
@@ -1362,6 +1492,7 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
     const int e3 = sg_igemm3_eligible(P);   // split-bf16 MFMA (sgan_igemm3.hip)
     if (e3 < 0) return e3;
     if (e3) return sg_launch_igemm3(P, st, ws, ws_bytes);
+    if (sg_use_c4(P)) return sg_launch_c4(P, st);     // first conv on the image: one MFMA per tap, weights in registers
     int BM, BN;
     sg_pick_tile(P, &BM, &BN);
     if (BN == 16) return sg_launch_igemm<128, 16, 4, 1>(P, st, ws, ws_bytes);
@@ -1391,7 +1522,7 @@ int sg_igemm_fuse_plan_f32(SgIgemmParams& P, SgFusePlan* out) {
     P.ksplit = 1;
     P.slab = nullptr;
     P.slab_stride = 0;
-    if (sg_use_small_n(P) || P.w_ks != 1 || P.pro_act != SGAN_ACT_NONE) return 0;
+    if (sg_use_small_n(P) || sg_use_c4(P) || P.w_ks != 1 || P.pro_act != SGAN_ACT_NONE) return 0;
     for (int g = 0; g < P.nprob; ++g)
         if (P.q[g].pro_stats) return 0;
     int BM, BN;
@@ -1408,6 +1539,7 @@ int sg_igemm_fuse_plan_f32(SgIgemmParams& P, SgFusePlan* out) {
 static int64_t sg_workspace_need(const SgIgemmParams& P) {
     if (sg_use_small_n(P)) return 0;
     if (sg_igemm3_eligible(P) > 0) return sg_igemm3_workspace_need(P);
+    if (sg_use_c4(P)) return 0;
     int BM, BN;
     sg_pick_tile(P, &BM, &BN);
     const int ks = sg_plan_ksplit(P, BM, BN);

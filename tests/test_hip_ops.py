@@ -117,6 +117,16 @@ def test_conv_layer_fwd_bwd(hip, case, math_mode):
         ops.conv_fwd(desc_plain, xb, in_norm, wm, bb, ob2, 0, None)      # same result without the hint
         assert rel(ob2, ob) < 1e-5
 
+    # the same forward without statistics (how a layer with no normalisation behind it is called): the first conv on the image
+    # (4 stored channels, > 16 result channels) then runs on sg_conv_c4_kernel -- one MFMA per tap, weights in registers
+    ob3 = torch.full_like(ob, float("nan"))
+    ops.conv_fwd(desc, xb, in_norm, wm, bb, ob3, 0, None)
+    torch.cuda.synchronize()
+    from supervised_gan_amd import _lib as _L
+    if pad4(cin) == 4 and cout > 16 and not norm and act == 0:
+        assert _L.lib().sgan_last_kernel().decode() == "sg_conv_c4_kernel"
+    assert rel(ob3, ob) < 2e-6
+
     # ---- backward data (+ act', norm sums) then norm backward ----
     Rb = to_buf(R)
     din = torch.full((H, W, pad4(cin)), float("nan"), device="cuda")

@@ -24,14 +24,20 @@ extern "C" int sgan_stat_replicas(void) { return SGAN_STAT_REPLICAS; }      // w
 // thread pool) calls this before its first entry point.
 extern "C" int sgan_set_device(int32_t device_id) {
     hipError_t e = hipSetDevice(device_id);
-    if (e != hipSuccess) return sgan_fail(SGAN_ERR_HIP, "hipSetDevice(%d): %s", (int)device_id, hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();      // HIP keeps the error sticky: the next launch check of this thread would report it again
+        return sgan_fail(SGAN_ERR_HIP, "hipSetDevice(%d): %s", (int)device_id, hipGetErrorString(e));
+    }
     return SGAN_OK;
 }
 extern "C" int sgan_stream_device(void* stream, int32_t* device_id) {      // which device a stream's launches will run on
     if (!device_id) return sgan_fail(SGAN_ERR_INVALID, "null device_id");
     hipDevice_t dev;
     hipError_t e = hipStreamGetDevice((hipStream_t)stream, &dev);
-    if (e != hipSuccess) return sgan_fail(SGAN_ERR_HIP, "hipStreamGetDevice: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return sgan_fail(SGAN_ERR_HIP, "hipStreamGetDevice: %s", hipGetErrorString(e));
+    }
     *device_id = (int32_t)dev;
     return SGAN_OK;
 }

@@ -1009,14 +1009,20 @@ __global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmPara
 // one float per lane and tap straight from the image (L1 serves the overlap of neighbouring taps and pixels) and stores the tile
 // from the accumulators.  No LDS, no barrier.  Exact fp32, same products and tap order as the generic kernel.
 // ------------------------------------------------------------------------------------------
-template <int NB, int RB>     // N / 16 column blocks; 16-pixel row blocks per wave (64 RB result pixels per workgroup)
+// EPI: the full epilogue of the generic kernel (backward-data: times act'(norm(x)) of the forward tensor, the two norm-backward sums,
+// accumulate; forward: the statistics of the result).  Those launches tile N in 16 NB columns (grid.y) -- the image gradient that
+// reaches the logits head (1 -> 256 channels) and the generator's last layer (2 -> 32) are K = 64 problems of the same shape.
+template <int NB, int RB, bool EPI>     // 16-column blocks per workgroup; 16-pixel row blocks per wave (64 RB result pixels per workgroup)
 __global__ __launch_bounds__(256) void sg_conv_c4_kernel(const SgIgemmParams G) {
     __shared__ int4 ttab[16];
     __shared__ __attribute__((aligned(16))) float Ws[16 * NB * 16 * 4];      // [tap][n][4 channels], zero for taps / columns that do not exist
+    __shared__ __attribute__((aligned(16))) float cf[EPI ? 4 * NB * 16 : 4];  // EPI: mean | rstd | gamma | beta of the forward tensor's norm
+    __shared__ double red[EPI ? 2 * NB * 16 : 2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     int g, phz, mtile;
     sg_decode_tile(G, blockIdx.x, g, phz, mtile);
+    const int n0 = EPI ? (int)blockIdx.y * NB * 16 : 0;
     const SgLocal P = sg_local(G, g);
     const int Hp = G.q[g].Hp[phz], Wp = G.q[g].Wp[phz];
     const int M = Hp * Wp;
@@ -1031,10 +1037,25 @@ __global__ __launch_bounds__(256) void sg_conv_c4_kernel(const SgIgemmParams G) 
     }
     __syncthreads();
     for (int e = tid; e < 16 * NW; e += 256) {      // one (tap, column) per item: its four channel weights
-        const int t = e / NW, n = e - t * NW;
+        const int t = e / NW, n = n0 + e - t * NW;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (t < ntaps && n < P.N) v = *reinterpret_cast<const f32x4*>(P.w + ttab[t].z + n * P.w_ns);
         *reinterpret_cast<f32x4*>(Ws + e * 4) = v;
+    }
+    const bool dact = EPI && P.xref != nullptr, want_stats = EPI && P.stats != nullptr;
+    const bool xnorm = dact && P.xn.stats != nullptr;
+    if constexpr (EPI) {
+        if (tid < NW) {
+            const int n = n0 + tid;
+            float mean = 0.f, rstd = 1.f, gm = 1.f, bt = 0.f;
+            if (xnorm && n < P.N) {
+                sg_mean_rstd(P.xn, P.N, n, mean, rstd);
+                gm = P.xn.gamma ? P.xn.gamma[n] : 1.f;
+                bt = P.xn.beta ? P.xn.beta[n] : 0.f;
+            }
+            cf[tid] = mean; cf[NW + tid] = rstd; cf[2 * NW + tid] = gm; cf[3 * NW + tid] = bt;
+        }
+        if (tid < 2 * NW) red[tid] = 0.0;
     }
     // The MFMA runs "transposed": rows = result channels (weights as the A operand), columns = the 16 pixels of a row block (the
     // gathered image as B).  k of one MFMA = four TAPS of one channel: lane (fr, fq) loads the whole 16-byte pixel of tap 4 T + fq
@@ -1069,7 +1090,15 @@ __global__ __launch_bounds__(256) void sg_conv_c4_kernel(const SgIgemmParams G) 
         bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (P.bias)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bias4[j][r] = (j * 16 + 4 * fq + r < P.N) ? P.bias[j * 16 + 4 * fq + r] : 0.f;
+            for (int r = 0; r < 4; ++r) bias4[j][r] = (n0 + j * 16 + 4 * fq + r < P.N) ? P.bias[n0 + j * 16 + 4 * fq + r] : 0.f;
+    }
+    const float xn_neg = P.xn.act == SGAN_ACT_NONE ? 1.f : (P.xn.act == SGAN_ACT_RELU ? 0.f : P.xn.slope);
+    double s1[EPI ? NB : 1][4], s2[EPI ? NB : 1][4];
+    if constexpr (EPI) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[j][r] = 0.0; s2[j][r] = 0.0; }
     }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -1086,34 +1115,96 @@ __global__ __launch_bounds__(256) void sg_conv_c4_kernel(const SgIgemmParams G) 
         float* o = P.out + (int64_t)opix[rb] * P.out_ld;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int n = j * 16 + 4 * fq;
+            const int nl = j * 16 + 4 * fq, n = n0 + nl;
             if (n >= P.N) continue;      // N is a multiple of 4: whole 16-byte groups
             f32x4 v = acc[j] + bias4[j];
-            if (P.out_act == SGAN_ACT_TANH) {
+            if constexpr (EPI) {
+                if (dact) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(P.xref + (int64_t)opix[rb] * P.xref_ld + n);
+                    const f32x4 mean = *reinterpret_cast<const f32x4*>(cf + nl), rstd = *reinterpret_cast<const f32x4*>(cf + NW + nl);
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(cf + 2 * NW + nl), bt = *reinterpret_cast<const f32x4*>(cf + 3 * NW + nl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xhat = (x[r] - mean[r]) * rstd[r];
+                        const float y = xnorm ? (gm[r] * xhat + bt[r]) : x[r];
+                        v[r] *= (y > 0.f ? 1.f : xn_neg);
+                        s1[j][r] += (double)v[r];
+                        s2[j][r] += (double)(v[r] * xhat);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s1[j][r] += (double)v[r];
+                        s2[j][r] += (double)v[r] * (double)v[r];
+                    }
+                }
+            }
+            if (!dact && P.out_act == SGAN_ACT_TANH) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            }
+            if constexpr (EPI) {
+                if (P.accum) v += *reinterpret_cast<const f32x4*>(o + n);
             }
             *reinterpret_cast<f32x4*>(o + n) = v;
         }
     }
+    if constexpr (EPI) {
+        if (want_stats) {      // lanes of one fq hold the same channels for 16 pixels: fold them, then the waves meet in LDS
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double a1 = s1[j][r], a2 = s2[j][r];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+                    if (fr == 0) {
+                        atomicAdd(&red[j * 16 + 4 * fq + r], a1);
+                        atomicAdd(&red[NW + j * 16 + 4 * fq + r], a2);
+                    }
+                }
+            __syncthreads();
+            if (tid < NW && n0 + tid < P.N) {
+                double* st = sg_stat_replica(P.stats, P.stats_rep, blockIdx.x);
+                atomicAdd(&st[n0 + tid], red[tid]);
+                atomicAdd(&st[P.stats_sq + n0 + tid], red[NW + tid]);
+            }
+        }
+    }
 }
 
-// 4 gathered channels, k-contiguous weights, <= 16 taps per phase, 16 < N <= 64, nothing but bias (+ tanh) in the epilogue
+// 4 gathered channels, k-contiguous weights, <= 16 taps per phase, N > 16.  Plain launches (bias / tanh only): N <= 64 in one
+// workgroup column.  Launches with the full epilogue (forward-tensor derivative, statistics, accumulate): any N, tiled by 32.
+static bool sg_c4_needs_epi(const SgIgemmParams& P) {
+    for (int g = 0; g < P.nprob; ++g)
+        if (P.q[g].stats || P.q[g].xref || P.q[g].accum) return true;
+    return false;
+}
+
 static bool sg_use_c4(const SgIgemmParams& P) {
-    static const int off = getenv("SGAN_NO_C4") ? 1 : 0;
-    if (off || P.Ck != 4 || P.w_ks != 1 || (P.w_ns & 3) || P.N <= 16 || P.N > 64 || (P.N & 3) || P.pro_act != SGAN_ACT_NONE) return false;
+    static const int off = getenv("SGAN_NO_C4") ? atoi(getenv("SGAN_NO_C4")) : 0;      // 1: never; 2: not for the full-epilogue launches
+    if (off == 1 || P.Ck != 4 || P.w_ks != 1 || (P.w_ns & 3) || P.N <= 16 || (P.N & 3) || P.pro_act != SGAN_ACT_NONE) return false;
     for (int ph = 0; ph < P.nphase; ++ph)
         if (P.ntaps[ph] > 16) return false;
-    for (int g = 0; g < P.nprob; ++g)
-        if (P.q[g].stats || P.q[g].xref || P.q[g].accum || P.q[g].pro_stats || (P.q[g].out_ld & 3) || (P.q[g].in_ld & 3)) return false;
+    const bool epi = sg_c4_needs_epi(P);
+    if (epi ? off == 2 : P.N > 64) return false;
+    for (int g = 0; g < P.nprob; ++g) {
+        const SgProb& Q = P.q[g];
+        if (Q.pro_stats || (Q.out_ld & 3) || (Q.in_ld & 3) || (Q.xref && (Q.xref_ld & 3))) return false;
+        if (epi && (!Q.xref != !P.q[0].xref || !Q.stats != !P.q[0].stats)) return false;      // one epilogue shape per launch
+    }
     return true;
 }
 
 template <int RB>
 static void sg_launch_c4_rb(SgIgemmParams& P, int tiles, hipStream_t st) {
-    if (P.N <= 32) hipLaunchKernelGGL((sg_conv_c4_kernel<2, RB>), dim3(tiles), dim3(256), 0, st, P);
-    else if (P.N <= 48) hipLaunchKernelGGL((sg_conv_c4_kernel<3, RB>), dim3(tiles), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((sg_conv_c4_kernel<4, RB>), dim3(tiles), dim3(256), 0, st, P);
+    if (sg_c4_needs_epi(P)) {
+        hipLaunchKernelGGL((sg_conv_c4_kernel<2, RB, true>), dim3(tiles, (P.N + 31) / 32), dim3(256), 0, st, P);
+        return;
+    }
+    if (P.N <= 32) hipLaunchKernelGGL((sg_conv_c4_kernel<2, RB, false>), dim3(tiles), dim3(256), 0, st, P);
+    else if (P.N <= 48) hipLaunchKernelGGL((sg_conv_c4_kernel<3, RB, false>), dim3(tiles), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((sg_conv_c4_kernel<4, RB, false>), dim3(tiles), dim3(256), 0, st, P);
 }
 
 static int sg_launch_c4(SgIgemmParams& P, hipStream_t st) {

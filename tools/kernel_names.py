@@ -24,7 +24,7 @@ def short(name):
     m = re.match(r"(sg_wgrad_kernel)<(.*),(true|false)>$", n)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    m = re.match(r"sg_conv_c4_kernel<\d+,\d+>$", n)      # column blocks, row blocks per wave
+    m = re.match(r"sg_conv_c4_kernel<\d+,\d+,(?:true|false)>$", n)      # column blocks, row blocks per wave, full epilogue
     if m:
         return "sg_conv_c4_kernel"
     m = re.match(r"sg_conv_head_kernel<\d+>$", n)      # tile height

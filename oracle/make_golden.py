@@ -398,12 +398,13 @@ def golden_unet_small(only=()):
     """unet_128 (7 downs) at 256x256, ngf=8: all skips + dropout; 4 skips + Gaussian noise, no dropout; --use_residual (2 -> 2 channels)."""
     for tag, kw in (("skipall_dropout", dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False)),
                     ("skip4_noise", dict(use_dropout=False, num_skips=4, add_gaussian_noise=True)),
-                    ("residual", dict(use_dropout=False, num_skips=-1, add_gaussian_noise=False, use_residual=True, out_nc=2))):
+                    ("residual", dict(use_dropout=False, num_skips=-1, add_gaussian_noise=False, use_residual=True, out_nc=2)),
+                    ("batchnorm", dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False, norm="batch"))):
         if only and tag not in only:
             continue
         ngf, in_nc, out_nc, hw = 8, 2, kw.get("out_nc", 1), 256
-        sd = O.init_unet(31, 7, in_nc, out_nc, ngf, kw["num_skips"])
-        g = RN.define_G(in_nc, out_nc, ngf, "unet_128", "instance", kw["use_dropout"], n_layers_G_skip=kw["num_skips"],
+        sd = O.init_unet(31, 7, in_nc, out_nc, ngf, kw["num_skips"], norm=kw.get("norm", "instance"))
+        g = RN.define_G(in_nc, out_nc, ngf, "unet_128", kw.get("norm", "instance"), kw["use_dropout"], n_layers_G_skip=kw["num_skips"],
                         add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, use_residual=kw.get("use_residual", False), gpu_ids=[])
         load_sd(g, sd)
         x = O.np_uniform(301, (1, in_nc, hw, hw)).requires_grad_(True)
@@ -415,6 +416,9 @@ def golden_unet_small(only=()):
         arrs = {"y": y.detach().numpy(), "dx": x.grad.numpy(), "loss": np.float64(loss.item())}
         for k, p in g.named_parameters():
             arrs["grad/" + k] = p.grad.numpy()
+        for k, v in g.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                arrs["buf/" + k] = v.numpy()
         save(f"unet_small_{tag}.npz", **arrs)
 
 
@@ -1124,6 +1128,8 @@ def main():
     if "residual" in only:       # only the --use_residual vectors (added after the others; same generators)
         golden_resnet_small(("6_residual",))
         golden_unet_small(("residual",))
+    if "unet_batchnorm" in only:
+        golden_unet_small(("batchnorm",))
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
         golden_autoencoder_dropout()

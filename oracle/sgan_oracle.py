@@ -467,12 +467,32 @@ def unet_plan(num_downs: int, ngf: int, input_nc: int, output_nc: int, num_skips
     return levels
 
 
-def init_unet(seed: int, num_downs: int, input_nc: int, output_nc: int, ngf: int = 64, num_skips: int = -1):
+def _next_key(key: str) -> str:
+    """The next numbered child of the same nn.Sequential (a conv's norm layer follows it)."""
+    parts = key.split(".")
+    return ".".join(parts[:-1] + [str(int(parts[-1]) + 1)])
+
+
+def _init_bn(sd, key: str, c: int, seed: int):
+    """BatchNorm2d(affine=True) entries as weights_init leaves them (:17-19: gamma N(1, .02), beta 0) + fresh running statistics."""
+    sd[key + ".weight"] = np_normal(seed, (c,), 1.0, 0.02)
+    sd[key + ".bias"] = torch.zeros(c)
+    sd[key + ".running_mean"] = torch.zeros(c)
+    sd[key + ".running_var"] = torch.ones(c)
+    sd[key + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+
+def init_unet(seed: int, num_downs: int, input_nc: int, output_nc: int, ngf: int = 64, num_skips: int = -1, norm: str = "instance"):
     """numpy-seeded state dict with UnetGenerator's keys/shapes; N(0, 0.02) conv weights (weights_init
-    :13-19), torch-default uniform biases."""
+    :13-19), torch-default uniform biases; norm 'batch': the BatchNorm2d layers behind the down / up convs (:387-389)."""
     sd = OrderedDict()
     k = 0
     for lv in unet_plan(num_downs, ngf, input_nc, output_nc, num_skips):
+        if norm == "batch":
+            if lv["down_norm"]:
+                _init_bn(sd, _next_key(lv["down"][0]), lv["down"][2], seed * 1000 + 500 + k)
+            if lv["up_norm"]:
+                _init_bn(sd, _next_key(lv["up"][0]), lv["up"][2], seed * 1000 + 501 + k)
         key, ci, co = lv["down"]
         sd[key + ".weight"] = np_normal(seed * 1000 + k, (co, ci, 4, 4), 0.0, 0.02)
         b = 1.0 / math.sqrt(ci * 16)
@@ -542,12 +562,21 @@ def gauss_noise_np(seed: int, shape) -> torch.Tensor:
 
 def unet_forward(sd, x, num_downs: int, ngf: int, num_skips: int = -1, use_dropout: bool = False, mask_seed: int = 0,
                  add_gaussian_noise: bool = False, gaussian_sigma: float = 0.1, noise_seed: int = 0, tanh: bool = True,
-                 use_residual: bool = False):
+                 use_residual: bool = False, norm: str = "instance"):
     """UnetGenerator.forward (:362-367: `activation(x + y) if self.use_residual else activation(y)`) with
     UnetSkipConnectionBlock.forward (:409-419) inlined."""
     input_nc = sd["model.0.weight"].shape[1]
     output_nc = sd["model.3.weight"].shape[1]
     levels = unet_plan(num_downs, ngf, input_nc, output_nc, num_skips, use_dropout)
+
+    def nrm(h, conv_key):
+        """norm_layer behind the conv `conv_key` (get_norm_layer, :43-50): InstanceNorm2d(affine=False) or BatchNorm2d in train mode."""
+        if norm != "batch":
+            return F.instance_norm(h, eps=IN_EPS)
+        k = _next_key(conv_key)
+        sd[k + ".num_batches_tracked"] += 1
+        return F.batch_norm(h, sd[k + ".running_mean"], sd[k + ".running_var"], sd[k + ".weight"], sd[k + ".bias"], training=True,
+                            momentum=BN_MOMENTUM, eps=BN_EPS)
 
     def block(l, xin):
         lv = levels[l]
@@ -555,11 +584,11 @@ def unet_forward(sd, x, num_downs: int, ngf: int, num_skips: int = -1, use_dropo
         h = F.leaky_relu(xin, 0.2)
         h = F.conv2d(h, sd[dk + ".weight"], sd[dk + ".bias"], stride=2, padding=1)
         if not lv["innermost"]:
-            h = F.instance_norm(h, eps=IN_EPS)
+            h = nrm(h, dk)
             h = block(l + 1, h)
         h = F.relu(h)
         h = F.conv_transpose2d(h, sd[uk + ".weight"], sd[uk + ".bias"], stride=2, padding=1)
-        h = F.instance_norm(h, eps=IN_EPS)
+        h = nrm(h, uk)
         if lv["dropout"]:
             h = h * dropout_mask_np(mask_seed, h.shape)
         if add_gaussian_noise:

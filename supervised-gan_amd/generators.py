@@ -570,8 +570,8 @@ class UnetGenerator(ChainNet):
 
     def __init__(self, input_nc, output_nc, num_downs, ngf=64, norm="instance", use_dropout=False, use_residual=False,
                  add_gaussian_noise=False, gaussian_sigma=0.1, num_skips=-1, gpu_ids=[]):
-        if norm != "instance":
-            raise NotImplementedError("UnetGenerator on the MI355X path implements --norm instance (the reference default)")
+        nrm = {"instance": "in", "batch": "bn"}[norm]      # get_norm_layer (networks.py:43-50): InstanceNorm2d(affine=False) / BatchNorm2d(affine=True)
+        self.bn = nrm == "bn"
         self.use_residual = bool(use_residual)
         if num_downs < 5:
             raise ValueError("UnetGenerator needs num_downs >= 5")
@@ -596,8 +596,8 @@ class UnetGenerator(ChainNet):
             else:
                 prefix = "1" + ".model.3" * (l - 1)
                 dk, uk = prefix + ".model.1", prefix + (".model.3" if inner else ".model.5")
-                d = LayerSpec(dk, CONV, 4, 2, 1, c[l - 1], c[l], True, None if inner else "in", ACT_NONE)
-                u = LayerSpec(uk, CONVT, 4, 2, 1, c[l] if inner else c[l] * (2 if skip[l + 1] else 1), c[l - 1], True, "in", ACT_NONE)
+                d = LayerSpec(dk, CONV, 4, 2, 1, c[l - 1], c[l], True, None if inner else nrm, ACT_NONE)
+                u = LayerSpec(uk, CONVT, 4, 2, 1, c[l] if inner else c[l] * (2 if skip[l + 1] else 1), c[l - 1], True, nrm, ACT_NONE)
             self.down.append(d)
             self.up.append(u)
         # parameter order = the reference's nn.Sequential traversal: down[0], (down[1], (down[2] ... up[2]), up[1]), up[0]
@@ -662,18 +662,51 @@ class UnetGenerator(ChainNet):
     def _wb(self, L):
         return super()._wb(L)
 
+    def _affine(self, L, grad=False):
+        """(gamma, beta) of layer L's BatchNorm in the flat parameter (or gradient) storage; (None, None) for InstanceNorm."""
+        if L.norm != "bn":
+            return None, None
+        flat = self._gflat if grad else self._flat
+        return flat[L.g_off: L.g_off + L.cout_s], flat[L.be_off: L.be_off + L.cout_s]
+
     def _x_norm(self, l, hw, xstat, act, slope=0.0):
         """How a consumer reads x_l from its raw conv output."""
         if l == 0 or l == self.n - 1:
             return ops.norm_desc(None, None, None, 1, 0.0, act, slope)
         st, sq = xstat[l]
-        return ops.norm_desc(st, None, None, hw[l][0] * hw[l][1], IN_EPS, act, slope, sq)
+        g, b = self._affine(self.down[l])
+        return ops.norm_desc(st, g, b, hw[l][0] * hw[l][1], IN_EPS, act, slope, sq)
 
-    def _cat_norm(self, l, hw, catstat):
-        """ReLU(cat_l) as read by up[l-1]: identity for y_l (and x_0), InstanceNorm statistics for x_{l-1}."""
+    def _cat_affine(self):
+        """--norm batch: per concat buffer the affine its consumer applies on load -- (1, 0) for the up half (materialised with its
+        own affine already), (gamma, beta) of down[l-1]'s BatchNorm for the skip half.  Two torch.cat launches per forward."""
+        n, c, skip = self.n, self.c, self.skip
+        dev = self._flat.device
+        key = ("catconst", str(dev))
+        if key not in self._geom_cache:
+            self._geom_cache[key] = {l: (torch.ones(c[l - 1], device=dev), torch.zeros(c[l - 1], device=dev)) for l in range(2, n)}
+        const = self._geom_cache[key]
+        gs, bs, where, o = [], [], {}, 0
+        for l in range(2, n):
+            if not skip[l]:
+                continue
+            g, b = self._affine(self.down[l - 1])
+            gs += [const[l][0], g]
+            bs += [const[l][1], b]
+            where[l] = (o, 2 * c[l - 1])
+            o += 2 * c[l - 1]
+        if not gs:
+            return {}
+        G, B = torch.cat(gs), torch.cat(bs)
+        return {l: (G[o: o + w], B[o: o + w]) for l, (o, w) in where.items()}
+
+    def _cat_norm(self, l, hw, catstat, cataff=None):
+        """ReLU(cat_l) as read by up[l-1]: identity for y_l (and x_0), the norm of x_{l-1} (its statistics, and with --norm batch
+        its affine: `cataff` from _cat_affine) for the skip half."""
         if l == 1 or not self.skip[l]:
             return ops.norm_desc(None, None, None, 1, 0.0, ACT_RELU, 0.0)
-        return ops.norm_desc(catstat[l], None, None, hw[l - 1][0] * hw[l - 1][1], IN_EPS, ACT_RELU, 0.0, 0)
+        g, b = cataff[l] if (self.bn and cataff) else (None, None)
+        return ops.norm_desc(catstat[l], g, b, hw[l - 1][0] * hw[l - 1][1], IN_EPS, ACT_RELU, 0.0, 0)
 
     def _random(self, l, shape, dev):
         """Dropout mask / Gaussian noise of level l.  Every (level, kind) is its own Philox stream (seed), all read the same
@@ -718,6 +751,7 @@ class UnetGenerator(ChainNet):
         self._rng_drawn = 0     # longest stream drawn in this pass (in Philox blocks of 4 values)
         lay, total, tmpl = self._stat_template(hw, dev)
         arena = tmpl.clone()
+        cataff = self._cat_affine() if self.bn else None
         catw = [0] * (n + 1)
         cat, catstat, ustat = [None] * (n + 1), [None] * (n + 1), [None] * (n + 1)
         for l in range(1, n):
@@ -756,22 +790,34 @@ class UnetGenerator(ChainNet):
             if l == n - 1:
                 src, in_norm = xr[l], ops.norm_desc(None, None, None, 1, 0.0, ACT_RELU, 0.0)
             else:
-                src, in_norm = cat[l + 1], self._cat_norm(l + 1, hw, catstat)
+                src, in_norm = cat[l + 1], self._cat_norm(l + 1, hw, catstat, cataff)
             u[l] = torch.empty(hw[l - 1] + (c[l - 1],), dtype=torch.float32, device=dev)
             ops.conv_fwd(upd[l], src, in_norm, wt, b, u[l], ACT_NONE, ustat[l])
             mask, noise = self._random(l, u[l].shape, dev)
             masks[l] = mask
-            un = ops.norm_desc(ustat[l], None, None, hw[l - 1][0] * hw[l - 1][1], IN_EPS, ACT_NONE, 0.0)
+            ug, ub = self._affine(L)
+            un = ops.norm_desc(ustat[l], ug, ub, hw[l - 1][0] * hw[l - 1][1], IN_EPS, ACT_NONE, 0.0)
             ops.norm_apply_fwd(u[l], un, cat[l][:, :, :c[l - 1]], mask, noise, self.gauss_sigma if noise is not None else 0.0)
         L = self.up[0]
         wt, b = self._wb(L)
         out = torch.empty((H, W, L.cout_s), dtype=torch.float32, device=dev)
         final_act = self._take_call_act()
-        ops.conv_fwd(upd[0], cat[1], self._cat_norm(1, hw, catstat), wt, b, out, final_act, None)
+        ops.conv_fwd(upd[0], cat[1], self._cat_norm(1, hw, catstat, cataff), wt, b, out, final_act, None)
         if self._rng_drawn:
             ops.rng_advance(self._rng_offset, self._rng_drawn)
+        if self.bn and update_running and self.training:      # running statistics of every BatchNorm (train-mode side effect of the forward)
+            rl = []
+            for l in range(1, n - 1):
+                nb = self._bn_boxes[self.down[l].key]
+                st, sq = xstat[l]
+                rl.append((st, nb.running_mean, nb.running_var, nb.num_batches_tracked, c[l], hw[l][0] * hw[l][1], sq if sq else c[l]))
+            for l in range(1, n):
+                nb = self._bn_boxes[self.up[l].key]
+                rl.append((ustat[l], nb.running_mean, nb.running_var, nb.num_batches_tracked, c[l - 1], hw[l - 1][0] * hw[l - 1][1], c[l - 1]))
+            for i0 in range(0, len(rl), 8):
+                ops.bn_running_update(rl[i0: i0 + 8], BN_MOMENTUM)
         saved = dict(final_act=final_act, x=x, hw=hw, cat=cat, catw=catw, catstat=catstat, ustat=ustat, xr=xr, xstat=xstat, u=u, masks=masks,
-                     out=out, lay=lay, total=total, bwd=_BwdArena(arena[total:]))
+                     out=out, lay=lay, total=total, bwd=_BwdArena(arena[total:]), cataff=cataff)
         return [out], saved
 
     def _run_backward(self, x, outs, S, dout, need_dx, want_wgrad):
@@ -817,22 +863,25 @@ class UnetGenerator(ChainNet):
             else:
                 ops.conv_dgrad_grouped(djob)
 
+        cataff = S.get("cataff")
         # final transposed conv: gradient of ReLU(cat_1)
-        nrm = self._cat_norm(1, hw, catstat)
+        nrm = self._cat_norm(1, hw, catstat, cataff)
         bwd(self.up[0], upd[0], cat[1], nrm, d0, dcat[1], None)
         # decoder, outermost block first
         d_inner = None
         for l in range(1, n):
             dy = dcat[l][:, :, :c[l - 1]]
-            un = ops.norm_desc(ustat[l], None, None, hw[l - 1][0] * hw[l - 1][1], IN_EPS, ACT_NONE, 0.0)
+            ug, ub = self._affine(self.up[l])
+            un = ops.norm_desc(ustat[l], ug, ub, hw[l - 1][0] * hw[l - 1][1], IN_EPS, ACT_NONE, 0.0)
             ops.norm_apply_bwd_sums(dy, u[l], un, usum[l], masks[l])
-            ops.norm_bwd_apply(dy, u[l], un, usum[l])                       # dy is now d(up[l] output)
+            dug, dub = self._affine(self.up[l], grad=True) if want_wgrad else (None, None)
+            ops.norm_bwd_apply(dy, u[l], un, usum[l], dug, dub)             # dy is now d(up[l] output)
             if l == n - 1:
                 src, nrm = xr[l], ops.norm_desc(None, None, None, 1, 0.0, ACT_RELU, 0.0)
                 d_inner = torch.empty(hw[l] + (c[l],), dtype=torch.float32, device=dev)
                 din, sums = d_inner, None
             else:
-                src, nrm = cat[l + 1], self._cat_norm(l + 1, hw, catstat)
+                src, nrm = cat[l + 1], self._cat_norm(l + 1, hw, catstat, cataff)
                 din = dcat[l + 1]
                 sums = csum[l + 1] if (skip[l + 1] and l + 1 > 1) else None
             bwd(self.up[l], upd[l], src, nrm, dy, din, sums)
@@ -850,7 +899,8 @@ class UnetGenerator(ChainNet):
                 din = torch.empty(hw[l - 1] + (c[l - 1],), dtype=torch.float32, device=dev)
                 bwd(self.down[l], dn[l], src, nrm, dr, din, sums, sq)
             if normed:
-                ops.norm_bwd_apply(din, src, nrm, sums, None, None, sq)
+                dg, db = self._affine(self.down[l - 1], grad=True) if want_wgrad else (None, None)
+                ops.norm_bwd_apply(din, src, nrm, sums, dg, db, sq)
             dr = din
         wgrad(self.down[0], dn[0], x, None, dr)
         dx = None

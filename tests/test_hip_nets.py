@@ -213,7 +213,8 @@ def test_grouped_chains_equal_individual_chains(N):
 # ------------------------------------------------------------------------------------------------
 UNET_SMALL = {"skipall_dropout": dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False),
               "skip4_noise": dict(use_dropout=False, num_skips=4, add_gaussian_noise=True),
-              "residual": dict(use_dropout=False, num_skips=-1, add_gaussian_noise=False, use_residual=True, out_nc=2)}
+              "residual": dict(use_dropout=False, num_skips=-1, add_gaussian_noise=False, use_residual=True, out_nc=2),
+              "batchnorm": dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False, norm="batch")}
 
 
 def inject_unet_random(G, H, mask_seed, noise_seed):
@@ -235,9 +236,10 @@ def test_unet_small(N, golden_dir, tag):
     g = load(golden_dir, f"unet_small_{tag}.npz")
     kw = UNET_SMALL[tag]
     onc = kw.get("out_nc", 1)      # "residual": --use_residual, tanh(x + y) on 2 -> 2 channels (models/networks.py:367)
-    G = N.define_G(2, onc, 8, "unet_128", "instance", kw["use_dropout"], n_layers_G_skip=kw["num_skips"],
+    norm = kw.get("norm", "instance")      # "batchnorm": --norm batch (affine + running statistics, networks.py:43-50,387-389)
+    G = N.define_G(2, onc, 8, "unet_128", norm, kw["use_dropout"], n_layers_G_skip=kw["num_skips"],
                    add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, use_residual=kw.get("use_residual", False), gpu_ids=[0])
-    sd = O.init_unet(31, 7, 2, onc, 8, kw["num_skips"])
+    sd = O.init_unet(31, 7, 2, onc, 8, kw["num_skips"], norm=norm)
     assert set(G.state_dict().keys()) == set(sd.keys())
     assert list(G.state_dict().keys())[:3] == ['model.0.weight', 'model.0.bias', 'model.1.model.1.weight']     # nn.Sequential order
     assert list(G.state_dict().keys())[-2:] == ['model.3.weight', 'model.3.bias']
@@ -262,6 +264,9 @@ def test_unet_small(N, golden_dir, tag):
             assert np.abs(params[name].grad.cpu().numpy()).max() < TOL * scale, name
         else:
             assert rel(params[name].grad, g[k]) < TOL, name
+    for k in g.files:      # --norm batch: the running statistics the forward left behind
+        if k.startswith("buf/"):
+            assert rel(G.state_dict()[k[4:]].double(), g[k].astype(np.float64)) < TOL, k
 
 
 @pytest.mark.parametrize("tag,which,nb,drop,res", [("6", "resnet_6blocks", 6, False, False), ("9_dropout", "resnet_9blocks", 9, True, False),

@@ -271,7 +271,8 @@ def test_fcgan_step(golden_dir, name, kw):
 # ------------------------------------------------------------------------------------------------
 UNET_SMALL = {"skipall_dropout": dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False),
               "skip4_noise": dict(use_dropout=False, num_skips=4, add_gaussian_noise=True),
-              "residual": dict(use_dropout=False, num_skips=-1, add_gaussian_noise=False, use_residual=True, out_nc=2)}
+              "residual": dict(use_dropout=False, num_skips=-1, add_gaussian_noise=False, use_residual=True, out_nc=2),
+              "batchnorm": dict(use_dropout=True, num_skips=-1, add_gaussian_noise=False, norm="batch")}
 
 
 def unet_small_inputs(out_nc=1):
@@ -282,20 +283,24 @@ def unet_small_inputs(out_nc=1):
 def test_unet_small(golden_dir, tag):
     g = load(golden_dir, f"unet_small_{tag}.npz")
     kw = UNET_SMALL[tag]
-    sd = O.init_unet(31, 7, 2, kw.get("out_nc", 1), 8, kw["num_skips"])
-    for v in sd.values():
-        v.requires_grad_(True)
+    norm = kw.get("norm", "instance")      # "batchnorm": --norm batch, BatchNorm2d(affine) behind the down / up convs (networks.py:387-389)
+    sd = O.init_unet(31, 7, 2, kw.get("out_nc", 1), 8, kw["num_skips"], norm=norm)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
     x, r = unet_small_inputs(kw.get("out_nc", 1))
     x.requires_grad_(True)
     y = O.unet_forward(sd, x, 7, 8, kw["num_skips"], kw["use_dropout"], mask_seed=40,
                        add_gaussian_noise=kw["add_gaussian_noise"], gaussian_sigma=0.1, noise_seed=50,
-                       use_residual=kw.get("use_residual", False))
+                       use_residual=kw.get("use_residual", False), norm=norm)
     (y * r).sum().backward()
     assert rel(y, g["y"]) < TIGHT * 5
     assert rel(x.grad, g["dx"]) < 1e-4
     undet = O.norm_cancelled_keys_unet(7, 8, kw["num_skips"])
     for k, v in sd.items():
-        if k in undet:
+        if "running" in k or "num_batches" in k:
+            assert rel(v.double(), g["buf/" + k].astype(np.float64)) < 1e-5, k
+        elif k in undet:
             assert float(v.grad.abs().max()) <= 1e-3 * float(sd[k.replace(".bias", ".weight")].grad.abs().max())
         else:
             assert rel(v.grad, g["grad/" + k]) < 1e-4, k

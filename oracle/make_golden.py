@@ -447,12 +447,13 @@ class SeqDropoutInjector:
 def golden_resnet_small(only=()):
     """resnet_6blocks without dropout and resnet_9blocks with dropout at 64x64, ngf 8, 2 -> 1 channels (models/networks.py:221-311)."""
     for tag, which, nb, drop, res in (("6", "resnet_6blocks", 6, False, False), ("9_dropout", "resnet_9blocks", 9, True, False),
-                                      ("6_residual", "resnet_6blocks", 6, False, True)):
+                                      ("6_residual", "resnet_6blocks", 6, False, True), ("6_batchnorm", "resnet_6blocks", 6, True, False)):
         if only and tag not in only:
             continue
+        norm = "batch" if "batchnorm" in tag else "instance"
         ngf, in_nc, out_nc, hw = 8, 2, 2 if res else 1, 64
-        sd = O.init_resnet(41, in_nc, out_nc, ngf, nb, drop)
-        g = RN.define_G(in_nc, out_nc, ngf, which, "instance", drop, use_residual=res, gpu_ids=[])
+        sd = O.init_resnet(41, in_nc, out_nc, ngf, nb, drop, norm=norm)
+        g = RN.define_G(in_nc, out_nc, ngf, which, norm, drop, use_residual=res, gpu_ids=[])
         load_sd(g, sd)
         x = O.np_uniform(311, (1, in_nc, hw, hw)).requires_grad_(True)
         r = O.np_normal(312, (1, out_nc, hw, hw))
@@ -463,6 +464,9 @@ def golden_resnet_small(only=()):
         arrs = {"y": y.detach().numpy(), "dx": x.grad.numpy(), "loss": np.float64(loss.item())}
         for k, p in g.named_parameters():
             arrs["grad/" + k] = p.grad.numpy()
+        for k, v in g.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                arrs["buf/" + k] = v.numpy()
         save(f"resnet_small_{tag}.npz", **arrs)
 
 
@@ -1130,6 +1134,8 @@ def main():
         golden_unet_small(("residual",))
     if "unet_batchnorm" in only:
         golden_unet_small(("batchnorm",))
+    if "resnet_batchnorm" in only:
+        golden_resnet_small(("6_batchnorm",))
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
         golden_autoencoder_dropout()

@@ -505,7 +505,7 @@ def init_unet(seed: int, num_downs: int, input_nc: int, output_nc: int, ngf: int
     return sd
 
 
-def init_resnet(seed: int, input_nc: int, output_nc: int, ngf: int, n_blocks: int, use_dropout: bool = False):
+def init_resnet(seed: int, input_nc: int, output_nc: int, ngf: int, n_blocks: int, use_dropout: bool = False, norm: str = "instance"):
     """numpy-seeded state dict with ResnetGenerator's keys / shapes (models/networks.py:232-262, :282-300, norm 'instance'):
     N(0, 0.02) conv weights (weights_init :13-19), torch-default uniform biases."""
     sd = OrderedDict()
@@ -520,27 +520,38 @@ def init_resnet(seed: int, input_nc: int, output_nc: int, ngf: int, n_blocks: in
         sd[key + ".weight"] = np_normal(seed * 1000 + 2 * k, (ci, co, ks, ks) if tr else (co, ci, ks, ks), 0.0, 0.02)
         b = 1.0 / math.sqrt((co if tr else ci) * ks * ks)      # torch computes fan_in from weight.size(1)
         sd[key + ".bias"] = np_uniform(seed * 1000 + 2 * k + 1, (co,), -b, b)
+        if norm == "batch" and k < len(convs) - 1:      # every conv but the last is followed by norm_layer(co)
+            _init_bn(sd, _next_key(key), co, seed * 1000 + 700 + k)
     return sd
 
 
-def resnet_forward(sd, x, n_blocks: int, use_dropout: bool = False, mask_seed: int = 0, tanh: bool = True, use_residual: bool = False):
+def resnet_forward(sd, x, n_blocks: int, use_dropout: bool = False, mask_seed: int = 0, tanh: bool = True, use_residual: bool = False,
+                   norm: str = "instance"):
     """ResnetGenerator.forward (models/networks.py:221-268) with ResnetBlock (:271-311), padding_type 'reflect', InstanceNorm:
     the i-th block's Dropout(0.5) mask is dropout_mask_np(mask_seed + i, shape)."""
-    inorm = lambda t: F.instance_norm(t, eps=1e-5)      # noqa: E731
+    def inorm(t, conv_key):
+        """norm_layer behind the conv `conv_key`: InstanceNorm2d(affine=False), or BatchNorm2d in train mode with --norm batch."""
+        if norm != "batch":
+            return F.instance_norm(t, eps=1e-5)
+        k = _next_key(conv_key)
+        sd[k + ".num_batches_tracked"] += 1
+        return F.batch_norm(t, sd[k + ".running_mean"], sd[k + ".running_var"], sd[k + ".weight"], sd[k + ".bias"], training=True,
+                            momentum=BN_MOMENTUM, eps=BN_EPS)
+
     rpad = lambda t, p: F.pad(t, (p, p, p, p), mode="reflect")      # noqa: E731
-    h = F.relu(inorm(F.conv2d(rpad(x, 3), sd["model.1.weight"], sd["model.1.bias"])))
+    h = F.relu(inorm(F.conv2d(rpad(x, 3), sd["model.1.weight"], sd["model.1.bias"]), "model.1"))
     for key in ("model.4", "model.7"):
-        h = F.relu(inorm(F.conv2d(h, sd[key + ".weight"], sd[key + ".bias"], stride=2, padding=1)))
+        h = F.relu(inorm(F.conv2d(h, sd[key + ".weight"], sd[key + ".bias"], stride=2, padding=1), key))
     second = 6 if use_dropout else 5
     for i in range(n_blocks):
         p = f"model.{10 + i}.conv_block."
-        t = F.relu(inorm(F.conv2d(rpad(h, 1), sd[p + "1.weight"], sd[p + "1.bias"])))
+        t = F.relu(inorm(F.conv2d(rpad(h, 1), sd[p + "1.weight"], sd[p + "1.bias"]), p + "1"))
         if use_dropout:
             t = t * dropout_mask_np(mask_seed + i, t.shape)
-        h = h + inorm(F.conv2d(rpad(t, 1), sd[p + f"{second}.weight"], sd[p + f"{second}.bias"]))
+        h = h + inorm(F.conv2d(rpad(t, 1), sd[p + f"{second}.weight"], sd[p + f"{second}.bias"]), p + f"{second}")
     nb = 10 + n_blocks
     for key in (f"model.{nb}", f"model.{nb + 3}"):
-        h = F.relu(inorm(F.conv_transpose2d(h, sd[key + ".weight"], sd[key + ".bias"], stride=2, padding=1, output_padding=1)))
+        h = F.relu(inorm(F.conv_transpose2d(h, sd[key + ".weight"], sd[key + ".bias"], stride=2, padding=1, output_padding=1), key))
     y = F.conv2d(rpad(h, 3), sd[f"model.{nb + 7}.weight"], sd[f"model.{nb + 7}.bias"])
     # the reference applies Tanh TWICE without --use_residual: once as the last module of self.model (:261-262) and again in
     # forward() (:268: `nn.Tanh()(y)`); with --use_residual the Sequential ends in the conv (:258-259) and forward() is tanh(x + y)

@@ -345,20 +345,19 @@ class ResnetGenerator(ChainNet):
     final_act = ACT_TANH
 
     def __init__(self, input_nc, output_nc, ngf=64, norm="instance", use_dropout=False, n_blocks=6, use_residual=False, gpu_ids=[]):
-        if norm != "instance":
-            raise NotImplementedError("ResnetGenerator on the MI355X path implements --norm instance")
+        nrm = {"instance": "in", "batch": "bn"}[norm]      # get_norm_layer (networks.py:43-50)
         self.use_residual = bool(use_residual)      # the Sequential then ends without its nn.Tanh (:258-259); forward() adds the input
         self.n_blocks, self.use_dropout, self.input_nc, self.output_nc = int(n_blocks), bool(use_dropout), input_nc, output_nc
         C = 4 * ngf
-        self.c0 = LayerSpec("1", CONV, 7, 1, 0, input_nc, ngf, True, "in", ACT_RELU)
-        self.d1 = LayerSpec("4", CONV, 3, 2, 1, ngf, 2 * ngf, True, "in", ACT_RELU)
-        self.d2 = LayerSpec("7", CONV, 3, 2, 1, 2 * ngf, C, True, "in", ACT_RELU)
+        self.c0 = LayerSpec("1", CONV, 7, 1, 0, input_nc, ngf, True, nrm, ACT_RELU)
+        self.d1 = LayerSpec("4", CONV, 3, 2, 1, ngf, 2 * ngf, True, nrm, ACT_RELU)
+        self.d2 = LayerSpec("7", CONV, 3, 2, 1, 2 * ngf, C, True, nrm, ACT_RELU)
         second = 6 if use_dropout else 5
-        self.blocks = [(LayerSpec("%d.conv_block.1" % (10 + i), CONV, 3, 1, 0, C, C, True, "in", ACT_RELU),
-                        LayerSpec("%d.conv_block.%d" % (10 + i, second), CONV, 3, 1, 0, C, C, True, "in", ACT_NONE)) for i in range(n_blocks)]
+        self.blocks = [(LayerSpec("%d.conv_block.1" % (10 + i), CONV, 3, 1, 0, C, C, True, nrm, ACT_RELU),
+                        LayerSpec("%d.conv_block.%d" % (10 + i, second), CONV, 3, 1, 0, C, C, True, nrm, ACT_NONE)) for i in range(n_blocks)]
         nb = 10 + n_blocks
-        self.u1 = LayerSpec(str(nb), CONVT, 3, 2, 1, C, 2 * ngf, True, "in", ACT_RELU)
-        self.u2 = LayerSpec(str(nb + 3), CONVT, 3, 2, 1, 2 * ngf, ngf, True, "in", ACT_RELU)
+        self.u1 = LayerSpec(str(nb), CONVT, 3, 2, 1, C, 2 * ngf, True, nrm, ACT_RELU)
+        self.u2 = LayerSpec(str(nb + 3), CONVT, 3, 2, 1, 2 * ngf, ngf, True, nrm, ACT_RELU)
         self.cl = LayerSpec(str(nb + 7), CONV, 7, 1, 0, ngf, output_nc, True, None, ACT_NONE)
         super().__init__([self.c0, self.d1, self.d2] + [l for ab in self.blocks for l in ab] + [self.u1, self.u2, self.cl])
         self.gpu_ids = gpu_ids
@@ -389,7 +388,10 @@ class ResnetGenerator(ChainNet):
             self._geom_cache[key] = ops.conv_desc(L.kind, L.k, L.stride, L.pad, hin, win, L.cin_s, hout, wout, L.cout_s, L.cin, L.cout)
         return self._geom_cache[key]
 
-    def _in(self, st, count, act):
+    def _in(self, L, st, count, act):
+        """How a consumer reads layer L's raw output: its norm (InstanceNorm, or BatchNorm with the layer's affine) + activation."""
+        if L.norm == "bn":
+            return ops.norm_desc(st, self._flat[L.g_off: L.g_off + L.cout_s], self._flat[L.be_off: L.be_off + L.cout_s], count, BN_EPS, act, 0.0)
         return ops.norm_desc(st, None, None, count, IN_EPS, act, 0.0)
 
     # ---- programs ------------------------------------------------------------------------------
@@ -417,11 +419,11 @@ class ResnetGenerator(ChainNet):
         c0 = E(H, W, ngf)
         ops.conv_fwd(self._desc(self.c0, H + 6, W + 6, H, W), xp, None, *self._wb(self.c0), c0, ACT_NONE, st[self.c0.key])
         d1 = E(h2, w2, self.d1.cout_s)
-        ops.conv_fwd(self._desc(self.d1, H, W, h2, w2), c0, self._in(st[self.c0.key], H * W, ACT_RELU), *self._wb(self.d1), d1, ACT_NONE, st[self.d1.key])
+        ops.conv_fwd(self._desc(self.d1, H, W, h2, w2), c0, self._in(self.c0, st[self.c0.key], H * W, ACT_RELU), *self._wb(self.d1), d1, ACT_NONE, st[self.d1.key])
         d2 = E(h4, w4, C)
-        ops.conv_fwd(self._desc(self.d2, h2, w2, h4, w4), d1, self._in(st[self.d1.key], h2 * w2, ACT_RELU), *self._wb(self.d2), d2, ACT_NONE, st[self.d2.key])
+        ops.conv_fwd(self._desc(self.d2, h2, w2, h4, w4), d1, self._in(self.d1, st[self.d1.key], h2 * w2, ACT_RELU), *self._wb(self.d2), d2, ACT_NONE, st[self.d2.key])
         b = E(h4, w4, C)
-        ops.pad_reflect_fwd(d2, self._in(st[self.d2.key], h4 * w4, ACT_RELU), 0, b)
+        ops.pad_reflect_fwd(d2, self._in(self.d2, st[self.d2.key], h4 * w4, ACT_RELU), 0, b)
         if self.use_dropout and (self._rng_offset is None or self._rng_offset.device != dev):
             self._rng_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         d3 = self._desc(self.blocks[0][0], h4 + 2, w4 + 2, h4, w4) if self.blocks else None
@@ -440,11 +442,11 @@ class ResnetGenerator(ChainNet):
                 else:
                     ops.dropout_mask(mask, 0.5, self._rng_seed + i, self._rng_offset, advance=False)
             p2 = E(h4 + 2, w4 + 2, C)
-            ops.pad_reflect_fwd(a, self._in(st[A.key], h4 * w4, ACT_RELU), 1, p2, mask)
+            ops.pad_reflect_fwd(a, self._in(A, st[A.key], h4 * w4, ACT_RELU), 1, p2, mask)
             c = E(h4, w4, C)
             ops.conv_fwd(d3, p2, None, *self._wb(B), c, ACT_NONE, st[B.key])
             bn = E(h4, w4, C)
-            ops.norm_apply_fwd(c, self._in(st[B.key], h4 * w4, ACT_NONE), bn, None, b, 1.0)      # x + IN(conv)
+            ops.norm_apply_fwd(c, self._in(B, st[B.key], h4 * w4, ACT_NONE), bn, None, b, 1.0)      # x + IN(conv)
             blk.append((p1, a, mask, p2, c))
             b = bn
         if self.use_dropout and getattr(self, "mask_source", None) is None and self.blocks:
@@ -452,11 +454,19 @@ class ResnetGenerator(ChainNet):
         u1 = E(h2, w2, self.u1.cout_s)
         ops.conv_fwd(self._desc(self.u1, h4, w4, h2, w2), b, None, *self._wb(self.u1), u1, ACT_NONE, st[self.u1.key])
         u2 = E(H, W, ngf)
-        ops.conv_fwd(self._desc(self.u2, h2, w2, H, W), u1, self._in(st[self.u1.key], h2 * w2, ACT_RELU), *self._wb(self.u2), u2, ACT_NONE, st[self.u2.key])
+        ops.conv_fwd(self._desc(self.u2, h2, w2, H, W), u1, self._in(self.u1, st[self.u1.key], h2 * w2, ACT_RELU), *self._wb(self.u2), u2, ACT_NONE, st[self.u2.key])
         pl = E(H + 6, W + 6, ngf)
-        ops.pad_reflect_fwd(u2, self._in(st[self.u2.key], H * W, ACT_RELU), 3, pl)
+        ops.pad_reflect_fwd(u2, self._in(self.u2, st[self.u2.key], H * W, ACT_RELU), 3, pl)
         y = E(H, W, self.cl.cout_s)
         ops.conv_fwd(self._desc(self.cl, H + 6, W + 6, H, W), pl, None, *self._wb(self.cl), y, final_act, None)
+        if self._bn_boxes and update_running and self.training:      # --norm batch: running statistics of every BatchNorm
+            cnt = {self.c0.key: H * W, self.d1.key: h2 * w2, self.d2.key: h4 * w4, self.u1.key: h2 * w2, self.u2.key: H * W}
+            rl = []
+            for L in normed:
+                nb = self._bn_boxes[L.key]
+                rl.append((st[L.key], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, cnt.get(L.key, h4 * w4), L.cout_s))
+            for i0 in range(0, len(rl), 8):
+                ops.bn_running_update(rl[i0: i0 + 8], BN_MOMENTUM)
         S.update(xp=xp, c0=c0, d1=d1, d2=d2, blk=blk, b_last=b, u1=u1, u2=u2, pl=pl, y=y)
         return [y], S
 
@@ -484,8 +494,13 @@ class ResnetGenerator(ChainNet):
             if want_wgrad:
                 ops.conv_wgrad(desc, src, nrm, d, *self._gwb(L))
 
+        def affine_grads(L):
+            if L.norm != "bn" or not want_wgrad:
+                return None, None
+            return self._gflat[L.g_off: L.g_off + L.cout_s], self._gflat[L.be_off: L.be_off + L.cout_s]
+
         def norm_bwd(d, xraw, L, count, act):
-            ops.norm_bwd_apply(d, xraw, self._in(st[L.key], count, act), sums[L.key])
+            ops.norm_bwd_apply(d, xraw, self._in(L, st[L.key], count, act), sums[L.key], *affine_grads(L))
 
         # last conv (k7 over the padded, activated u2)
         dcl = self._desc(self.cl, H + 6, W + 6, H, W)
@@ -493,10 +508,10 @@ class ResnetGenerator(ChainNet):
         dpl = E(H + 6, W + 6, ngf)
         ops.conv_dgrad(dcl, dy, self._wt(self.cl), dpl, None, None, None, w_transposed=True)
         du2 = E(H, W, ngf)
-        ops.pad_reflect_bwd(dpl, 3, du2, S["u2"], self._in(st[self.u2.key], H * W, ACT_RELU), None, sums[self.u2.key])
+        ops.pad_reflect_bwd(dpl, 3, du2, S["u2"], self._in(self.u2, st[self.u2.key], H * W, ACT_RELU), None, sums[self.u2.key])
         norm_bwd(du2, S["u2"], self.u2, H * W, ACT_RELU)
         # the two transposed convs
-        n_u1 = self._in(st[self.u1.key], h2 * w2, ACT_RELU)
+        n_u1 = self._in(self.u1, st[self.u1.key], h2 * w2, ACT_RELU)
         du = self._desc(self.u2, h2, w2, H, W)
         wgrad(self.u2, du, S["u1"], n_u1, du2)
         du1 = E(h2, w2, self.u1.cout_s)
@@ -510,14 +525,14 @@ class ResnetGenerator(ChainNet):
         d3 = self._desc(self.blocks[0][0], h4 + 2, w4 + 2, h4, w4) if self.blocks else None
         for (A, B), (p1, a, mask, p2, c) in zip(reversed(self.blocks), reversed(S["blk"])):
             dc = db.clone()
-            n_c = self._in(st[B.key], h4 * w4, ACT_NONE)
+            n_c = self._in(B, st[B.key], h4 * w4, ACT_NONE)
             ops.norm_apply_bwd_sums(dc, c, n_c, sums[B.key])
-            ops.norm_bwd_apply(dc, c, n_c, sums[B.key])
+            ops.norm_bwd_apply(dc, c, n_c, sums[B.key], *affine_grads(B))
             wgrad(B, d3, p2, None, dc)
             dp2 = E(h4 + 2, w4 + 2, C)
             ops.conv_dgrad(d3, dc, self._wt(B), dp2, None, None, None, w_transposed=True)
             da = E(h4, w4, C)
-            ops.pad_reflect_bwd(dp2, 1, da, a, self._in(st[A.key], h4 * w4, ACT_RELU), mask, sums[A.key])
+            ops.pad_reflect_bwd(dp2, 1, da, a, self._in(A, st[A.key], h4 * w4, ACT_RELU), mask, sums[A.key])
             norm_bwd(da, a, A, h4 * w4, ACT_RELU)
             wgrad(A, d3, p1, None, da)
             dp1 = E(h4 + 2, w4 + 2, C)
@@ -527,15 +542,15 @@ class ResnetGenerator(ChainNet):
             db.add_(dbi)
         # block input = relu(IN(d2)), materialised with pad 0
         dd2 = E(h4, w4, C)
-        ops.pad_reflect_bwd(db, 0, dd2, S["d2"], self._in(st[self.d2.key], h4 * w4, ACT_RELU), None, sums[self.d2.key])
+        ops.pad_reflect_bwd(db, 0, dd2, S["d2"], self._in(self.d2, st[self.d2.key], h4 * w4, ACT_RELU), None, sums[self.d2.key])
         norm_bwd(dd2, S["d2"], self.d2, h4 * w4, ACT_RELU)
-        n_d1 = self._in(st[self.d1.key], h2 * w2, ACT_RELU)
+        n_d1 = self._in(self.d1, st[self.d1.key], h2 * w2, ACT_RELU)
         dd = self._desc(self.d2, h2, w2, h4, w4)
         wgrad(self.d2, dd, S["d1"], n_d1, dd2)
         dd1 = E(h2, w2, self.d1.cout_s)
         ops.conv_dgrad(dd, dd2, self._wt(self.d2), dd1, S["d1"], n_d1, sums[self.d1.key], w_transposed=True)
         norm_bwd(dd1, S["d1"], self.d1, h2 * w2, ACT_RELU)
-        n_c0 = self._in(st[self.c0.key], H * W, ACT_RELU)
+        n_c0 = self._in(self.c0, st[self.c0.key], H * W, ACT_RELU)
         dd = self._desc(self.d1, H, W, h2, w2)
         wgrad(self.d1, dd, S["c0"], n_c0, dd1)
         dc0 = E(H, W, ngf)

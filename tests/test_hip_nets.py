@@ -270,15 +270,16 @@ def test_unet_small(N, golden_dir, tag):
 
 
 @pytest.mark.parametrize("tag,which,nb,drop,res", [("6", "resnet_6blocks", 6, False, False), ("9_dropout", "resnet_9blocks", 9, True, False),
-                                                   ("6_residual", "resnet_6blocks", 6, False, True)])
+                                                   ("6_residual", "resnet_6blocks", 6, False, True), ("6_batchnorm", "resnet_6blocks", 6, True, False)])
 def test_resnet_small(N, golden_dir, tag, which, nb, drop, res):
     """--which_model_netG resnet_6blocks / resnet_9blocks (models/networks.py:221-311) on the HIP path against the reference golden:
     reflection padding (materialised gather), 49-tap k7 layers, stride-2 convs, residual blocks with dropout, ConvT k3 s2 with
     output padding; state_dict keys and order as the reference's nn.Sequential."""
     g = load(golden_dir, f"resnet_small_{tag}.npz")
     onc = 2 if res else 1      # --use_residual: no Tanh module at the end of the Sequential, forward() = tanh(x + y) (:258-268)
-    G = N.define_G(2, onc, 8, which, "instance", drop, use_residual=res, gpu_ids=[0])
-    sd = O.init_resnet(41, 2, onc, 8, nb, drop)
+    norm = "batch" if "batchnorm" in tag else "instance"      # --norm batch: BatchNorm2d (affine, running statistics) behind every conv but the last
+    G = N.define_G(2, onc, 8, which, norm, drop, use_residual=res, gpu_ids=[0])
+    sd = O.init_resnet(41, 2, onc, 8, nb, drop, norm=norm)
     assert list(G.state_dict().keys()) == list(sd.keys())
     G.load_state_dict(sd)
     G.mask_source = lambda i, shape: O.dropout_mask_np(60 + i, (1, shape[2], shape[0], shape[1]))[0].permute(1, 2, 0).contiguous().cuda()
@@ -296,11 +297,14 @@ def test_resnet_small(N, golden_dir, tag, which, nb, drop, res):
         if not k.startswith("grad/"):
             continue
         name = k[5:]
-        if name.endswith(".bias") and name != last:
+        if name.endswith(".bias") and name != last and params[name.replace(".bias", ".weight")].dim() == 4:
             scale = np.abs(params[name.replace(".bias", ".weight")].grad.cpu().numpy()).max()
             assert np.abs(params[name].grad.cpu().numpy()).max() < TOL * scale, name
         else:
             assert rel(params[name].grad, g[k]) < TOL, name
+    for k in g.files:      # --norm batch: the running statistics the forward left behind (running_mean follows the undetermined conv bias: skipped)
+        if k.startswith("buf/") and not k.endswith("running_mean"):
+            assert rel(G.state_dict()[k[4:]].double(), g[k].astype(np.float64)) < TOL, k
     if drop:      # without injected masks: Philox masks, a fresh set per forward, still a valid tanh image
         G.mask_source = None
         y1, y2 = G.forward(x.detach()), G.forward(x.detach())

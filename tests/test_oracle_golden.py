@@ -307,7 +307,8 @@ def test_unet_small(golden_dir, tag):
 
 
 RESNET_SMALL = {"6": dict(n_blocks=6, use_dropout=False), "9_dropout": dict(n_blocks=9, use_dropout=True),
-                "6_residual": dict(n_blocks=6, use_dropout=False, use_residual=True, out_nc=2)}
+                "6_residual": dict(n_blocks=6, use_dropout=False, use_residual=True, out_nc=2),
+                "6_batchnorm": dict(n_blocks=6, use_dropout=True, norm="batch")}
 
 
 @pytest.mark.parametrize("tag", list(RESNET_SMALL))
@@ -317,18 +318,22 @@ def test_resnet_small(golden_dir, tag):
     g = load(golden_dir, f"resnet_small_{tag}.npz")
     kw = RESNET_SMALL[tag]
     onc = kw.get("out_nc", 1)
-    sd = O.init_resnet(41, 2, onc, 8, kw["n_blocks"], kw["use_dropout"])
-    assert {"grad/" + k for k in sd} == {k for k in g.files if k.startswith("grad/")}
-    for v in sd.values():
-        v.requires_grad_(True)
+    norm = kw.get("norm", "instance")      # "6_batchnorm": --norm batch (BatchNorm2d with affine + running statistics behind every conv but the last)
+    sd = O.init_resnet(41, 2, onc, 8, kw["n_blocks"], kw["use_dropout"], norm=norm)
+    assert {"grad/" + k for k, v in sd.items() if v.is_floating_point() and "running" not in k} == {k for k in g.files if k.startswith("grad/")}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
     x, r = O.np_uniform(311, (1, 2, 64, 64)).requires_grad_(True), O.np_normal(312, (1, onc, 64, 64))
-    y = O.resnet_forward(sd, x, kw["n_blocks"], kw["use_dropout"], mask_seed=60, use_residual=kw.get("use_residual", False))
+    y = O.resnet_forward(sd, x, kw["n_blocks"], kw["use_dropout"], mask_seed=60, use_residual=kw.get("use_residual", False), norm=norm)
     (y * r).sum().backward()
     assert rel(y, g["y"]) < TIGHT * 5
     assert rel(x.grad, g["dx"]) < 1e-4
     last = f"model.{17 + kw['n_blocks']}.bias"
     for k, v in sd.items():
-        if k.endswith(".bias") and k != last:       # a bias in front of an InstanceNorm: analytically zero gradient
+        if "running" in k or "num_batches" in k:
+            assert rel(v.double(), g["buf/" + k].astype(np.float64)) < 1e-5, k
+        elif k.endswith(".bias") and k != last and sd[k.replace(".bias", ".weight")].dim() == 4:       # a conv bias in front of a norm: analytically zero gradient
             assert float(v.grad.abs().max()) <= 1e-3 * float(sd[k.replace(".bias", ".weight")].grad.abs().max())
         else:
             assert rel(v.grad, g["grad/" + k]) < 1e-4, k

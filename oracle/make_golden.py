@@ -575,13 +575,16 @@ def golden_fcgan_star_small():
     save("fcgan_star_small.npz", **arrs)
 
 
-def golden_crn_small():
+def golden_crn_small(only=()):
     """crn at 128x128 (label 2 ch, noise 8 x 2 x 2), ngf 8: ConvTranspose upsampling with 1-layer blocks, and the README's
     bilinear upsampling with 2-layer blocks; shared label block."""
-    for tag, mode, nlb in (("convt_b1", "convt", 1), ("bilinear_b2", "bilinear", 2)):
+    for tag, mode, nlb in (("convt_b1", "convt", 1), ("bilinear_b2", "bilinear", 2), ("bilinear_b2_batchnorm", "bilinear", 2)):
+        if only and tag not in only:
+            continue
+        norm = "batch" if "batchnorm" in tag else "instance"
         in_nc, out_nc, nz, ngf, hw = 2, 1, 8, 8, 128
-        sd = O.init_crn(41, in_nc, out_nc, nz, ngf, mode, nlb, True)
-        g = RN.define_G(in_nc, out_nc, ngf, "crn", "instance", False, n_layers_G=5, noise_nc=nz, upsample_mode=mode,
+        sd = O.init_crn(41, in_nc, out_nc, nz, ngf, mode, nlb, True, norm=norm)
+        g = RN.define_G(in_nc, out_nc, ngf, "crn", norm, False, n_layers_G=5, noise_nc=nz, upsample_mode=mode,
                         n_layers_CRN_block=nlb, share_label_weights=True, gpu_ids=[])
         assert list(g.state_dict().keys()) == list(sd.keys()), (list(g.state_dict().keys()), list(sd.keys()))
         load_sd(g, sd)
@@ -594,6 +597,9 @@ def golden_crn_small():
         arrs = {"y": y.detach().numpy(), "dlabel": label.grad.numpy(), "dz": z.grad.numpy(), "loss": np.float64(loss.item())}
         for k, p in g.named_parameters():
             arrs["grad/" + k] = p.grad.numpy()
+        for k, v in g.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                arrs["buf/" + k] = v.numpy()
         save(f"crn_small_{tag}.npz", **arrs)
 
 
@@ -1136,6 +1142,8 @@ def main():
         golden_unet_small(("batchnorm",))
     if "resnet_batchnorm" in only:
         golden_resnet_small(("6_batchnorm",))
+    if "crn_batchnorm" in only:
+        golden_crn_small(("bilinear_b2_batchnorm",))
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
         golden_autoencoder_dropout()

@@ -834,9 +834,17 @@ def crn_plan(input_nc: int, output_nc: int, noise_nc: int, ngf: int, upsample_mo
     return convs
 
 
+def _crn_norm_key(key: str, upsample_mode: str) -> str:
+    """The norm_layer module behind a CRN conv: the next child, except in the bilinear upsample block (Conv2d, Upsample, norm: :749-753)."""
+    if key.endswith(".0.model.0") and upsample_mode == "bilinear":
+        return key[:-1] + "2"
+    return _next_key(key)
+
+
 def init_crn(seed: int, input_nc: int, output_nc: int, noise_nc: int, ngf: int = 64, upsample_mode: str = "convt",
-             n_layers_block: int = 1, share_label_weights: bool = True):
+             n_layers_block: int = 1, share_label_weights: bool = True, norm: str = "instance"):
     sd = OrderedDict()
+    last = f"blockh0.1.model.{3 * (n_layers_block - 1) + 1}"
     for k, (key, kind, cin, cout, bias) in enumerate(crn_plan(input_nc, output_nc, noise_nc, ngf, upsample_mode, n_layers_block,
                                                               share_label_weights)):
         if kind == "convt":
@@ -846,16 +854,27 @@ def init_crn(seed: int, input_nc: int, output_nc: int, noise_nc: int, ngf: int =
             if bias:
                 b = 1.0 / math.sqrt(cin * 9)
                 sd[key + ".bias"] = np_uniform(seed * 1000 + 2 * k + 1, (cout,), -b, b)
+        if norm == "batch" and key != last:
+            _init_bn(sd, _crn_norm_key(key, upsample_mode), cout, seed * 1000 + 800 + k)
     return sd
 
 
 def crn_forward(sd, label, noise, ngf: int, upsample_mode: str = "convt", n_layers_block: int = 1,
-                share_label_weights: bool = True, tanh: bool = True, gauss_seed=None, gauss_sigma: float = 0.1):
+                share_label_weights: bool = True, tanh: bool = True, gauss_seed=None, gauss_sigma: float = 0.1, norm: str = "instance"):
     """CascadedRefinementNetwork.forward (:708-733) with CrnUpsampleBlock (:737-757) and CrnInterBlock (:760-787)
-    inlined; InstanceNorm2d(affine=False).  gauss_seed: --add_gaussian_noise, every upsample block but blockh0 adds
+    inlined; InstanceNorm2d(affine=False), or with norm 'batch' BatchNorm2d in train mode (the shared label block's one is applied,
+    and its running statistics updated, once per scale).  gauss_seed: --add_gaussian_noise, every upsample block but blockh0 adds
     gauss_sigma * gauss_noise_np(gauss_seed, shape) to its normalised output (:655-680,757-760)."""
     def conv3(x, key):
         return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride=1, padding=1)
+
+    def nrm(h, conv_key):
+        if norm != "batch":
+            return F.instance_norm(h, eps=IN_EPS)
+        k = _crn_norm_key(conv_key, upsample_mode)
+        sd[k + ".num_batches_tracked"] += 1
+        return F.batch_norm(h, sd[k + ".running_mean"], sd[k + ".running_var"], sd[k + ".weight"], sd[k + ".bias"], training=True,
+                            momentum=BN_MOMENTUM, eps=BN_EPS)
 
     def block(s, x):
         k0 = f"blockh{s}.0.model.0"
@@ -863,19 +882,21 @@ def crn_forward(sd, label, noise, ngf: int, upsample_mode: str = "convt", n_laye
             h = F.conv_transpose2d(x, sd[k0 + ".weight"], None, stride=2, padding=1)
         else:
             h = F.interpolate(conv3(x, k0), scale_factor=2, mode="bilinear", align_corners=False)
-        h = F.instance_norm(h, eps=IN_EPS)
+        h = nrm(h, k0)
         if gauss_seed is not None and s > 0:
             h = h + gauss_sigma * gauss_noise_np(gauss_seed, h.shape)
         for i in range(n_layers_block):
-            h = conv3(F.relu(h), f"blockh{s}.1.model.{3 * i + 1}")
+            ki = f"blockh{s}.1.model.{3 * i + 1}"
+            h = conv3(F.relu(h), ki)
             if not (s == 0 and i == n_layers_block - 1):
-                h = F.instance_norm(h, eps=IN_EPS)
+                h = nrm(h, ki)
         return h
 
     h = block(5, torch.cat([F.avg_pool2d(label, 64, 64), noise], 1))
     for s in range(4, -1, -1):
         l = F.avg_pool2d(label, 2 ** (s + 1), 2 ** (s + 1))
-        l = F.instance_norm(conv3(l, "blockl.0" if share_label_weights else f"blockl{s}.0"), eps=IN_EPS)
+        kl = "blockl.0" if share_label_weights else f"blockl{s}.0"
+        l = nrm(conv3(l, kl), kl)
         h = block(s, torch.cat([l, h], 1))
     return torch.tanh(h) if tanh else h
 

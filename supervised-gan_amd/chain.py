@@ -40,6 +40,7 @@ class LayerSpec:
     act: int                 # activation after the norm (applied by the consumer on load)
     slope: float = 0.0
     drop: float = 0.0        # nn.Dropout(p) between this layer's norm and its activation (training mode only)
+    norm_key: Optional[str] = None   # state-dict prefix of the BatchNorm when it is not the next numbered child (CRN bilinear upsample block)
     # filled by the net
     w_off: int = 0
     b_off: int = -1
@@ -122,8 +123,8 @@ class ChainNet(nn.Module):
                 nb.register_buffer("running_mean", torch.zeros(L.cout))
                 nb.register_buffer("running_var", torch.ones(L.cout))
                 nb.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
-                parts = L.key.split(".")      # the norm is the next numbered child of the same nn.Sequential
-                self._add_box(".".join(parts[:-1] + [str(int(parts[-1]) + 1)]), nb)
+                parts = L.key.split(".")      # the norm is the next numbered child of the same nn.Sequential (unless the layer says otherwise)
+                self._add_box(L.norm_key or ".".join(parts[:-1] + [str(int(parts[-1]) + 1)]), nb)
                 self._bn_boxes[L.key] = nb
         self._rebind()
         self._default_bias_init()

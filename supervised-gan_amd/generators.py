@@ -957,8 +957,8 @@ class CascadedRefinementNetwork(ChainNet):
     def __init__(self, input_nc, output_nc, noise_nc, ngf=64, n_layers=5, norm="instance", upsample_mode='convt',
                  add_gaussian_noise=False, gaussian_sigma=0.1, share_label_weights=True, n_layers_block=1, gpu_ids=[]):
         assert n_layers == 5
-        if norm != "instance":
-            raise NotImplementedError("CascadedRefinementNetwork on the MI355X path implements --norm instance")
+        nrm = {"instance": "in", "batch": "bn"}[norm]      # get_norm_layer (networks.py:43-50)
+        self.bn = nrm == "bn"
         if upsample_mode not in ('convt', 'bilinear'):
             raise NotImplementedError('UpsampleBlock mode [%s] is not recognized' % upsample_mode)
         if input_nc > 4:
@@ -974,26 +974,26 @@ class CascadedRefinementNetwork(ChainNet):
         for s in range(5, -1, -1):
             cin = noise_nc + input_nc if s == 5 else 2 * ngf
             if upsample_mode == 'convt':
-                u = LayerSpec(f"blockh{s}.0.model.0", CONVT, 4, 2, 1, cin, ngf, False, "in", ACT_NONE)
-            else:
-                u = LayerSpec(f"blockh{s}.0.model.0", CONV, 3, 1, 1, cin, ngf, True, "in", ACT_NONE)
+                u = LayerSpec(f"blockh{s}.0.model.0", CONVT, 4, 2, 1, cin, ngf, False, nrm, ACT_NONE)
+            else:      # [Conv2d, Upsample, norm]: the norm is child 2 (networks.py:749-753)
+                u = LayerSpec(f"blockh{s}.0.model.0", CONV, 3, 1, 1, cin, ngf, True, nrm, ACT_NONE, norm_key=f"blockh{s}.0.model.2")
             self.up[s] = u
             layers.append(u)
             self.inter[s] = []
             for i in range(n_layers_block):
                 last = s == 0 and i == n_layers_block - 1
                 L = LayerSpec(f"blockh{s}.1.model.{3 * i + 1}", CONV, 3, 1, 1, ngf, output_nc if last else ngf, True,
-                              None if last else "in", ACT_NONE)
+                              None if last else nrm, ACT_NONE)
                 self.inter[s].append(L)
                 layers.append(L)
         if share_label_weights:
-            L = LayerSpec("blockl.0", CONV, 3, 1, 1, input_nc, ngf, True, "in", ACT_NONE)
+            L = LayerSpec("blockl.0", CONV, 3, 1, 1, input_nc, ngf, True, nrm, ACT_NONE)
             layers.append(L)
             for s in range(5):
                 self.lab[s] = L
         else:
             for s in range(4, -1, -1):
-                self.lab[s] = LayerSpec(f"blockl{s}.0", CONV, 3, 1, 1, input_nc, ngf, True, "in", ACT_NONE)
+                self.lab[s] = LayerSpec(f"blockl{s}.0", CONV, 3, 1, 1, input_nc, ngf, True, nrm, ACT_NONE)
                 layers.append(self.lab[s])
         super().__init__(layers)
         del self.model          # the reference keeps its blocks as direct attributes: no `model.` prefix in state_dict keys
@@ -1009,6 +1009,26 @@ class CascadedRefinementNetwork(ChainNet):
             ho, wo = L.out_hw(h, w)
             self._geom_cache[key] = ops.conv_desc(L.kind, L.k, L.stride, L.pad, h, w, L.cin_s, ho, wo, L.cout_s, L.cin, L.cout)
         return self._geom_cache[key]
+
+    def _aff(self, L, grad=False):
+        """(gamma, beta) of layer L's BatchNorm in the flat parameter (or gradient) storage; (None, None) for InstanceNorm."""
+        if L is None or L.norm != "bn":
+            return None, None
+        flat = self._gflat if grad else self._flat
+        return flat[L.g_off: L.g_off + L.cout_s], flat[L.be_off: L.be_off + L.cout_s]
+
+    def _cat_affine(self):
+        """--norm batch: per concat buffer cat([l_s, h_{s+1}]) the affine of its two halves side by side (the label conv's BatchNorm,
+        the BatchNorm of stage s + 1's last inter conv).  Two torch.cat launches per forward."""
+        gs, bs = [], []
+        for s in range(5):
+            for L in (self.lab[s], self.inter[s + 1][-1]):
+                g, b = self._aff(L)
+                gs.append(g)
+                bs.append(b)
+        G, B = torch.cat(gs), torch.cat(bs)
+        C2 = 2 * pad4(self.ngf)
+        return {s: (G[s * C2: (s + 1) * C2], B[s * C2: (s + 1) * C2]) for s in range(5)}
 
     def run_forward(self, x, update_running=True):
         """x: dict(label=[H, W, 4] buffer, first=[H/64, W/64, pad4(input_nc + noise_nc)] buffer = cat([AvgPool64(label), noise]))
@@ -1047,7 +1067,10 @@ class CascadedRefinementNetwork(ChainNet):
             wt, b = self._wb(L)
             ops.conv_fwd(self._desc(L, *res[s]), lv[s], None, wt, b, cat[s][:, :, :ngf], ACT_NONE, st(("cat", s), 2 * C2), C2)
         final_act = self._take_call_act()
-        saved = dict(final_act=final_act, label=label, first=x["first"], lv=lv, cat=cat, c={}, u={}, un={}, t={}, arena=arena, lay=lay, off=off, res=res)
+        cataff = self._cat_affine() if self.bn else {s: (None, None) for s in range(5)}
+        saved = dict(final_act=final_act, label=label, first=x["first"], lv=lv, cat=cat, c={}, u={}, un={}, t={}, arena=arena, lay=lay, off=off, res=res,
+                     cataff=cataff)
+        running = []      # --norm batch: (layer, statistics, count, sq stride) in the reference's module order, for the running-statistics updates
         out = None
         drawn = 0
         for s in range(5, -1, -1):
@@ -1055,9 +1078,12 @@ class CascadedRefinementNetwork(ChainNet):
             U = self.up[s]
             wt, b = self._wb(U)
             src = x["first"] if s == 5 else cat[s]
-            nrm = None if s == 5 else ops.norm_desc(st(("cat", s), 2 * C2), None, None, h * w, IN_EPS, ACT_NONE, 0.0)
+            nrm = None if s == 5 else ops.norm_desc(st(("cat", s), 2 * C2), *cataff[s], h * w, IN_EPS, ACT_NONE, 0.0)
+            if s <= 4:
+                running.append((self.lab[s], st(("cat", s), 2 * C2), h * w, C2))
             u = torch.empty((2 * h, 2 * w, ngf), dtype=torch.float32, device=dev)
             ustat = st(("u", s), 2 * ngf)
+            running.append((U, ustat, 4 * h * w, 0))
             if self.mode == 'convt':
                 ops.conv_fwd(self._desc(U, h, w), src, nrm, wt, b, u, ACT_NONE, ustat)
             else:
@@ -1077,12 +1103,13 @@ class CascadedRefinementNetwork(ChainNet):
                     ops.normal_fill(nz, self._rng_seed + s, self._rng_offset, advance=False)
                     drawn = max(drawn, (nz.numel() + 3) // 4)
                 tn = torch.empty_like(u)
-                ops.norm_apply_fwd(u, ops.norm_desc(ustat, None, None, 4 * h * w, IN_EPS, ACT_NONE, 0.0), tn, None, nz, self.gauss_sigma)
+                ops.norm_apply_fwd(u, ops.norm_desc(ustat, *self._aff(U), 4 * h * w, IN_EPS, ACT_NONE, 0.0), tn, None, nz, self.gauss_sigma)
                 saved["un"][s] = tn
                 cur, cur_stat = tn, None
+            cur_L = U if cur_stat is not None else None      # whose norm the next conv applies on load
             for i, L in enumerate(self.inter[s]):
                 wt, b = self._wb(L)
-                nrm = ops.norm_desc(cur_stat, None, None, 4 * h * w, IN_EPS, ACT_RELU, 0.0)
+                nrm = ops.norm_desc(cur_stat, *self._aff(cur_L), 4 * h * w, IN_EPS, ACT_RELU, 0.0)
                 last_i = i == nlb - 1
                 if last_i and s == 0:
                     out = torch.empty((2 * h, 2 * w, L.cout_s), dtype=torch.float32, device=dev)
@@ -1090,12 +1117,19 @@ class CascadedRefinementNetwork(ChainNet):
                 elif last_i:   # feeds the next stage: right half of its concat buffer, statistics into the matching slice
                     dst = cat[s - 1][:, :, ngf:]
                     ops.conv_fwd(self._desc(L, 2 * h, 2 * w), cur, nrm, wt, b, dst, ACT_NONE, st(("cat", s - 1), 2 * C2)[ngf:], C2)
+                    running.append((L, st(("cat", s - 1), 2 * C2)[ngf:], 4 * h * w, C2))
                 else:
                     t = torch.empty((2 * h, 2 * w, ngf), dtype=torch.float32, device=dev)
                     tstat = st(("t", s, i), 2 * ngf)
                     ops.conv_fwd(self._desc(L, 2 * h, 2 * w), cur, nrm, wt, b, t, ACT_NONE, tstat)
                     saved["t"][(s, i)] = t
-                    cur, cur_stat = t, tstat
+                    cur, cur_stat, cur_L = t, tstat, L
+                    running.append((L, tstat, 4 * h * w, 0))
+        if self.bn and update_running and self.training:
+            # one launch per entry: the shared label block's BatchNorm is updated five times per forward, in order
+            for L, stt, cnt, sq in running:
+                nb = self._bn_boxes[L.key]
+                ops.bn_running_update([(stt, nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, cnt, sq if sq else L.cout_s)], BN_MOMENTUM)
         if drawn:
             ops.rng_advance(self._rng_offset, drawn)      # every stage read the same offset with its own seed
         saved["out"] = out
@@ -1143,16 +1177,17 @@ class CascadedRefinementNetwork(ChainNet):
                 src = (S["un"][s] if noisy else u) if i == 0 else S["t"][(s, i - 1)]
                 sstat = (None if noisy else ustat) if i == 0 else st(("t", s, i - 1), 2 * ngf)
                 ssum = sm(("u", s), 2 * ngf) if i == 0 else sm(("t", s, i - 1), 2 * ngf)
-                nrm = ops.norm_desc(sstat, None, None, 4 * h * w, IN_EPS, ACT_RELU, 0.0)
+                src_L = (None if noisy else self.up[s]) if i == 0 else self.inter[s][i - 1]      # whose norm `src` carries
+                nrm = ops.norm_desc(sstat, *self._aff(src_L), 4 * h * w, IN_EPS, ACT_RELU, 0.0)
                 desc = self._desc(L, 2 * h, 2 * w)
                 din = torch.empty((2 * h, 2 * w, ngf), dtype=torch.float32, device=dev)
                 bwd(L, desc, src, nrm, d, din, None if noisy else ssum)
                 if noisy:      # din = d t (the noise has no gradient): sums of the norm backward, then the norm backward itself
-                    unrm = ops.norm_desc(ustat, None, None, 4 * h * w, IN_EPS, ACT_NONE, 0.0)
+                    unrm = ops.norm_desc(ustat, *self._aff(self.up[s]), 4 * h * w, IN_EPS, ACT_NONE, 0.0)
                     ops.norm_apply_bwd_sums(din, u, unrm, ssum, None)
-                    ops.norm_bwd_apply(din, u, unrm, ssum)
+                    ops.norm_bwd_apply(din, u, unrm, ssum, *(self._aff(self.up[s], grad=True) if want_wgrad else (None, None)))
                 else:
-                    ops.norm_bwd_apply(din, src, nrm, ssum)
+                    ops.norm_bwd_apply(din, src, nrm, ssum, *(self._aff(src_L, grad=True) if want_wgrad else (None, None)))
                 d = din
             # d = gradient w.r.t. u_s (raw, before its InstanceNorm)
             U = self.up[s]
@@ -1162,7 +1197,7 @@ class CascadedRefinementNetwork(ChainNet):
                 ops.bilinear_up2_bwd(d, dc)
                 d = dc
             src = S["first"] if s == 5 else cat[s]
-            nrm = None if s == 5 else ops.norm_desc(st(("cat", s), 2 * C2), None, None, h * w, IN_EPS, ACT_NONE, 0.0)
+            nrm = None if s == 5 else ops.norm_desc(st(("cat", s), 2 * C2), *S["cataff"][s], h * w, IN_EPS, ACT_NONE, 0.0)
             if s == 5:
                 wgrad(U, desc, src, nrm, d)
                 if need_dx:
@@ -1172,7 +1207,15 @@ class CascadedRefinementNetwork(ChainNet):
             dc_ = torch.empty_like(cat[s])
             csum = sm(("cat", s), 2 * C2)
             bwd(U, desc, src, nrm, d, dc_, csum)
-            ops.norm_bwd_apply(dc_, cat[s], nrm, csum)          # both halves at once: raw gradients of l_s and of h_{s+1}
+            if self.bn and want_wgrad:      # the two halves' affine gradients come out side by side: add them where each layer keeps its own
+                dgb = torch.zeros(2 * C2, dtype=torch.float32, device=dev)
+                ops.norm_bwd_apply(dc_, cat[s], nrm, csum, dgb[:C2], dgb[C2:])
+                for L_, lo in ((self.lab[s], 0), (self.inter[s + 1][-1], ngf)):
+                    dg, db = self._aff(L_, grad=True)
+                    dg.add_(dgb[lo: lo + ngf])
+                    db.add_(dgb[C2 + lo: C2 + lo + ngf])
+            else:
+                ops.norm_bwd_apply(dc_, cat[s], nrm, csum)          # both halves at once: raw gradients of l_s and of h_{s+1}
             # label branch of this stage
             Ll = self.lab[s]
             ldesc = self._desc(Ll, h, w)

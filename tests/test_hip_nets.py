@@ -334,16 +334,17 @@ def test_unet_own_dropout_and_noise(N):
 # ------------------------------------------------------------------------------------------------
 # Cascaded refinement network (models/networks.py:642-794)
 # ------------------------------------------------------------------------------------------------
-CRN_SMALL = {"convt_b1": ("convt", 1), "bilinear_b2": ("bilinear", 2)}
+CRN_SMALL = {"convt_b1": ("convt", 1), "bilinear_b2": ("bilinear", 2), "bilinear_b2_batchnorm": ("bilinear", 2)}
 
 
 @pytest.mark.parametrize("tag", list(CRN_SMALL))
 def test_crn_small(N, golden_dir, tag):
     g = load(golden_dir, f"crn_small_{tag}.npz")
     mode, nlb = CRN_SMALL[tag]
-    G = N.define_G(2, 1, 8, "crn", "instance", False, n_layers_G=5, noise_nc=8, upsample_mode=mode, n_layers_CRN_block=nlb,
+    norm = "batch" if "batchnorm" in tag else "instance"      # --norm batch (the bilinear block's norm is child 2 of its Sequential; shared label norm)
+    G = N.define_G(2, 1, 8, "crn", norm, False, n_layers_G=5, noise_nc=8, upsample_mode=mode, n_layers_CRN_block=nlb,
                    share_label_weights=True, gpu_ids=[0])
-    sd = O.init_crn(41, 2, 1, 8, 8, mode, nlb, True)
+    sd = O.init_crn(41, 2, 1, 8, 8, mode, nlb, True, norm=norm)
     assert list(G.state_dict().keys()) == list(sd.keys())          # the reference's module order, no `model.` prefix
     G.load_state_dict(sd)
     label = O.np_uniform(401, (1, 2, 128, 128)).cuda().requires_grad_(True)
@@ -367,6 +368,9 @@ def test_crn_small(N, golden_dir, tag):
             assert np.abs(params[name].grad.cpu().numpy()).max() < TOL * scale, name
         else:
             assert rel(params[name].grad, g[k]) < TOL, name
+    for k in g.files:      # --norm batch: running statistics (running_mean follows the undetermined conv bias only where there is one ... it is determined here: first step)
+        if k.startswith("buf/"):
+            assert rel(G.state_dict()[k[4:]].double(), g[k].astype(np.float64)) < TOL, k
 
 
 def test_crn_small_noise(N, golden_dir):

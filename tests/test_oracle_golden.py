@@ -400,26 +400,30 @@ def test_cgan_step(golden_dir, name, kw):
 # ------------------------------------------------------------------------------------------------
 # Cascaded refinement network (BASELINE configs[4]'s G2)
 # ------------------------------------------------------------------------------------------------
-CRN_SMALL = {"convt_b1": ("convt", 1), "bilinear_b2": ("bilinear", 2)}
+CRN_SMALL = {"convt_b1": ("convt", 1), "bilinear_b2": ("bilinear", 2), "bilinear_b2_batchnorm": ("bilinear", 2)}
 
 
 @pytest.mark.parametrize("tag", list(CRN_SMALL))
 def test_crn_small(golden_dir, tag):
     g = load(golden_dir, f"crn_small_{tag}.npz")
     mode, nlb = CRN_SMALL[tag]
-    sd = O.init_crn(41, 2, 1, 8, 8, mode, nlb, True)
-    for v in sd.values():
-        v.requires_grad_(True)
+    norm = "batch" if "batchnorm" in tag else "instance"      # --norm batch: BatchNorm2d behind every conv but the last; the shared label block's one runs five times
+    sd = O.init_crn(41, 2, 1, 8, 8, mode, nlb, True, norm=norm)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
     label = O.np_uniform(401, (1, 2, 128, 128)).requires_grad_(True)
     z = O.np_normal(402, (1, 8, 2, 2)).requires_grad_(True)
     r = O.np_normal(403, (1, 1, 128, 128))
-    y = O.crn_forward(sd, label, z, 8, mode, nlb, True)
+    y = O.crn_forward(sd, label, z, 8, mode, nlb, True, norm=norm)
     (y * r).sum().backward()
     assert rel(y, g["y"]) < TIGHT * 5
     assert rel(label.grad, g["dlabel"]) < 1e-4 and rel(z.grad, g["dz"]) < 1e-4
     undet = O.norm_cancelled_keys_crn(2, 1, 8, 8, mode, nlb, True)
     for k, v in sd.items():
-        if k in undet:
+        if "running" in k or "num_batches" in k:
+            assert rel(v.double(), g["buf/" + k].astype(np.float64)) < 1e-5, k
+        elif k in undet:
             assert float(v.grad.abs().max()) <= 1e-3 * float(sd[k.replace(".bias", ".weight")].grad.abs().max()), k
         else:
             assert rel(v.grad, g["grad/" + k]) < 1e-4, k

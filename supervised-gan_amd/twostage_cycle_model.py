@@ -421,9 +421,6 @@ class TwoStageFactDModel(TwoStageModel):
         if self.isTrain:
             assert self.n_netD1 == self.n_netD2, "factored discriminators come in (D1_i, D2_i) pairs"
 
-    def graph_spec(self):
-        raise NotImplementedError("twostage_factd runs eagerly (its un-fused discriminator products are not in the graphed step)")
-
     @staticmethod
     def _mul(in1, in2):
         """util.mul (util/util.py:131-145): in1 reflection-padded up to in2's size; the reference returns None when in1 is larger."""

@@ -29,6 +29,16 @@ TWOSTAGE = ["--model", "twostage_cycle", "--which_direction", "AtoB", "--dataset
             "--GAN_losses_D2", "real_fake", "fake_fake", "--GAN_losses_G2", "real_fake", "fake_fake"]
 
 
+# twostage_factd (models/twostage_factD_model.py): no cycle, D1_i / D2_i pairs whose maps nest (4-layer D1 on the half-size label)
+FACTD = ["--model", "twostage_factd", "--which_direction", "AtoB", "--dataset_mode", "single", "--fineSize", "256",
+         "--transform_1to2", "bilinear_2", "--which_channel", "rg_b", "--which_model_netG1", "fcgan", "--n_layers_G1", "5", "--ngf1", "8",
+         "--n_layers_D1", "4", "4", "--ndf1", "8", "--scale_factor1", "1", "2", "--lambda_D1", "0.5", "0.4", "--which_model_netG2", "crn",
+         "--ngf2", "8", "--upsample_mode2", "bilinear", "--n_layers_CRN_block2", "2", "--n_layers_D2", "3", "3", "--ndf2", "8",
+         "--scale_factor2", "1", "2", "--lambda_D2", "0.6", "0.4", "--noise_nc1", "8", "--noiseSize1", "2", "--noise_nc2", "8",
+         "--noiseSize2", "4", "--no_dropout1", "--no_dropout2", "--no_lsgan1", "--no_lsgan2",
+         "--GAN_losses_D2", "real_fake", "fake_fake", "--GAN_losses_G2", "real_fake", "fake_fake"]
+
+
 CGAN_CYCLE = ["--model", "cgan_cycle", "--which_direction", "AtoB", "--dataset_mode", "single", "--fineSize", "256", "--which_channel", "rg_b",
               "--which_model_netG1", "unet_128", "--ngf1", "8", "--which_model_netG2", "unet_128", "--ngf2", "8", "--n_layers_D1", "3", "3",
               "--ndf1", "8", "--scale_factor1", "1", "2", "--lambda_D1", "0.6", "0.4", "--no_dropout1", "--no_dropout2", "--no_lsgan1",
@@ -51,8 +61,8 @@ def _ring(hw, n=4):
 
 
 @pytest.mark.parametrize("argv,hw,out", [(FCGAN, 128, "fake"), (CGAN, 256, "fake_B"), (TWOSTAGE, 256, "fake_B_from_fake_A"),
-                                         (CGAN_CYCLE, 256, "recon_A")],
-                         ids=["fcgan", "cgan", "twostage_cycle", "cgan_cycle"])
+                                         (CGAN_CYCLE, 256, "recon_A"), (FACTD, 256, "fake_B_from_fake_A")],
+                         ids=["fcgan", "cgan", "twostage_cycle", "cgan_cycle", "twostage_factd"])
 def test_graphed_step_equals_eager(argv, hw, out):
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need an MI355X; no CUDA/HIP device is visible")

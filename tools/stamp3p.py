@@ -31,7 +31,19 @@ for H in sizes:
     desc = ops.conv_desc(0, k, s, p, H, H, cin, Ho, Ho, cout)
     jf.append((desc, x, nrm, wm, b, y, st_out)); jd.append((desc, r, wt, dx, x, nrm, sums, 0, False, True))
     keep.append((x, y, r, dx, st_in, st_out, sums, nrm, desc))
-fn = (lambda: ops.conv_fwd_grouped(jf)) if op == "fwd" else (lambda: ops.conv_dgrad_grouped(jd))
+if op == "gfwd":      # the generator's second layer: ConvT k4 s2 p1 256 -> 256, 16x16 -> 32x32, BatchNorm + ReLU on load (64 workgroups)
+    k, s, p, cin, cout, H = 4, 2, 1, 256, 256, 16
+    w = torch.randn(k * k * cout * cin, device="cuda") * 0.05
+    wm, wt = derived_copies(w, k, cout, cin)
+    x = torch.randn(H, H, cin, device="cuda"); y = torch.empty(2 * H, 2 * H, cout, device="cuda")
+    st_in = ops.stat_arena(2 * cin, "cuda"); st_in[cin:] = H * H
+    st_out = ops.stat_arena(2 * cout, "cuda")
+    gam, bet = torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda")
+    nrm = ops.norm_desc(st_in, gam, bet, H * H, 1e-5, 1, 0.0, 0, ops.stat_rep(st_in))
+    desc = ops.conv_desc(1, k, s, p, H, H, cin, 2 * H, 2 * H, cout)
+    jf = [(desc, x, nrm, wm, torch.randn(cout, device="cuda"), y, st_out, 0, ops.stat_rep(st_out))]
+    keep.append((x, y, st_in, st_out, gam, bet, nrm, desc))
+fn = (lambda: ops.conv_fwd_grouped(jf)) if op in ("fwd", "gfwd") else (lambda: ops.conv_dgrad_grouped(jd))
 for _ in range(5):
     fn()
 torch.cuda.synchronize()

@@ -12,7 +12,10 @@ def short(name):
     m = re.match(r"(sg_igemm3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false),(?:true|false)>$", n)   # prologue flag, fp16 / bf16 planes
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    m = re.match(r"(sg_igemm3p_kernel)<(\d+),.*>$", n)      # patch-tile count, prologue flag, plane type
+    m = re.match(r"(sg_igemm3p)(?:_kw2)?_kernel<(\d+),.*>$", n)      # patch-tile count, prologue flag, plane type; _kw2: two wave groups
+    if m:
+        return f"{m.group(1)}_kernel<{m.group(2)}>"
+    m = re.match(r"(sg_igemm3p_kernel)<(\d+),.*>$", n)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
     m = re.match(r"(sg_wgrad3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false)>$", n)

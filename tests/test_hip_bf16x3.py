@@ -274,6 +274,43 @@ def test_fused_backward_is_taken(ops):
     assert _FUSED_SEEN.get((SHAPES[0], "f32")), _FUSED_SEEN
 
 
+@pytest.mark.parametrize("shape", [("conv", 4, 1, 2, 128, 256, 33, 29), ("convT", 4, 2, 1, 256, 256, 16, 16), ("conv", 3, 1, 1, 160, 64, 24, 24),
+                                   ("conv", 4, 1, 2, 224, 128, 20, 20)], ids=["4blocks", "8blocks_convT", "5blocks", "7blocks"])
+def test_patch_kernel_two_wave_groups(ops, shape):
+    """Forward launches of fewer workgroups than CUs run the patch kernel with two wave groups per workgroup (sg_igemm3p_kw2_kernel:
+    the channel blocks split between the groups, uneven for 5 and 7 blocks, group 1's accumulators handed over through LDS):
+    against an fp64 result, and twenty repeats bit for bit (a race between the groups would show as a run that differs)."""
+    from hip_utils import master_weight, pad_vec, stats_of, to_buf
+    from supervised_gan_amd import _lib
+    kind, k, s, p, cin, cout, H, W = shape
+    tr = kind == "convT"
+    _select_tile("auto")
+    ops.set_math("bf16x3")
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(1, cin, H, W, generator=g)
+    w = torch.randn(*((cin, cout, k, k) if tr else (cout, cin, k, k)), generator=g) * 0.05
+    b = torch.randn(cout, generator=g) * 0.1
+    a = F.relu(F.instance_norm(x.double(), eps=1e-5))
+    ref = F.conv_transpose2d(a, w.double(), b.double(), stride=s, padding=p) if tr else F.conv2d(a, w.double(), b.double(), stride=s, padding=p)
+    Ho, Wo = ref.shape[2:]
+    desc = ops.conv_desc(1 if tr else 0, k, s, p, H, W, cin, Ho, Wo, cout)
+    nd = ops.norm_desc(stats_of(x), None, None, H * W, 1e-5, 1, 0.0)
+    xb, wm, bb = to_buf(x), master_weight(w, tr), pad_vec(b)
+    first = None
+    for _ in range(20):
+        ob = torch.full((Ho, Wo, cout), float("nan"), device="cuda")
+        ost = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
+        ops.conv_fwd(desc, xb, nd, wm, bb, ob, 0, ost)
+        assert _lib.lib().sgan_last_kernel().decode() == "sg_igemm3p_kernel<64>"
+        if first is None:
+            first = ob.clone()
+        else:
+            assert torch.equal(ob, first)
+    got = first.permute(2, 0, 1).unsqueeze(0).double().cpu()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 3e-6
+    assert float((ost.cpu() - torch.cat([ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))])).abs().max() / (ref * ref).sum((0, 2, 3)).max()) < 1e-5
+
+
 def test_bf16x3_needs_packed_weights(ops):
     """No silent change of arithmetic: a layer the split kernels cover, asked for in bf16x3 without the packed copy, raises."""
     from supervised_gan_amd._lib import SganError

@@ -586,10 +586,7 @@ extern "C" int sgan_debug_stamps(void* dst, int n) {
 #define SG3P_MARK(i)
 #endif
 
-// KW = 2 (512 threads): two groups of four waves split the channel blocks between them (group `grp` takes blocks grp, grp + 2, ...),
-// each with its own patch and weight-tile buffers, in step through shared barriers; group 1 hands its accumulators to group 0 through
-// LDS before the epilogue.  For launches of fewer workgroups than CUs, whose time is the serial k-chain of one workgroup.
-template <int BN, int A_IT, bool PRO, bool F16, int KW = 1>
+template <int BN, int A_IT, bool PRO, bool F16>
 __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* smem, const int bid, const int nblocks) {
     constexpr int NT = 256, WGN = 2, WTM = 32, WTN = BN / WGN, MB = 1, NB = WTN / 32;
     constexpr int B_IT = BN * 8 / NT;
@@ -603,8 +600,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
 #ifdef SG3P_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) sg3p_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
-    const int grp = KW == 1 ? 0 : (int)(threadIdx.x >> 8);      // wave group
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
     const int ntn = (G.N + BN - 1) / BN;
     const int item = sg_xcd_remap(bid, nblocks);
@@ -619,10 +615,9 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     const int RS = sg3p_row_stride(PW);
     const int npix = PH * PW;
 
-    const int gsz = ((PH * RS + 255) & ~255) + 2 * BN * 128;      // one wave group's buffers
-    char* Ap = smem + grp * gsz;                             // [PH][RS] patch of the current channel block
-    char* Bs = Ap + ((PH * RS + 255) & ~255);                // [2][BN * 128]
-    double* red = reinterpret_cast<double*>(smem + KW * gsz);              // [2 * BN]
+    char* Ap = smem;                                         // [PH][RS] patch of the current channel block
+    char* Bs = smem + ((PH * RS + 255) & ~255);              // [2][BN * 128]
+    double* red = reinterpret_cast<double*>(Bs + 2 * BN * 128);            // [2 * BN]
     int4* ttab = reinterpret_cast<int4*>(red + 2 * BN);                    // per tap {patch byte offset, -, -, weight slab offset}
     float* pscale = reinterpret_cast<float*>(ttab + SGAN_MAX_TAPS);        // [Ck]
     float* pshift = pscale + G.Ck;
@@ -633,17 +628,32 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     const int oa = G.oa[phz], ob = G.ob[phz];
     const int Ck = P.Ck, N = P.N;
     const int ntaps = G.ntaps[phz];
-    const int ncb_all = Ck >> 5;                   // channel blocks of the layer
-    const int ncb = (ncb_all + KW - 1) / KW;       // ... of one wave group (its block i is block i * KW + grp of the layer; the same
-    const int nunits = ntaps * ncb;                // count for every group: a block past the end loads zeros)
+    const int ncb = Ck >> 5;
+    const int nunits = ntaps * ncb;
     const int dy0 = G.pdy0[phz], dx0 = G.pdx0[phz];
 
-    if (threadIdx.x < SGAN_MAX_TAPS) {
+    if (tid < SGAN_MAX_TAPS) {
         const bool v = tid < ntaps;
         const SgTap tp = G.taps[v ? G.tap0[phz] + tid : 0];
         ttab[tid] = make_int4(v ? ((int)tp.dy - dy0) * RS + ((int)tp.dx - dx0) * SG3P_PS : 0, 0, 0, v ? tp.w_off : 0);
     }
-    for (int i = threadIdx.x; i < 2 * BN; i += NT * KW) red[i] = 0.0;
+    for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.0;
+    if constexpr (PRO) {
+        for (int c = tid; c < Ck; c += NT) {
+            float sc = 1.f, sh = 0.f;
+            if (P.pro.stats) {
+                float mean, rstd;
+                sg_mean_rstd(P.pro, Ck, c, mean, rstd);
+                const float gm = P.pro.gamma ? P.pro.gamma[c] : 1.f;
+                const float bt = P.pro.beta ? P.pro.beta[c] : 0.f;
+                sc = gm * rstd;
+                sh = bt - mean * sc;
+            }
+            pscale[c] = sc;
+            pshift[c] = sh;
+        }
+    }
+
     // ---- patch staging: item e = 4 * patch pixel + k-group (8 channels = two 16-byte loads -> one hi and one lo chunk) ----
     const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
     const int kg = tid & 3;
@@ -661,19 +671,17 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     auto issue_a = [&](int cb) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int pcb = cb * KW + grp;      // the layer's block
-            const int o = ((a_goff[it] != OOB) & (cb < ncb) & (pcb < ncb_all)) ? a_goff[it] + pcb * 128 : OOB;     // past the last block: zeros
+            const int o = ((a_goff[it] != OOB) & (cb < ncb)) ? a_goff[it] + cb * 128 : OOB;     // past the last block: zeros, never used
             a_reg[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o, 0, 0));
             a_reg[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o + 16, 0, 0));
         }
     };
-    issue_a(0);      // before the tap table / statistics work below: their latency hides this one
     auto store_a = [&](int cb) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             f32x4 v0 = a_reg[it][0], v1 = a_reg[it][1];
             if constexpr (PRO) {   // zero padding applies AFTER norm + activation (see sg_igemm3_kernel)
-                const int c = min(cb * KW + grp, ncb_all - 1) * 32 + kg * 8;
+                const int c = cb * 32 + kg * 8;
                 const f32x4 sc0 = *reinterpret_cast<const f32x4*>(pscale + c), sc1 = *reinterpret_cast<const f32x4*>(pscale + c + 4);
                 const f32x4 sh0 = *reinterpret_cast<const f32x4*>(pshift + c), sh1 = *reinterpret_cast<const f32x4*>(pshift + c + 4);
                 const float okf = a_goff[it] != OOB ? 1.f : 0.f;
@@ -710,8 +718,8 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     // round trip into the in-order instruction stream of every wave (two per step: this one and the fragment offset below).
     int w_pref = 0;            // set behind the barrier that publishes the tap table
     auto next_b_addrs = [&]() {
-        const bool in_range = (ld_cb < ncb) & (ld_cb * KW + grp < ncb_all);
-        const int woff = w_pref + (ld_cb * KW + grp) * 32;
+        const bool in_range = ld_cb < ncb;
+        const int woff = w_pref + ld_cb * 32;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) b_off_n[it] = (b_rowok[it] & in_range) ? (b_base[it] + woff) << 2 : OOB;
         ++ld_tap;
@@ -750,23 +758,6 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
 #pragma unroll
         for (int p = 0; p < 2; ++p) f_off[s][p] = ((2 * (2 * s + fh) + p) ^ fswz) << 4;
     const int fb_row = (wn * WTN + fr) * 128;
-
-    // (the first patch's loads are already in flight: issued above, before this per-channel work)
-    if constexpr (PRO) {
-        for (int c = threadIdx.x; c < Ck; c += NT * KW) {
-            float sc = 1.f, sh = 0.f;
-            if (P.pro.stats) {
-                float mean, rstd;
-                sg_mean_rstd(P.pro, Ck, c, mean, rstd);
-                const float gm = P.pro.gamma ? P.pro.gamma[c] : 1.f;
-                const float bt = P.pro.beta ? P.pro.beta[c] : 0.f;
-                sc = gm * rstd;
-                sh = bt - mean * sc;
-            }
-            pscale[c] = sc;
-            pshift[c] = sh;
-        }
-    }
 
     __syncthreads();   // tap table, scale / shift visible
     const Sg3EpiConst<NB> epi_const = sg3_epilogue_constants<WTN, NB>(P, n0, wn, tid);
@@ -833,6 +824,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     auto prefetch = [&](auto K_) { next_b_addrs(); issue_b(K_); };
     auto maybe = [&](auto K_, int u) { if (u + decltype(K_)::value < nunits) iteration(K_); };
 
+    issue_a(0);
     prefetch(std::integral_constant<int, 0>{}); prefetch(std::integral_constant<int, 1>{});
     if constexpr (NSET == 4) { prefetch(std::integral_constant<int, 2>{}); prefetch(std::integral_constant<int, 3>{}); }
     store_a(0);
@@ -860,25 +852,6 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     }
     SG3P_MARK(3);
 
-    if constexpr (KW > 1) {      // group 1's partial sums -> group 0 (through group 1's own buffers: nobody reads them any more)
-        __syncthreads();
-        float* xch = reinterpret_cast<float*>(smem);      // both groups' buffers are free now: 2 gsz >= the 32 KB of one accumulator set
-        if (grp == 1) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * NT + tid] = acc[0][j][r];
-        }
-        __syncthreads();
-        if (grp == 1) {
-            if (P.stats != nullptr && P.ksplit <= 1) __syncthreads();      // the barrier inside group 0's epilogue
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][j][r] += xch[(j * 16 + r) * NT + tid];
-    }
     sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, 0, n0, wm, wn, tid, (unsigned)bid, epi_const, [&](int row) -> int64_t {
         const int py = ty0 + (row >> 3), px = tx0 + (row & 7);
         if (py >= Hp || px >= Wp) return -1;
@@ -894,12 +867,6 @@ template <int BN, int A_IT, bool PRO, bool F16>
 __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     sg_igemm3p_body<BN, A_IT, PRO, F16>(G, smem, blockIdx.x, gridDim.x);
-}
-
-template <int BN, int A_IT, bool PRO, bool F16>
-__global__ __launch_bounds__(512) void sg_igemm3p_kw2_kernel(const SgIgemmParams G) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    sg_igemm3p_body<BN, A_IT, PRO, F16, 2>(G, smem, blockIdx.x, gridDim.x);
 }
 
 #ifndef SG_KERNELS_ONLY      // sgan_fused.hip includes this file for the kernel bodies only
@@ -1041,21 +1008,6 @@ static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {   /
     bool pro = P.pro_act != SGAN_ACT_NONE;
     for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
     sg_prof_begin(st);
-    // fewer workgroups than CUs and a deep channel loop: two wave groups per workgroup halve the serial chain (forward launches with
-    // a prologue only -- the generator's middle layers; SGAN_P_KW2 = 0 switches it off, = N sets the workgroup limit)
-    static const int kw2_max = getenv("SGAN_P_KW2") ? atoi(getenv("SGAN_P_KW2")) : 128;
-    if constexpr (BN == 64 && A_IT == 2) {
-        if (P.planes_f16 && pro && (int)grid.x <= kw2_max && (P.Ck >> 5) >= 4) {
-            const size_t lds2 = (size_t)2 * (maxlds + 2 * BN * 128) + (size_t)4 * BN * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
-            if (lds2 <= 160 * 1024) {
-                hipLaunchKernelGGL((sg_igemm3p_kw2_kernel<BN, A_IT, true, true>), grid, dim3(512), lds2, st, P);
-                SGAN_LAUNCH_CHECK();
-                g_sgan_last_kernel = name;
-                sg_prof_end(st, g_sgan_last_kernel);
-                return SGAN_OK;
-            }
-        }
-    }
     if (P.planes_f16) {
         if (pro) hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, true, true>), grid, dim3(256), lds, st, P);
         else hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, false, true>), grid, dim3(256), lds, st, P);

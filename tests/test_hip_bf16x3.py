@@ -276,10 +276,9 @@ def test_fused_backward_is_taken(ops):
 
 @pytest.mark.parametrize("shape", [("conv", 4, 1, 2, 128, 256, 33, 29), ("convT", 4, 2, 1, 256, 256, 16, 16), ("conv", 3, 1, 1, 160, 64, 24, 24),
                                    ("conv", 4, 1, 2, 224, 128, 20, 20)], ids=["4blocks", "8blocks_convT", "5blocks", "7blocks"])
-def test_patch_kernel_two_wave_groups(ops, shape):
-    """Forward launches of fewer workgroups than CUs run the patch kernel with two wave groups per workgroup (sg_igemm3p_kw2_kernel:
-    the channel blocks split between the groups, uneven for 5 and 7 blocks, group 1's accumulators handed over through LDS):
-    against an fp64 result, and twenty repeats bit for bit (a race between the groups would show as a run that differs)."""
+def test_patch_kernel_small_launches_repeat(ops, shape):
+    """Forward launches of the patch kernel with fewer workgroups than CUs and 4 / 8 / 5 / 7 channel blocks: against an fp64 result,
+    and twenty repeats bit for bit (a synchronisation slip inside the kernel would show as a run that differs)."""
     from hip_utils import master_weight, pad_vec, stats_of, to_buf
     from supervised_gan_amd import _lib
     kind, k, s, p, cin, cout, H, W = shape

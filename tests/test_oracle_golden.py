@@ -193,7 +193,10 @@ def check_grads(grads, g, prefix, undet, tol=TOL, f64=None, tally=None):
                 nbad = int((err > bound).sum())
                 l2 = float(np.linalg.norm(smp - truth) / (np.linalg.norm(truth) + 1e-30)) if scale_key is None else 0.0
                 if os.environ.get("SGAN_TEST_VERBOSE"):
-                    print(f"flips-clause tensor {prefix}/{k}: e {e:.2e} e_ref {e_ref:.2e} nbad {nbad}/{err.size} l2 {l2:.2e}")
+                    print(f"flips-clause tensor {prefix}/{k}: e {e:.2e} e_ref {e_ref:.2e} nbad {nbad}/{err.size} l2 {l2:.2e}"
+                          + ("  <-- beyond the gate" if not (nbad <= max(8, 0.10 * err.size) and l2 <= 5e-3 and e <= 5e-2) else ""))
+                    if os.environ.get("SGAN_TEST_VERBOSE") == "noassert":
+                        continue
                 assert nbad <= max(8, 0.10 * err.size) and l2 <= 5e-3 and e <= 5e-2, (prefix, k, e, e_ref, nbad, err.size, l2)
             continue
         e_max, e_l2 = grad_errors(v, g, prefix, k, scale_key)

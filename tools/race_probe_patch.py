@@ -1,5 +1,5 @@
-"""Repeat-run determinism probe of the two-wave-group patch kernel (sg_igemm3p_kw2_kernel): the same forward launch 300 times, every
-result compared bit for bit with the first (a race between the wave groups would show as a run that differs).  python tools/race_probe_kw2.py"""
+"""Repeat-run determinism probe of the patch kernel on small forward launches (fewer workgroups than CUs; 4 / 8 / 5 / 7 channel blocks):
+the same launch 300 times, every result compared bit for bit with the first and with an fp64 reference.  python tools/race_probe_patch.py"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -840,6 +840,11 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
         read_half(std::integral_constant<int, 0>{}, Ab, Bs + fb_row);
         read_half(std::integral_constant<int, 1>{}, Ab, Bs + fb_row);
     }
+    // Step 0's fragments are read HERE, not inside an iteration: iteration 0 ends by storing step 2's weight tile into the same LDS
+    // buffer, and nothing but this barrier keeps a wave that runs ahead from doing so while a delayed wave (a cold instruction
+    // cache, a crowded SIMD) is still reading.  Without it the full-size twostage parity run came out a few percent wrong about
+    // once in a few dozen runs; every later step is covered by the barrier that ends the iteration before it.
+    __syncthreads();
     SG3P_MARK(2);
     {
         int u = 0;

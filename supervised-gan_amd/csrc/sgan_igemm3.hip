@@ -835,6 +835,10 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     prefetch(std::integral_constant<int, 1>{});
     next_b_addrs();
     __syncthreads();
+#ifdef SG3P_DELAY_WAVE   // tools/race_stress.sh: hold one wave back here, the way a cold instruction cache would, only for longer
+    if ((threadIdx.x >> 6) == SG3P_DELAY_WAVE) { for (int i = 0; i < 4; ++i) asm volatile("s_sleep 127" ::: "memory"); }
+    __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads behind the sleep
+#endif
     {
         const char* Ab = Ap + fa_base + ttab[0].x;
         read_half(std::integral_constant<int, 0>{}, Ab, Bs + fb_row);
@@ -844,7 +848,10 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     // buffer, and nothing but this barrier keeps a wave that runs ahead from doing so while a delayed wave (a cold instruction
     // cache, a crowded SIMD) is still reading.  Without it the full-size twostage parity run came out a few percent wrong about
     // once in a few dozen runs; every later step is covered by the barrier that ends the iteration before it.
+    // (tools/race_stress.sh builds the kernel with one wave held back, with and without this barrier.)
+#ifndef SG3P_NO_STEP0_BARRIER
     __syncthreads();
+#endif
     SG3P_MARK(2);
     {
         int u = 0;

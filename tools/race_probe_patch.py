@@ -1,5 +1,5 @@
 """Repeat-run determinism probe of the patch kernel on small forward launches (fewer workgroups than CUs; 4 / 8 / 5 / 7 channel blocks):
-the same launch 300 times, every result compared bit for bit with the first and with an fp64 reference.  python tools/race_probe_patch.py"""
+the same launch 300 times (RACE_REPEATS), every result compared bit for bit with the first and with an fp64 reference.  python tools/race_probe_patch.py"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -19,7 +19,7 @@ for kind, k, s, p, cin, cout, H, W in (("conv", 4, 1, 2, 128, 256, 33, 29), ("co
     nd = ops.norm_desc(stats_of(x), None, None, H * W, 1e-5, 1, 0.0)
     xb = to_buf(x)
     first = None
-    for it in range(300):
+    for it in range(int(os.environ.get("RACE_REPEATS", 300))):
         ob = torch.full((Ho, Wo, cout), float("nan"), device="cuda")
         ost = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
         ops.conv_fwd(desc, xb, nd, wm, bb, ob, 0, ost)

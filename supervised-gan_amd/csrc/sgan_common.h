@@ -9,6 +9,21 @@
 
 #include "../../include/sgan_hip.h"
 
+// Every workgroup barrier of the library goes through SG_SYNC().  A stress build (tools/race_stress_all.sh, -DSG_STRESS_DELAY=<wave>)
+// holds one wave of every workgroup back for ~6400 cycles after each barrier, so that the other waves run as far ahead as the
+// barriers let them: an LDS buffer that is overwritten without a barrier after its last read then gives wrong results every time
+// instead of once in a thousand runs.  The product build is the plain barrier.
+#ifdef SG_STRESS_DELAY
+#define SG_SYNC()                                                                                   \
+    do {                                                                                            \
+        __syncthreads();                                                                            \
+        if ((int)(threadIdx.x >> 6) == SG_STRESS_DELAY) asm volatile("s_sleep 100" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    } while (0)
+#else
+#define SG_SYNC() __syncthreads()
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

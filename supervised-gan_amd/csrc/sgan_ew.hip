@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(const SgNormBwdT
             if (J.dbeta) atomicAdd(&J.dbeta[c], (float)s1);
         }
     }
-    __syncthreads();
+    SG_SYNC();
     const int CQ = C >> 2;
     const int64_t total = (int64_t)J.npix * CQ;
     float* dy = J.dy;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void sg_norm_apply_fwd_kernel(const float* u, 
         cA[c] = (un.gamma ? un.gamma[c] : 1.f) * rstd;
         cB[c] = un.beta ? un.beta[c] : 0.f;
     }
-    __syncthreads();
+    SG_SYNC();
     const int CQ = C >> 2;
     const int64_t total = (int64_t)npix * CQ;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void sg_norm_apply_bwd_sums_kernel(float* dt, 
         cRstd[c] = rstd;
     }
     for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-    __syncthreads();
+    SG_SYNC();
     const int CQ = C >> 2;
     const int64_t total = (int64_t)npix * CQ;
     if (256 % CQ == 0) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void sg_norm_apply_bwd_sums_kernel(float* dt, 
             }
         }
     }
-    __syncthreads();
+    SG_SYNC();
     for (int c = threadIdx.x; c < C; c += 256) {
         atomicAdd(&sums[c], (double)red[c]);
         atomicAdd(&sums[C + c], (double)red[C + c]);
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void sg_pad_reflect_fwd_kernel(const float* x,
         cSc[c] = sc;
         cSh[c] = sh;
     }
-    __syncthreads();
+    SG_SYNC();
     const int CQ = C >> 2, Wp = W + 2 * pad, Hp = H + 2 * pad;
     const int64_t total = (int64_t)Hp * Wp * CQ;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void sg_pad_reflect_bwd_kernel(const float* do
         cB[c] = (xn.stats && xn.beta) ? xn.beta[c] : 0.f;
     }
     for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.0;
-    __syncthreads();
+    SG_SYNC();
     const int CQ = C >> 2, Wp = W + 2 * pad;
     const int64_t total = (int64_t)H * W * CQ;
     const bool has_x = x != nullptr;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void sg_pad_reflect_bwd_kernel(const float* do
         *reinterpret_cast<f32x4*>(din + pix * din_ld + c) = d;
     }
     if (sums) {
-        __syncthreads();
+        SG_SYNC();
         for (int c = threadIdx.x; c < C; c += 256) {
             atomicAdd(&sums[c], red[c]);
             atomicAdd(&sums[(sums_sq ? sums_sq : C) + c], red[C + c]);
@@ -474,7 +474,7 @@ __device__ __forceinline__ void sg_block_partial(double acc, double* part) {
     __shared__ double wsum[4];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
-    __syncthreads();
+    SG_SYNC();
     if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void sg_transpose_weights_kernel(const float* 
         const int co = by * 32 + r, ci = bx * 32 + lx;
         tile[r][lx] = (co < S.cout && ci < S.cin) ? src[(int64_t)co * S.cin + ci] : 0.f;
     }
-    __syncthreads();
+    SG_SYNC();
     for (int r = ly; r < 32; r += 8) {
         const int ci = bx * 32 + r, co = by * 32 + lx;
         if (ci < S.cin && co < S.cout) dst[(int64_t)ci * S.cout + co] = tile[lx][r];
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void sg_pack_weights_kernel(const float* flat,
         const int co = by * 32 + r, ci = bx * 32 + lx;
         tile[r][lx] = (co < S.cout && ci < S.cin) ? src[(int64_t)co * S.cin + ci] : 0.f;
     }
-    __syncthreads();
+    SG_SYNC();
     if (flat_t) {
         float* dst = flat_t + slab;
         for (int r = ly; r < 32; r += 8) {
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(256) void sg_gauss_fwd_kernel(const float* in, int 
         const int c = i % C, t = i / C;
         gs[i] = c < Creal ? g[(int64_t)c * gcs + t] : 0.f;
     }
-    __syncthreads();
+    SG_SYNC();
     const int CQ = C >> 2;
     const int64_t total = (int64_t)Ho * Wo * CQ;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -973,7 +973,7 @@ __global__ __launch_bounds__(256) void sg_gauss_bwd_kernel(const float* dout, in
         const int c = i % C, t = i / C;
         gs[i] = c < Creal ? g[(int64_t)c * gcs + t] : 0.f;
     }
-    __syncthreads();
+    SG_SYNC();
     const int CQ = C >> 2;
     const int64_t total = (int64_t)H * W * CQ;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void sg_gauss_multi_fwd_kernel(const SgGaussTa
         const int c = i % C, t = i / C;
         gs[i] = c < T.Creal ? J.g[(int64_t)c * J.gcs + t] : 0.f;
     }
-    __syncthreads();
+    SG_SYNC();
     const int CQ = C >> 2;
     const int64_t total = (int64_t)Ho * Wo * CQ;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(256) void sg_gauss_multi_bwd_kernel(const SgGaussTa
             o += kk * C;
         }
     }
-    __syncthreads();
+    SG_SYNC();
     const int H = T.j[0].Hd, W = T.j[0].Wd, CQ = C >> 2;
     const int64_t total = (int64_t)H * W * CQ;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(256) void sg_bilinear_up2_fwd_kernel(const float* i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem);   // [2C], fp64 from the first add (see sg_igemm_kernel)
     for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.0;
-    __syncthreads();
+    SG_SYNC();
     const int CQ = C >> 2, Wo = 2 * W;
     const int64_t total = (int64_t)4 * H * W * CQ;
     const int c = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % CQ) * 4;
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(256) void sg_bilinear_up2_fwd_kernel(const float* i
             atomicAdd(&red[c + j], s1[j]);
             atomicAdd(&red[C + c + j], s2[j]);
         }
-        __syncthreads();
+        SG_SYNC();
         for (int i = threadIdx.x; i < C; i += 256) {
             atomicAdd(&stats[i], red[i]);
             atomicAdd(&stats[stats_sq + i], red[C + i]);
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(256) void sg_avgpool_pyramid_fwd_kernel(const float
     }
     int n = 32;   // side of the level held in lv[] (row pitch stays 32)
     for (int s = 1; s < 6; ++s) {
-        __syncthreads();
+        SG_SYNC();
         const int m = n >> 1;
         f32x4 v[4];
         int cnt = 0;
@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(256) void sg_avgpool_pyramid_fwd_kernel(const float
             const int y = i / m, x = i % m;
             v[cnt] = 0.25f * ((lv[(2 * y) * 32 + 2 * x] + lv[(2 * y) * 32 + 2 * x + 1]) + (lv[(2 * y + 1) * 32 + 2 * x] + lv[(2 * y + 1) * 32 + 2 * x + 1]));
         }
-        __syncthreads();
+        SG_SYNC();
         cnt = 0;
         for (int i = threadIdx.x; i < m * m; i += 256, ++cnt) {
             const int y = i / m, x = i % m;
@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(1024) void sg_gan_loss_fwd_kernel(const float* logi
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
-    __syncthreads();
+    SG_SYNC();
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < 16; ++i) t += wsum[i];
@@ -1488,13 +1488,13 @@ __global__ __launch_bounds__(256) void sg_gan_loss_multi_fwd_kernel(SgLossMulti 
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
-    __syncthreads();
+    SG_SYNC();
     if (threadIdx.x == 0) {
         part[j * SG_LOSS_BLOCKS + b] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
         __threadfence();                                     // the partial is out before the ticket is taken
         last = atomicAdd(counter, 1u) == (unsigned)(SG_LOSS_BLOCKS * J.n - 1);
     }
-    __syncthreads();
+    SG_SYNC();
     if (!last || threadIdx.x >= 64) return;
     __threadfence();                                         // every other workgroup's partial is visible from here on
     const int t = threadIdx.x;
@@ -1889,7 +1889,7 @@ __global__ __launch_bounds__(256) void sg_normal_fill_kernel(float* dst, int64_t
                                                              int hw, int cs) {
     const uint64_t off = offset ? offset[0] : 0;
     if (advance_by) {
-        __syncthreads();
+        SG_SYNC();
         if (threadIdx.x == 0) offset[0] = off + advance_by;
     }
     const int64_t nq = (n + 3) >> 2;

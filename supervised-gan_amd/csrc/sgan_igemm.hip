@@ -172,7 +172,7 @@ __device__ __forceinline__ void sg_igemm_body(const SgIgemmParams& G, char* smem
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    __syncthreads();  // tap table visible
+    SG_SYNC();  // tap table visible
 
     // Pure address arithmetic for the next tile (no memory traffic except the LDS tap table): scheduled
     // inside the MFMA block of the previous tile.  Invalid elements get offset 0 and are zeroed when the
@@ -336,7 +336,7 @@ __device__ __forceinline__ void sg_igemm_body(const SgIgemmParams& G, char* smem
         mfma_tile(S & 1);                                         // tile kt
         if constexpr (!(SG_ABLATE & 4)) store_tile(std::integral_constant<int, (S + 1) % NSET>{});   // tile kt+1
         next_addrs();                                             // tile kt+NSET+1
-        __syncthreads();
+        SG_SYNC();
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -352,7 +352,7 @@ __device__ __forceinline__ void sg_igemm_body(const SgIgemmParams& G, char* smem
     issue_loads(I3{});   // tile 3
     next_addrs();        // offsets of tile 4
     store_tile(I0{});
-    __syncthreads();
+    SG_SYNC();
     {
         int kt = 0;
         for (; kt + 3 < nkt; kt += 4) {
@@ -375,9 +375,9 @@ __device__ __forceinline__ void sg_igemm_body(const SgIgemmParams& G, char* smem
 #pragma unroll
                 for (int j = 0; j < NB; ++j) xch[(i * NB + j) * 256 + tid] = acc[i][j];
         }
-        __syncthreads();
+        SG_SYNC();
         if (kg == 1) {
-            if (P.ksplit <= 1 && want_stats) __syncthreads();   // keep the barrier count of group 0's epilogue
+            if (P.ksplit <= 1 && want_stats) SG_SYNC();   // keep the barrier count of group 0's epilogue
             return;
         }
 #pragma unroll
@@ -481,7 +481,7 @@ __device__ __forceinline__ void sg_igemm_body(const SgIgemmParams& G, char* smem
         }
     }
     if (want_stats) {
-        __syncthreads();
+        SG_SYNC();
         if (tid < BN && n0 + tid < N) {
 #ifndef SG_NO_STAT_ATOMICS      // diagnostics build: what the same-address fp64 atomics cost
             double* st = sg_stat_replica(P.stats, P.stats_rep, bid);
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
             pshift[c] = sh;
         }
     }
-    __syncthreads();
+    SG_SYNC();
     // LPP lanes share a pixel; every lane works on R pixels at once (PPB apart), so one set of weight chunks and one
     // scale/shift chunk serve R gathered chunks, and a workgroup's setup is spread over PPB * R pixels.  The loop is
     // load-latency bound: the loads of U chunks (U * (R + NW) 16-byte loads per lane) are issued before any of them is
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void sg_conv_head_kernel(const SgIgemmParams G
     float acc = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) issue(d, s_regs[d]);
-    __syncthreads();      // tap offsets, weights, scale / shift visible
+    SG_SYNC();      // tap offsets, weights, scale / shift visible
     for (int cb0 = 0; cb0 < ncb; cb0 += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void sg_conv_head_kernel(const SgIgemmParams G
         if (cb >= ncb) break;
         store(cb, s_regs[d]);
         issue(cb + D, s_regs[d]);
-        __syncthreads();
+        SG_SYNC();
         const float* wrow = Ws + cb * 32 + co * CPG;
 #pragma unroll 4
         for (int t = 0; t < ntaps; ++t) {
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void sg_conv_head_kernel(const SgIgemmParams G
                 acc += a0[0] * w0[0] + a0[1] * w0[1];
             }
         }
-        __syncthreads();   // everyone is done with the patch before the next block overwrites it
+        SG_SYNC();   // everyone is done with the patch before the next block overwrites it
       }
     }
 #pragma unroll
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmPara
         pscale[c] = sc;
         pshift[c] = sh;
     }
-    __syncthreads();
+    SG_SYNC();
 
     // ---- Z = X W^T: wave w owns tile rows 2w, 2w+1 (64 pixels = 4 MFMA row blocks), all 64 columns ----
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in), 0, 0x7FFFFFFF, 0x00020000);
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmPara
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Zs[(wid * 64 + i * 16 + fq * 4 + r) * SG_SC_LDZ + j * 16 + fr] = acc[i][j][r];
-    __syncthreads();
+    SG_SYNC();
 
     // ---- overlap-add: the (TH-2) x (TW-2) interior in all 4 phases, row-major over output pixels (coalesced 16-byte stores) ----
     constexpr int OH = 2 * (SG_SC_TH - 2), OW = 2 * (SG_SC_TW - 2);
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(256) void sg_conv_c4_kernel(const SgIgemmParams G) 
         const SgTap tp = G.taps[t0 + (tid < ntaps ? tid : 0)];
         ttab[tid] = make_int4((int)tp.dy, (int)tp.dx, tp.w_off, 0);
     }
-    __syncthreads();
+    SG_SYNC();
     for (int e = tid; e < 16 * NW; e += 256) {      // one (tap, column) per item: its four channel weights
         const int t = e / NW, n = n0 + e - t * NW;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256) void sg_conv_c4_kernel(const SgIgemmParams G) 
             xv[rb][T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? ((iy * P.Win + ix) * P.in_ld) << 2 : OOB, 0, 0));
         }
     }
-    __syncthreads();      // weights staged
+    SG_SYNC();      // weights staged
     f32x4 wreg[4][NB];    // [T][j]: the four channel weights of (tap 4 T + fq, column 16 j + fr)
 #pragma unroll
     for (int T = 0; T < 4; ++T)
@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(256) void sg_conv_c4_kernel(const SgIgemmParams G) 
                         atomicAdd(&red[NW + j * 16 + 4 * fq + r], a2);
                     }
                 }
-            __syncthreads();
+            SG_SYNC();
             if (tid < NW && n0 + tid < P.N) {
                 double* st = sg_stat_replica(P.stats, P.stats_rep, blockIdx.x);
                 atomicAdd(&st[n0 + tid], red[tid]);
@@ -1280,7 +1280,7 @@ __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmPa
         cG[c] = (xnorm && P.xn.gamma) ? P.xn.gamma[c] : 1.f;
         cB[c] = (xnorm && P.xn.beta) ? P.xn.beta[c] : 0.f;
     }
-    __syncthreads();
+    SG_SYNC();
     const float xn_neg = P.xn.act == SGAN_ACT_NONE ? 1.f : (P.xn.act == SGAN_ACT_RELU ? 0.f : P.xn.slope);
     const int64_t total = (int64_t)P.Hout * P.Wout * NQ;
     const int64_t stride = (int64_t)gridDim.x * 256;   // host makes this a multiple of NQ
@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmPa
             atomicAdd(&red[n + j], s1[j]);
             atomicAdd(&red[N + n + j], s2[j]);
         }
-        __syncthreads();
+        SG_SYNC();
         for (int c = threadIdx.x; c < N; c += 256) {
 #ifndef SG_NO_STAT_ATOMICS      // diagnostics build: what the same-address fp64 atomics cost
             double* st = sg_stat_replica(P.stats, P.stats_rep, blockIdx.x);

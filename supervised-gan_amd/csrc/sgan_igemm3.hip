@@ -200,7 +200,7 @@ __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB]
                 atomicAdd(&red[BN + nl], b);
             }
         }
-        __syncthreads();
+        SG_SYNC();
         if (tid < BN && n0 + tid < N) {
 #ifndef SG_NO_STAT_ATOMICS      // diagnostics build: what the same-address fp64 atomics cost
             double* st = sg_stat_replica(P.stats, P.stats_rep, bid);
@@ -336,7 +336,7 @@ __device__ __forceinline__ void sg_igemm3_body(const SgIgemmParams& G, char* sme
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    __syncthreads();  // tap table visible
+    SG_SYNC();  // tap table visible
     const Sg3EpiConst<NB> epi_const = sg3_epilogue_constants<WTN, NB>(P, n0, wn, tid);
 
     int ld_left = nkt;
@@ -502,7 +502,7 @@ __device__ __forceinline__ void sg_igemm3_body(const SgIgemmParams& G, char* sme
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
             __builtin_amdgcn_sched_group_barrier(0x006, PER, 0);    // VALU / SALU in its shadow
         }
-        if constexpr (!KB2 || (S & 1)) __syncthreads();
+        if constexpr (!KB2 || (S & 1)) SG_SYNC();
     };
     auto prefetch = [&](auto K_) { next_addrs(); issue_loads(K_); };
     auto maybe = [&](auto K_, int kt) { if (kt + decltype(K_)::value < nkt) iteration(K_); };
@@ -522,7 +522,7 @@ __device__ __forceinline__ void sg_igemm3_body(const SgIgemmParams& G, char* sme
         load_scales(std::integral_constant<int, 1>{});
         store_tile(std::integral_constant<int, 1>{});
     }
-    __syncthreads();
+    SG_SYNC();
     {
         int kt = 0;
         for (; kt + NSET - 1 < nkt; kt += NSET) SG3_FOR_SETS(iteration);
@@ -759,7 +759,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
         for (int p = 0; p < 2; ++p) f_off[s][p] = ((2 * (2 * s + fh) + p) ^ fswz) << 4;
     const int fb_row = (wn * WTN + fr) * 128;
 
-    __syncthreads();   // tap table, scale / shift visible
+    SG_SYNC();   // tap table, scale / shift visible
     const Sg3EpiConst<NB> epi_const = sg3_epilogue_constants<WTN, NB>(P, n0, wn, tid);
     SG3P_MARK(1);
 
@@ -805,7 +805,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
             if (cur_cb < ncb) {       // nobody reads the old patch any more (the reads of this step were issued a step ago)
                 store_a(cur_cb);
                 issue_a(cur_cb + 1);
-                __syncthreads();
+                SG_SYNC();
             }
         }
         const char* Ab = Ap + fa_base + tapx_pref;
@@ -819,7 +819,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
         store_b(std::integral_constant<int, (S + 2) % NSET>{});
         issue_b(std::integral_constant<int, (S + 2) % NSET>{});
         next_b_addrs();
-        __syncthreads();
+        SG_SYNC();
     };
     auto prefetch = [&](auto K_) { next_b_addrs(); issue_b(K_); };
     auto maybe = [&](auto K_, int u) { if (u + decltype(K_)::value < nunits) iteration(K_); };
@@ -834,7 +834,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     store_b(std::integral_constant<int, 1>{});
     prefetch(std::integral_constant<int, 1>{});
     next_b_addrs();
-    __syncthreads();
+    SG_SYNC();
 #ifdef SG3P_DELAY_WAVE   // tools/race_stress.sh: hold one wave back here, the way a cold instruction cache would, only for longer
     if ((threadIdx.x >> 6) == SG3P_DELAY_WAVE) { for (int i = 0; i < 4; ++i) asm volatile("s_sleep 127" ::: "memory"); }
     __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads behind the sleep
@@ -850,7 +850,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     // once in a few dozen runs; every later step is covered by the barrier that ends the iteration before it.
     // (tools/race_stress.sh builds the kernel with one wave held back, with and without this barrier.)
 #ifndef SG3P_NO_STEP0_BARRIER
-    __syncthreads();
+    SG_SYNC();
 #endif
     SG3P_MARK(2);
     {

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
         for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = (P.dbias != nullptr) && (blockIdx.x == 0);
 
-    __syncthreads();  // pscale/pshift visible
+    SG_SYNC();  // pscale/pshift visible
     using J0 = std::integral_constant<int, 0>;
     using J1 = std::integral_constant<int, 1>;
     using J2 = std::integral_constant<int, 2>;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
         store_chunk(std::integral_constant<int, (S + 1) % NS>{}, buf ^ 1);   // chunk it_no + 1
         next_addrs();
         ++it_no;
-        __syncthreads();
+        SG_SYNC();
     };
     next_addrs();
     issue_loads(J0{});
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     issue_loads(J2{});
     next_addrs();
     store_chunk(J0{}, 0);
-    __syncthreads();
+    SG_SYNC();
     {
         const int n_it = ch_end - ch_begin;
         int i = 0;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
     if (do_bias) {   // (uniform) combine the per-thread column sums: threads tid = d_c4 + DQ * row share a channel quad
         f32x4* red = reinterpret_cast<f32x4*>(smem);   // the staging buffers are dead: every wave is past the last barrier
         red[tid] = bacc;
-        __syncthreads();
+        SG_SYNC();
         if (tid < BCO && co0 + tid < Cout) {
             float sb = 0.f;
 #pragma unroll
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
             pss[c] = sc;
             pss[G.Cin + c] = sh;
         }
-        __syncthreads();
+        SG_SYNC();
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int c = SWAP ? row_l + j : j;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
             if (fq == 0) redb[wid * ROWS + fr * MB + i] = b;
         }
     }
-    __syncthreads();
+    SG_SYNC();
     float* part = ws ? ws + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (ROWS * COLS + ROWS) : nullptr;
     for (int e = tid; e < ROWS * COLS; e += 256) {
         const float v = (red[e] + red[ROWS * COLS + e]) + (red[2 * ROWS * COLS + e] + red[3 * ROWS * COLS + e]);
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_reduce_kernel(const SgWgrad
                 for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
                 if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][c] = v;
             }
-            __syncthreads();
+            SG_SYNC();
             if (threadIdx.x < 4 && (int)threadIdx.x < G.Cout)
                 atomicAdd(Q.dbias + threadIdx.x, (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]));
         }
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_reduce_kernel(const SgWgrad
         }
     }
     sred[cl][el] = sum;
-    __syncthreads();
+    SG_SYNC();
     if (cl != 0 || e >= PS) return;
 #pragma unroll
     for (int c = 1; c < 8; ++c) sum += sred[c][el];

@@ -255,7 +255,7 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
     const int fG = lane >> 4, fq = (lane >> 2) & 3, fp4 = lane & 3;
     const int f_lane = (8 * (fG >> 1) + fq) * 64 + (16 * (fG & 1) + 4 * fp4) * 2;
 
-    __syncthreads();  // pscale / pshift visible
+    SG_SYNC();  // pscale / pshift visible
     using J0 = std::integral_constant<int, 0>;
     using J1 = std::integral_constant<int, 1>;
     using J2 = std::integral_constant<int, 2>;
@@ -302,7 +302,7 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
             __builtin_amdgcn_sched_group_barrier(0x006, PER, 0);
         }
         ++it_no;
-        __syncthreads();
+        SG_SYNC();
     };
     next_addrs();
     issue_loads(J0{});
@@ -312,7 +312,7 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
     issue_loads(J2{});
     next_addrs();
     store_chunk(J0{}, 0);
-    __syncthreads();
+    SG_SYNC();
     {
         const int n_it = ch_end - ch_begin;
         int i = 0;
@@ -348,14 +348,14 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
         }
     }
     if (do_bias) {   // (uniform) threads with equal (channel block, chunk) -- tid & 0x83 -- share 8 channels: sum over their 32 pixel rows
-        __syncthreads();   // every wave is past its last fragment read: the staging buffers are free
+        SG_SYNC();   // every wave is past its last fragment read: the staging buffers are free
         f32x4* red = reinterpret_cast<f32x4*>(smem);   // [D_IT][2][256]
 #pragma unroll
         for (int it = 0; it < D_IT; ++it) {
             red[(it * 2 + 0) * 256 + tid] = bacc[it][0];
             red[(it * 2 + 1) * 256 + tid] = bacc[it][1];
         }
-        __syncthreads();
+        SG_SYNC();
         if (tid < BCO) {
             const int blk = tid >> 5, cq = (tid & 31) >> 3, half = (tid >> 2) & 1, e = tid & 3;   // channel tid of the tile
             const int it = blk >> 1, t0 = ((blk & 1) << 7) + cq;

@@ -83,6 +83,56 @@ def _act(t):
     return t
 
 
+def _avail(t):
+    """fp32 elements between a tensor's first element and the end of its storage."""
+    return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+
+
+def _fits(t, H, W, Cs, what):
+    """The C ABI takes raw pointers: it cannot see how much memory stands behind them, so the one place that can -- this wrapper --
+    checks every conv operand against its descriptor BEFORE anything is launched: an [H][W][Cs] NHWC tensor with pixel stride
+    stride(1) must lie inside its storage.  (Round 2's memory access fault was exactly this: a descriptor that had become legal
+    described a larger layer than the tensors handed in with it)"""
+    _act(t)
+    if t.shape[0] * t.shape[1] != H * W or t.shape[2] < Cs or (H * W - 1) * t.stride(1) + Cs > _avail(t):
+        raise L.SganError(f"{what}: tensor {tuple(t.shape)} (pixel stride {t.stride(1)}, {_avail(t)} elements of storage) does not "
+                          f"match the descriptor's {H}x{W}x{Cs}; nothing was launched")
+    return t
+
+
+def _check_fwd_jobs(jobs):
+    for job in jobs:
+        desc, x, _, w, _, out = job[:6]
+        _fits(x, desc.Hin, desc.Win, desc.Cin, "conv_fwd x")
+        _fits(out, desc.Hout, desc.Wout, desc.Cout, "conv_fwd out")
+        _fits_w(w, desc, "conv_fwd w")
+
+
+def _check_dgrad_jobs(jobs):
+    for job in jobs:
+        desc, dout, w, din, x = job[:5]
+        _fits(dout, desc.Hout, desc.Wout, desc.Cout, "conv_dgrad dout")
+        _fits(din, desc.Hin, desc.Win, desc.Cin, "conv_dgrad din")
+        _fits_w(w, desc, "conv_dgrad w")
+        if x is not None:
+            _fits(x, desc.Hin, desc.Win, desc.Cin, "conv_dgrad x")
+
+
+def _check_wgrad_jobs(jobs):
+    for desc, x, _, dout, dw, _ in jobs:
+        _fits(x, desc.Hin, desc.Win, desc.Cin, "conv_wgrad x")
+        _fits(dout, desc.Hout, desc.Wout, desc.Cout, "conv_wgrad dout")
+        _fits_w(dw, desc, "conv_wgrad dw")
+
+
+def _fits_w(w, desc, what):
+    need = desc.k * desc.k * desc.Cin * desc.Cout
+    if w is None or _avail(w) < need:
+        raise L.SganError(f"{what}: weight tensor holds {0 if w is None else _avail(w)} elements, the descriptor's k{desc.k} "
+                          f"{desc.Cin}->{desc.Cout} layer needs {need}; nothing was launched")
+    return w
+
+
 def conv_desc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin=0, Cout=0):
     """Cin / Cout: logical channel counts (0 = unknown), a hint that lets kernels skip the zero padding channels."""
     return L.ConvDesc(kind, k, stride, pad, Hin, Win, Cin_s, Hout, Wout, Cout_s, Cin, Cout, _math)
@@ -145,6 +195,8 @@ def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None, sums_sq=0
 
 def conv_wgrad(desc, x, in_norm, dout, dw, dbias):
     desc.math = _math
+    _fits(x, desc.Hin, desc.Win, desc.Cin, "conv_wgrad x"); _fits(dout, desc.Hout, desc.Wout, desc.Cout, "conv_wgrad dout")
+    _fits_w(dw, desc, "conv_wgrad dw")
     args = (C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(_act(dout)), dout.stride(1), _ptr(dw), _ptr(dbias))
     ws = _workspace(L.lib().sgan_conv_wgrad(*args, None, -1, None), x.device) if min(desc.Cin, desc.Cout) <= 4 else None
     L.check(L.lib().sgan_conv_wgrad(*args, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "sgan_conv_wgrad")
@@ -164,6 +216,7 @@ def conv_fwd_grouped(jobs, out_act=ACT_NONE):
                               _ptr(_act(out)).value, out.stride(1), _ptr(st).value, int(job[7]) if len(job) > 7 else 0, _pk(w),
                               int(job[8]) if (len(job) > 8 and st is not None) else 0)
     ws = _workspace(L.lib().sgan_conv_fwd_grouped(arr, len(jobs), out_act, None, -1, None), jobs[0][1].device)
+    _check_fwd_jobs(jobs)      # after the size query: a descriptor the library rejects is reported in the library's words
     L.check(L.lib().sgan_conv_fwd_grouped(arr, len(jobs), out_act, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_fwd_grouped")
 
@@ -194,6 +247,7 @@ def conv_dgrad_grouped(jobs):
     """jobs: list of (desc, dout, w, din, x, x_norm, bwd_sums[, sums_sq, accumulate, w_transposed, sums_rep])."""
     arr = _dgrad_array(jobs)
     ws = _workspace(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device)
+    _check_dgrad_jobs(jobs)
     L.check(L.lib().sgan_conv_dgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
             "sgan_conv_dgrad_grouped")
 
@@ -201,6 +255,7 @@ def conv_dgrad_grouped(jobs):
 def conv_wgrad_grouped(jobs):
     """jobs: list of (desc, x, in_norm, dout, dw, dbias)."""
     arr = _wgrad_array(jobs)
+    _check_wgrad_jobs(jobs)
     d0 = jobs[0][0]
     ws = _workspace(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), None, -1, None), jobs[0][1].device) if min(d0.Cin, d0.Cout) <= 4 else None
     L.check(L.lib().sgan_conv_wgrad_grouped(arr, len(jobs), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
@@ -213,6 +268,8 @@ def conv_bwd_grouped(djobs, wjobs, dgrad_math=None):
     ("f32" / "bf16x3"; None = the current mode)."""
     dm = _DGRAD_MATH if _DGRAD_MATH is not None else (_MATH_NAMES[dgrad_math] if dgrad_math else _math)
     if _math == L.MATH_BF16X3:
+        _check_dgrad_jobs(djobs)
+        _check_wgrad_jobs(wjobs)
         rc = L.lib().sgan_conv_bwd_fused(_dgrad_array(djobs), len(djobs), _wgrad_array(wjobs), len(wjobs), dm, _stream())
         if rc == 0:
             return True

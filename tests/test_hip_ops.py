@@ -792,6 +792,20 @@ def test_c_abi_error_paths(hip):
         ops.conv_fwd(good, x, ops.norm_desc(None, None, None, 256, 0.0, 2, 1.5), w, None, y)
     rc = L_raw().sgan_conv_fwd(None, None, 0, None, None, None, None, 0, 0, None, None, 0, None)
     assert rc < 0 and L_raw().sgan_last_error()
+    # Round 2's memory access fault: this very test asked for k = 7 as its "unsupported kernel size" in a build whose
+    # tap table had just grown to 49 entries.  The descriptor was legal, so the library ran a k7 8 -> 8 layer on a 16 x 16 map over the
+    # buffers above: 3136 weights read from a 1024-element tensor, 2048 results stored into a 648-element one.  The C ABI cannot
+    # see allocation sizes; the wrapper that owns the tensors now refuses before anything is launched.
+    with pytest.raises(SganError, match="does not match the descriptor"):
+        ops.conv_fwd(ops.conv_desc(0, 7, 1, 3, 16, 16, 8, 16, 16, 8), x, None, w, None, y)
+    y16 = torch.zeros(16, 16, 8, device="cuda")
+    with pytest.raises(SganError, match="weight tensor holds 1024"):
+        ops.conv_fwd(ops.conv_desc(0, 7, 1, 3, 16, 16, 8, 16, 16, 8), x, None, w, None, y16)
+    with pytest.raises(SganError, match="does not match the descriptor"):
+        ops.conv_dgrad(ops.conv_desc(0, 7, 1, 3, 16, 16, 8, 16, 16, 8), y, torch.zeros(49 * 64, device="cuda"), x)
+    with pytest.raises(SganError, match="does not match the descriptor"):
+        ops.conv_wgrad(ops.conv_desc(0, 7, 1, 3, 16, 16, 8, 16, 16, 8), x, None, y, torch.zeros(49 * 64, device="cuda"), None)
+    assert float(y.abs().max()) == 0.0 and float(y16.abs().max()) == 0.0           # nothing ran
     D = N.define_D(2, 8, "dcgan", gpu_ids=[0])             # five k4 s2 p1 convs, then k4 s1 p0 on what must be a 4x4 map
     with pytest.raises(SganError, match="too small"):
         D.forward(torch.rand(1, 2, 32, 32, device="cuda"))
@@ -801,6 +815,71 @@ def test_c_abi_error_paths(hip):
 def L_raw():
     from supervised_gan_amd import _lib
     return _lib.lib()
+
+
+GUARD = 4096      # fp32 elements of sentinel behind every operand (16 KB: more than any vector over-read)
+
+
+def _guarded(t, fill=float("nan")):
+    """A copy of `t` whose storage ends in GUARD sentinel elements (NaN: an over-READ that is used turns the result NaN; an
+    over-WRITE changes the sentinel's bit pattern).  Returns (view shaped like t, the guard)."""
+    flat = torch.full((t.numel() + GUARD,), fill, dtype=t.dtype, device="cuda")
+    flat[: t.numel()] = t.reshape(-1)
+    return flat[: t.numel()].view(t.shape), flat[t.numel():]
+
+
+def _guard_intact(g):
+    return bool(torch.isnan(g).all())
+
+
+@pytest.mark.parametrize("case", [
+    ("conv", 7, 1, 3, 8, 8, 16, 16),        # the layer round 2's fault ran on undersized buffers (k7, 49 taps)
+    ("conv", 7, 1, 0, 8, 64, 22, 22),       # resnet head after the reflection pad (49 taps, p0)
+    ("conv", 7, 1, 0, 64, 2, 22, 22),       # resnet output layer: 49 taps into a 4-channel stored result
+    ("convT", 3, 2, 1, 32, 16, 9, 7),       # resnet up layer with output_padding = 1 (Hout = 2 Hin)
+    ("conv", 4, 2, 2, 2, 32, 37, 41),       # first PatchGAN conv (4 stored channels: c4 / thin kernels)
+    ("conv", 4, 1, 2, 256, 1, 10, 12),      # logits head
+], ids=lambda c: f"{c[0]}_k{c[1]}s{c[2]}p{c[3]}_{c[4]}to{c[5]}_{c[6]}x{c[7]}")
+def test_conv_operands_with_guarded_tails(hip, case, math_mode):
+    """Every operand of forward / backward-data / backward-weight is placed so that its storage ends in a NaN guard: results match
+    torch (an over-read that reaches a product would make them NaN) and every guard keeps its bit pattern (no store past an end).
+    Regression shapes for the round-2 fault: the 49-tap layers, ConvT output padding, the 4-channel kernels."""
+    from hip_utils import from_buf, from_master, master_weight, pad_vec, rel, to_buf
+    from supervised_gan_amd.ops import pad4
+    ops = hip
+    kind, k, s, p, cin, cout, H, W = case
+    tr = kind == "convT"
+    op = 1 if (tr and k == 3) else 0
+    g = torch.Generator().manual_seed(4242)
+    x = torch.randn(1, cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(*((cin, cout, k, k) if tr else (cout, cin, k, k)), generator=g) * 0.05).requires_grad_(True)
+    b = (torch.randn(cout, generator=g) * 0.1).requires_grad_(True)
+    out = F.conv_transpose2d(x, w, b, stride=s, padding=p, output_padding=op) if tr else F.conv2d(x, w, b, stride=s, padding=p)
+    R = torch.randn(out.shape, generator=g)
+    (out * R).sum().backward()
+    Ho, Wo = out.shape[2:]
+    desc = ops.conv_desc(1 if tr else 0, k, s, p, H, W, pad4(cin), Ho, Wo, pad4(cout), cin, cout)
+    guards = []
+
+    def G(t):
+        v, gd = _guarded(t)
+        guards.append(gd)
+        return v
+    xb, Rb, bb = G(to_buf(x.detach())), G(to_buf(R)), G(pad_vec(b.detach()))
+    wm0 = master_weight(w.detach(), tr)
+    wm, wt = G(wm0), G(wm0._sgan_wt)
+    pf, pb = G(wm0._sgan_pk), G(wm0._sgan_wt._sgan_pk)
+    ops.with_packed(wm, pf); ops.with_packed(wt, pb)
+    ob, din = G(torch.zeros(Ho, Wo, pad4(cout), device="cuda")), G(torch.zeros(H, W, pad4(cin), device="cuda"))
+    dw, db = G(torch.zeros_like(wm0)), G(torch.zeros(pad4(cout), device="cuda"))
+    ops.conv_fwd(desc, xb, None, wm, bb, ob)
+    ops.conv_dgrad(desc, Rb, wt, din, None, None, None, w_transposed=True)
+    ops.conv_wgrad(desc, xb, None, Rb, dw, db)
+    torch.cuda.synchronize()
+    assert rel(from_buf(ob, cout), out) < 1e-4
+    assert rel(from_buf(din, cin), x.grad) < TOL
+    assert rel(from_master(dw, k, cin, cout, tr), w.grad) < TOL and rel(db[:cout], b.grad) < TOL
+    assert all(_guard_intact(gd) for gd in guards), [i for i, gd in enumerate(guards) if not _guard_intact(gd)]
 
 
 def test_image_prep_bit_exact(hip):

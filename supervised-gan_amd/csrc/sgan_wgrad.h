@@ -26,6 +26,7 @@ struct SgWgradParams {   // kernel argument: common layer description + up to 8 
     int32_t w_ns;
     int32_t nphase, nprob;
     int32_t pro_act;
+    int32_t thin_real;   // thin kernels: channels of the 4-wide side that carry data (Cin_logical / Cout_logical hint, else 4)
     float pro_slope, pro_eps;
     int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
     SgTap taps[SGAN_MAX_TAPS];          // every phase's taps back to back (k * k in all)

@@ -376,25 +376,76 @@ static int sg_launch_wgrad(SgWgradParams& P, hipStream_t st) {
 // the loop) and keeps its whole 16*MB x 64 partial in accumulators:
 //   * B operand, lane (fr, fq): tap fr of pixel p + fq, its 4 channels = one 16-byte load;
 //   * A operand, lane (fr, fq): rows r0 + fr*MB + i (i < MB) of the same pixel = consecutive floats;
-//   * the four waves of a workgroup combine their partials through LDS; the workgroup's tile goes to the
-//     caller's workspace and a second small kernel adds the tiles of all pixel splits into dW (hundreds of
-//     workgroups adding into the same few thousand addresses would serialise in the memory-side atomic units).
+//   * the waves of a workgroup combine their partials through LDS and the workgroup adds its tile into dW (see below).
 // (The row permutation relative to the wide kernel is only a relabelling of MFMA tiles.)
 // ------------------------------------------------------------------------------------------
 #ifndef SG_THIN_U
-#define SG_THIN_U 2
-#endif
+#define SG_THIN_U 4      // steps per load group, two groups in flight (U = 8 measured slower: 20.3 vs 17.5 us on the six-problem first-layer launch;
+#endif                   // in-kernel stamps: ~1000 cycles per 4-pixel step, one memory round trip per group turn)
 
+#ifndef SG_THIN_ABL
+#define SG_THIN_ABL 0     // diagnostics builds only (wrong results): 1 no final atomics, 2 no main loop, 4 no norm prologue
+#endif
+#ifdef SGTHIN_STAMP      // diagnostics build: per-workgroup s_memtime stamps (tools/stamp_thin.py reads them through sgan_debug_stamps_thin)
+__device__ unsigned long long sgthin_stamps[8 * 4096];
+#define SGT_MARK(i)                                                                                        \
+    do {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (threadIdx.x == 0 && blockIdx.z * gridDim.y + blockIdx.y < 4096) {                              \
+            unsigned long long t_;                                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+            sgthin_stamps[(blockIdx.z * gridDim.y + blockIdx.y) * 8 + (i)] = (i) >= 6 ? __builtin_amdgcn_s_memrealtime() : t_; \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    } while (0)
+extern "C" int sgan_debug_stamps_thin(void* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sgthin_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define SGT_MARK(i)
+#endif
+#define SG_THIN_NW 8      // waves per workgroup: two per SIMD, so a SIMD has a second instruction stream while one waits on its loads
+
+// Round 3: ONE pass.  Round 2 ran ~1024 four-wave workgroups of ~170 pixels each (11 steps per wave), wrote 8.5 MB of partial tiles
+// and summed them in a second launch (8 launches per fcgan step, 8-9 us each plus the boundary).  Now ~256 eight-wave workgroups (one
+// per CU, 2 waves per SIMD: the exact-fp32 MFMAs of this kernel are 4.5 us of matrix-pipe time spread over every SIMD of the chip),
+// 2 x SG_THIN_U steps in flight per wave, the eight partials of a workgroup meet in LDS and the workgroup adds its tile to dW with
+// fp32 atomics whose 64 lanes cover 256 CONTIGUOUS bytes (lane -> (row, thin channel) of one tap: the full-rate form of
+// MI355X_MICROARCH.md "Global float atomics"; round 2's direct-atomic experiment scattered 16-byte pieces 512 B apart).
 template <int MB, bool PRO, bool SWAP>
-__global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams G, float* ws) {
-    constexpr int ROWS = 16 * MB, COLS = 64, NB = 4;
+__global__ __launch_bounds__(64 * SG_THIN_NW) void sg_wgrad_thin_kernel(const SgWgradParams G, int nbias_z0) {
+    constexpr int ROWS = 16 * MB, COLS = 64, NB = 4, NW = SG_THIN_NW, NT = 64 * NW;
     static_assert(MB == 1 || MB == 2 || MB == 4, "operand widths");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);   // [4 waves][ROWS][COLS]
-    float* redb = red + 4 * ROWS * COLS;           // [4 waves][ROWS]
+    float* red = reinterpret_cast<float*>(smem);   // [4 slots][ROWS][COLS]: waves w and w + 4 share slot w
+    float* redb = red + 4 * ROWS * COLS;           // [4 slots][ROWS]
     float* pss = redb + 4 * ROWS;                  // [2 * Cin] prologue scale | shift
+    int* woff = reinterpret_cast<int*>(pss + 2 * G.Cin);   // [16] weight slab offset of a tap
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+    SGT_MARK(0); SGT_MARK(6);
+    if constexpr (SWAP) {
+        if ((int)blockIdx.z >= nbias_z0) {   // bias gradient of a thin-Cout layer: sum of dOut over its pixels (<= 4 channels), few workgroups
+            const SgWgradProb& Q = G.q[(blockIdx.z - nbias_z0) >> 2];
+            if (!Q.dbias || blockIdx.y != 0) return;
+            const int npix = Q.Hout * Q.Wout, part = (blockIdx.z - nbias_z0) & 3;
+            f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int p = part * NT + tid; p < npix; p += 4 * NT) s4 += *reinterpret_cast<const f32x4*>(Q.dout + (int64_t)p * Q.dout_ld);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = s4[c];
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                if (lane == 0) red[wid * 4 + c] = v;
+            }
+            SG_SYNC();
+            if (tid < 4 && tid < G.Cout) {
+                float v = 0.f;
+                for (int w = 0; w < NW; ++w) v += red[w * 4 + tid];
+                atomicAdd(Q.dbias + tid, v);
+            }
+            return;
+        }
+    }
     int g = 0;
     for (int gi = 1; gi < G.nprob; ++gi)
         if ((int)blockIdx.z >= G.q[gi].z0) g = gi;
@@ -405,15 +456,16 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
     if (M == 0) return;
     const int rows_total = SWAP ? G.Cin : G.Cout;
     const int r0 = blockIdx.y * ROWS;
-    // this wave's pixel range: the workgroup's share of M, cut into 4 (multiples of 4 pixels)
-    const int per_wg = ((M + Q.nsplit - 1) / Q.nsplit + 15) & ~15;
-    const int per_wave = per_wg >> 2;
+    // this wave's pixel range: the workgroup's share of M, cut into NW (multiples of 4 pixels)
+    const int per_wg = ((M + Q.nsplit - 1) / Q.nsplit + 4 * NW - 1) / (4 * NW) * (4 * NW);
+    const int per_wave = per_wg / NW;
     const int m_begin = split * per_wg + wid * per_wave;
     const int m_end = min(M, m_begin + per_wave);
 
     // lane constants: column group = tap fr, rows r0 + fr*MB + i
     const bool kok = fr < G.ntaps[phz];
     const int tdy = kok ? (int)G.taps[G.tap0[phz] + fr].dy : 0, tdx = kok ? (int)G.taps[G.tap0[phz] + fr].dx : 0;
+    if (tid < 16) woff[tid] = tid < G.ntaps[phz] ? G.taps[G.tap0[phz] + tid].w_off : -1;
     const int row_l = r0 + fr * MB;
     const bool rok = row_l < rows_total;
     const int gs = G.is, os = G.os, oa = G.oa[phz], ob = G.ob[phz];
@@ -433,9 +485,9 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
         pn.stats = Q.pro_stats; pn.gamma = Q.pro_gamma; pn.beta = Q.pro_beta; pn.count = Q.pro_count;
         pn.eps = G.pro_eps; pn.act = G.pro_act; pn.slope = G.pro_slope; pn.sq_stride = Q.pro_sq; pn.rep_stride = Q.pro_rep;
         pro_neg = G.pro_act == SGAN_ACT_NONE ? 1.f : (G.pro_act == SGAN_ACT_RELU ? 0.f : G.pro_slope);
-        for (int c = tid; c < G.Cin; c += 256) {
+        for (int c = tid; c < G.Cin; c += NT) {
             float sc = 1.f, sh = 0.f;
-            if (pn.stats) {
+            if (pn.stats && !(SG_THIN_ABL & 4)) {
                 float mean, rstd;
                 sg_mean_rstd(pn, G.Cin, c, mean, rstd);
                 const float gm = pn.gamma ? pn.gamma[c] : 1.f;
@@ -456,6 +508,8 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
         }
     }
     const bool do_bias = !SWAP && Q.dbias != nullptr;
+    // thin channels that carry data (2 of the 4 stored for the fcgan image, 1 for the logits): the MFMAs of the padding are skipped
+    const int nthin = G.thin_real;
 
     f32x4 acc[MB][NB];
 #pragma unroll
@@ -528,14 +582,16 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
             for (int i = 0; i < MB; ++i) {
                 bsum[i] += a[i];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NB; ++j)
+                    if (j < nthin) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);      // wave-uniform skip
             }
         }
     };
-    const int nsteps = (max(m_end - m_begin, 0) + 3) >> 2;
+    const int nsteps = (SG_THIN_ABL & 2) ? 0 : (max(m_end - m_begin, 0) + 3) >> 2;
     const int ngroups = (nsteps + U - 1) / U;
     // branch-free body (loads past the range carry the out-of-range offset and return zeros): a conditional load
     // would make the compiler wait for ALL outstanding loads at the join, serialising the two slots
+    SGT_MARK(1);
     load_group(0);
     for (int gk = 0; gk < ngroups; gk += 2) {
         load_group(1);
@@ -544,9 +600,10 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
         compute_group(1);
     }
 
-    // ---- combine the four waves through LDS (plain stores, then every thread sums 4 partials per element) ----
-    {
-        float* mine = red + wid * ROWS * COLS;
+    // ---- combine the eight waves through LDS: waves 4..7 store, waves 0..3 add their own on top (same lane -> element map),
+    //      then every thread sums the four slots of its elements ----
+    auto stash = [&](bool add) {
+        float* mine = red + (wid & 3) * ROWS * COLS;
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -554,112 +611,58 @@ __global__ __launch_bounds__(256) void sg_wgrad_thin_kernel(const SgWgradParams 
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][e][r];
-                *reinterpret_cast<f32x4*>(mine + ((fq * 4 + r) * MB + i) * COLS + fr * NB) = v;
+                f32x4* dst = reinterpret_cast<f32x4*>(mine + ((fq * 4 + r) * MB + i) * COLS + fr * NB);
+                if (add) v += *dst;
+                *dst = v;
             }
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
             float b = bsum[i];
             b += __shfl_xor(b, 16);
             b += __shfl_xor(b, 32);
-            if (fq == 0) redb[wid * ROWS + fr * MB + i] = b;
+            if (fq == 0) redb[(wid & 3) * ROWS + fr * MB + i] = add ? redb[(wid & 3) * ROWS + fr * MB + i] + b : b;
         }
-    }
+    };
+    SGT_MARK(2);
+    if (wid >= 4) stash(false);
     SG_SYNC();
-    float* part = ws ? ws + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * (ROWS * COLS + ROWS) : nullptr;
-    for (int e = tid; e < ROWS * COLS; e += 256) {
+    if (wid < 4) stash(true);
+    SG_SYNC();
+    SGT_MARK(3);
+    // fp32 atomics, 64 consecutive lanes -> 64 consecutive floats of dW:
+    //   cin4 (SWAP = false): dW[tap][co][c4]  -> e' = tap * (ROWS * 4) + rl * 4 + c4
+    //   cout4 (SWAP = true): dW[tap][c4][ci]  -> e' = (tap * 4 + c4) * ROWS + rl
+    for (int e2 = tid; e2 < ROWS * COLS; e2 += NT) {
+        int rl, kl;
+        if constexpr (SWAP) { kl = e2 / ROWS; rl = e2 - kl * ROWS; }
+        else { const int t = e2 / (ROWS * 4), r = e2 - t * (ROWS * 4); rl = r >> 2; kl = t * 4 + (r & 3); }
+        const int e = rl * COLS + kl;
         const float v = (red[e] + red[ROWS * COLS + e]) + (red[2 * ROWS * COLS + e] + red[3 * ROWS * COLS + e]);
-        if (part) {
-            part[e] = v;
-        } else {   // no workspace: straight to dW (same result, contended atomics)
-            const int rl = e / COLS, kl = e - rl * COLS, t = kl >> 2, c4 = kl & 3;
-            const int row = r0 + rl;
-            if (row < rows_total && t < G.ntaps[phz] && c4 < (SWAP ? G.Cout : G.Cin))
-                atomicAdd(Q.dw + G.taps[G.tap0[phz] + t].w_off + (SWAP ? (int64_t)c4 * G.w_ns + row : (int64_t)row * G.w_ns + c4), v);
-        }
+        const int t = kl >> 2, c4 = kl & 3, row = r0 + rl;
+        const int wo = woff[t];
+        if (row < rows_total && wo >= 0 && c4 < (SWAP ? G.Cout : G.Cin) && (!(SG_THIN_ABL & 1) || v == 123.f))
+            atomicAdd(Q.dw + wo + (SWAP ? (int64_t)c4 * G.w_ns + row : (int64_t)row * G.w_ns + c4), v);
     }
-    if (tid < ROWS) {
-        const float b = (redb[tid] + redb[ROWS + tid]) + (redb[2 * ROWS + tid] + redb[3 * ROWS + tid]);
-        if (part) part[ROWS * COLS + tid] = do_bias ? b : 0.f;
-        else if (do_bias && r0 + tid < rows_total) atomicAdd(Q.dbias + r0 + tid, b);
-    }
-}
-
-// second stage: dW[tile element] += sum over the pixel splits of one (problem, phase, row block).  A workgroup is
-// 32 elements x 8 split lanes of 16 splits each; the 8 lanes meet in LDS and one atomic per element leaves.
-// SWAP launches carry extra z-slices (one per problem) that sum dOut over all pixels into dbias.
-template <int ROWS, bool SWAP>
-__global__ __launch_bounds__(256) void sg_wgrad_thin_reduce_kernel(const SgWgradParams G, const float* ws, int nrb) {
-    constexpr int COLS = 64, PS = ROWS * COLS + ROWS, CH = 16;
-    __shared__ float sred[8][33];
-    const int ngroups = G.nprob * G.nphase * nrb;
-    if ((int)blockIdx.z >= ngroups) {
-        if constexpr (SWAP) {   // bias gradient of a thin-Cout layer: sum of dOut over its pixels (<= 4 channels)
-            const SgWgradProb& Q = G.q[blockIdx.z - ngroups];
-            if (!Q.dbias) return;
-            const int npix = Q.Hout * Q.Wout;
-            const int nb = min((int)gridDim.x, 16);      // few workgroups: every one ends in an atomic on the same address
-            if (blockIdx.y != 0 || (int)blockIdx.x >= nb) return;
-            f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += nb * 256)
-                s4 += *reinterpret_cast<const f32x4*>(Q.dout + (int64_t)p * Q.dout_ld);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float v = s4[c];
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][c] = v;
-            }
-            SG_SYNC();
-            if (threadIdx.x < 4 && (int)threadIdx.x < G.Cout)
-                atomicAdd(Q.dbias + threadIdx.x, (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]));
-        }
-        return;
-    }
-    int t = blockIdx.z;
-    const int rb = t % nrb; t /= nrb;     // t = problem * nphase + phase
-    const int g = t / G.nphase, phz = t - g * G.nphase;
-    const SgWgradProb& Q = G.q[g];
-    if (Q.Hp[phz] * Q.Wp[phz] == 0) return;
-    const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + el;
-    const int sp0 = (blockIdx.y * 8 + cl) * CH;
-    if (blockIdx.y * 8 * CH >= Q.nsplit) return;
-    float sum = 0.f;
-    if (e < PS) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int sp = sp0 + u;
-            if (sp < Q.nsplit) sum += ws[((int64_t)(Q.z0 + phz * Q.nsplit + sp) * nrb + rb) * PS + e];
-        }
-    }
-    sred[cl][el] = sum;
-    SG_SYNC();
-    if (cl != 0 || e >= PS) return;
-#pragma unroll
-    for (int c = 1; c < 8; ++c) sum += sred[c][el];
-    const int rows_total = SWAP ? G.Cin : G.Cout;
-    if (e < ROWS * COLS) {
-        const int rl = e / COLS, kl = e - rl * COLS, tp = kl >> 2, c4 = kl & 3;
-        const int row = rb * ROWS + rl;
-        if (row < rows_total && tp < G.ntaps[phz] && c4 < (SWAP ? G.Cout : G.Cin))
-            atomicAdd(Q.dw + G.taps[G.tap0[phz] + tp].w_off + (SWAP ? (int64_t)c4 * G.w_ns + row : (int64_t)row * G.w_ns + c4), sum);
-    } else if (!SWAP && Q.dbias && rb * ROWS + (e - ROWS * COLS) < rows_total) {
-        atomicAdd(Q.dbias + rb * ROWS + (e - ROWS * COLS), sum);
-    }
+    if (tid < ROWS && do_bias && r0 + tid < rows_total)
+        atomicAdd(Q.dbias + r0 + tid, (redb[tid] + redb[ROWS + tid]) + (redb[2 * ROWS + tid] + redb[3 * ROWS + tid]));
+    SGT_MARK(4); SGT_MARK(7);
 }
 
 template <int MB, bool SWAP>
 static int sg_launch_wgrad_thin(SgWgradParams& P, hipStream_t st, const char* name, void* workspace, int64_t workspace_bytes) {
     constexpr int ROWS = 16 * MB, COLS = 64, PS = ROWS * COLS + ROWS;
+    (void)workspace;
+    if (workspace_bytes == -1) return 0;      // single pass since round 3: no workspace
     const int nrb = sgw_cdiv(SWAP ? P.Cin : P.Cout, ROWS);
-    // ~4 waves per SIMD over the whole launch (1024 workgroups), >= 128 pixels per workgroup
+    // one eight-wave workgroup per CU over the whole launch, >= 256 pixels per workgroup
     long pix_total = 0;
     for (int g = 0; g < P.nprob; ++g)
         for (int i = 0; i < P.nphase; ++i) pix_total += (long)P.q[g].Hp[i] * P.q[g].Wp[i];
-    if (pix_total == 0) return workspace_bytes == -1 ? 0 : SGAN_OK;
+    if (pix_total == 0) return SGAN_OK;
     const char* want_env = getenv("SGAN_THIN_WANT");        // tuning knobs
-    const int min_pix = getenv("SGAN_THIN_MINPIX") ? atoi(getenv("SGAN_THIN_MINPIX")) : 128;
-    const double want = (want_env ? atof(want_env) : 1024.0) / (double)nrb;
-    int z = 0, max_split = 1;
+    const int min_pix = getenv("SGAN_THIN_MINPIX") ? atoi(getenv("SGAN_THIN_MINPIX")) : 256;
+    const double want = (want_env ? atof(want_env) : 256.0) / (double)nrb;
+    int z = 0;
     for (int g = 0; g < P.nprob; ++g) {
         long pg = 0;
         int maxM = 0;
@@ -674,31 +677,17 @@ static int sg_launch_wgrad_thin(SgWgradParams& P, hipStream_t st, const char* na
         P.q[g].nsplit = nsplit;
         P.q[g].z0 = z;
         z += P.nphase * nsplit;
-        max_split = max(max_split, nsplit);
     }
-    const int64_t need = (int64_t)z * nrb * PS * 4;
-    if (workspace_bytes == -1) return (int)((need + 1023) >> 10);   // query (KiB)
-    float* ws = (workspace && workspace_bytes >= need) ? (float*)workspace : nullptr;
-    // tuning knob: partial tiles straight to dW with atomics, no second stage.  Measured on the fcgan first-layer launch: 104 us with
-    // 1024 workgroups, 35 us with 128, against 22 us for the two stages -- same-address fp32 atomics from eight XCDs serialise
-    static const int thin_atomic = getenv("SGAN_THIN_ATOMIC") ? 1 : 0;
-    if (!SWAP && thin_atomic) ws = nullptr;
-    if (SWAP && !ws) return 1;    // the bias of a thin-Cout layer rides on the second stage: caller falls back to the tiled kernel
-    dim3 grid(1, nrb, z);
-    const size_t lds = (size_t)(4 * PS + 2 * P.Cin) * 4;
+    dim3 grid(1, nrb, z + (SWAP ? 4 * P.nprob : 0));      // SWAP: four bias workgroups per problem behind the tiles
+    const size_t lds = (size_t)(4 * PS + 2 * P.Cin + 16) * 4;
     bool pro = P.pro_act != SGAN_ACT_NONE;
     for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
     sg_prof_begin(st);
-    if (pro) hipLaunchKernelGGL((sg_wgrad_thin_kernel<MB, true, SWAP>), grid, dim3(256), lds, st, P, ws);
-    else hipLaunchKernelGGL((sg_wgrad_thin_kernel<MB, false, SWAP>), grid, dim3(256), lds, st, P, ws);
+    if (pro) hipLaunchKernelGGL((sg_wgrad_thin_kernel<MB, true, SWAP>), grid, dim3(64 * SG_THIN_NW), lds, st, P, z);
+    else hipLaunchKernelGGL((sg_wgrad_thin_kernel<MB, false, SWAP>), grid, dim3(64 * SG_THIN_NW), lds, st, P, z);
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = name;
     sg_prof_end(st, g_sgan_last_kernel);
-    if (ws) {
-        dim3 g2(sgw_cdiv(PS, 32), sgw_cdiv(max_split, 128), P.nprob * P.nphase * nrb + (SWAP ? P.nprob : 0));
-        hipLaunchKernelGGL((sg_wgrad_thin_reduce_kernel<ROWS, SWAP>), g2, dim3(256), 0, st, P, ws, nrb);
-        SGAN_LAUNCH_CHECK();
-    }
     return SGAN_OK;
 }
 
@@ -781,14 +770,15 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
     hipStream_t st = (hipStream_t)stream;
     if (!getenv("SGAN_NO_THIN_WGRAD") && d0->k * d0->k <= 16) {
         if (d0->Cin == 4 && P.nphase == 1) {      // conv-form gather of a 4-channel image
+            P.thin_real = (d0->Cin_logical > 0 && d0->Cin_logical < 4) ? d0->Cin_logical : 4;
             if (d0->Cout <= 16) return sg_launch_wgrad_thin<1, false>(P, st, "sg_wgrad_thin_kernel<1,cin4>", workspace, workspace_bytes);
             if (d0->Cout <= 32) return sg_launch_wgrad_thin<2, false>(P, st, "sg_wgrad_thin_kernel<2,cin4>", workspace, workspace_bytes);
             return sg_launch_wgrad_thin<4, false>(P, st, "sg_wgrad_thin_kernel<4,cin4>", workspace, workspace_bytes);
         }
-        if (d0->Cout == 4 && d0->Cin >= 16 && (d0->kind == SGAN_CONVT || d0->stride == 1) &&
-            (workspace_bytes == -1 || workspace != nullptr)) {
+        if (d0->Cout == 4 && d0->Cin >= 16 && (d0->kind == SGAN_CONVT || d0->stride == 1)) {
             SgWgradParams S = P;
             sg_thin_swap_geometry(S, d0, jobs, n);
+            S.thin_real = (d0->Cout_logical > 0 && d0->Cout_logical < 4) ? d0->Cout_logical : 4;
             int rc;
             if (d0->Cin <= 32) rc = sg_launch_wgrad_thin<2, true>(S, st, "sg_wgrad_thin_kernel<2,cout4>", workspace, workspace_bytes);
             else rc = sg_launch_wgrad_thin<4, true>(S, st, "sg_wgrad_thin_kernel<4,cout4>", workspace, workspace_bytes);

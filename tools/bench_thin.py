@@ -19,11 +19,11 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (5 * n)
 
-def jobs_conv(kind, k, s, p, cin, cout, sizes, norm):
+def jobs_conv(kind, k, s, p, cin, cout, sizes, norm, lcin=0, lcout=0):
     jobs = []
     for H in sizes:
         Ho = (H - 1) * s - 2 * p + k if kind else (H + 2 * p - k) // s + 1
-        desc = ops.conv_desc(kind, k, s, p, H, H, cin, Ho, Ho, cout)
+        desc = ops.conv_desc(kind, k, s, p, H, H, cin, Ho, Ho, cout, lcin or cin, lcout or cout)
         x = torch.randn(H, H, cin, device="cuda"); r = torch.randn(Ho, Ho, cout, device="cuda")
         dw = torch.zeros(k * k * cin * cout, device="cuda"); db = torch.zeros(cout, device="cuda")
         nrm = None
@@ -33,9 +33,11 @@ def jobs_conv(kind, k, s, p, cin, cout, sizes, norm):
         jobs.append((desc, x, nrm, r, dw, db))
     return jobs
 
-cases = {"D0 4->32 n=6": jobs_conv(0, 4, 2, 2, 4, 32, [512, 256, 128] * 2, False),
-         "Dhead 256->4 n=6": jobs_conv(0, 4, 1, 2, 256, 4, [66, 34, 18] * 2, True),
-         "G5 T 32->4": jobs_conv(1, 4, 2, 1, 32, 4, [256], True)}
+cases = {"D0 4->32 n=6": jobs_conv(0, 4, 2, 2, 4, 32, [512, 256, 128] * 2, False, lcin=2),
+         "Dhead 256->4 n=6": jobs_conv(0, 4, 1, 2, 256, 4, [66, 34, 18] * 2, True, lcout=1),
+         "G5 T 32->4": jobs_conv(1, 4, 2, 1, 32, 4, [256], True, lcout=2),
+         "D0 4->32 n=3": jobs_conv(0, 4, 2, 2, 4, 32, [512, 256, 128], False, lcin=2),
+         "Dhead 256->4 n=3": jobs_conv(0, 4, 1, 2, 256, 4, [66, 34, 18], True, lcout=1)}
 if __name__ == "__main__":
   for want in sys.argv[1:] or ["1024"]:
       w, mp = want.split(":") if ":" in want else (want, "256")

@@ -448,6 +448,19 @@ typedef struct sgan_adam_seg {
 int sgan_adam_multi(const sgan_adam_seg* segs, int32_t nseg, const float* lr_dev, float beta1, float beta2,
                     float eps, int32_t* state_dev, void* stream);
 
+/* ---- The whole optimizer step of ONE flat arena segment in one launch: Adam (as sgan_adam_multi, same `state_dev` layout plus a ticket
+ * word state_dev[3] that must start at 0) and the three derived weight copies of sgan_pack_weights for the conv weight ranges
+ * `segs` inside the segment (offsets relative to `p`, sorted, disjoint; flat_t / packed_fwd / packed_bwd use the same offsets; any may be
+ * NULL).  zero_grads != 0: the consumed gradients are overwritten with zeros.
+ * Replaces: torch.optim.Adam.step() + zero_grad() (models/fcgan_model.py:98-109,182-191) and the weight re-layout that follows it. */
+int sgan_adam_pack(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2, float eps,
+                   int32_t* state_dev, float* flat_t, void* packed_fwd, void* packed_bwd, const sgan_wt_seg* segs, int32_t nseg,
+                   int32_t zero_grads, void* stream);
+
+/* ---- Zero up to 64 device buffers in one launch (the statistics arenas of a training step).  bytes[i] and ptrs[i]: multiples of 16.
+ * Replaces: the aten fill launches behind torch.zeros / Tensor.zero_(). */
+int sgan_zero_multi(void* const* ptrs, const int64_t* bytes, int32_t n, void* stream);
+
 /* ---- SGD over the same segment table: buf = momentum * buf + g ; p -= lr * buf  (torch.optim.SGD with dampening 0, no Nesterov,
  * no weight decay; `m` of a segment is the momentum buffer, NULL / momentum 0 = plain gradient descent; `v` is ignored).
  * The reference's trainers are hard-wired to Adam (options/train_options.py:30 parses --optimizer and nobody reads it); this

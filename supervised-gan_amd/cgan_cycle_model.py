@@ -190,6 +190,7 @@ class CGANCycleModel(BaseModel):
         self._backward(self.loss_G)
 
     def optimize_parameters(self):
+        ops.begin_step()      # one launch zeroes every statistics arena of the step
         o = self.opt
         self.forward()
         for n_up, opt_, back in ((o.n_update_D1, self.optimizer_D1, self.backward_D1), (o.n_update_G, self.optimizer_G, self.backward_G)):

@@ -24,6 +24,45 @@
 #define SG_SYNC() __syncthreads()
 #endif
 
+// The parameter blocks of the conv kernels are 1-2.5 KB of kernel arguments read through the scalar cache, and the set-up walks them
+// in three or four DEPENDENT steps (which problem is this workgroup's -> that problem's fields -> the phase's extents -> ...): in-kernel
+// stamps put 4000-5000 cycles (2 us) between a workgroup's first instruction and its tap table, nearly all of it scalar-cache misses
+// taken one after the other.  Touching one dword of every 64-byte line up front takes the misses TOGETHER (one round trip); the
+// dependent reads that follow hit the cache.
+// One asm statement: every load AND the wait (the compiler does not know that an asm output arrives late: with the wait outside it
+// could hand the destination register to another value while the load is still in flight).  All loads share one scratch register.
+// The base comes from __builtin_amdgcn_kernarg_segment_ptr(): taking the address of the by-value parameter itself makes hipcc copy the
+// whole block to scratch memory first.  Called from the __global__ wrappers with the total size of their parameters.
+#ifndef SG_NO_KERNARG_WARM
+#define SG_WARM_8(o) "s_load_dword %0, %1, " #o "+0x0\n s_load_dword %0, %1, " #o "+0x40\n s_load_dword %0, %1, " #o "+0x80\n s_load_dword %0, %1, " #o "+0xc0\n" \
+                     "s_load_dword %0, %1, " #o "+0x100\n s_load_dword %0, %1, " #o "+0x140\n s_load_dword %0, %1, " #o "+0x180\n s_load_dword %0, %1, " #o "+0x1c0\n"
+template <int BYTES>      // touches the first (BYTES rounded down to a multiple of 512, at most 4096) bytes of the kernel arguments
+__device__ __forceinline__ void sg_warm_kernargs() {
+    const void* k = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    int scratch;
+    constexpr int NB = BYTES / 512 > 8 ? 8 : BYTES / 512;
+    if constexpr (NB == 8)
+        asm volatile(SG_WARM_8(0x0) SG_WARM_8(0x200) SG_WARM_8(0x400) SG_WARM_8(0x600) SG_WARM_8(0x800) SG_WARM_8(0xa00) SG_WARM_8(0xc00) SG_WARM_8(0xe00) "s_waitcnt lgkmcnt(0)" : "=&s"(scratch) : "s"(k) : "memory");
+    else if constexpr (NB == 7)
+        asm volatile(SG_WARM_8(0x0) SG_WARM_8(0x200) SG_WARM_8(0x400) SG_WARM_8(0x600) SG_WARM_8(0x800) SG_WARM_8(0xa00) SG_WARM_8(0xc00) "s_waitcnt lgkmcnt(0)" : "=&s"(scratch) : "s"(k) : "memory");
+    else if constexpr (NB == 6)
+        asm volatile(SG_WARM_8(0x0) SG_WARM_8(0x200) SG_WARM_8(0x400) SG_WARM_8(0x600) SG_WARM_8(0x800) SG_WARM_8(0xa00) "s_waitcnt lgkmcnt(0)" : "=&s"(scratch) : "s"(k) : "memory");
+    else if constexpr (NB == 5)
+        asm volatile(SG_WARM_8(0x0) SG_WARM_8(0x200) SG_WARM_8(0x400) SG_WARM_8(0x600) SG_WARM_8(0x800) "s_waitcnt lgkmcnt(0)" : "=&s"(scratch) : "s"(k) : "memory");
+    else if constexpr (NB == 4)
+        asm volatile(SG_WARM_8(0x0) SG_WARM_8(0x200) SG_WARM_8(0x400) SG_WARM_8(0x600) "s_waitcnt lgkmcnt(0)" : "=&s"(scratch) : "s"(k) : "memory");
+    else if constexpr (NB == 3)
+        asm volatile(SG_WARM_8(0x0) SG_WARM_8(0x200) SG_WARM_8(0x400) "s_waitcnt lgkmcnt(0)" : "=&s"(scratch) : "s"(k) : "memory");
+    else if constexpr (NB == 2)
+        asm volatile(SG_WARM_8(0x0) SG_WARM_8(0x200) "s_waitcnt lgkmcnt(0)" : "=&s"(scratch) : "s"(k) : "memory");
+    else if constexpr (NB == 1)
+        asm volatile(SG_WARM_8(0x0) "s_waitcnt lgkmcnt(0)" : "=&s"(scratch) : "s"(k) : "memory");
+}
+#else
+template <int BYTES>
+__device__ __forceinline__ void sg_warm_kernargs() {}
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

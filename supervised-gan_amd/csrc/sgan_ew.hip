@@ -105,6 +105,7 @@ struct SgNormBwdTable { SgNormBwdJob j[8]; };
 
 // blockIdx.y = job; every job strides over its own elements with its own block count (<= gridDim.x)
 __global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(const SgNormBwdTable T) {
+    sg_warm_kernargs<(int)sizeof(SgNormBwdTable)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     const SgNormBwdJob& J = T.j[blockIdx.y];
     if ((int)blockIdx.x >= J.blocks) return;
     const int C = J.C;
@@ -745,6 +746,7 @@ struct SgBnRunTable {
 };
 
 __global__ __launch_bounds__(256) void sg_bn_running_kernel(SgBnRunTable T) {
+    sg_warm_kernargs<(int)sizeof(SgBnRunTable)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     const sgan_bn_running_desc& L = T.l[blockIdx.x];
     const double inv = 1.0 / (double)L.count;
     const double unb = L.count > 1 ? (double)L.count / (double)(L.count - 1) : 1.0;
@@ -1006,6 +1008,7 @@ struct SgGaussJob {
 struct SgGaussTable { SgGaussJob j[4]; int32_t n, C, Creal, accumulate; };
 
 __global__ __launch_bounds__(256) void sg_gauss_multi_fwd_kernel(const SgGaussTable T) {
+    sg_warm_kernargs<(int)sizeof(SgGaussTable)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gs = reinterpret_cast<float*>(smem);   // [k*k][C] (zero for padding channels)
     const SgGaussJob& J = T.j[blockIdx.y];
@@ -1035,6 +1038,7 @@ __global__ __launch_bounds__(256) void sg_gauss_multi_fwd_kernel(const SgGaussTa
 
 // backward of several pre-filters of ONE image: every thread owns an image (pixel, channel quad) and sums the jobs
 __global__ __launch_bounds__(256) void sg_gauss_multi_bwd_kernel(const SgGaussTable T) {
+    sg_warm_kernargs<(int)sizeof(SgGaussTable)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gs = reinterpret_cast<float*>(smem);   // job after job: [k*k][C]
     const int C = T.C;
@@ -1443,6 +1447,7 @@ struct SgLossMulti {
 // each[] and the weighted total and leaves the counter at zero for the next call: one launch, no zero fill per call.
 #define SG_LOSS_BLOCKS 16
 __global__ __launch_bounds__(256) void sg_gan_loss_multi_fwd_kernel(SgLossMulti J, double* part, unsigned* counter, float* each, float* total) {
+    sg_warm_kernargs<(int)sizeof(SgLossMulti)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     __shared__ double wsum[4];
     __shared__ int last;
     const int j = blockIdx.y, b = blockIdx.x;
@@ -1514,6 +1519,7 @@ __global__ __launch_bounds__(256) void sg_gan_loss_multi_fwd_kernel(SgLossMulti 
 }
 
 __global__ __launch_bounds__(256) void sg_gan_loss_multi_bwd_kernel(SgLossMulti J, const float* gout) {
+    sg_warm_kernargs<(int)sizeof(SgLossMulti)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     const int j = blockIdx.y;
     const float go = gout[0] * J.weight[j] / (float)J.npix[j];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < J.npix[j]; i += gridDim.x * 256) {
@@ -1826,6 +1832,193 @@ extern "C" int sgan_adam_multi(const sgan_adam_seg* segs, int32_t nseg, const fl
     if (bx > 1024) bx = 1024;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(sg_adam_kernel, dim3(bx, nseg), dim3(256), 0, st, T, state_dev, beta1, beta2, eps);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sgan_adam_pack: the whole optimizer step of one flat arena segment in ONE launch (round 2: adam_prep + adam + pack_weights,
+// nine launches per fcgan step).  Workgroups [0, ntiles) own one 32 x 32 (co, ci) tile of one tap of a conv weight range: Adam on the
+// tile, the updated tile stays in LDS and leaves as the master value, the fp32 transposed copy and the two split 16-bit copies
+// (exactly sg_pack_weights_kernel's writes).  Workgroups behind them run plain Adam over the ranges between the conv weights
+// (biases, BatchNorm affines), 1024 elements each.  The step counter: every workgroup reads t, derives the two bias corrections
+// in fp64 (thread 0, broadcast through LDS), then takes a ticket; whoever draws the last ticket knows that every other workgroup
+// has read t already and stores t + 1 (and clears the ticket) -- a captured hipGraph replays with the right t.
+// zero_grads: the consumed gradient is overwritten with zeros (the caller's next zero_grad() is then a no-op).
+// ------------------------------------------------------------------------------------------
+struct SgAdamPackTable {
+    sgan_wt_seg s[64];
+    int32_t first[65];          // first tile of conv range i
+    int64_t gap0[65], gapn[65]; // ranges outside every conv weight
+    int32_t gfirst[66];         // first 1024-element chunk of gap i
+    int32_t n, ngap, ntiles;
+};
+
+__device__ __forceinline__ void sg_adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps, float step_size, float inv_sqrt_bc2) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p -= step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+}
+
+__global__ __launch_bounds__(256) void sg_adam_pack_kernel(float* P, float* Gr, float* M, float* V, float* flat_t, float* pk_f, float* pk_b,
+                                                           const SgAdamPackTable T, int32_t* state, const float* lr, float b1, float b2,
+                                                           float eps, int zero_grads, int nitems) {
+    sg_warm_kernargs<(int)sizeof(SgAdamPackTable)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
+    __shared__ float tile[32][33];
+    __shared__ float bc[2];
+    int t_step = 0;
+    if (threadIdx.x == 0) {
+        t_step = state[0] + 1;
+        const double bc1 = 1.0 - pow((double)b1, (double)t_step);
+        const double bc2 = 1.0 - pow((double)b2, (double)t_step);
+        bc[0] = (float)((double)lr[0] / bc1);
+        bc[1] = (float)(1.0 / sqrt(bc2));
+    }
+    SG_SYNC();
+    const float step_size = bc[0], inv_sqrt_bc2 = bc[1];
+    // a few hundred workgroups walk the work items: the ticket below is one same-address atomic per WORKGROUP (~12 ns each at the
+    // memory side; one workgroup per tile was 3700 of them per launch -- 40 us of serialised atomics, measured as a slower step)
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        if (item >= T.ntiles) {       // plain ranges
+            const int c = item - T.ntiles;
+            int i = 0;
+            for (int k = 1; k < T.ngap; ++k)
+                if (c >= T.gfirst[k]) i = k;
+            const int64_t e0 = T.gap0[i] + (int64_t)(c - T.gfirst[i]) * 1024, e1 = T.gap0[i] + T.gapn[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t e = e0 + u * 256 + threadIdx.x;
+                if (e < e1) {
+                    float p = P[e], m = M[e], v = V[e];
+                    sg_adam1(p, Gr[e], m, v, b1, b2, eps, step_size, inv_sqrt_bc2);
+                    P[e] = p; M[e] = m; V[e] = v;
+                    if (zero_grads) Gr[e] = 0.f;
+                }
+            }
+            continue;
+        }
+        int i = 0;
+        for (int k = 1; k < T.n; ++k)
+            if (item >= T.first[k]) i = k;
+        const sgan_wt_seg S = T.s[i];
+        int t = item - T.first[i];
+        const int tc = (S.cin + 31) / 32, tr = (S.cout + 31) / 32;
+        const int bx = t % tc; t /= tc;
+        const int by = t % tr; t /= tr;      // t = tap
+        const int64_t slab = S.off + t * (int64_t)S.cout * S.cin;
+        const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+        for (int r = ly; r < 32; r += 8) {
+            const int co = by * 32 + r, ci = bx * 32 + lx;
+            float p = 0.f;
+            if (co < S.cout && ci < S.cin) {
+                const int64_t e = slab + (int64_t)co * S.cin + ci;
+                float m = M[e], v = V[e];
+                p = P[e];
+                sg_adam1(p, Gr[e], m, v, b1, b2, eps, step_size, inv_sqrt_bc2);
+                P[e] = p; M[e] = m; V[e] = v;
+                if (zero_grads) Gr[e] = 0.f;
+            }
+            tile[r][lx] = p;
+        }
+        SG_SYNC();
+        if (flat_t) {
+            float* dst = flat_t + slab;
+            for (int r = ly; r < 32; r += 8) {
+                const int ci = bx * 32 + r, co = by * 32 + lx;
+                if (ci < S.cin && co < S.cout) dst[(int64_t)ci * S.cout + co] = tile[lx][r];
+            }
+        }
+        const int r = threadIdx.x >> 3, q = (threadIdx.x >> 1) & 3, pl = threadIdx.x & 1;
+        if (pk_f && (S.cin & 7) == 0) {
+            const int co = by * 32 + r, ci = bx * 32 + q * 8;
+            if (co < S.cout && ci < S.cin) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tile[r][q * 8 + e];
+                *reinterpret_cast<sg_u32x4*>(pk_f + slab + (int64_t)co * S.cin + ci + 4 * pl) = sg_split8_f16(v, pl);
+            }
+        }
+        if (pk_b && (S.cout & 7) == 0) {
+            const int ci = bx * 32 + r, co = by * 32 + q * 8;
+            if (ci < S.cin && co < S.cout) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tile[q * 8 + e][r];
+                *reinterpret_cast<sg_u32x4*>(pk_b + slab + (int64_t)ci * S.cout + co + 4 * pl) = sg_split8(v, pl);
+            }
+        }
+        SG_SYNC();      // the tile is rewritten by the next item
+    }
+    if (threadIdx.x == 0) {
+        // this workgroup read state[0] long ago (its value went into the bias corrections): it may be counted.  Whoever draws the
+        // last ticket knows that every workgroup has read t, and moves the counter on
+        const unsigned ticket = atomicAdd(reinterpret_cast<unsigned*>(state) + 3, 1u);
+        if (ticket == gridDim.x - 1) {
+            state[0] = t_step;
+            reinterpret_cast<float*>(state)[1] = step_size;
+            reinterpret_cast<float*>(state)[2] = inv_sqrt_bc2;
+            reinterpret_cast<unsigned*>(state)[3] = 0u;
+        }
+    }
+}
+
+extern "C" int sgan_adam_pack(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2, float eps,
+                              int32_t* state_dev, float* flat_t, void* packed_fwd, void* packed_bwd, const sgan_wt_seg* segs, int32_t nseg,
+                              int32_t zero_grads, void* stream) {
+    SGAN_CHECK(p && g && m && v && n > 0 && lr_dev && state_dev && nseg >= 0 && nseg <= 64 && (nseg == 0 || segs), "bad argument");
+    SgAdamPackTable T;
+    memset(&T, 0, sizeof(T));
+    int64_t cur = 0;
+    int tiles = 0, chunks = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const int64_t len = (int64_t)segs[i].taps * segs[i].cout * segs[i].cin;
+        SGAN_CHECK(segs[i].taps > 0 && segs[i].cout > 0 && segs[i].cin > 0 && (segs[i].off & 3) == 0, "bad conv range %d", i);
+        SGAN_CHECK(segs[i].off >= cur && segs[i].off + len <= n, "conv ranges must be sorted, disjoint and inside the segment (range %d)", i);
+        if (segs[i].off > cur) {
+            T.gap0[T.ngap] = cur; T.gapn[T.ngap] = segs[i].off - cur; T.gfirst[T.ngap] = chunks;
+            chunks += (int)((segs[i].off - cur + 1023) / 1024);
+            ++T.ngap;
+        }
+        T.s[i] = segs[i];
+        T.first[i] = tiles;
+        tiles += segs[i].taps * ((segs[i].cout + 31) / 32) * ((segs[i].cin + 31) / 32);
+        cur = segs[i].off + len;
+    }
+    if (cur < n) {
+        T.gap0[T.ngap] = cur; T.gapn[T.ngap] = n - cur; T.gfirst[T.ngap] = chunks;
+        chunks += (int)((n - cur + 1023) / 1024);
+        ++T.ngap;
+    }
+    T.n = nseg; T.ntiles = tiles; T.first[nseg] = tiles; T.gfirst[T.ngap] = chunks;
+    static const int max_wg = getenv("SGAN_ADAM_WGS") ? atoi(getenv("SGAN_ADAM_WGS")) : 1024;      // tuning knob
+    const int nitems = tiles + chunks;
+    hipLaunchKernelGGL(sg_adam_pack_kernel, dim3((unsigned)(nitems < max_wg ? nitems : max_wg)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       flat_t, (float*)packed_fwd, (float*)packed_bwd, T, state_dev, lr_dev, beta1, beta2, eps, (int)zero_grads, nitems);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// Zero up to 64 buffers in one launch (statistics arenas of a training step: ops.begin_step).  Sizes in bytes, multiples of 16.
+struct SgZeroTable { void* p[64]; int64_t n16[64]; int32_t n; };
+__global__ __launch_bounds__(256) void sg_zero_multi_kernel(const SgZeroTable T) {
+    f32x4* dst = reinterpret_cast<f32x4*>(T.p[blockIdx.y]);
+    const int64_t n = T.n16[blockIdx.y];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) dst[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+extern "C" int sgan_zero_multi(void* const* ptrs, const int64_t* bytes, int32_t n, void* stream) {
+    SGAN_CHECK(ptrs && bytes && n >= 1 && n <= 64, "1..64 buffers");
+    SgZeroTable T;
+    int64_t maxn = 0;
+    for (int i = 0; i < n; ++i) {
+        SGAN_CHECK(ptrs[i] && bytes[i] > 0 && (bytes[i] & 15) == 0 && ((uintptr_t)ptrs[i] & 15) == 0, "buffer %d: 16-byte aligned pointer and size", i);
+        T.p[i] = ptrs[i]; T.n16[i] = bytes[i] >> 4;
+        if (T.n16[i] > maxn) maxn = T.n16[i];
+    }
+    T.n = n;
+    int bx = (int)((maxn + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(sg_zero_multi_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, T);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
 }

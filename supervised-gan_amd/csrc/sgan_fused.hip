@@ -13,16 +13,19 @@
 #include "sgan_wgrad3.hip"
 
 // DV: 1 = patch kernel with <= 128 patch pixels, 2 = patch kernel up to 256, 3 = sg_igemm3 64 x 64 (two k-tiles per barrier),
-//     4 = exact-fp32 sg_igemm 128 x 32 (backward-data into a layer without a normalisation: chain._dgrad_math);
+//     4 = exact-fp32 sg_igemm 128 x 32 (backward-data into a layer without a normalisation: chain._dgrad_math),
+//     5 = patch kernel, stride-2 gather (parity planes; ConvTranspose2d stride 2 backward-data);
 // WV: 1 = backward-weight 64 x 64 tiles, 2 = 32 x 128
 template <int DV, int WV, bool WPRO>
 __global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G, const SgWgradParams W, int ndg, int wx, int wy) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    sg_warm_kernargs<(int)(sizeof(SgIgemmParams) + sizeof(SgWgradParams))>();
     const int b = blockIdx.x;
     if (b < ndg) {
         if constexpr (DV == 1) sg_igemm3p_body<64, 2, false, false>(G, smem, b, ndg);
         else if constexpr (DV == 2) sg_igemm3p_body<64, 4, false, false>(G, smem, b, ndg);
         else if constexpr (DV == 3) sg_igemm3_body<64, 64, 2, 2, false, false, true>(G, smem, b, ndg, 0);
+        else if constexpr (DV == 5) sg_igemm3p_body<64, 6, false, false, true>(G, smem, b, ndg);
         else sg_igemm_body<128, 32, 4, 1, true, false, 1>(G, smem, b, ndg, 0);
     } else {
         const int w = b - ndg;
@@ -74,7 +77,9 @@ extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd,
         case 31: sg_fused_launch<3, 1>(P, W, pd, pw, st); break;
         case 32: sg_fused_launch<3, 2>(P, W, pd, pw, st); break;
         case 41: sg_fused_launch<4, 1>(P, W, pd, pw, st); break;
-        default: sg_fused_launch<4, 2>(P, W, pd, pw, st); break;
+        case 42: sg_fused_launch<4, 2>(P, W, pd, pw, st); break;
+        case 51: sg_fused_launch<5, 1>(P, W, pd, pw, st); break;
+        default: sg_fused_launch<5, 2>(P, W, pd, pw, st); break;
     }
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = pd.variant == 4 ? "sg_bwd_fused_kernel<f32 dgrad>" : "sg_bwd_fused_kernel";      // both halves split-bf16 unless said otherwise

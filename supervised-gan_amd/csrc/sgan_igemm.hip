@@ -494,6 +494,7 @@ __device__ __forceinline__ void sg_igemm_body(const SgIgemmParams& G, char* smem
 
 template <int BM, int BN, int WGM, int WGN, bool BKC, bool PRO, int KW = 1>
 __global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams G) {
+    sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     extern __shared__ __attribute__((aligned(16))) char smem[];
     sg_igemm_body<BM, BN, WGM, WGN, BKC, PRO, KW>(G, smem, blockIdx.x, gridDim.x, blockIdx.z);
 }
@@ -510,6 +511,7 @@ __global__ __launch_bounds__(256 * KW) void sg_igemm_kernel(const SgIgemmParams 
 // ------------------------------------------------------------------------------------------
 template <int LPP, int R, int U, int NR, bool BKC>
 __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParams G) {
+    sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* tdy = reinterpret_cast<int*>(smem);
     int* tdx = tdy + SGAN_MAX_TAPS;
@@ -666,6 +668,7 @@ __global__ __launch_bounds__(256) void sg_conv_small_n_kernel(const SgIgemmParam
 // bandwidth-bound: one 8 x 8 tile per CU leaves one wave per SIMD).
 template <int TH>
 __global__ __launch_bounds__(256) void sg_conv_head_kernel(const SgIgemmParams G) {
+    sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     constexpr int NG = 256 / (8 * TH), CPG = 32 / NG;       // channel groups per pixel, channels per group: (4, 8) (8, 4) (16, 2)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -888,6 +891,7 @@ static int sg_launch_small_n(SgIgemmParams& P, hipStream_t st) {
 #define SG_SC_TW 32
 #define SG_SC_LDZ 68
 __global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmParams G) {
+    sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Zs = reinterpret_cast<float*>(smem);                    // [256][SG_SC_LDZ]
     float* pscale = Zs + 256 * SG_SC_LDZ;                          // [Ck]
@@ -1014,6 +1018,7 @@ __global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmPara
 // reaches the logits head (1 -> 256 channels) and the generator's last layer (2 -> 32) are K = 64 problems of the same shape.
 template <int NB, int RB, bool EPI>     // 16-column blocks per workgroup; 16-pixel row blocks per wave (64 RB result pixels per workgroup)
 __global__ __launch_bounds__(256) void sg_conv_c4_kernel(const SgIgemmParams G) {
+    sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     __shared__ int4 ttab[16];
     __shared__ __attribute__((aligned(16))) float Ws[16 * NB * 16 * 4];      // [tap][n][4 channels], zero for taps / columns that do not exist
     __shared__ __attribute__((aligned(16))) float cf[EPI ? 4 * NB * 16 : 4];  // EPI: mean | rstd | gamma | beta of the forward tensor's norm
@@ -1260,6 +1265,7 @@ static int sg_launch_scatter4(SgIgemmParams& P, hipStream_t st) {
 // accumulated in registers and reach memory as one LDS atomic + one fp64 atomic per channel per block.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sg_splitk_epilogue_kernel(const SgIgemmParams G) {
+    sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const SgLocal P = sg_local(G, 0);   // split-K is single-problem
     const int N = P.N, NQ = N >> 2;

@@ -541,6 +541,7 @@ __device__ __forceinline__ void sg_igemm3_body(const SgIgemmParams& G, char* sme
 template <int BM, int BN, int WGM, int WGN, bool PRO, bool F16, bool KB2 = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemmParams G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();
     sg_igemm3_body<BM, BN, WGM, WGN, PRO, F16, KB2>(G, smem, blockIdx.x, gridDim.x, blockIdx.z);
 }
 
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void sg_igemm3_kernel(const SgIgemm
 // ------------------------------------------------------------------------------------------
 #define SG3P_PS 144
 #ifndef SG3P_ABL
-#define SG3P_ABL 0   // diagnostics builds only (wrong results, tools/abl3p.sh): 1 no weight loads, 2 no weight LDS stores
+#define SG3P_ABL 0   // diagnostics builds only (wrong results, tools/abl3p.sh): 1 no weight loads, 2 no weight LDS stores, 4 no statistics -> scale / shift in the set-up
 #endif
 __host__ __device__ __forceinline__ int sg3p_row_stride(int ppw) { return ((ppw * SG3P_PS + 127) & ~255) + 128; }
 
@@ -586,7 +587,12 @@ extern "C" int sgan_debug_stamps(void* dst, int n) {
 #define SG3P_MARK(i)
 #endif
 
-template <int BN, int A_IT, bool PRO, bool F16>
+// S2: stride-2 gather (Conv2d stride 2 forward, ConvTranspose2d stride 2 backward-data; one phase).  The patch of an 8 x 8 result tile is
+// then (14 + span)^2 pixels, kept in LDS as FOUR parity planes [row & 1][col & 1][row >> 1][col >> 1], each laid out like a stride-1
+// patch: tap (ty, tx) of result pixel (py, px) reads patch pixel (2 py + ty, 2 px + tx) = plane (ty & 1, tx & 1) at (py + (ty >> 1),
+// px + (tx >> 1)) -- the same lane addressing as stride 1 plus a per-tap constant, so the fragment reads stay conflict free and the
+// loop body does not change.  Each input element is staged (18 / 8)^2 = 5 times for a 4 x 4 kernel instead of 16 (sg_igemm3_kernel).
+template <int BN, int A_IT, bool PRO, bool F16, bool S2 = false>
 __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* smem, const int bid, const int nblocks) {
     constexpr int NT = 256, WGN = 2, WTM = 32, WTN = BN / WGN, MB = 1, NB = WTN / 32;
     constexpr int B_IT = BN * 8 / NT;
@@ -612,11 +618,12 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     const int ty0 = (mtile / tiles_x) * 8, tx0 = (mtile % tiles_x) * 8;
     const int n0 = (item % ntn) * BN;
     const int PH = G.pph[phz], PW = G.ppw[phz];
-    const int RS = sg3p_row_stride(PW);
+    const int RS = sg3p_row_stride(S2 ? (PW + 1) >> 1 : PW);
+    const int PLANE = S2 ? ((PH + 1) >> 1) * RS : 0;         // bytes of one parity plane
     const int npix = PH * PW;
 
-    char* Ap = smem;                                         // [PH][RS] patch of the current channel block
-    char* Bs = smem + ((PH * RS + 255) & ~255);              // [2][BN * 128]
+    char* Ap = smem;                                         // [PH][RS] patch of the current channel block (S2: four parity planes)
+    char* Bs = smem + (((S2 ? 4 * PLANE : PH * RS) + 255) & ~255);              // [2][BN * 128]
     double* red = reinterpret_cast<double*>(Bs + 2 * BN * 128);            // [2 * BN]
     int4* ttab = reinterpret_cast<int4*>(red + 2 * BN);                    // per tap {patch byte offset, -, -, weight slab offset}
     float* pscale = reinterpret_cast<float*>(ttab + SGAN_MAX_TAPS);        // [Ck]
@@ -632,16 +639,19 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     const int nunits = ntaps * ncb;
     const int dy0 = G.pdy0[phz], dx0 = G.pdx0[phz];
 
+    SG3P_MARK(5);
     if (tid < SGAN_MAX_TAPS) {
         const bool v = tid < ntaps;
         const SgTap tp = G.taps[v ? G.tap0[phz] + tid : 0];
-        ttab[tid] = make_int4(v ? ((int)tp.dy - dy0) * RS + ((int)tp.dx - dx0) * SG3P_PS : 0, 0, 0, v ? tp.w_off : 0);
+        const int ty = (int)tp.dy - dy0, tx = (int)tp.dx - dx0;
+        const int poff = S2 ? ((ty & 1) * 2 + (tx & 1)) * PLANE + (ty >> 1) * RS + (tx >> 1) * SG3P_PS : ty * RS + tx * SG3P_PS;
+        ttab[tid] = make_int4(v ? poff : 0, 0, 0, v ? tp.w_off : 0);
     }
     for (int i = tid; i < 2 * BN; i += NT) red[i] = 0.0;
     if constexpr (PRO) {
         for (int c = tid; c < Ck; c += NT) {
             float sc = 1.f, sh = 0.f;
-            if (P.pro.stats) {
+            if (P.pro.stats && !(SG3P_ABL & 4)) {
                 float mean, rstd;
                 sg_mean_rstd(P.pro, Ck, c, mean, rstd);
                 const float gm = P.pro.gamma ? P.pro.gamma[c] : 1.f;
@@ -662,10 +672,11 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     for (int it = 0; it < A_IT; ++it) {
         const int p = (tid + it * NT) >> 2;
         const int pr = p / PW, pc = p - pr * PW;
-        const int iy = (ty0 + pr) * P.is + dy0, ix = (tx0 + pc) * P.is + dx0;
+        const int iy = ty0 * P.is + dy0 + pr, ix = tx0 * P.is + dx0 + pc;
         const bool ok = (p < npix) & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
         a_goff[it] = ok ? ((iy * P.Win + ix) * P.in_ld + kg * 8) << 2 : OOB;
-        a_dst[it] = p < npix ? pr * RS + pc * SG3P_PS + kg * 32 : -1;
+        const int ldst = S2 ? ((pr & 1) * 2 + (pc & 1)) * PLANE + (pr >> 1) * RS + (pc >> 1) * SG3P_PS : pr * RS + pc * SG3P_PS;
+        a_dst[it] = p < npix ? ldst + kg * 32 : -1;
     }
     f32x4 a_reg[A_IT][2];
     auto issue_a = [&](int cb) {
@@ -875,10 +886,11 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
 #endif
 }
 
-template <int BN, int A_IT, bool PRO, bool F16>
+template <int BN, int A_IT, bool PRO, bool F16, bool S2 = false>
 __global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    sg_igemm3p_body<BN, A_IT, PRO, F16>(G, smem, blockIdx.x, gridDim.x);
+    sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();
+    sg_igemm3p_body<BN, A_IT, PRO, F16, S2>(G, smem, blockIdx.x, gridDim.x);
 }
 
 #ifndef SG_KERNELS_ONLY      // sgan_fused.hip includes this file for the kernel bodies only
@@ -954,11 +966,13 @@ static int sg3_launch(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_by
 }
 
 // ---- patch-stationary kernel: plan (patch extents per phase) and launch ----
-struct Sg3pPlan { bool ok; int a_it; long tiles; double waste; int min_taps; };
+struct Sg3pPlan { bool ok; int a_it; long tiles; double waste; int min_taps; bool s2; long wgs; };
 
 static Sg3pPlan sg3p_plan(SgIgemmParams& P) {
-    Sg3pPlan pl = {false, 0, 0, 1.0, 1 << 30};
-    if (P.is != 1 || (P.Ck & 31) || P.N <= 32) return pl;
+    Sg3pPlan pl = {false, 0, 0, 1.0, 1 << 30, false, 0};
+    if ((P.is != 1 && !(P.is == 2 && P.nphase == 1)) || (P.Ck & 31) || P.N <= 32) return pl;
+    static const int no_s2 = getenv("SGAN_NO_PATCH_S2") ? atoi(getenv("SGAN_NO_PATCH_S2")) : 0;      // tuning knob
+    if (P.is == 2 && no_s2) return pl;
     int maxpix = 0;
     for (int ph = 0; ph < P.nphase; ++ph) {
         int dy0 = 1 << 30, dy1 = -(1 << 30), dx0 = 1 << 30, dx1 = -(1 << 30);
@@ -969,12 +983,12 @@ static Sg3pPlan sg3p_plan(SgIgemmParams& P) {
             dx0 = min(dx0, (int)tp.dx); dx1 = max(dx1, (int)tp.dx);
         }
         P.pdy0[ph] = dy0; P.pdx0[ph] = dx0;
-        P.pph[ph] = 8 + dy1 - dy0; P.ppw[ph] = 8 + dx1 - dx0;
+        P.pph[ph] = 7 * P.is + 1 + dy1 - dy0; P.ppw[ph] = 7 * P.is + 1 + dx1 - dx0;
         maxpix = max(maxpix, P.pph[ph] * P.ppw[ph]);
         pl.min_taps = min(pl.min_taps, P.ntaps[ph]);
     }
-    if (maxpix > 256) return pl;
-    pl.a_it = maxpix <= 128 ? 2 : 4;
+    if (maxpix > (P.is == 2 ? 384 : 256)) return pl;
+    pl.a_it = P.is == 2 ? 6 : (maxpix <= 128 ? 2 : 4);
     long padded = 0, real = 0;
     for (int g = 0; g < P.nprob; ++g)
         for (int ph = 0; ph < P.nphase; ++ph) {
@@ -985,8 +999,16 @@ static Sg3pPlan sg3p_plan(SgIgemmParams& P) {
         }
     if (real == 0) return pl;
     pl.waste = (double)padded / (double)real;
+    pl.s2 = P.is == 2;
+    pl.wgs = pl.tiles * sg3_cdiv(P.N, 64);
     pl.ok = true;
     return pl;
+}
+
+// LDS bytes of the patch image of phase ph (stride 2: four parity planes)
+static int sg3p_patch_lds(const SgIgemmParams& P, int ph) {
+    if (P.is == 2) return (4 * ((P.pph[ph] + 1) / 2) * sg3p_row_stride((P.ppw[ph] + 1) / 2) + 255) & ~255;
+    return (P.pph[ph] * sg3p_row_stride(P.ppw[ph]) + 255) & ~255;
 }
 
 // The patch kernel stages each input element once per channel block instead of once per tap: it wins where a result pixel has many
@@ -995,11 +1017,15 @@ static bool sg3p_wanted(const Sg3pPlan& pl) {
     if (!pl.ok) return false;
     const char* force = getenv("SGAN_IGEMM3P");
     if (force) return atoi(force) != 0;
+    // stride 2: only where the grid alone fills a good part of the chip -- the deep, narrow generator layers (16 .. 64 workgroups of
+    // 64 .. 128 steps) stay on sg_igemm3_kernel, which can split K across workgroups
+    static const long s2_min = getenv("SGAN_PATCH_S2_MIN") ? atol(getenv("SGAN_PATCH_S2_MIN")) : 100;
+    if (pl.s2 && pl.wgs < s2_min) return false;
     if (pl.min_taps >= 9) return pl.waste < 1.6;
     return pl.min_taps >= 4 && pl.waste < 1.3;
 }
 
-template <int BN, int A_IT>
+template <int BN, int A_IT, bool S2 = false>
 static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {   // BN: 64, or 128 (wave tile 32 x 64) for wide results
     int t = 0, maxlds = 0;
     for (int g = 0; g < P.nprob; ++g)
@@ -1010,7 +1036,7 @@ static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {   /
     for (int g = 0; g < P.nprob; ++g)
         for (int ph = P.nphase; ph < SGAN_MAX_PHASES; ++ph) P.q[g].tile0[ph] = 1 << 30;
     if (t == 0) return SGAN_OK;
-    for (int ph = 0; ph < P.nphase; ++ph) maxlds = max(maxlds, (P.pph[ph] * sg3p_row_stride(P.ppw[ph]) + 255) & ~255);
+    for (int ph = 0; ph < P.nphase; ++ph) maxlds = max(maxlds, sg3p_patch_lds(P, ph));
     P.ksplit = 1;
     P.slab = nullptr;
     P.slab_stride = 0;
@@ -1021,11 +1047,11 @@ static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {   /
     for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
     sg_prof_begin(st);
     if (P.planes_f16) {
-        if (pro) hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, true, true>), grid, dim3(256), lds, st, P);
-        else hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, false, true>), grid, dim3(256), lds, st, P);
+        if (pro) hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, true, true, S2>), grid, dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, false, true, S2>), grid, dim3(256), lds, st, P);
     } else {
-        if (pro) hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, true, false>), grid, dim3(256), lds, st, P);
-        else hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, false, false>), grid, dim3(256), lds, st, P);
+        if (pro) hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, true, false, S2>), grid, dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, false, false, S2>), grid, dim3(256), lds, st, P);
     }
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = name;
@@ -1053,11 +1079,11 @@ int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out) {
             }
         for (int g = 0; g < P.nprob; ++g)
             for (int ph = P.nphase; ph < SGAN_MAX_PHASES; ++ph) P.q[g].tile0[ph] = 1 << 30;
-        for (int ph = 0; ph < P.nphase; ++ph) maxlds = max(maxlds, (P.pph[ph] * sg3p_row_stride(P.ppw[ph]) + 255) & ~255);
-        out->variant = pl.a_it == 2 ? 1 : 2;
+        for (int ph = 0; ph < P.nphase; ++ph) maxlds = max(maxlds, sg3p_patch_lds(P, ph));
+        out->variant = pl.a_it == 2 ? 1 : (pl.a_it == 4 ? 2 : 5);
         out->nblocks = t * sg3_cdiv(P.N, 64);
         out->lds = (size_t)maxlds + (size_t)2 * 64 * 128 + (size_t)4 * 64 * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
-        out->name = "sg_igemm3p_kernel<64>";
+        out->name = pl.a_it == 6 ? "sg_igemm3p_kernel<64,s2>" : "sg_igemm3p_kernel<64>";
         return 0;
     }
     const Sg3Tile tl = sg3_pick_tile(P);
@@ -1077,6 +1103,7 @@ int sg_launch_igemm3(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_byt
     const Sg3pPlan pl = sg3p_plan(P);
     if (sg3p_wanted(pl)) {
         if (pl.a_it == 2) return sg3p_launch<64, 2>(P, st, "sg_igemm3p_kernel<64>");
+        if (pl.a_it == 6) return sg3p_launch<64, 6, true>(P, st, "sg_igemm3p_kernel<64,s2>");
         return sg3p_launch<64, 4>(P, st, "sg_igemm3p_kernel<64>");
     }
     const Sg3Tile t = sg3_pick_tile(P);

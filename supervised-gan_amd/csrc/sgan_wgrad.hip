@@ -22,6 +22,7 @@
 // PRO: the forward input gets the producer's norm + activation applied while it is staged
 template <int BCO, int BKC, int WGC, int WGK, bool PRO>
 __global__ __launch_bounds__(256) void sg_wgrad_kernel(const SgWgradParams G) {
+    sg_warm_kernargs<(int)sizeof(SgWgradParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     constexpr int BP = 32;
     constexpr int WTC = BCO / WGC, WTK = BKC / WGK, MB = WTC / 16, NB = WTK / 16;
     constexpr int LDD = (BCO % 32 == 0) ? BCO + 16 : BCO;
@@ -414,6 +415,7 @@ extern "C" int sgan_debug_stamps_thin(void* dst, int n) {
 // MI355X_MICROARCH.md "Global float atomics"; round 2's direct-atomic experiment scattered 16-byte pieces 512 B apart).
 template <int MB, bool PRO, bool SWAP>
 __global__ __launch_bounds__(64 * SG_THIN_NW) void sg_wgrad_thin_kernel(const SgWgradParams G, int nbias_z0) {
+    sg_warm_kernargs<(int)sizeof(SgWgradParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     constexpr int ROWS = 16 * MB, COLS = 64, NB = 4, NW = SG_THIN_NW, NT = 64 * NW;
     static_assert(MB == 1 || MB == 2 || MB == 4, "operand widths");
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -369,6 +369,7 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
 
 template <int BCO, int BKC, int WGC, int WGK, bool PRO>
 __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
+    sg_warm_kernargs<(int)sizeof(SgWgradParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     extern __shared__ __attribute__((aligned(16))) char smem[];
     sg_wgrad3_body<BCO, BKC, WGC, WGK, PRO>(G, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }

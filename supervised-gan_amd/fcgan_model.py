@@ -83,7 +83,7 @@ class FCGANModel(BaseModel):
             self.fake_pool = ImagePool(opt.pool_size)
             self.old_lr = opt.lr
             self.criterionGAN = networks.GANLoss(use_lsgan=not opt.no_lsgan)
-            self.optimizer_G = FusedAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999))
+            self.optimizer_G = FusedAdam(self.netG.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999), zero_grads_in_step=True)
             params = []
             for netD in self.netD:
                 params += list(netD.model.parameters())   # "all learnable parameters should be in netD.model"
@@ -221,6 +221,7 @@ class FCGANModel(BaseModel):
         return self._each_D[self.n_netD:].sum()
 
     def optimize_parameters(self):
+        ops.begin_step()      # one launch zeroes every statistics arena of the step
         self.forward()
         for _ in range(self.opt.n_update_D):
             self.optimizer_D.zero_grad()

@@ -72,6 +72,7 @@ class GraphedStep:
             torch.cuda.synchronize()
         self.gA = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gA, capture_error_mode=self._mode):
+            ops.begin_step()      # the statistics arenas of the whole step (graph A and every piece of graph B), one launch
             m.forward()
             self._fakeA = spec["sources"]()
         pool = self.gA.pool()

@@ -7,13 +7,22 @@ One sgan_adam_multi launch updates every parameter of the optimizer; the step co
 live in device memory so that a captured hipGraph of the training step replays correctly."""
 import torch
 
+import os
+
 from . import ops
 from ._lib import SganError
 
+_NO_ADAM_PACK = os.environ.get("SGAN_NO_ADAM_PACK", "0") not in ("", "0")      # diagnostics: the three-launch optimizer step of round 2
+
 
 class FusedAdam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, zero_grads_in_step=False):
+        """zero_grads_in_step: step() leaves the gradients it consumed zeroed and the next zero_grad() is a no-op.  Only for
+        optimizers whose gradients nobody writes between step() and zero_grad() (the generator's: the discriminators' are also
+        written -- and discarded -- by the generator step, models/fcgan_model.py:165-176)."""
         params = list(params)
+        self._zero_in_step = bool(zero_grads_in_step) and not _NO_ADAM_PACK
+        self._grads_clean = False
         if not params:
             raise ValueError("optimizer got an empty parameter list")
         self.param_groups = [{"params": params, "lr": float(lr), "betas": tuple(betas), "eps": float(eps)}]
@@ -57,6 +66,7 @@ class FusedAdam:
         """Forget the moments and the step counter (as a freshly constructed optimizer)."""
         self._state = None
         self._lr_host = None
+        self._grads_clean = False
 
     def sync_lr(self):
         """Push param_groups[0]['lr'] to the device scalar (call outside graph capture)."""
@@ -67,8 +77,48 @@ class FusedAdam:
             self._lr_host = lr
 
     def zero_grad(self, set_to_none=False):
+        if self._grads_clean:       # step() zeroed what it consumed and nobody has written since
+            self._grads_clean = False
+            return
         for _, ag, off, n in self._segs:
             ag[off: off + n].zero_()
+
+    def _fused_plan(self):
+        """(nets, conv ranges relative to the segment, derived buffers) when the whole optimizer is ONE arena segment whose networks
+        keep their derived weight copies at the arena's offsets -- then Adam, the three copies and the gradient zeroing are one launch
+        (sgan_adam_pack).  None: several segments (AdamGroups of networks with separate storage) -> sgan_adam_multi + lazy repack."""
+        if len(self._segs) != 1 or _NO_ADAM_PACK:
+            return None
+        ap, ag, off, n = self._segs[0]
+        nets = list(self._nets.values())
+        if not all(hasattr(net, "_refresh_derived") and net._arena[0] is ap for net in nets):
+            return None
+        for net in nets:
+            net._refresh_derived()       # storage exists and every copy is current (a no-op in steady state)
+        bufs = {(net._flat_t.data_ptr() - 4 * net._arena[2], net._pk_f.data_ptr() - 4 * net._arena[2],
+                 net._pk_b.data_ptr() - 4 * net._arena[2]) for net in nets}
+        if len(bufs) != 1:               # the copies of the networks are not slices of one arena-wide buffer
+            return None
+        net0 = nets[0]
+        base0 = net0._arena[2]
+        der = getattr(ap, "_sgan_derived", None)
+        if der is not None and net0._flat_t.data_ptr() == der[0].data_ptr() + 4 * base0:
+            views = tuple(d[off: off + n] for d in der)
+        elif len(nets) == 1 and base0 == 0:
+            views = tuple(d[off: off + n] for d in (net0._flat_t, net0._pk_f, net0._pk_b))
+        else:
+            return None
+        segs = []
+        for net in nets:
+            for o, taps, co, ci in net._conv_segments(net._arena[2]):
+                if o >= off and o + taps * co * ci <= off + n:
+                    segs.append((o - off, taps, co, ci))
+                elif o + taps * co * ci > off and o < off + n:
+                    return None          # a conv weight only partly inside the segment
+        segs.sort()
+        if len(segs) > 64:
+            return None
+        return nets, segs, views
 
     def segments(self):
         """[(params, grads)] flat views -- what the data-parallel all-reduce works on."""
@@ -80,6 +130,16 @@ class FusedAdam:
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         g = self.param_groups[0]
+        plan = self._fused_plan() if type(self) is FusedAdam else None
+        if plan is not None:
+            nets, csegs, (ft, pf, pb) = plan
+            ap, ag, off, n = self._segs[0]
+            ops.adam_pack(ap[off: off + n], ag[off: off + n], self._m[0], self._v[0], self._lr_dev, g["betas"][0], g["betas"][1], g["eps"],
+                          self._state, ft, pf, pb, csegs, self._zero_in_step)
+            for net in nets:                # the derived copies were written by the same launch: they are current
+                net._wt_key = net._derived_key()
+            self._grads_clean = self._zero_in_step
+            return
         segs = [(ap[off: off + n], ag[off: off + n], m, v, n)
                 for (ap, ag, off, n), m, v in zip(self._segs, self._m, self._v)]
         ops.adam_multi(segs, self._lr_dev, g["betas"][0], g["betas"][1], g["eps"], self._state)

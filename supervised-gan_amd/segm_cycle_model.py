@@ -10,7 +10,7 @@ from collections import OrderedDict
 import torch
 import torch.nn.functional as F
 
-from . import networks
+from . import networks, ops
 from .base_model import BaseModel
 from .cgan_cycle_model import CGANCycleModel
 from .image_pool import ImagePool
@@ -150,6 +150,7 @@ class SegmentationCycleModel(CGANCycleModel):
         self._backward(self.loss_G)
 
     def optimize_parameters(self):
+        ops.begin_step()      # one launch zeroes every statistics arena of the step
         o = self.opt
         self.forward()
         for n_up, opt_, back in ((o.n_update_D2, self.optimizer_D2, self.backward_D2), (o.n_update_G, self.optimizer_G, self.backward_G)):

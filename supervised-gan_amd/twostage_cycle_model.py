@@ -338,6 +338,7 @@ class TwoStageCycleModel(BaseModel):
         self._backward(self.loss_G)
 
     def optimize_parameters(self):
+        ops.begin_step()      # one launch zeroes every statistics arena of the step
         o = self.opt
         self.forward()
         ups = (o.n_update_D1, o.n_update_D2, o.n_update_G) if self.cycle else (1, 1, 1)     # twostage_model.py:379-395: one each

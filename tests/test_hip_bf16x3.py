@@ -138,9 +138,11 @@ def test_igemm3_vs_fp32_kernel_and_fp64(ops, shape, tile):
         ops.conv_dgrad(desc, Rb, wm._sgan_wt, din, xb, in_norm, sums, w_transposed=True)
         kd = _lib.lib().sgan_last_kernel().decode()
         if mode == "bf16x3" and tile == "patch" and cin % 32 == 0 and cout % 32 == 0 and H * W >= 256:
-            # unit-stride gathers: the forward of a stride-1 Conv2d / of any ConvTranspose2d, the backward-data of any Conv2d
-            # (result channels > 32: narrower layers keep the 128 x 32 tile of sg_igemm3_kernel)
-            assert ("igemm3p" in kf) == ((tr or s == 1) and cout > 32) and ("igemm3p" in kd) == ((not tr or s == 1) and cin > 32), (kf, kd)
+            # unit-stride gathers (forward of a stride-1 Conv2d / of any ConvTranspose2d, backward-data of any Conv2d) and, since
+            # round 3, stride-2 gathers through the parity-plane patch (forward of a stride-2 Conv2d, backward-data of a stride-2
+            # ConvTranspose2d); result channels > 32: narrower layers keep the 128 x 32 tile of sg_igemm3_kernel
+            assert ("igemm3p" in kf) == (cout > 32) and ("igemm3p" in kd) == (cin > 32), (kf, kd)
+            assert ("s2" in kf) == (not tr and s == 2 and cout > 32) and ("s2" in kd) == (tr and s == 2 and cin > 32), (kf, kd)
         if norm:
             ops.norm_bwd_apply(din, xb, in_norm, sums)
         dw, db = torch.zeros_like(wm), torch.zeros_like(bb)
@@ -275,7 +277,9 @@ def test_fused_backward_is_taken(ops):
 
 
 @pytest.mark.parametrize("shape", [("conv", 4, 1, 2, 128, 256, 33, 29), ("convT", 4, 2, 1, 256, 256, 16, 16), ("conv", 3, 1, 1, 160, 64, 24, 24),
-                                   ("conv", 4, 1, 2, 224, 128, 20, 20)], ids=["4blocks", "8blocks_convT", "5blocks", "7blocks"])
+                                   ("conv", 4, 1, 2, 224, 128, 20, 20), ("conv", 4, 2, 2, 64, 128, 65, 63), ("conv", 4, 2, 1, 96, 64, 34, 40),
+                                   ("conv", 3, 2, 1, 64, 64, 41, 37)],
+                         ids=["4blocks", "8blocks_convT", "5blocks", "7blocks", "stride2_k4p2", "stride2_k4p1_3blocks", "stride2_k3"])
 def test_patch_kernel_small_launches_repeat(ops, shape):
     """Forward launches of the patch kernel with fewer workgroups than CUs and 4 / 8 / 5 / 7 channel blocks: against an fp64 result,
     and twenty repeats bit for bit (a synchronisation slip inside the kernel would show as a run that differs)."""
@@ -283,7 +287,8 @@ def test_patch_kernel_small_launches_repeat(ops, shape):
     from supervised_gan_amd import _lib
     kind, k, s, p, cin, cout, H, W = shape
     tr = kind == "convT"
-    _select_tile("auto")
+    s2 = not tr and s == 2       # stride-2 gather: the parity-plane patch (forced: these grids are under its automatic threshold)
+    _select_tile("patch" if s2 else "auto")
     ops.set_math("bf16x3")
     g = torch.Generator().manual_seed(31)
     x = torch.randn(1, cin, H, W, generator=g)
@@ -300,7 +305,7 @@ def test_patch_kernel_small_launches_repeat(ops, shape):
         ob = torch.full((Ho, Wo, cout), float("nan"), device="cuda")
         ost = torch.zeros(2 * cout, dtype=torch.float64, device="cuda")
         ops.conv_fwd(desc, xb, nd, wm, bb, ob, 0, ost)
-        assert _lib.lib().sgan_last_kernel().decode() == "sg_igemm3p_kernel<64>"
+        assert _lib.lib().sgan_last_kernel().decode() == ("sg_igemm3p_kernel<64,s2>" if s2 else "sg_igemm3p_kernel<64>")
         if first is None:
             first = ob.clone()
         else:
@@ -308,6 +313,7 @@ def test_patch_kernel_small_launches_repeat(ops, shape):
     got = first.permute(2, 0, 1).unsqueeze(0).double().cpu()
     assert float((got - ref).abs().max() / ref.abs().max()) < 3e-6
     assert float((ost.cpu() - torch.cat([ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))])).abs().max() / (ref * ref).sum((0, 2, 3)).max()) < 1e-5
+    _select_tile("auto")
 
 
 def test_bf16x3_needs_packed_weights(ops):

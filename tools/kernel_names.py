@@ -12,9 +12,9 @@ def short(name):
     m = re.match(r"(sg_igemm3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false),(?:true|false)>$", n)   # prologue flag, fp16 / bf16 planes
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    m = re.match(r"(sg_igemm3p)(?:_kw2)?_kernel<(\d+),.*>$", n)      # patch-tile count, prologue flag, plane type; _kw2: two wave groups
+    m = re.match(r"(sg_igemm3p)(?:_kw2)?_kernel<(\d+),(.*)>$", n)      # N tile, staging passes, prologue flag, plane type, stride-2 flag
     if m:
-        return f"{m.group(1)}_kernel<{m.group(2)}>"
+        return f"{m.group(1)}_kernel<{m.group(2)},s2>" if m.group(3).endswith(",true") and m.group(3).count(",") == 3 else f"{m.group(1)}_kernel<{m.group(2)}>"
     m = re.match(r"(sg_igemm3p_kernel)<(\d+),.*>$", n)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"

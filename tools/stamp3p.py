@@ -43,7 +43,23 @@ if op == "gfwd":      # the generator's second layer: ConvT k4 s2 p1 256 -> 256,
     desc = ops.conv_desc(1, k, s, p, H, H, cin, 2 * H, 2 * H, cout)
     jf = [(desc, x, nrm, wm, torch.randn(cout, device="cuda"), y, st_out, 0, ops.stat_rep(st_out))]
     keep.append((x, y, st_in, st_out, gam, bet, nrm, desc))
-fn = (lambda: ops.conv_fwd_grouped(jf)) if op in ("fwd", "gfwd") else (lambda: ops.conv_dgrad_grouped(jd))
+if op in ("s2fwd1", "s2fwd2"):      # the stride-2 PatchGAN layers (32 -> 64 from 257^2, 64 -> 128 from 129^2), parity-plane patch kernel
+    k, s, p = 4, 2, 2
+    cin, cout, sizes = (32, 64, [257, 129, 65]) if op == "s2fwd1" else (64, 128, [129, 65, 33])
+    sizes = sizes * (nprob // 3)
+    w = torch.randn(k * k * cout * cin, device="cuda") * 0.05
+    wm, wt = derived_copies(w, k, cout, cin)
+    b = torch.randn(cout, device="cuda")
+    jf = []
+    for H in sizes:
+        Ho = (H + 2 * p - k) // s + 1
+        x = torch.randn(H, H, cin, device="cuda"); y = torch.empty(Ho, Ho, cout, device="cuda")
+        st_in = torch.zeros(2 * cin, dtype=torch.float64, device="cuda"); st_in[cin:] = H * H
+        st_out = ops.stat_arena(2 * cout, "cuda")
+        nrm = ops.norm_desc(st_in, None, None, H * H, 1e-5, 2, 0.2)
+        desc = ops.conv_desc(0, k, s, p, H, H, cin, Ho, Ho, cout)
+        jf.append((desc, x, nrm, wm, b, y, st_out, 0, ops.stat_rep(st_out))); keep.append((x, y, st_in, st_out, nrm, desc))
+fn = (lambda: ops.conv_fwd_grouped(jf)) if op in ("fwd", "gfwd", "s2fwd1", "s2fwd2") else (lambda: ops.conv_dgrad_grouped(jd))
 for _ in range(5):
     fn()
 torch.cuda.synchronize()
@@ -58,6 +74,8 @@ d = np.diff(st[:, :5], axis=1)
 names = ["setup (tap table, scale/shift, barrier)", "first patch + weight tile", "tap loop", "epilogue"]
 for i, n in enumerate(names):
     print(f"  {n:42s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f} cycles")
+if (st[:, 5] > 0).all():
+    print(f"  of the set-up: kernel arguments + tile decode (up to the tap table) median {np.median(st[:, 5] - st[:, 0]):9.0f} cycles")
 tot = st[:, 4] - st[:, 0]
 print(f"  workgroup total median {np.median(tot):.0f} cycles")
 rt0 = st[:, 6].min()

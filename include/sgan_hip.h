@@ -174,12 +174,17 @@ typedef struct sgan_conv_dgrad_job {
                                    * 16-byte LDS stores like the forward pass */
     const void* w_packed;         /* SGAN_MATH_BF16X3: the `packed_bwd` copy of the weights (sgan_pack_weights); else NULL */
     int32_t bwd_sums_rep_stride;  /* > 0: bwd_sums is the first of SGAN_STAT_REPLICAS copies this far apart */
+    const float* dout_amax;       /* device scalar max|dout| (sgan_norm_bwd_apply_multi publishes it) or NULL.  With it (and w_packed_f16)
+                                   * SGAN_MATH_BF16X3 runs backward-data on fp16 planes of dout * 2^s, s from the exponent of the maximum:
+                                   * 11 + 11 significant bits, an fp32-equivalent product like the forward pass.  Without: bf16 planes (8 + 8) */
+    const void* w_packed_f16;     /* the `packed_bwd_f16` copy of the weights (sgan_pack_weights); NULL: bf16 planes */
 } sgan_conv_dgrad_job;
 typedef struct sgan_conv_wgrad_job {
     const sgan_conv_desc* d;
     const float* in; int32_t in_ld; const sgan_norm_desc* in_norm;
     const float* dout; int32_t dout_ld;
     float* dw; float* dbias;
+    const float* dout_amax;       /* as sgan_conv_dgrad_job.dout_amax: with it backward-weight runs on fp16 planes (dout scaled), else bf16 */
 } sgan_conv_wgrad_job;
 int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, int32_t out_act, void* workspace,
                           int64_t workspace_bytes, void* stream);
@@ -210,11 +215,13 @@ int sgan_transpose_weights(const float* flat, float* flat_t, const sgan_wt_seg* 
  *   flat_t     [tap][ci][co] fp32                          transposed master copy (as sgan_transpose_weights), or NULL
  *   packed_fwd [tap][co][ci/8]{8 x bf16 hi | 8 x bf16 lo}  split-bf16 rows for the forward pass   (cin  % 8 == 0), or NULL
  *   packed_bwd [tap][ci][co/8]{8 x bf16 hi | 8 x bf16 lo}  split-bf16 rows for backward-data      (cout % 8 == 0), or NULL
+ *   packed_bwd_f16: the same rows as fp16 planes of w * 2^10 (like packed_fwd, which holds fp16 planes of w * 2^10 too): what
+ *                   backward-data reads when the gradient's maximum is known (sgan_conv_dgrad_job.dout_amax), or NULL
  * hi = bf16(x) (round to nearest even), lo = bf16(x - hi).  A copy occupies 4 bytes per weight like the master.  Segments
  * whose channel count does not divide are left untouched in that copy (such layers run the fp32 kernels).  Run after each
  * optimizer step / checkpoint load, before the next forward. */
-int sgan_pack_weights(const float* flat, float* flat_t, void* packed_fwd, void* packed_bwd, const sgan_wt_seg* segs,
-                      int32_t n /* <= 64 */, void* stream);
+int sgan_pack_weights(const float* flat, float* flat_t, void* packed_fwd, void* packed_bwd, void* packed_bwd_f16,
+                      const sgan_wt_seg* segs, int32_t n /* <= 64 */, void* stream);
 
 /* ---- backward-weight ---------------------------------------------------------------------------
  * dw += act(norm(in))^T (x) dout over all pixels (master layout), dbias += sum_pixels dout.
@@ -244,6 +251,8 @@ typedef struct sgan_norm_bwd_job {
     const double* bwd_sums; int32_t bwd_sums_sq_stride;
     float* dgamma; float* dbeta;
     int32_t bwd_sums_rep_stride;   /* > 0: bwd_sums is the first of SGAN_STAT_REPLICAS copies this far apart (summed on read) */
+    float* amax_out;               /* NULL, or a device scalar that starts at 0: max|dy| of the result is stored there (an atomic max on the
+                                    * bit pattern) -- the `dout_amax` of the backward-data / backward-weight calls that read dy next */
 } sgan_norm_bwd_job;
 int sgan_norm_bwd_apply_multi(const sgan_norm_bwd_job* jobs, int32_t n /* 1..8 */, void* stream);
 
@@ -454,8 +463,8 @@ int sgan_adam_multi(const sgan_adam_seg* segs, int32_t nseg, const float* lr_dev
  * NULL).  zero_grads != 0: the consumed gradients are overwritten with zeros.
  * Replaces: torch.optim.Adam.step() + zero_grad() (models/fcgan_model.py:98-109,182-191) and the weight re-layout that follows it. */
 int sgan_adam_pack(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2, float eps,
-                   int32_t* state_dev, float* flat_t, void* packed_fwd, void* packed_bwd, const sgan_wt_seg* segs, int32_t nseg,
-                   int32_t zero_grads, void* stream);
+                   int32_t* state_dev, float* flat_t, void* packed_fwd, void* packed_bwd, void* packed_bwd_f16, const sgan_wt_seg* segs,
+                   int32_t nseg, int32_t zero_grads, void* stream);
 
 /* ---- Zero up to 64 device buffers in one launch (the statistics arenas of a training step).  bytes[i] and ptrs[i]: multiples of 16.
  * Replaces: the aten fill launches behind torch.zeros / Tensor.zero_(). */

@@ -41,7 +41,8 @@ class ConvDgradJob(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("w", C.c_void_p),
                 ("din", C.c_void_p), ("din_ld", C.c_int32), ("x", C.c_void_p), ("x_ld", C.c_int32),
                 ("x_norm", C.POINTER(NormDesc)), ("bwd_sums", C.c_void_p), ("bwd_sums_sq_stride", C.c_int32),
-                ("accumulate", C.c_int32), ("w_transposed", C.c_int32), ("w_packed", C.c_void_p), ("bwd_sums_rep_stride", C.c_int32)]
+                ("accumulate", C.c_int32), ("w_transposed", C.c_int32), ("w_packed", C.c_void_p), ("bwd_sums_rep_stride", C.c_int32),
+                ("dout_amax", C.c_void_p), ("w_packed_f16", C.c_void_p)]
 
 
 class WtSeg(C.Structure):
@@ -50,13 +51,13 @@ class WtSeg(C.Structure):
 
 class ConvWgradJob(C.Structure):
     _fields_ = [("d", C.POINTER(ConvDesc)), ("inp", C.c_void_p), ("in_ld", C.c_int32), ("in_norm", C.POINTER(NormDesc)),
-                ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("dw", C.c_void_p), ("dbias", C.c_void_p)]
+                ("dout", C.c_void_p), ("dout_ld", C.c_int32), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("dout_amax", C.c_void_p)]
 
 
 class NormBwdJob(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("dy_ld", C.c_int32), ("x", C.c_void_p), ("x_ld", C.c_int32), ("npix", C.c_int32),
                 ("C", C.c_int32), ("x_norm", C.POINTER(NormDesc)), ("bwd_sums", C.c_void_p), ("bwd_sums_sq_stride", C.c_int32),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("bwd_sums_rep_stride", C.c_int32)]
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("bwd_sums_rep_stride", C.c_int32), ("amax_out", C.c_void_p)]
 
 
 class GanLossJob(C.Structure):
@@ -87,7 +88,7 @@ SIGNATURES = {
     "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
     "sgan_norm_bwd_apply_multi": [C.POINTER(NormBwdJob), _I, _P],
     "sgan_transpose_weights": [_P, _P, C.POINTER(WtSeg), _I, _P],
-    "sgan_pack_weights": [_P, _P, _P, _P, C.POINTER(WtSeg), _I, _P],
+    "sgan_pack_weights": [_P, _P, _P, _P, _P, C.POINTER(WtSeg), _I, _P],
     "sgan_bce01_fwd": [_P, _I, _P, _I, _I, _I, _P, _P, _I, _P, C.c_int64, _P],
     "sgan_bilinear_up2_fwd": [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "sgan_bilinear_up2_bwd": [_P, _I, _I, _I, _I, _P, _I, _P],
@@ -125,7 +126,7 @@ SIGNATURES = {
     "sgan_slice_nhwc": [_P, _I, _I, _I, _L, _P, _I, _I, _P],
     "sgan_adam_multi": [C.POINTER(AdamSeg), _I, _P, _F, _F, _F, _P, _P],
     "sgan_sgd_multi": [C.POINTER(AdamSeg), _I, _P, _F, _P],
-    "sgan_adam_pack": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _P, _P, _P, _P, C.POINTER(WtSeg), _I, _I, _P],
+    "sgan_adam_pack": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _P, _P, _P, _P, _P, C.POINTER(WtSeg), _I, _I, _P],
     "sgan_zero_multi": [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _I, _P],
     "sgan_normal_fill": [_P, _L, C.c_uint64, _P, _I, _P],
     "sgan_normal_fill_nhwc": [_P, _I, _I, _I, _I, C.c_uint64, _P, _I, _P],

@@ -299,7 +299,7 @@ class ChainNet(nn.Module):
         """Weights of layer L from the transposed copy [tap][Cin][Cout] that backward-data reads (+ its split-bf16 twin)."""
         self._refresh_derived()
         n = L.k * L.k * L.cout_s * L.cin_s
-        return ops.with_packed(self._flat_t[L.w_off: L.w_off + n], self._pk_b[L.w_off: L.w_off + n])
+        return ops.with_packed(self._flat_t[L.w_off: L.w_off + n], self._pk_b[L.w_off: L.w_off + n], self._pk_bh[L.w_off: L.w_off + n])
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -337,7 +337,8 @@ class ChainNet(nn.Module):
             self._flat_t = torch.zeros_like(self._flat)
             self._pk_f = torch.zeros_like(self._flat)
             self._pk_b = torch.zeros_like(self._flat)
-        ops.pack_weights(self._flat, self._flat_t, self._pk_f, self._pk_b, self._conv_segments())
+            self._pk_bh = torch.zeros_like(self._flat)
+        ops.pack_weights(self._flat, self._flat_t, self._pk_f, self._pk_b, self._conv_segments(), self._pk_bh)
         self._wt_key = key
 
     def _conv_segments(self, base=0):
@@ -356,18 +357,18 @@ class ChainNet(nn.Module):
             return False
         der = getattr(arena_p, "_sgan_derived", None)
         if der is None or der[0].shape != arena_p.shape or der[0].device != arena_p.device:
-            der = arena_p._sgan_derived = tuple(torch.zeros_like(arena_p) for _ in range(3))
+            der = arena_p._sgan_derived = tuple(torch.zeros_like(arena_p) for _ in range(4))
         segs, stale = [], []
         for n in mates:
             off = n._arena[2]
             if getattr(n, "_flat_t", None) is None or n._flat_t.data_ptr() != der[0].data_ptr() + 4 * off:
-                n._flat_t, n._pk_f, n._pk_b = (d[off: off + n._nflat] for d in der)
+                n._flat_t, n._pk_f, n._pk_b, n._pk_bh = (d[off: off + n._nflat] for d in der)
                 n._wt_key = None
             key = n._derived_key()
             if n._wt_key != key:
                 segs += n._conv_segments(off)
                 stale.append((n, key))
-        ops.pack_weights(arena_p, der[0], der[1], der[2], segs)
+        ops.pack_weights(arena_p, der[0], der[1], der[2], segs, der[3])
         for n, key in stale:
             n._wt_key = key
         return True
@@ -504,10 +505,11 @@ class ChainNet(nn.Module):
                 P = self.layers[li - 1]
                 din = torch.empty((h, w, P.cout_s), dtype=torch.float32, device=dev)
                 djob = [(desc, dcur, self._wt(L), din, src, in_norm, None if dropped else sums[li - 1], 0, False, True, brep)]
+                dm = _dgrad_math(P, [dcur])
                 if wjob:
-                    ops.conv_bwd_grouped(djob, wjob, _dgrad_math(P))      # both halves in one launch where the fused kernel covers the layer
+                    ops.conv_bwd_grouped(djob, wjob, dm)      # both halves in one launch where the fused kernel covers the layer
                 else:
-                    with ops.math_scope(_dgrad_math(P)):
+                    with ops.math_scope(dm):
                         ops.conv_dgrad_grouped(djob)
                 if dropped:      # din = d t * ReLU'(t); through the mask, with the two norm-backward sums of the masked gradient
                     raw_norm = self._norm_of(li - 1, stats, h * w)
@@ -518,7 +520,7 @@ class ChainNet(nn.Module):
                 elif P.norm:
                     dg = self._gflat[P.g_off: P.g_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
                     db = self._gflat[P.be_off: P.be_off + P.cout_s] if (P.norm == "bn" and want_wgrad) else None
-                    ops.norm_bwd_apply(din, src, in_norm, sums[li - 1], dg, db, 0, brep)
+                    ops.norm_bwd_apply(din, src, in_norm, sums[li - 1], dg, db, 0, brep, publish_amax=_wants_amax(self.layers, li - 1))
                 dcur = din
                 continue
             if wjob:
@@ -529,13 +531,25 @@ class ChainNet(nn.Module):
         return dx
 
 
-def _dgrad_math(P):
-    """Arithmetic of the backward-data launch whose result is the gradient of layer P's output.  Behind a normalisation the
+def _wants_amax(layers, li):
+    """Does the backward-data launch that READS the gradient of layer li's output need fp16 planes?  Only where bf16 planes are not
+    enough: its result is the gradient of a layer WITHOUT normalisation (see _dgrad_math) -- for the PatchGAN chains, the launch
+    into the first conv's output.  Everywhere else bf16 planes stay (measured: fp16 planes cost the fused backward launches ~11 %,
+    138 -> 149 us on the six-problem 128 -> 256 launch, for an accuracy the norm backward does not need)."""
+    return li >= 1 and layers[li - 1].norm is None
+
+
+def _dgrad_math(P, douts=()):
+    """Arithmetic of the backward-data launch whose result is the gradient of layer P's output.  Round 3: when every gradient tensor
+    the launch reads carries its published maximum (ops.norm_bwd_apply_multi(publish_amax=True)) it runs on fp16 planes scaled by
+    it -- 11 + 11 significant bits, an fp32-equivalent product -- and the rule below is not needed (returns None).  Otherwise:  Behind a normalisation the
     result goes through the norm backward, which re-centres it with sums taken from the very same values: the 5e-6 element errors
     of the split products stay 5e-6.  Without one (the first PatchGAN layer) the result is used as is, and the layer's bias
     gradient sums it over every pixel -- terms that cancel to a small residual (the gradient that reaches it left a normalisation
     as a zero-sum field) while unbiased element errors do not: measured 7e-3 of the bias gradient against the fp64 reference,
     where the reference's own fp32 is at 7e-6.  Those launches run on the exact-fp32 kernel (one per discriminator pass)."""
+    if douts and all(ops.has_amax(d) for d in douts):
+        return None
     return None if P.norm else "f32"
 
 
@@ -689,7 +703,7 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
                 din = torch.empty((h, w, Pv.cout_s), dtype=torch.float32, device=dev)
                 dins.append(din)
                 jobs.append((desc, dcur[j], net._wt(net.layers[li]), din, srcs[j], norms[j], sums[j][li - 1], 0, False, True, brep))
-            dm = _dgrad_math(nets[0].layers[li - 1])
+            dm = _dgrad_math(nets[0].layers[li - 1], dcur)
             if wjobs:
                 ops.conv_bwd_grouped(jobs, wjobs, dm)
             else:
@@ -707,7 +721,7 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
                     nb.append((dins[j], srcs[j], norms[j], sums[j][li - 1], dg, db, 0, brep))
                 dcur[j] = dins[j]
             if nb:
-                ops.norm_bwd_apply_multi(nb)
+                ops.norm_bwd_apply_multi(nb, publish_amax=_wants_amax(nets[0].layers, li - 1))
         else:
             dj = [j for j in range(J) if need_dx[j]]
             if dj:

@@ -174,6 +174,14 @@ __device__ __forceinline__ void sg_mean_rstd(const SgNorm& n, int C, int c, floa
     rstd = (float)(1.0 / sqrt(var + (double)n.eps));
 }
 
+// fp16 planes: scale 2^s that brings a tensor of maximum magnitude `amax` under 2^15 (s = 14 - floor(log2 amax)); 0 / denormal -> 1
+__device__ __forceinline__ int sg_f16_shift(float amax) {
+    const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 255u);
+    int s = e ? 141 - e : 0;
+    return s > 100 ? 100 : (s < -100 ? -100 : s);
+}
+__device__ __forceinline__ float sg_pow2(int s) { return __builtin_bit_cast(float, (unsigned)(s + 127) << 23); }
+
 __device__ __forceinline__ float sg_act(float y, int act, float slope) {
     if (act == SGAN_ACT_RELU) return y > 0.f ? y : 0.f;
     if (act == SGAN_ACT_LRELU) return y > 0.f ? y : y * slope;

@@ -97,7 +97,7 @@ static inline int ew_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b);
 // InstanceNorm / BatchNorm(batch 1) backward, in place on dy
 // ------------------------------------------------------------------------------------------
 struct SgNormBwdJob {
-    float* dy; const float* x; const double* sums; float* dgamma; float* dbeta;
+    float* dy; const float* x; const double* sums; float* dgamma; float* dbeta; unsigned* amax;
     SgNorm xn;
     int32_t dy_ld, x_ld, npix, C, sums_sq, sums_rep, blocks;
 };
@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(const SgNormBwdT
     // four chunks per trip, all eight loads in flight before the first store: dy is updated in place, so the compiler keeps every
     // load behind the previous trip's store and a one-chunk loop waits out a memory round trip per chunk
     const int64_t stride = (int64_t)J.blocks * 256;
+    float amax = 0.f;      // max |result| of this thread (published below: the fp16-plane scale of the kernels that read dy next)
     for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += 4 * stride) {
         f32x4 d[4], xv[4];
         int64_t od[4];
@@ -161,8 +162,20 @@ __global__ __launch_bounds__(256) void sg_norm_bwd_apply_kernel(const SgNormBwdT
             for (int j = 0; j < 4; ++j) {
                 const float xhat = (xv[u][j] - cMean[c + j]) * cRstd[c + j];
                 d[u][j] = cA[c + j] * (d[u][j] - cS1[c + j] - xhat * cS2[c + j]);
+                amax = fmaxf(amax, fabsf(d[u][j]));
             }
             *reinterpret_cast<f32x4*>(dy + od[u]) = d[u];
+        }
+    }
+    if (J.amax) {      // non-negative floats order like their bit patterns: an integer atomic max -- one per WORKGROUP, and only when the
+        // published value (read past the L1) is still below this workgroup's: thousands of same-address atomics cost 12 ns each
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        SG_SYNC();      // the coefficient arrays are free
+        if ((threadIdx.x & 63) == 0) cA[threadIdx.x >> 6] = amax;
+        SG_SYNC();
+        if (threadIdx.x == 0) {
+            const unsigned mine = __builtin_bit_cast(unsigned, fmaxf(fmaxf(cA[0], cA[1]), fmaxf(cA[2], cA[3])));
+            if (mine > __hip_atomic_load(J.amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(J.amax, mine);
         }
     }
 }
@@ -178,6 +191,7 @@ extern "C" int sgan_norm_bwd_apply_multi(const sgan_norm_bwd_job* jobs, int32_t 
                        (S.x_ld & 3) == 0 && S.npix > 0, "bad dims in job %d", i);
         SgNormBwdJob& J = T.j[i];
         J.dy = S.dy; J.x = S.x; J.sums = S.bwd_sums; J.dgamma = S.dgamma; J.dbeta = S.dbeta;
+        J.amax = reinterpret_cast<unsigned*>(S.amax_out);
         J.xn = sg_norm_from(S.x_norm);
         J.dy_ld = S.dy_ld; J.x_ld = S.x_ld; J.npix = S.npix; J.C = S.C;
         J.sums_sq = S.bwd_sums_sq_stride ? S.bwd_sums_sq_stride : S.C;
@@ -201,7 +215,7 @@ extern "C" int sgan_norm_bwd_apply_multi(const sgan_norm_bwd_job* jobs, int32_t 
 extern "C" int sgan_norm_bwd_apply(float* dy, int32_t dy_ld, const float* x, int32_t x_ld, int32_t npix, int32_t C,
                                    const sgan_norm_desc* x_norm, const double* bwd_sums, int32_t bwd_sums_sq_stride,
                                    float* dgamma, float* dbeta, void* stream) {
-    sgan_norm_bwd_job j = {dy, dy_ld, x, x_ld, npix, C, x_norm, bwd_sums, bwd_sums_sq_stride, dgamma, dbeta, 0};
+    sgan_norm_bwd_job j = {dy, dy_ld, x, x_ld, npix, C, x_norm, bwd_sums, bwd_sums_sq_stride, dgamma, dbeta, 0, nullptr};
     return sgan_norm_bwd_apply_multi(&j, 1, stream);
 }
 
@@ -670,7 +684,7 @@ __device__ __forceinline__ sg_u32x4 sg_split8_f16(const float* v, int plane) {
     return (sg_u32x4){h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
 }
 
-__global__ __launch_bounds__(256) void sg_pack_weights_kernel(const float* flat, float* flat_t, float* pk_f, float* pk_b, const SgWtTable T) {
+__global__ __launch_bounds__(256) void sg_pack_weights_kernel(const float* flat, float* flat_t, float* pk_f, float* pk_b, float* pk_bh, const SgWtTable T) {
     __shared__ float tile[32][33];
     int i = 0;
     for (int k = 1; k < T.n; ++k)
@@ -712,12 +726,13 @@ __global__ __launch_bounds__(256) void sg_pack_weights_kernel(const float* flat,
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = tile[q * 8 + e][r];
             *reinterpret_cast<sg_u32x4*>(pk_b + slab + (int64_t)ci * S.cout + co + 4 * p) = sg_split8(v, p);
+            if (pk_bh) *reinterpret_cast<sg_u32x4*>(pk_bh + slab + (int64_t)ci * S.cout + co + 4 * p) = sg_split8_f16(v, p);
         }
     }
 }
 
-extern "C" int sgan_pack_weights(const float* flat, float* flat_t, void* packed_fwd, void* packed_bwd, const sgan_wt_seg* segs,
-                                 int32_t n, void* stream) {
+extern "C" int sgan_pack_weights(const float* flat, float* flat_t, void* packed_fwd, void* packed_bwd, void* packed_bwd_f16,
+                                 const sgan_wt_seg* segs, int32_t n, void* stream) {
     SGAN_CHECK(flat && segs && n >= 1 && n <= 64, "1..64 segments");
     SGAN_CHECK(flat_t || packed_fwd || packed_bwd, "no destination");
     SgWtTable T;
@@ -730,8 +745,9 @@ extern "C" int sgan_pack_weights(const float* flat, float* flat_t, void* packed_
         tiles += (int64_t)segs[i].taps * ((segs[i].cout + 31) / 32) * ((segs[i].cin + 31) / 32);
     }
     T.first[n] = tiles;
+    SGAN_CHECK(!packed_bwd_f16 || packed_bwd, "packed_bwd_f16 rides on the packed_bwd pass");
     hipLaunchKernelGGL(sg_pack_weights_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, flat, flat_t,
-                       (float*)packed_fwd, (float*)packed_bwd, T);
+                       (float*)packed_fwd, (float*)packed_bwd, (float*)packed_bwd_f16, T);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
 }
@@ -1861,7 +1877,7 @@ __device__ __forceinline__ void sg_adam1(float& p, float g, float& m, float& v, 
 }
 
 __global__ __launch_bounds__(256) void sg_adam_pack_kernel(float* P, float* Gr, float* M, float* V, float* flat_t, float* pk_f, float* pk_b,
-                                                           const SgAdamPackTable T, int32_t* state, const float* lr, float b1, float b2,
+                                                           float* pk_bh, const SgAdamPackTable T, int32_t* state, const float* lr, float b1, float b2,
                                                            float eps, int zero_grads, int nitems) {
     sg_warm_kernargs<(int)sizeof(SgAdamPackTable)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     __shared__ float tile[32][33];
@@ -1946,6 +1962,7 @@ __global__ __launch_bounds__(256) void sg_adam_pack_kernel(float* P, float* Gr, 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = tile[q * 8 + e][r];
                 *reinterpret_cast<sg_u32x4*>(pk_b + slab + (int64_t)ci * S.cout + co + 4 * pl) = sg_split8(v, pl);
+                if (pk_bh) *reinterpret_cast<sg_u32x4*>(pk_bh + slab + (int64_t)ci * S.cout + co + 4 * pl) = sg_split8_f16(v, pl);
             }
         }
         SG_SYNC();      // the tile is rewritten by the next item
@@ -1964,8 +1981,8 @@ __global__ __launch_bounds__(256) void sg_adam_pack_kernel(float* P, float* Gr, 
 }
 
 extern "C" int sgan_adam_pack(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2, float eps,
-                              int32_t* state_dev, float* flat_t, void* packed_fwd, void* packed_bwd, const sgan_wt_seg* segs, int32_t nseg,
-                              int32_t zero_grads, void* stream) {
+                              int32_t* state_dev, float* flat_t, void* packed_fwd, void* packed_bwd, void* packed_bwd_f16,
+                              const sgan_wt_seg* segs, int32_t nseg, int32_t zero_grads, void* stream) {
     SGAN_CHECK(p && g && m && v && n > 0 && lr_dev && state_dev && nseg >= 0 && nseg <= 64 && (nseg == 0 || segs), "bad argument");
     SgAdamPackTable T;
     memset(&T, 0, sizeof(T));
@@ -1994,7 +2011,7 @@ extern "C" int sgan_adam_pack(float* p, float* g, float* m, float* v, int64_t n,
     static const int max_wg = getenv("SGAN_ADAM_WGS") ? atoi(getenv("SGAN_ADAM_WGS")) : 1024;      // tuning knob
     const int nitems = tiles + chunks;
     hipLaunchKernelGGL(sg_adam_pack_kernel, dim3((unsigned)(nitems < max_wg ? nitems : max_wg)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                       flat_t, (float*)packed_fwd, (float*)packed_bwd, T, state_dev, lr_dev, beta1, beta2, eps, (int)zero_grads, nitems);
+                       flat_t, (float*)packed_fwd, (float*)packed_bwd, (float*)packed_bwd_f16, T, state_dev, lr_dev, beta1, beta2, eps, (int)zero_grads, nitems);
     SGAN_LAUNCH_CHECK();
     return SGAN_OK;
 }

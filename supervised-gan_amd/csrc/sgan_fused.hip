@@ -13,25 +13,28 @@
 #include "sgan_wgrad3.hip"
 
 // DV: 1 = patch kernel with <= 128 patch pixels, 2 = patch kernel up to 256, 3 = sg_igemm3 64 x 64 (two k-tiles per barrier),
-//     4 = exact-fp32 sg_igemm 128 x 32 (backward-data into a layer without a normalisation: chain._dgrad_math),
 //     5 = patch kernel, stride-2 gather (parity planes; ConvTranspose2d stride 2 backward-data);
+//     6 = sg_igemm3 128 x 32 (<= 32 result channels: backward-data into the first PatchGAN layer).  Round 2's variant 4 (the exact-fp32
+//         sg_igemm 128 x 32 tile for backward-data into a layer without a normalisation) is retired: that launch now runs variant 6 on
+//         fp16 planes scaled by the gradient's published maximum -- an fp32-equivalent product at the split kernels' speed;
 // WV: 1 = backward-weight 64 x 64 tiles, 2 = 32 x 128
-template <int DV, int WV, bool WPRO>
+// F16: the backward-data half on fp16 planes (every job brought the maximum of its gradient tensor); the backward-weight half is bf16
+template <int DV, int WV, bool WPRO, bool F16>
 __global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G, const SgWgradParams W, int ndg, int wx, int wy) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     sg_warm_kernargs<(int)(sizeof(SgIgemmParams) + sizeof(SgWgradParams))>();
     const int b = blockIdx.x;
     if (b < ndg) {
-        if constexpr (DV == 1) sg_igemm3p_body<64, 2, false, false>(G, smem, b, ndg);
-        else if constexpr (DV == 2) sg_igemm3p_body<64, 4, false, false>(G, smem, b, ndg);
-        else if constexpr (DV == 3) sg_igemm3_body<64, 64, 2, 2, false, false, true>(G, smem, b, ndg, 0);
-        else if constexpr (DV == 5) sg_igemm3p_body<64, 6, false, false, true>(G, smem, b, ndg);
-        else sg_igemm_body<128, 32, 4, 1, true, false, 1>(G, smem, b, ndg, 0);
+        if constexpr (DV == 1) sg_igemm3p_body<64, 2, false, F16>(G, smem, b, ndg);
+        else if constexpr (DV == 2) sg_igemm3p_body<64, 4, false, F16>(G, smem, b, ndg);
+        else if constexpr (DV == 3) sg_igemm3_body<64, 64, 2, 2, false, F16, true>(G, smem, b, ndg, 0);
+        else if constexpr (DV == 5) sg_igemm3p_body<64, 6, false, F16, true>(G, smem, b, ndg);
+        else sg_igemm3_body<128, 32, 4, 1, false, F16, false>(G, smem, b, ndg, 0);
     } else {
         const int w = b - ndg;
         const int bx = w % wx, by = (w / wx) % wy, bz = w / (wx * wy);
-        if constexpr (WV == 1) sg_wgrad3_body<64, 64, 2, 2, WPRO>(W, smem, bx, by, bz);
-        else sg_wgrad3_body<32, 128, 1, 4, WPRO>(W, smem, bx, by, bz);
+        if constexpr (WV == 1) sg_wgrad3_body<64, 64, 2, 2, WPRO, false>(W, smem, bx, by, bz);
+        else sg_wgrad3_body<32, 128, 1, 4, WPRO, false>(W, smem, bx, by, bz);
     }
 }
 
@@ -39,8 +42,15 @@ template <int DV, int WV>
 static void sg_fused_launch(const SgIgemmParams& P, const SgWgradParams& W, const SgFusePlan& pd, const SgFusePlan& pw, hipStream_t st) {
     const dim3 grid(pd.nblocks + pw.nblocks);
     const size_t lds = pd.lds > pw.lds ? pd.lds : pw.lds;
-    if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
-    else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
+    if constexpr (DV == 6) {       // fp16 planes are asked for where they matter: backward-data into a layer without a normalisation
+        if (P.planes_f16) {
+            if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
+            else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
+            return;
+        }
+    }
+    if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
+    else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
 }
 
 // 0: launched; 1: this pair is not covered (launch sgan_conv_dgrad_grouped and sgan_conv_wgrad_grouped instead); < 0: error
@@ -50,19 +60,23 @@ extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd,
     if (off) return 1;
     SgIgemmParams P;
     SgWgradParams W;
-    int rc = sg_build_dgrad_params(djobs, nd, P);
+    int rc = sg_build_dgrad_params(djobs, nd, P, true);      // fp16 planes when every job brought its gradient's maximum
     if (rc) return rc;
-    rc = sg_build_wgrad_params(wjobs, nw, W);
+    rc = sg_build_wgrad_params(wjobs, nw, W, false);         // the backward-weight half of a fused launch stays on bf16 planes
     if (rc) return rc;
     if (wjobs[0].d->math != SGAN_MATH_BF16X3 || sg_dgrad_is_skinny(P)) return 1;
     if (dgrad_math >= 0) P.math = dgrad_math;      // the two job lists may share descriptors: the backward-data mode comes apart
     const int e3 = sg_igemm3_eligible(P);
     if (e3 < 0) return e3;
     SgFusePlan pd, pw;
-    static const int no_f32 = getenv("SGAN_NO_F32_FUSION") ? 1 : 0;      // tuning knob
-    if (e3 == 0 && no_f32) return 1;
-    if (e3 == 0) sg_igemm_fuse_plan_f32(P, &pd);
-    else sg_igemm3_fuse_plan(P, &pd);
+    if (e3 == 0) return 1;      // exact-fp32 backward-data (tiny maps, SGAN_MATH_F32): the two grouped calls
+    sg_igemm3_fuse_plan(P, &pd);
+    if (pd.variant != 6 && P.planes_f16) {      // only variant 6 is instantiated with fp16 planes: the others run this pair on bf16 planes
+        rc = sg_build_dgrad_params(djobs, nd, P, false);
+        if (rc) return rc;
+        if (dgrad_math >= 0) P.math = dgrad_math;
+        sg_igemm3_fuse_plan(P, &pd);
+    }
     if (pd.variant == 0 || pd.nblocks == 0) return 1;
     sg_wgrad3_fuse_plan(W, &pw);
     if (pw.variant == 0 || pw.nblocks == 0) return 1;
@@ -76,13 +90,13 @@ extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd,
         case 22: sg_fused_launch<2, 2>(P, W, pd, pw, st); break;
         case 31: sg_fused_launch<3, 1>(P, W, pd, pw, st); break;
         case 32: sg_fused_launch<3, 2>(P, W, pd, pw, st); break;
-        case 41: sg_fused_launch<4, 1>(P, W, pd, pw, st); break;
-        case 42: sg_fused_launch<4, 2>(P, W, pd, pw, st); break;
         case 51: sg_fused_launch<5, 1>(P, W, pd, pw, st); break;
-        default: sg_fused_launch<5, 2>(P, W, pd, pw, st); break;
+        case 52: sg_fused_launch<5, 2>(P, W, pd, pw, st); break;
+        case 61: sg_fused_launch<6, 1>(P, W, pd, pw, st); break;
+        default: sg_fused_launch<6, 2>(P, W, pd, pw, st); break;
     }
     SGAN_LAUNCH_CHECK();
-    g_sgan_last_kernel = pd.variant == 4 ? "sg_bwd_fused_kernel<f32 dgrad>" : "sg_bwd_fused_kernel";      // both halves split-bf16 unless said otherwise
+    g_sgan_last_kernel = "sg_bwd_fused_kernel";
     sg_prof_end(st, g_sgan_last_kernel);
     return SGAN_OK;
 }

@@ -23,6 +23,7 @@ struct SgProb {
     const double* xn_stats;   // norm the forward consumer applied to xref (or null)
     const float* xn_gamma;
     const float* xn_beta;
+    const float* amax;  // split kernels with fp16 planes: device scalar max|gathered tensor| (backward-data: sgan_conv_dgrad_job.dout_amax) or null
     int32_t Hin, Win, in_ld;     // gathered tensor geometry
     int32_t Hout, Wout, out_ld;  // result tensor geometry
     int32_t xref_ld, pro_count, xn_count;
@@ -63,8 +64,10 @@ struct SgLocal {
     int32_t Hin, Win, Ck, in_ld, Hout, Wout, N, out_ld, xref_ld, is, os, w_ns, w_ks, out_act, ksplit;
     float* slab; int64_t slab_stride;
     int32_t stats_sq, accum, stats_rep;
+    float a_scale, out_scale;   // fp16 planes: the gathered operand is staged times a_scale (a power of two), the accumulator leaves times out_scale
     SgNorm pro, xn;
 };
+
 
 __device__ __forceinline__ SgLocal sg_local(const SgIgemmParams& G, int g) {
     const SgProb& Q = G.q[g];
@@ -78,6 +81,10 @@ __device__ __forceinline__ SgLocal sg_local(const SgIgemmParams& G, int g) {
     P.stats_sq = Q.stats_sq ? Q.stats_sq : G.N; P.accum = Q.accum; P.stats_rep = Q.stats_rep;
     P.xn.stats = Q.xn_stats; P.xn.gamma = Q.xn_gamma; P.xn.beta = Q.xn_beta; P.xn.count = Q.xn_count;
     P.xn.eps = G.xn_eps; P.xn.act = G.xn_act; P.xn.slope = G.xn_slope; P.xn.sq_stride = Q.xn_sq; P.xn.rep_stride = Q.xn_rep;
+    // fp16 planes: the packed weights hold w * 2^SGAN_F16_WEIGHT_SHIFT; a gathered gradient is scaled up by its own power of two
+    const int sh = (G.planes_f16 && Q.amax) ? sg_f16_shift(*Q.amax) : 0;
+    P.a_scale = sg_pow2(sh);
+    P.out_scale = G.planes_f16 ? sg_pow2(-SGAN_F16_WEIGHT_SHIFT - sh) : 1.f;
     return P;
 }
 
@@ -116,6 +123,5 @@ int64_t sg_igemm3_workspace_need(const SgIgemmParams& P);
 
 // ---- one launch for a layer's backward-data and backward-weight (sgan_fused.hip) ----
 int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out);
-int sg_igemm_fuse_plan_f32(SgIgemmParams& P, SgFusePlan* out);                              // sgan_igemm.hip: exact-fp32 backward-data
-int sg_build_dgrad_params(const sgan_conv_dgrad_job* jobs, int32_t n, SgIgemmParams& P);   // sgan_igemm.hip: the argument checks + parameter block of sgan_conv_dgrad_grouped
+int sg_build_dgrad_params(const sgan_conv_dgrad_job* jobs, int32_t n, SgIgemmParams& P, bool allow_f16 = true);   // sgan_igemm.hip: the argument checks + parameter block of sgan_conv_dgrad_grouped
 bool sg_dgrad_is_skinny(const SgIgemmParams& P);                                           // routed to the direct small-N kernels

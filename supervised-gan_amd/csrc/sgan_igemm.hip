@@ -1612,26 +1612,6 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
     return sg_launch_igemm<64, 64, 2, 2>(P, st, ws, ws_bytes);
 }
 
-// Plan of an exact-fp32 backward-data launch for sg_bwd_fused_kernel (sgan_fused.hip): variant 4 = the 128 x 32 tile, unsplit,
-// no prologue -- what backward-data into a layer without a normalisation runs on (the first PatchGAN layer); 0 = not covered
-int sg_igemm_fuse_plan_f32(SgIgemmParams& P, SgFusePlan* out) {
-    out->variant = 0;
-    P.ksplit = 1;
-    P.slab = nullptr;
-    P.slab_stride = 0;
-    if (sg_use_small_n(P) || sg_use_c4(P) || P.w_ks != 1 || P.pro_act != SGAN_ACT_NONE) return 0;
-    for (int g = 0; g < P.nprob; ++g)
-        if (P.q[g].pro_stats) return 0;
-    int BM, BN;
-    sg_pick_tile(P, &BM, &BN);
-    if (BM != 128 || BN != 32 || sg_plan_ksplit(P, BM, BN) != 1) return 0;
-    const int tiles = sg_fill_tiles(P, BM);
-    out->variant = 4;
-    out->nblocks = tiles * sg_cdiv(P.N, BN);
-    out->lds = (size_t)((2 * BM * 32 + 2 * BN * 32) + 4 * BN) * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
-    out->name = "sg_igemm_kernel<128,32,4,1,true>";
-    return 0;
-}
 
 static int64_t sg_workspace_need(const SgIgemmParams& P) {
     if (sg_use_small_n(P)) return 0;
@@ -1725,6 +1705,7 @@ extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, i
         SgProb& Q = P.q[g];
         SGAN_CHECK(J.d->math == d0->math, "grouped jobs must share the math mode");
         Q.in = J.in; Q.out = J.out; Q.w = J.w; Q.wp = J.w_packed; Q.bias = J.bias; Q.xref = nullptr; Q.stats = J.out_stats;
+        Q.amax = nullptr;
         Q.Hin = J.d->Hin; Q.Win = J.d->Win; Q.in_ld = J.in_ld; Q.Hout = J.d->Hout; Q.Wout = J.d->Wout; Q.out_ld = J.out_ld;
         sg_set_norm(J.in_norm, &Q.pro_stats, &Q.pro_gamma, &Q.pro_beta, &Q.pro_count, &Q.pro_sq, &Q.pro_rep);
         Q.xn_count = 1;
@@ -1737,7 +1718,7 @@ extern "C" int sgan_conv_fwd_grouped(const sgan_conv_fwd_job* jobs, int32_t n, i
 
 bool sg_dgrad_is_skinny(const SgIgemmParams& P) { return sg_use_small_n(P); }
 
-int sg_build_dgrad_params(const sgan_conv_dgrad_job* jobs, int32_t n, SgIgemmParams& P) {
+int sg_build_dgrad_params(const sgan_conv_dgrad_job* jobs, int32_t n, SgIgemmParams& P, bool allow_f16) {
     SGAN_CHECK(jobs && n >= 1 && n <= SG_MAX_PROB, "1..%d jobs", SG_MAX_PROB);
     const sgan_conv_desc* descs[SG_MAX_PROB];
     for (int g = 0; g < n; ++g) descs[g] = jobs[g].d;
@@ -1752,6 +1733,13 @@ int sg_build_dgrad_params(const sgan_conv_dgrad_job* jobs, int32_t n, SgIgemmPar
     P.pro_act = SGAN_ACT_NONE;
     const sgan_norm_desc* x0 = jobs[0].x ? jobs[0].x_norm : nullptr;
     P.xn_act = x0 ? x0->act : SGAN_ACT_NONE; P.xn_slope = x0 ? x0->slope : 0.f; P.xn_eps = x0 ? x0->eps : 0.f;
+    // fp16 planes (an fp32-equivalent product, as in the forward pass) when every job brings its gradient's maximum and the fp16 copy
+    // of its weights; else bf16 planes
+    bool f16 = allow_f16;
+    for (int g = 0; g < n; ++g) f16 = f16 && jobs[g].dout_amax && jobs[g].w_packed_f16 && jobs[g].w_transposed;
+    static const int no_f16 = getenv("SGAN_NO_F16_BWD") ? atoi(getenv("SGAN_NO_F16_BWD")) : 0;      // diagnostics: bf16 planes as in round 2
+    if (no_f16) f16 = false;
+    P.planes_f16 = f16 ? 1 : 0;
     for (int g = 0; g < n; ++g) {
         const sgan_conv_dgrad_job& J = jobs[g];
         SGAN_CHECK(J.dout && J.w && J.din, "null tensor in job %d", g);
@@ -1764,7 +1752,8 @@ int sg_build_dgrad_params(const sgan_conv_dgrad_job* jobs, int32_t n, SgIgemmPar
         SGAN_CHECK((xn ? xn->act : SGAN_ACT_NONE) == P.xn_act, "grouped jobs must share the activation");
         SgProb& Q = P.q[g];
         SGAN_CHECK(J.d->math == d0->math, "grouped jobs must share the math mode");
-        Q.in = J.dout; Q.out = J.din; Q.w = J.w; Q.wp = J.w_transposed ? J.w_packed : nullptr; Q.bias = nullptr; Q.xref = J.x; Q.stats = J.bwd_sums;
+        Q.in = J.dout; Q.out = J.din; Q.w = J.w; Q.wp = J.w_transposed ? (f16 ? J.w_packed_f16 : J.w_packed) : nullptr; Q.bias = nullptr; Q.xref = J.x; Q.stats = J.bwd_sums;
+        Q.amax = f16 ? J.dout_amax : nullptr;
         Q.Hin = J.d->Hout; Q.Win = J.d->Wout; Q.in_ld = J.dout_ld; Q.Hout = J.d->Hin; Q.Wout = J.d->Win; Q.out_ld = J.din_ld;
         Q.xref_ld = J.x_ld;
         Q.pro_count = 1;
@@ -1797,7 +1786,7 @@ extern "C" int sgan_conv_dgrad(const sgan_conv_desc* d, const float* dout, int32
                                float* din, int32_t din_ld, const float* x, int32_t x_ld, const sgan_norm_desc* x_norm,
                                double* bwd_sums, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!d) return sgan_fail(SGAN_ERR_INVALID, "null desc");
-    sgan_conv_dgrad_job j = {d, dout, dout_ld, w, din, din_ld, x, x_ld, x_norm, bwd_sums, 0, 0, 0, nullptr};
+    sgan_conv_dgrad_job j = {d, dout, dout_ld, w, din, din_ld, x, x_ld, x_norm, bwd_sums, 0, 0, 0, nullptr, 0, nullptr, nullptr};
     return sgan_conv_dgrad_grouped(&j, 1, workspace, workspace_bytes, stream);
 }
 #endif      // SG_KERNELS_ONLY

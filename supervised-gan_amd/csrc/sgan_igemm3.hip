@@ -107,11 +107,12 @@ __device__ __forceinline__ void sg3_epilogue(const SgLocal& P, f32x16 (&acc)[MB]
                                              int tid, unsigned bid, const Sg3EpiConst<NB>& EC, RowPix rowpix) {
     const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
     const int N = P.N;
-    if constexpr (F16) {     // the fp16 weight planes hold w * 2^SGAN_F16_WEIGHT_SHIFT (an exact power of two)
+    if constexpr (F16) {     // the fp16 weight planes hold w * 2^SGAN_F16_WEIGHT_SHIFT, a gathered gradient came in times 2^s: exact powers of two
+        const float os = P.out_scale;
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc[i][j] *= 1.f / (float)(1 << SGAN_F16_WEIGHT_SHIFT);
+            for (int j = 0; j < NB; ++j) acc[i][j] *= os;
     }
     const bool want_stats = P.stats != nullptr;
     if (P.ksplit > 1) {   // split-K: raw partial tile to this split's slab; sg_splitk_epilogue_kernel finishes
@@ -414,6 +415,7 @@ __device__ __forceinline__ void sg_igemm3_body(const SgIgemmParams& G, char* sme
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(p0[j], q0[j]); v1[j] = fmaxf(p1[j], q1[j]); }
             }
+            if constexpr (F16 && !PRO) { v0 *= P.a_scale; v1 *= P.a_scale; }     // backward-data on fp16 planes: the gradient times 2^s
             u32x4 hi, lo;
             if constexpr (SG3_ABL & 2) { hi = __builtin_bit_cast(u32x4, v0); lo = __builtin_bit_cast(u32x4, v1); }
             else sg_split8<F16>(v0, v1, hi, lo);
@@ -702,6 +704,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(p0[j], q0[j]); v1[j] = fmaxf(p1[j], q1[j]); }
             }
+            if constexpr (F16 && !PRO) { v0 *= P.a_scale; v1 *= P.a_scale; }     // backward-data on fp16 planes: the gradient times 2^s
             u32x4 hi, lo;
             sg_split8<F16>(v0, v1, hi, lo);
             if (a_dst[it] >= 0) {
@@ -1063,7 +1066,7 @@ static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {   /
 // below do and says which body runs it.  variant 0: not one of the bodies the fused kernel carries (the caller launches separately).
 int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out) {
     out->variant = 0;
-    if (P.planes_f16 || P.pro_act != SGAN_ACT_NONE) return 0;
+    if (P.pro_act != SGAN_ACT_NONE) return 0;
     for (int g = 0; g < P.nprob; ++g)
         if (P.q[g].pro_stats) return 0;
     P.ksplit = 1;
@@ -1087,6 +1090,14 @@ int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out) {
         return 0;
     }
     const Sg3Tile tl = sg3_pick_tile(P);
+    if (tl.BM == 128 && tl.BN == 32 && sg_plan_ksplit(P, 128, 32) == 1) {      // <= 32 result channels (the first PatchGAN layer's input gradient)
+        const int tiles = sg_fill_tiles(P, 128);
+        out->variant = 6;
+        out->nblocks = tiles * sg3_cdiv(P.N, 32);
+        out->lds = (size_t)2 * (128 + 32) * 128 + (size_t)4 * 32 * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
+        out->name = "sg_igemm3_kernel<128,32,4,1>";
+        return 0;
+    }
     // a launch that would have been split-K on its own runs unsplit here when the split is shallow: the backward-weight
     // workgroups of the same grid fill the CUs the split was there to fill (SGAN_FUSE_MAX_KS: tuning knob)
     static const int max_ks = getenv("SGAN_FUSE_MAX_KS") ? atoi(getenv("SGAN_FUSE_MAX_KS")) : 1;

@@ -12,6 +12,7 @@ struct SgWgradProb {
     const double* pro_stats;
     const float* pro_gamma;
     const float* pro_beta;
+    const float* amax;   // fp16 planes: device scalar max|dout| (sgan_conv_wgrad_job.dout_amax), or null
     int32_t Hin, Win, in_ld;
     int32_t Hout, Wout, dout_ld;
     int32_t pro_count, pro_sq, pro_rep;
@@ -26,6 +27,7 @@ struct SgWgradParams {   // kernel argument: common layer description + up to 8 
     int32_t w_ns;
     int32_t nphase, nprob;
     int32_t pro_act;
+    int32_t planes_f16;  // split kernel: fp16 planes (every job brought dout_amax) instead of bf16
     int32_t thin_real;   // thin kernels: channels of the 4-wide side that carry data (Cin_logical / Cout_logical hint, else 4)
     float pro_slope, pro_eps;
     int32_t oa[SGAN_MAX_PHASES], ob[SGAN_MAX_PHASES], ntaps[SGAN_MAX_PHASES], ktot[SGAN_MAX_PHASES];
@@ -46,4 +48,4 @@ int sg_launch_wgrad3(SgWgradParams& P, hipStream_t st);
 
 // ---- one launch for a layer's backward-data and backward-weight (sgan_fused.hip) ----
 int sg_wgrad3_fuse_plan(SgWgradParams& P, SgFusePlan* out);
-int sg_build_wgrad_params(const sgan_conv_wgrad_job* jobs, int32_t n, SgWgradParams& P);   // sgan_wgrad.hip: checks + parameter block of sgan_conv_wgrad_grouped
+int sg_build_wgrad_params(const sgan_conv_wgrad_job* jobs, int32_t n, SgWgradParams& P, bool allow_f16 = true);   // sgan_wgrad.hip: checks + parameter block of sgan_conv_wgrad_grouped

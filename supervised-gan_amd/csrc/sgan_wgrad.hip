@@ -717,7 +717,7 @@ static void sg_thin_swap_geometry(SgWgradParams& P, const sgan_conv_desc* d0, co
     }
 }
 
-int sg_build_wgrad_params(const sgan_conv_wgrad_job* jobs, int32_t n, SgWgradParams& P) {
+int sg_build_wgrad_params(const sgan_conv_wgrad_job* jobs, int32_t n, SgWgradParams& P, bool allow_f16) {
     SGAN_CHECK(jobs && n >= 1 && n <= SGW_MAX_PROB, "1..%d jobs", SGW_MAX_PROB);
     memset(&P, 0, sizeof(P));
     P.nprob = n;
@@ -758,8 +758,13 @@ int sg_build_wgrad_params(const sgan_conv_wgrad_job* jobs, int32_t n, SgWgradPar
         Q.pro_count = J.in_norm ? J.in_norm->count : 1;
         Q.pro_sq = J.in_norm ? J.in_norm->sq_stride : 0;
         Q.pro_rep = J.in_norm ? J.in_norm->rep_stride : 0;
+        Q.amax = J.dout_amax;
     }
     P.Cin = d0->Cin; P.Cout = d0->Cout; P.w_ns = d0->Cin;
+    bool f16 = allow_f16;       // fp16 planes when every job brings its gradient's maximum (sgan_wgrad3.hip); else bf16 planes
+    for (int g = 0; g < n; ++g) f16 = f16 && jobs[g].dout_amax;
+    static const int no_f16 = getenv("SGAN_NO_F16_BWD") ? atoi(getenv("SGAN_NO_F16_BWD")) : 0;
+    P.planes_f16 = (f16 && !no_f16) ? 1 : 0;
     return SGAN_OK;
 }
 
@@ -800,6 +805,6 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
 extern "C" int sgan_conv_wgrad(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,
                                const float* dout, int32_t dout_ld, float* dw, float* dbias, void* workspace,
                                int64_t workspace_bytes, void* stream) {
-    sgan_conv_wgrad_job j = {d, in, in_ld, in_norm, dout, dout_ld, dw, dbias};
+    sgan_conv_wgrad_job j = {d, in, in_ld, in_norm, dout, dout_ld, dw, dbias, nullptr};
     return sgan_conv_wgrad_grouped(&j, 1, workspace, workspace_bytes, stream);
 }

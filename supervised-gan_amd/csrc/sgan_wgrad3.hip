@@ -28,16 +28,31 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+typedef _Float16 sgw_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sgw_f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
 __device__ __forceinline__ void sgw_split8(const f32x4 v0, const f32x4 v1, u32x4& hi, u32x4& lo) {   // as sg_split8 (sgan_igemm3.hip)
     float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x2 p = {x[2 * i], x[2 * i + 1]};
-        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(p, sg_bf16x2));
-        const f32x2 r = {x[2 * i] - __builtin_bit_cast(float, h << 16), x[2 * i + 1] - __builtin_bit_cast(float, h & 0xffff0000u)};
-        hi[i] = h;
-        lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sg_bf16x2));
+        if constexpr (F16) {
+            const sgw_f16x2 h = __builtin_convertvector(p, sgw_f16x2);
+            const f32x2 r = p - __builtin_convertvector(h, f32x2);
+            hi[i] = __builtin_bit_cast(unsigned, h);
+            lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sgw_f16x2));
+        } else {
+            const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(p, sg_bf16x2));
+            const f32x2 r = {x[2 * i] - __builtin_bit_cast(float, h << 16), x[2 * i + 1] - __builtin_bit_cast(float, h & 0xffff0000u)};
+            hi[i] = h;
+            lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sg_bf16x2));
+        }
     }
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 sgw_mfma(const sg_bf16x8 a, const sg_bf16x8 b, const f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sgw_f16x8, a), __builtin_bit_cast(sgw_f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // 8 consecutive k (pixels) of one column: two transposed LDS reads of 4 each
@@ -51,7 +66,9 @@ __device__ __forceinline__ sg_bf16x8 sgw_tr8(const char* p) {
 
 // BCO x BKC tile of dW per workgroup, WGC x WGK waves of (BCO / WGC) x (BKC / WGK) each (multiples of 32)
 // body with explicit workgroup coordinates: sg_bwd_fused_kernel (sgan_fused.hip) runs it beside the backward-data body in one launch
-template <int BCO, int BKC, int WGC, int WGK, bool PRO>
+// F16: fp16 planes (dout times 2^s, s from its published maximum; x is a post-normalisation activation): 11 + 11 significant bits, an
+// fp32-equivalent product; else bf16 planes (8 + 8)
+template <int BCO, int BKC, int WGC, int WGK, bool PRO, bool F16 = false>
 __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* smem, const int bx, const int by, const int bz) {
     constexpr int BP = 32;
     constexpr int WTC = BCO / WGC, WTK = BKC / WGK, MB = WTC / 32, NB = WTK / 32;
@@ -88,6 +105,8 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
     const int ch_begin = split * per, ch_end = min(nchunk_total, ch_begin + per);
     if (ch_begin >= ch_end) return;
     const int Cin = P.Cin, Cout = P.Cout;
+    const int f16_shift = (F16 && Q.amax) ? sg_f16_shift(*Q.amax) : 0;
+    const float d_scale = sg_pow2(f16_shift), out_scale = sg_pow2(-f16_shift);
     if constexpr (PRO) {
         for (int c = tid; c < Cin; c += 256) {
             float sc = 1.f, sh = 0.f;
@@ -222,7 +241,7 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
                 for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(p0[j], q0[j]); v1[j] = fmaxf(p1[j], q1[j]); }
             }
             u32x4 hi, lo;
-            sgw_split8(v0, v1, hi, lo);
+            sgw_split8<F16>(v0, v1, hi, lo);
             if (BKC / 32 % 2 == 0 || a_blk[it] < BKC / 32) {
                 *reinterpret_cast<u32x4*>(Ab + a_blk[it] * 2048 + s_dst) = hi;
                 *reinterpret_cast<u32x4*>(Ab + A_PLANE + a_blk[it] * 2048 + s_dst) = lo;
@@ -233,7 +252,8 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
             bacc[it][0] += d_reg[S][it][0];
             bacc[it][1] += d_reg[S][it][1];
             u32x4 hi, lo;
-            sgw_split8(d_reg[S][it][0], d_reg[S][it][1], hi, lo);
+            if constexpr (F16) sgw_split8<true>(d_reg[S][it][0] * d_scale, d_reg[S][it][1] * d_scale, hi, lo);
+            else sgw_split8<false>(d_reg[S][it][0], d_reg[S][it][1], hi, lo);
             if (BCO / 32 % 2 == 0 || d_blk[it] < BCO / 32) {
                 *reinterpret_cast<u32x4*>(Db + d_blk[it] * 2048 + s_dst) = hi;
                 *reinterpret_cast<u32x4*>(Db + D_PLANE + d_blk[it] * 2048 + s_dst) = lo;
@@ -289,9 +309,9 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dl[s][i], ah[s][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[s][i], al[s][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dh[s][i], ah[s][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = sgw_mfma<F16>(dl[s][i], ah[s][j], acc[i][j]);
+                    acc[i][j] = sgw_mfma<F16>(dh[s][i], al[s][j], acc[i][j]);
+                    acc[i][j] = sgw_mfma<F16>(dh[s][i], ah[s][j], acc[i][j]);
                 }
         next_addrs();
         constexpr int NMFMA = 6 * MB * NB;
@@ -340,7 +360,7 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wc * WTC + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
 #ifndef SGW3_NO_ATOMICS      // diagnostics build: what the gradient atomics cost
-                if (co < Cout) atomicAdd(base + (int64_t)co * P.w_ns, acc[i][j][r]);
+                if (co < Cout) atomicAdd(base + (int64_t)co * P.w_ns, F16 ? acc[i][j][r] * out_scale : acc[i][j][r]);
 #else
                 if (co < Cout && acc[i][j][r] == 12345.678f) base[(int64_t)co * P.w_ns] = 0.f;
 #endif
@@ -367,11 +387,11 @@ __device__ __forceinline__ void sg_wgrad3_body(const SgWgradParams& G, char* sme
     }
 }
 
-template <int BCO, int BKC, int WGC, int WGK, bool PRO>
+template <int BCO, int BKC, int WGC, int WGK, bool PRO, bool F16 = false>
 __global__ __launch_bounds__(256) void sg_wgrad3_kernel(const SgWgradParams G) {
     sg_warm_kernargs<(int)sizeof(SgWgradParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    sg_wgrad3_body<BCO, BKC, WGC, WGK, PRO>(G, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    sg_wgrad3_body<BCO, BKC, WGC, WGK, PRO, F16>(G, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 #ifndef SG_KERNELS_ONLY      // sgan_fused.hip includes this file for the kernel bodies only
@@ -420,8 +440,13 @@ static int sgw3_launch(SgWgradParams& P, hipStream_t st, const char* name) {
     bool pro;
     if (!sgw3_prepare(P, BCO, BKC, &grid, &lds, &pro)) return 1;
     sg_prof_begin(st);
-    if (pro) hipLaunchKernelGGL((sg_wgrad3_kernel<BCO, BKC, WGC, WGK, true>), grid, dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((sg_wgrad3_kernel<BCO, BKC, WGC, WGK, false>), grid, dim3(256), lds, st, P);
+    if (P.planes_f16) {
+        if (pro) hipLaunchKernelGGL((sg_wgrad3_kernel<BCO, BKC, WGC, WGK, true, true>), grid, dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((sg_wgrad3_kernel<BCO, BKC, WGC, WGK, false, true>), grid, dim3(256), lds, st, P);
+    } else {
+        if (pro) hipLaunchKernelGGL((sg_wgrad3_kernel<BCO, BKC, WGC, WGK, true, false>), grid, dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((sg_wgrad3_kernel<BCO, BKC, WGC, WGK, false, false>), grid, dim3(256), lds, st, P);
+    }
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) return sgan_fail(SGAN_ERR_HIP, "%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_));
     g_sgan_last_kernel = name;

@@ -53,10 +53,23 @@ class math_scope:
         return False
 
 
-def with_packed(w: torch.Tensor, packed) -> torch.Tensor:
-    """Tag a weight slice with the matching slice of the split-bf16 copy (sgan_pack_weights) for the job builders."""
+def with_packed(w: torch.Tensor, packed, packed_f16=None) -> torch.Tensor:
+    """Tag a weight slice with the matching slice of the split 16-bit copy (sgan_pack_weights) for the job builders; packed_f16:
+    the fp16-plane twin of the backward copy (backward-data with a known gradient maximum reads it)."""
     w._sgan_pk = packed
+    w._sgan_pk16 = packed_f16
     return w
+
+
+def _amax(t):
+    """Device scalar max|t| when the producer published one (norm_bwd_apply*), else None."""
+    a = getattr(t, "_sgan_amax", None)
+    return a.data_ptr() if (a is not None and _math == L.MATH_BF16X3) else None
+
+
+def _pk16(w):
+    pk = getattr(w, "_sgan_pk16", None)
+    return pk.data_ptr() if (pk is not None and _math == L.MATH_BF16X3) else None
 
 
 def _pk(w):
@@ -243,12 +256,7 @@ def conv_dgrad(desc, dout, w, din, x=None, x_norm=None, bwd_sums=None, sums_sq=0
 
 
 def conv_wgrad(desc, x, in_norm, dout, dw, dbias):
-    desc.math = _math
-    _fits(x, desc.Hin, desc.Win, desc.Cin, "conv_wgrad x"); _fits(dout, desc.Hout, desc.Wout, desc.Cout, "conv_wgrad dout")
-    _fits_w(dw, desc, "conv_wgrad dw")
-    args = (C.byref(desc), _ptr(_act(x)), x.stride(1), _nd(in_norm), _ptr(_act(dout)), dout.stride(1), _ptr(dw), _ptr(dbias))
-    ws = _workspace(L.lib().sgan_conv_wgrad(*args, None, -1, None), x.device) if min(desc.Cin, desc.Cout) <= 4 else None
-    L.check(L.lib().sgan_conv_wgrad(*args, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()), "sgan_conv_wgrad")
+    return conv_wgrad_grouped([(desc, x, in_norm, dout, dw, dbias)])
 
 
 def _pn(d):
@@ -279,7 +287,7 @@ def _dgrad_array(jobs):
                                 din.stride(1), _ptr(x).value, x.stride(1) if x is not None else 0, _pn(x_norm), _ptr(sums).value,
                                 int(job[7]) if len(job) > 7 else 0, int(bool(job[8])) if len(job) > 8 else 0,
                                 int(bool(job[9])) if len(job) > 9 else 0, _pk(w),
-                                int(job[10]) if (len(job) > 10 and sums is not None) else 0)
+                                int(job[10]) if (len(job) > 10 and sums is not None) else 0, _amax(dout), _pk16(w))
     return arr
 
 
@@ -288,7 +296,7 @@ def _wgrad_array(jobs):
     for i, (desc, x, in_norm, dout, dw, dbias) in enumerate(jobs):
         desc.math = _math
         arr[i] = L.ConvWgradJob(C.pointer(desc), _ptr(_act(x)).value, x.stride(1), _pn(in_norm), _ptr(_act(dout)).value,
-                                dout.stride(1), _ptr(dw).value, _ptr(dbias).value)
+                                dout.stride(1), _ptr(dw).value, _ptr(dbias).value, _amax(dout))
     return arr
 
 
@@ -338,36 +346,51 @@ def transpose_weights(flat, flat_t, segs):
         L.check(L.lib().sgan_transpose_weights(_ptr(flat), _ptr(flat_t), arr, len(part), _stream()), "sgan_transpose_weights")
 
 
-def pack_weights(flat, flat_t, pk_fwd, pk_bwd, segs):
+def pack_weights(flat, flat_t, pk_fwd, pk_bwd, segs, pk_bwd16=None):
     """Every derived weight copy of the conv ranges `segs` = [(off, taps, cout_s, cin_s)] of a flat parameter buffer in one
-    launch per 64 ranges: fp32 transposed copy + the two split-bf16 copies (sgan_pack_weights)."""
+    launch per 64 ranges: fp32 transposed copy + the split 16-bit copies (sgan_pack_weights)."""
     for i0 in range(0, len(segs), 64):
         part = segs[i0:i0 + 64]
         arr = (L.WtSeg * len(part))(*[L.WtSeg(int(o), int(t), int(co), int(ci)) for o, t, co, ci in part])
-        L.check(L.lib().sgan_pack_weights(_ptr(flat), _ptr(flat_t), _ptr(pk_fwd), _ptr(pk_bwd), arr, len(part), _stream()),
+        L.check(L.lib().sgan_pack_weights(_ptr(flat), _ptr(flat_t), _ptr(pk_fwd), _ptr(pk_bwd), _ptr(pk_bwd16), arr, len(part), _stream()),
                 "sgan_pack_weights")
 
 
-def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None, sums_sq=0, sums_rep=0):
-    if sums_rep:
-        return norm_bwd_apply_multi([(dy, x, x_norm, bwd_sums, dgamma, dbeta, sums_sq, sums_rep)])
+def norm_bwd_apply(dy, x, x_norm, bwd_sums, dgamma=None, dbeta=None, sums_sq=0, sums_rep=0, publish_amax=False):
+    if sums_rep or publish_amax:
+        return norm_bwd_apply_multi([(dy, x, x_norm, bwd_sums, dgamma, dbeta, sums_sq, sums_rep)], publish_amax)
     H, W, Cs = dy.shape
     L.check(L.lib().sgan_norm_bwd_apply(_ptr(_act(dy)), dy.stride(1), _ptr(_act(x)), x.stride(1), H * W, Cs, _nd(x_norm),
                                         _ptr(bwd_sums), int(sums_sq), _ptr(dgamma), _ptr(dbeta), _stream()), "sgan_norm_bwd_apply")
 
 
-def norm_bwd_apply_multi(jobs):
-    """jobs: list of (dy, x, x_norm, bwd_sums, dgamma, dbeta[, sums_sq, sums_rep]) -> one launch (<= 8 per launch)."""
+def norm_bwd_apply_multi(jobs, publish_amax=False):
+    """jobs: list of (dy, x, x_norm, bwd_sums, dgamma, dbeta[, sums_sq, sums_rep]) -> one launch (<= 8 per launch).
+    publish_amax: the kernel also leaves max|dy| of every result in a device scalar and tags the tensor with it (`dy._sgan_amax`): the
+    backward-data / backward-weight calls that read THIS tensor object next then run on fp16 planes scaled by it (an fp32-equivalent
+    product) instead of bf16 planes.  Only for callers that do not write dy again before it is consumed."""
     for i0 in range(0, len(jobs), 8):
         part = jobs[i0:i0 + 8]
         arr = (L.NormBwdJob * len(part))()
+        am = None
+        if publish_amax and _math == L.MATH_BF16X3 and not _NO_F16_BWD:
+            am = stat_arena(len(part), part[0][0].device).view(torch.float32)      # one zeroed 8-byte slot per job (low word = the maximum)
         for i, job in enumerate(part):
             dy, x, x_norm, sums, dg, db = job[:6]
             H, W, Cs = dy.shape
+            slot = am[2 * i: 2 * i + 1] if am is not None else None
             arr[i] = L.NormBwdJob(_ptr(_act(dy)).value, dy.stride(1), _ptr(_act(x)).value, x.stride(1), H * W, Cs, C.pointer(x_norm),
                                   _ptr(sums).value, int(job[6]) if len(job) > 6 else 0, _ptr(dg).value, _ptr(db).value,
-                                  int(job[7]) if len(job) > 7 else 0)
+                                  int(job[7]) if len(job) > 7 else 0, _ptr(slot).value)
+            dy._sgan_amax = slot
         L.check(L.lib().sgan_norm_bwd_apply_multi(arr, len(part), _stream()), "sgan_norm_bwd_apply_multi")
+
+
+_NO_F16_BWD = __import__("os").environ.get("SGAN_NO_F16_BWD", "0") not in ("", "0")      # diagnostics: bf16 planes in the backward pass as in round 2
+
+
+def has_amax(t) -> bool:
+    return getattr(t, "_sgan_amax", None) is not None and _math == L.MATH_BF16X3
 
 
 def norm_apply_fwd(u, u_norm, t, mask=None, noise=None, sigma=0.0):
@@ -631,12 +654,12 @@ def adam_multi(segs, lr_dev, beta1, beta2, eps, state_dev):
     L.check(L.lib().sgan_adam_multi(arr, len(segs), _ptr(lr_dev), beta1, beta2, eps, _ptr(state_dev), _stream()), "sgan_adam_multi")
 
 
-def adam_pack(p, g, m, v, lr_dev, beta1, beta2, eps, state_dev, flat_t, pk_f, pk_b, segs, zero_grads):
+def adam_pack(p, g, m, v, lr_dev, beta1, beta2, eps, state_dev, flat_t, pk_f, pk_b, pk_b16, segs, zero_grads):
     """One launch: Adam over the flat segment (p, g, m, v) + the derived weight copies of its conv ranges
     `segs` = [(off, taps, cout_s, cin_s)] (offsets relative to p; sorted) + optional zeroing of the consumed gradients."""
     arr = (L.WtSeg * max(len(segs), 1))(*[L.WtSeg(int(o), int(t), int(co), int(ci)) for o, t, co, ci in segs])
     L.check(L.lib().sgan_adam_pack(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr_dev), beta1, beta2, eps, _ptr(state_dev),
-                                   _ptr(flat_t), _ptr(pk_f), _ptr(pk_b), arr, len(segs), int(bool(zero_grads)), _stream()), "sgan_adam_pack")
+                                   _ptr(flat_t), _ptr(pk_f), _ptr(pk_b), _ptr(pk_b16), arr, len(segs), int(bool(zero_grads)), _stream()), "sgan_adam_pack")
 
 
 def zero_multi(bufs):

@@ -96,7 +96,7 @@ class FusedAdam:
         for net in nets:
             net._refresh_derived()       # storage exists and every copy is current (a no-op in steady state)
         bufs = {(net._flat_t.data_ptr() - 4 * net._arena[2], net._pk_f.data_ptr() - 4 * net._arena[2],
-                 net._pk_b.data_ptr() - 4 * net._arena[2]) for net in nets}
+                 net._pk_b.data_ptr() - 4 * net._arena[2], net._pk_bh.data_ptr() - 4 * net._arena[2]) for net in nets}
         if len(bufs) != 1:               # the copies of the networks are not slices of one arena-wide buffer
             return None
         net0 = nets[0]
@@ -105,7 +105,7 @@ class FusedAdam:
         if der is not None and net0._flat_t.data_ptr() == der[0].data_ptr() + 4 * base0:
             views = tuple(d[off: off + n] for d in der)
         elif len(nets) == 1 and base0 == 0:
-            views = tuple(d[off: off + n] for d in (net0._flat_t, net0._pk_f, net0._pk_b))
+            views = tuple(d[off: off + n] for d in (net0._flat_t, net0._pk_f, net0._pk_b, net0._pk_bh))
         else:
             return None
         segs = []
@@ -132,10 +132,10 @@ class FusedAdam:
         g = self.param_groups[0]
         plan = self._fused_plan() if type(self) is FusedAdam else None
         if plan is not None:
-            nets, csegs, (ft, pf, pb) = plan
+            nets, csegs, (ft, pf, pb, pbh) = plan
             ap, ag, off, n = self._segs[0]
             ops.adam_pack(ap[off: off + n], ag[off: off + n], self._m[0], self._v[0], self._lr_dev, g["betas"][0], g["betas"][1], g["eps"],
-                          self._state, ft, pf, pb, csegs, self._zero_in_step)
+                          self._state, ft, pf, pb, pbh, csegs, self._zero_in_step)
             for net in nets:                # the derived copies were written by the same launch: they are current
                 net._wt_key = net._derived_key()
             self._grads_clean = self._zero_in_step

@@ -41,10 +41,10 @@ def derived_copies(wm, k, cout_s, cin_s):
     """(wm, wt): the master weight tagged with its split-bf16 forward copy, and the transposed copy [tap][Cin][Cout] tagged with
     the split-bf16 backward copy -- what ChainNet._wb / _wt hand to the conv calls (one sgan_pack_weights launch)."""
     from supervised_gan_amd import ops
-    wt, pf, pb = torch.zeros_like(wm), torch.zeros_like(wm), torch.zeros_like(wm)
-    ops.pack_weights(wm, wt, pf, pb, [(0, k * k, cout_s, cin_s)])
+    wt, pf, pb, pbh = torch.zeros_like(wm), torch.zeros_like(wm), torch.zeros_like(wm), torch.zeros_like(wm)
+    ops.pack_weights(wm, wt, pf, pb, [(0, k * k, cout_s, cin_s)], pbh)
     ops.with_packed(wm, pf)
-    ops.with_packed(wt, pb)
+    ops.with_packed(wt, pb, pbh)
     wm._sgan_wt = wt
     return wm, wt
 

@@ -52,19 +52,19 @@ def test_pack_weights_bit_exact(ops):
     total = segs[1][0] + 9 * 16 * 12
     flat = (rng.standard_normal(total) * np.exp(rng.uniform(-12, 2, total))).astype(np.float32)      # |w| from 1e-6 to ~30
     f = torch.from_numpy(flat).cuda()
-    ft, pf, pb = torch.zeros_like(f), torch.zeros_like(f), torch.zeros_like(f)
-    ops.pack_weights(f, ft, pf, pb, segs)
+    ft, pf, pb, pbh = torch.zeros_like(f), torch.zeros_like(f), torch.zeros_like(f), torch.zeros_like(f)
+    ops.pack_weights(f, ft, pf, pb, segs, pbh)
     torch.cuda.synchronize()
-    ft, pf, pb = ft.cpu().numpy(), pf.cpu().numpy().view(np.uint16), pb.cpu().numpy().view(np.uint16)
+    ft, pf, pb, pbh = ft.cpu().numpy(), pf.cpu().numpy().view(np.uint16), pb.cpu().numpy().view(np.uint16), pbh.cpu().numpy().view(np.uint16)
     for off, taps, co, ci in segs:
         w = flat[off: off + taps * co * ci].reshape(taps, co, ci)
         assert np.array_equal(ft[off: off + taps * co * ci].reshape(taps, ci, co), w.transpose(0, 2, 1))
-        for name, pk, rows, cols, m in (("fwd", pf, co, ci, w), ("bwd", pb, ci, co, w.transpose(0, 2, 1))):
+        for name, pk, rows, cols, m in (("fwd", pf, co, ci, w), ("bwd", pb, ci, co, w.transpose(0, 2, 1)), ("bwd16", pbh, ci, co, w.transpose(0, 2, 1))):
             got = pk[2 * off: 2 * (off + taps * co * ci)].reshape(taps, rows, cols // 8 if cols % 8 == 0 else 1, -1)
             if cols % 8:
                 assert not got.any(), name       # untouched (zeros from the allocation)
                 continue
-            hi, lo = (_split_f16 if name == "fwd" else _split)(np.ascontiguousarray(m))
+            hi, lo = (_split if name == "bwd" else _split_f16)(np.ascontiguousarray(m))
             want = np.stack([hi.reshape(taps, rows, cols // 8, 8), lo.reshape(taps, rows, cols // 8, 8)], axis=3)
             assert np.array_equal(got.reshape(taps, rows, cols // 8, 2, 8), want), name
 
@@ -164,6 +164,24 @@ def test_igemm3_vs_fp32_kernel_and_fp64(ops, shape, tile):
     assert e3 < 3e-6 and d3 < 1e-4 and w3 < 3e-5 and b3 < 1e-5, (e3, d3, w3, b3)
     assert rel(res["bf16x3"][1], stats_of(out.detach(), "cpu")) < 1e-4
     assert rel(res["bf16x3"][0], res["f32"][0]) < 3e-6
+    # round 3: the same backward calls with the gradient's maximum published (what sgan_norm_bwd_apply_multi leaves behind):
+    # fp16 planes of dOut * 2^s -- fp32-equivalent like the forward pass.  Tiny gradients (1e-7 of scale) as they occur in training.
+    for gscale in (1.0, 3e-7):
+        Rs = Rb * gscale
+        Rs._sgan_amax = Rs.abs().max().reshape(1).float()
+        din = torch.full((H, W, cin), float("nan"), device="cuda")
+        sums = torch.zeros(2 * cin, dtype=torch.float64, device="cuda") if norm else None
+        ops.conv_dgrad(desc, Rs, wm._sgan_wt, din, xb, in_norm, sums, w_transposed=True)
+        if norm:
+            ops.norm_bwd_apply(din, xb, in_norm, sums)
+        dw, db = torch.zeros_like(wm), torch.zeros_like(bb)
+        ops.conv_wgrad(desc, xb, in_norm, Rs, dw, db)
+        torch.cuda.synchronize()
+        d16 = rel(from_buf(din, cin), x.grad * gscale)
+        w16 = rel(from_master(dw, k, cin, cout, tr), w.grad * gscale)
+        b16 = rel(db[:cout], b.grad * gscale)
+        print(f"fp16-plane backward (gradient scale {gscale:g}): dgrad {d16:.2e} wgrad {w16:.2e}")
+        assert d16 < 3e-6 and w16 < 3e-6 and b16 < 1e-5, (gscale, d16, d32, w16, w32, b16)      # the forward pass's bound: fp32-equivalent
 
 
 @pytest.mark.parametrize("tile", ["auto", "patch"])
@@ -213,16 +231,20 @@ def test_igemm3_grouped_and_splitk(ops, tile):
     assert rel(got["bf16x3"][0], got["f32"][0]) < 3e-5 and rel(got["bf16x3"][1], got["f32"][1]) < 1e-5
 
 
-@pytest.mark.parametrize("dmath", [None, "f32"])
+@pytest.mark.parametrize("dmath", [None, "f16"])
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"{c[0]}_k{c[1]}s{c[2]}_{c[4]}to{c[5]}_{c[6]}x{c[7]}" for c in SHAPES])
 def test_fused_backward_equals_the_two_launches(ops, shape, dmath):
     """sgan_conv_bwd_fused (one grid for a layer's backward-data and backward-weight) against sgan_conv_dgrad_grouped +
     sgan_conv_wgrad_grouped on the same two-problem job lists: the input gradients bit for bit (same body, same tile order), the
-    weight / bias gradients and the norm-backward sums up to the order of their atomic adds."""
+    weight / bias gradients and the norm-backward sums up to the order of their atomic adds.  dmath "f16": the gradient tensors carry
+    their published maximum, so backward-data runs on fp16 planes (round 3: what replaced the exact-fp32 variant for backward-data
+    into a layer without a normalisation); the backward-weight half reads an untagged alias and stays on bf16 planes in both runs."""
     from hip_utils import master_weight, pad_vec, rel, stats_of, to_buf
     from supervised_gan_amd import _lib
     kind, k, s, p, cin, cout, H, W, norm, act = shape
     tr = kind == "convT"
+    if dmath == "f16" and cin > 32:
+        pytest.skip("the fused launch carries fp16 planes only for its 128 x 32 backward-data variant (<= 32 result channels)")
     _select_tile("auto")
     ops.set_math("bf16x3")
     g = torch.Generator().manual_seed(17)
@@ -243,15 +265,16 @@ def test_fused_backward_equals_the_two_launches(ops, shape, dmath):
         for desc, xb, nd, dy, h, w_ in probs:
             din = torch.full((h, w_, cin), float("nan"), device="cuda")
             sums = torch.zeros(2 * cin, dtype=torch.float64, device="cuda") if norm else None
+            if dmath == "f16":
+                dy._sgan_amax = dy.abs().max().reshape(1).float()
             djobs.append((desc, dy, wm._sgan_wt, din, xb, nd, sums, 0, False, True, 0))
-            wjobs.append((desc, xb, nd, dy, dw, db))
+            wjobs.append((desc, xb, nd, dy.view_as(dy), dw, db))
             keep.append((din, sums))
         if mode == "apart":
             ops.conv_wgrad_grouped(wjobs)
-            with ops.math_scope(dmath):      # "f32": exact-fp32 backward-data next to the split-bf16 backward-weight (chain._dgrad_math)
-                ops.conv_dgrad_grouped(djobs)
+            ops.conv_dgrad_grouped(djobs)
         else:
-            fused = ops.conv_bwd_grouped(djobs, wjobs, dmath)
+            fused = ops.conv_bwd_grouped(djobs, wjobs, None)
             if fused:
                 assert _lib.lib().sgan_last_kernel().decode().startswith("sg_bwd_fused_kernel")
         torch.cuda.synchronize()
@@ -272,8 +295,8 @@ def test_fused_backward_is_taken(ops):
     want = [c for c in SHAPES if c[0] == "conv" and c[2] == 1 and c[4] >= 64 and c[5] >= 64 and c[6] * c[7] >= 256]
     assert sum(bool(v) for (c, m), v in _FUSED_SEEN.items() if m is None) > len(want)
     assert want and all(_FUSED_SEEN.get((c, None)) for c in want), {c: _FUSED_SEEN.get((c, None)) for c in want}
-    # exact-fp32 backward-data with <= 32 result channels (the 128 x 32 tile): the second PatchGAN layer's launch
-    assert _FUSED_SEEN.get((SHAPES[0], "f32")), _FUSED_SEEN
+    # backward-data with <= 32 result channels (the 128 x 32 tile) on fp16 planes: the second PatchGAN layer's launch
+    assert _FUSED_SEEN.get((SHAPES[0], "f16")) and _FUSED_SEEN.get((SHAPES[0], None)), _FUSED_SEEN
 
 
 @pytest.mark.parametrize("shape", [("conv", 4, 1, 2, 128, 256, 33, 29), ("convT", 4, 2, 1, 256, 256, 16, 16), ("conv", 3, 1, 1, 160, 64, 24, 24),

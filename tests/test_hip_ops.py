@@ -868,8 +868,8 @@ def test_conv_operands_with_guarded_tails(hip, case, math_mode):
     xb, Rb, bb = G(to_buf(x.detach())), G(to_buf(R)), G(pad_vec(b.detach()))
     wm0 = master_weight(w.detach(), tr)
     wm, wt = G(wm0), G(wm0._sgan_wt)
-    pf, pb = G(wm0._sgan_pk), G(wm0._sgan_wt._sgan_pk)
-    ops.with_packed(wm, pf); ops.with_packed(wt, pb)
+    pf, pb, pbh = G(wm0._sgan_pk), G(wm0._sgan_wt._sgan_pk), G(wm0._sgan_wt._sgan_pk16)
+    ops.with_packed(wm, pf); ops.with_packed(wt, pb, pbh)
     ob, din = G(torch.zeros(Ho, Wo, pad4(cout), device="cuda")), G(torch.zeros(H, W, pad4(cin), device="cuda"))
     dw, db = G(torch.zeros_like(wm0)), G(torch.zeros(pad4(cout), device="cuda"))
     ops.conv_fwd(desc, xb, None, wm, bb, ob)

@@ -158,6 +158,35 @@ def load_f64(golden_dir, name):
     return np.load(path) if os.path.exists(path) else None
 
 
+# Which tensors may pass through the "isolated activation flips" clause of check_grads, per golden (round 3: an explicit list, so that
+# a NEW tensor needing the clause fails the test instead of passing silently).  They are the discriminators' FIRST layer -- no
+# normalisation behind it, so all flips of the 4 M-activation first LeakyReLU land in its bias / weight gradient as whole-channel
+# jumps of ~1e-3 .. 5e-3 -- and a few single-row cases seen in the round-2 / round-3 runs (tools: SGAN_TEST_VERBOSE=1).
+# Caps: e <= 2e-2 (round 2: 5e-2), relative L2 <= 5e-3, bad elements <= max(8, 10 %); the first-layer tensors, where ONE flipped
+# activation moves a whole output channel (48 weights + the bias element), <= 25 %.
+_D_FIRST = r"(step1|probeG|probe)/gradD\d?_\d/model\.0\.(weight|bias)"
+FLIPS_ALLOWED = {
+    "fcgan_step_full.npz": [_D_FIRST],
+    "fcgan_step_full_nug1.npz": [_D_FIRST],
+    "cgan_step_full.npz": [_D_FIRST, r"(step1|probeG)/gradD_0/model\.(2|8)\.weight"],
+    "twostage_full.npz": [_D_FIRST, r"probe/gradD2_1/model\.11\.weight"],
+    "twostage_small.npz": [_D_FIRST], "twostage_factd_small.npz": [_D_FIRST], "twostage_multiclass_small.npz": [_D_FIRST],
+    "twostage_nocycle_small.npz": [_D_FIRST],
+    "cgan_cycle_small.npz": [_D_FIRST], "cgan_cycle_small_d34.npz": [_D_FIRST],
+    "cgan2_cycle_small.npz": [_D_FIRST], "cgan2_cycle_small_fakefake.npz": [_D_FIRST],
+}
+
+
+def _flips_allowed(g, full_name):
+    import re
+    zf = getattr(g, "zip", None)
+    name = os.path.basename(zf.filename) if zf is not None and zf.filename else ""
+    for pat in FLIPS_ALLOWED.get(name, ()):
+        if re.fullmatch(pat, full_name):
+            return True, bool(re.fullmatch(_D_FIRST, full_name))
+    return False, False
+
+
 def check_grads(grads, g, prefix, undet, tol=TOL, f64=None, tally=None):
     """Every gradient tensor within `tol` (max-abs error / max|g|) of the reference's fp32 golden.
 
@@ -169,8 +198,9 @@ def check_grads(grads, g, prefix, undet, tol=TOL, f64=None, tally=None):
     e = error against fp64 and e_ref = error of the reference's fp32 golden against fp64 (on the golden's strided sample, over
     max|g_fp64|) a tensor passes when
         e <= max(tol, 4 e_ref)                                   -- as accurate as the reference itself is there, or
-        <= 10 % of its sampled elements (or <= 8 of them: a bias gradient has 32 .. 512) are beyond max(tol, 4 e_ref) and its
-        relative L2 error is <= 5e-3                              -- isolated rows moved by single activation flips.
+        the tensor is on the golden's FLIPS_ALLOWED list (above), <= 10 % of its sampled elements (or <= 8 of them; first-layer
+        tensors: 25 %) are beyond max(tol, 4 e_ref), e <= 2e-2 and its relative L2 error is <= 5e-3
+                                                                  -- isolated rows moved by single activation flips.
     A kernel error would move most elements (and fails the exact adjoint identities of test_hip_ops at the same shapes).
     `tally` collects (prefix, name, e, e_ref, clause)."""
     for k, v in grads.items():
@@ -192,12 +222,16 @@ def check_grads(grads, g, prefix, undet, tol=TOL, f64=None, tally=None):
             if e > bound:
                 nbad = int((err > bound).sum())
                 l2 = float(np.linalg.norm(smp - truth) / (np.linalg.norm(truth) + 1e-30)) if scale_key is None else 0.0
+                listed, first_layer = _flips_allowed(g, f"{prefix}/{k}")
+                cap = max(8, (0.25 if first_layer else 0.10) * err.size)
+                ok = listed and nbad <= cap and l2 <= 5e-3 and e <= 2e-2
                 if os.environ.get("SGAN_TEST_VERBOSE"):
                     print(f"flips-clause tensor {prefix}/{k}: e {e:.2e} e_ref {e_ref:.2e} nbad {nbad}/{err.size} l2 {l2:.2e}"
-                          + ("  <-- beyond the gate" if not (nbad <= max(8, 0.10 * err.size) and l2 <= 5e-3 and e <= 5e-2) else ""))
+                          + ("" if listed else "  <-- NOT on the golden's FLIPS_ALLOWED list") + ("" if ok or not listed else "  <-- beyond the gate"))
                     if os.environ.get("SGAN_TEST_VERBOSE") == "noassert":
                         continue
-                assert nbad <= max(8, 0.10 * err.size) and l2 <= 5e-3 and e <= 5e-2, (prefix, k, e, e_ref, nbad, err.size, l2)
+                assert listed, ("a tensor that is not on FLIPS_ALLOWED needs the flips clause", prefix, k, e, e_ref, nbad, err.size, l2)
+                assert ok, (prefix, k, e, e_ref, nbad, err.size, l2)
             continue
         e_max, e_l2 = grad_errors(v, g, prefix, k, scale_key)
         if tally is not None:

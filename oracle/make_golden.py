@@ -215,6 +215,36 @@ def golden_d_small():
     save("nlayer_d_small_n4_lsgan.npz", **arrs)
 
 
+def golden_d_sep():
+    """NLayerDiscriminatorSep (`--which_model_netD n_layers_sep`).  ONE call of the reference is patched, like Py2Int a shim that
+    restores what the code evidently means: its CPU branch runs `y_B = self.netA(x_B)` (models/networks.py:940) -- the 2-channel
+    stem on the 1-channel half -- and raises; the data_parallel branch three lines above uses netB.  The patched forward below is
+    that method with `self.netB(x_B)`; everything else (constructor, layers, init) is the reference's."""
+    import functools
+    ndf, nl, hw = 8, 3, 128
+
+    def forward_netB(self, x):
+        if self.gauss_filter is not None:
+            x = self.gauss_filter(x)
+        return self.model(torch.cat([self.netA(x.narrow(1, 0, 2)), self.netB(x.narrow(1, 2, 1))], dim=1))
+    for s in (1, 2):
+        sf = Py2Int(s) if s > 1 else s
+        d = RN.define_D(3, ndf, "n_layers_sep", n_layers_D=nl, norm="instance", use_sigmoid=True, scale_factor=sf, gpu_ids=[])
+        d.forward = functools.partial(forward_netB, d)
+        sd = O.init_nlayer_d_sep(40 + s, ndf, nl, s)
+        load_sd(d, sd)
+        x = O.np_uniform(240 + s, (1, 3, hw, hw)).requires_grad_(True)
+        crit = RN.GANLoss(use_lsgan=False)
+        p = d.forward(x)
+        loss = crit(p, True) * 0.6 + crit(d.forward(x), False) * 0.4
+        loss.backward()
+        arrs = {"p": p.detach().numpy(), "loss": np.float64(loss.item()), "dx": x.grad.numpy()}
+        for k, prm in d.named_parameters():
+            if not k.startswith("gauss"):
+                arrs["grad/" + k] = prm.grad.numpy()
+        save(f"nlayer_d_sep_small_s{s}.npz", **arrs)
+
+
 class NoiseInjector:
     """Patch torch.Tensor.normal_ so latents of `shape` come from a numpy-seeded queue."""
     def __init__(self, shape, seed0):
@@ -1147,6 +1177,8 @@ def main():
     if not only or "autoencoder" in only:
         golden_autoencoder_small()
         golden_autoencoder_dropout()
+    if not only or "sep" in only:
+        golden_d_sep()
     if not only or "dcgan" in only:
         golden_dcgan_small()
         golden_g_nofcn_small()

@@ -219,6 +219,54 @@ def nlayer_d_forward(sd, x, n_layers: int = 3, scale_factor: int = 1, use_sigmoi
     return torch.sigmoid(x) if use_sigmoid else x
 
 
+def init_nlayer_d_sep(seed: int, ndf: int = 8, n_layers: int = 3, scale_factor: int = 1) -> "OrderedDict[str, torch.Tensor]":
+    """Numpy-seeded state_dict of NLayerDiscriminatorSep (models/networks.py:851-925), InstanceNorm: netA (2 -> ndf -> 2 ndf), netB
+    (1 -> ndf -> 2 ndf), model (4 ndf -> ... -> 1)."""
+    sd = OrderedDict()
+    s = seed * 1000
+
+    def conv(key, cout, cin):
+        nonlocal s
+        sd[key + ".weight"] = np_normal(s, (cout, cin, 4, 4), 0.0, 0.02); s += 1
+        bound = 1.0 / math.sqrt(cin * 16)
+        sd[key + ".bias"] = np_uniform(s, (cout,), -bound, bound); s += 1
+    if scale_factor > 1:
+        sd["gauss_filter.0.weight"] = gauss_filter_weight(3, scale_factor)
+    for net, cin in (("netA", 2), ("netB", 1)):
+        conv(f"{net}.0", ndf, cin)
+        conv(f"{net}.2", 2 * ndf, ndf)
+    nf, idx = 4, 0
+    for n in range(2, n_layers):
+        nf_prev, nf = nf, min(2 ** n, 8)
+        conv(f"model.{idx}", ndf * nf, ndf * nf_prev); idx += 3
+    nf_prev, nf = nf, min(2 ** n_layers, 8)
+    conv(f"model.{idx}", ndf * nf, ndf * nf_prev); idx += 3
+    conv(f"model.{idx}", 1, ndf * nf)
+    return sd
+
+
+def nlayer_d_sep_forward(sd, x, n_layers: int = 3, scale_factor: int = 1, use_sigmoid: bool = True):
+    """NLayerDiscriminatorSep.forward to its evident intent (models/networks.py:927-942): the label channels through netA, the image
+    channel through netB (the reference's CPU branch calls netA on both, :940, and raises; its data_parallel branch uses netB),
+    concatenated, then `model`.  InstanceNorm2d(affine=False)."""
+    if scale_factor > 1:
+        x = gauss_down(x, sd["gauss_filter.0.weight"], scale_factor)
+    ys = []
+    for net, sl in (("netA", slice(0, 2)), ("netB", slice(2, 3))):
+        y = F.leaky_relu(F.conv2d(x[:, sl], sd[f"{net}.0.weight"], sd[f"{net}.0.bias"], stride=2, padding=2), 0.2)
+        y = F.conv2d(y, sd[f"{net}.2.weight"], sd[f"{net}.2.bias"], stride=2, padding=2)
+        ys.append(F.leaky_relu(F.instance_norm(y, eps=IN_EPS), 0.2))
+    y = torch.cat(ys, 1)
+    idx = 0
+    for n in range(2, n_layers):
+        y = F.leaky_relu(F.instance_norm(F.conv2d(y, sd[f"model.{idx}.weight"], sd[f"model.{idx}.bias"], stride=2, padding=2), eps=IN_EPS), 0.2)
+        idx += 3
+    y = F.leaky_relu(F.instance_norm(F.conv2d(y, sd[f"model.{idx}.weight"], sd[f"model.{idx}.bias"], stride=1, padding=2), eps=IN_EPS), 0.2)
+    idx += 3
+    y = F.conv2d(y, sd[f"model.{idx}.weight"], sd[f"model.{idx}.bias"], stride=1, padding=2)
+    return torch.sigmoid(y) if use_sigmoid else y
+
+
 def gan_loss(pred, target_is_real: bool, use_lsgan: bool = False):
     """GANLoss.__call__ (models/networks.py:183-185): BCELoss / MSELoss vs a constant map."""
     t = torch.full_like(pred, 1.0 if target_is_real else 0.0)

@@ -602,7 +602,7 @@ class _ChainFn(torch.autograd.Function):
 # grouped execution: several chains of the same architecture, one kernel launch per layer
 # ------------------------------------------------------------------------------------------------
 def _same_architecture(a: "ChainNet", b: "ChainNet") -> bool:
-    if len(a.layers) != len(b.layers) or a.final_act != b.final_act:
+    if len(a.layers) != len(b.layers) or a.final_act != b.final_act or getattr(a, "no_group", False) or getattr(b, "no_group", False):
         return False
     key = lambda L: (L.kind, L.k, L.stride, L.pad, L.cin, L.cout, L.bias, L.norm, L.act, L.slope)
     return all(key(x) == key(y) for x, y in zip(a.layers, b.layers))

@@ -973,7 +973,8 @@ struct Sg3pPlan { bool ok; int a_it; long tiles; double waste; int min_taps; boo
 
 static Sg3pPlan sg3p_plan(SgIgemmParams& P) {
     Sg3pPlan pl = {false, 0, 0, 1.0, 1 << 30, false, 0};
-    if ((P.is != 1 && !(P.is == 2 && P.nphase == 1)) || (P.Ck & 31) || P.N <= 32) return pl;
+    static const int n32 = getenv("SGAN_PATCH_N32") ? atoi(getenv("SGAN_PATCH_N32")) : 0;      // tuning knob: 32 result channels on the 64-wide tile
+    if ((P.is != 1 && !(P.is == 2 && P.nphase == 1)) || (P.Ck & 31) || P.N < 32 || (P.N == 32 && !n32)) return pl;
     static const int no_s2 = getenv("SGAN_NO_PATCH_S2") ? atoi(getenv("SGAN_NO_PATCH_S2")) : 0;      // tuning knob
     if (P.is == 2 && no_s2) return pl;
     int maxpix = 0;

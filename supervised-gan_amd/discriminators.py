@@ -185,6 +185,161 @@ class NLayerDiscriminator(ChainNet):
         return p
 
 
+class NLayerDiscriminatorSep(NLayerDiscriminator):
+    """NLayerDiscriminatorSep (models/networks.py:851-942): the 3-channel pair is split into its 2 label channels and its image
+    channel, each goes through its own two-conv stem (netA, netB: Conv(k4,s2,p2)+LReLU -> Conv s2 + norm + LReLU), the two
+    feature maps are concatenated and `model` (the rest of the PatchGAN) runs on them.
+
+    On this path the two stems are ONE chain with block-diagonal weights: conv(2 -> ndf) (+) conv(1 -> ndf) is a conv 3 -> 2 ndf whose
+    master weight holds netA's taps in the (outputs 0 .. ndf-1, inputs 0 .. 1) block and netB's in (ndf .. 2 ndf-1, input 2), zeros
+    elsewhere; the second stem layer likewise (2 ndf -> 4 ndf).  Normalisation and LeakyReLU are per channel, and the channel
+    order of the result IS torch.cat([y_A, y_B], 1) -- so the whole discriminator is one layer program on the existing kernels
+    (the zero blocks cost 2x the MACs of two small layers).  The Parameters `netA.*` / `netB.*` are strided views of the diagonal
+    blocks under the reference's state_dict keys; the off-diagonal blocks are never written by init or load_state_dict and their
+    gradients are zeroed after every backward pass.
+
+    The reference's forward applies netA to BOTH halves on the CPU branch (`y_B = self.netA(x_B)`, :940) and therefore raises on
+    any input; its data_parallel branch uses netB, which is the evident intent and what this class computes (the golden comes
+    from the reference with that one call patched, oracle/make_golden.py)."""
+
+    no_group = True       # chain._same_architecture: never part of a grouped launch (the gradient masks live in run_backward)
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm="instance", use_sigmoid=False, scale_factor=1, num_classes=2, gpu_ids=[]):
+        assert input_nc == 3, "n_layers_sep splits a 3-channel pair (models/networks.py:862)"
+        assert n_layers >= 2 and pad4(ndf) == ndf, "n_layers_sep: n_layers >= 2, ndf a multiple of 4"
+        logit_nc = 1 if num_classes == 2 else int(num_classes)
+        nrm = {"instance": "in", "batch": "bn"}[norm]
+        kw, padw = 4, 2
+        layers = [LayerSpec("stem.0", CONV, kw, 2, padw, 3, 2 * ndf, True, None, ACT_LRELU, 0.2),
+                  LayerSpec("stem.2", CONV, kw, 2, padw, 2 * ndf, 4 * ndf, True, nrm, ACT_LRELU, 0.2)]
+        nf, idx = 4, 0      # models/networks.py:903: nf_mult = 2 * nf_mult after the stems
+        for n in range(2, n_layers):
+            nf_prev, nf = nf, min(2 ** n, 8)
+            layers.append(LayerSpec(f"model.{idx}", CONV, kw, 2, padw, ndf * nf_prev, ndf * nf, True, nrm, ACT_LRELU, 0.2))
+            idx += 3
+        nf_prev, nf = nf, min(2 ** n_layers, 8)
+        layers.append(LayerSpec(f"model.{idx}", CONV, kw, 1, padw, ndf * nf_prev, ndf * nf, True, nrm, ACT_LRELU, 0.2))
+        idx += 3
+        layers.append(LayerSpec(f"model.{idx}", CONV, kw, 1, padw, ndf * nf, logit_nc, True, None, ACT_NONE))
+        self._ndf = ndf
+        self._stem_boxes = {}
+        ChainNet.__init__(self, layers)
+        self.gpu_ids, self.logit_nc, self.use_sigmoid = gpu_ids, logit_nc, use_sigmoid
+        self.scale_factor, self.input_nc = int(scale_factor), input_nc
+        self.gauss_filter = None
+        self.fuse_sigmoid_into_loss = False
+        if self.scale_factor > 1:
+            sigma = self.scale_factor // 2
+            kg = 4 * sigma + 1
+            box = _ParamBox("conv")
+            box.weight = nn.Parameter(torch.zeros(input_nc, input_nc, kg, kg))
+            self.gauss_filter = nn.Module()
+            self.gauss_filter.add_module("0", box)
+            self._gauss = (kg, 2 * sigma)
+
+    # ---- module tree: `stem.*` boxes hold the full block-diagonal tensors and stay OUT of the tree; netA / netB boxes are registered ----
+    def _param_root(self):
+        return self
+
+    def _add_box(self, key, box):
+        if key.startswith("stem."):
+            self._stem_boxes[key] = box
+            if getattr(box, "_sgan_kind", None) == "conv":
+                for net in ("netA", "netB"):
+                    half = _ParamBox("conv")
+                    half.weight = nn.Parameter(torch.empty(0))
+                    half.bias = nn.Parameter(torch.empty(0))
+                    ChainNet._add_box(self, f"{net}.{key[5:]}", half)
+            else:      # BatchNorm behind the second stem conv: halves of gamma / beta / running statistics
+                for net in ("netA", "netB"):
+                    half = _ParamBox("bn")
+                    half.weight, half.bias = nn.Parameter(torch.empty(0)), nn.Parameter(torch.empty(0))
+                    n = box.running_mean.numel() // 2
+                    half.register_buffer("running_mean", torch.zeros(n))
+                    half.register_buffer("running_var", torch.ones(n))
+                    half.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+                    ChainNet._add_box(self, f"{net}.{key[5:]}", half)
+            return
+        ChainNet._add_box(self, key, box)
+
+    def _box(self, L):
+        return self._stem_boxes[L.key] if L.key.startswith("stem.") else ChainNet._box(self, L)
+
+    def _half_views(self, flat, L):
+        """((wA, bA), (wB, bB)) diagonal blocks of stem layer L in `flat`, logical [Cout/2, Cin_half, kh, kw] / [Cout/2]."""
+        m = flat[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s].view(L.k, L.k, L.cout_s, L.cin_s).permute(2, 3, 0, 1)
+        h = L.cout // 2
+        ca = 2 if L.key == "stem.0" else L.cin // 2          # netA reads the 2 label channels, netB the image channel
+        cb0, cb1 = (2, 3) if L.key == "stem.0" else (L.cin // 2, L.cin)
+        b = flat[L.b_off: L.b_off + L.cout]
+        return (m[:h, :ca], b[:h]), (m[h:L.cout, cb0:cb1], b[h:])
+
+    def _rebind(self):
+        ChainNet._rebind(self)
+        for L in self.layers:
+            if not L.key.startswith("stem."):
+                continue
+            n = L.k * L.k * L.cout_s * L.cin_s
+            for net, (w, b), (gw, gb), wseg, boff in zip(("netA", "netB"), self._half_views(self._flat, L), self._half_views(self._gflat, L),
+                                                         ((L.w_off, n), (L.w_off + n, 0)), (0, L.cout // 2)):
+                box = ChainNet._box(self, LayerSpec(f"{net}.{L.key[5:]}", CONV, 4, 2, 2, 1, 1, True, None, ACT_NONE))
+                box.weight.data, box.weight.grad = w, gw
+                box.bias.data, box.bias.grad = b, gb
+                box.weight._sgan_seg = (self, wseg[0], wseg[1])      # the optimizer's flat range: the whole slab rides with netA's half
+                box.bias._sgan_seg = (self, L.b_off + boff, L.cout // 2)
+            if L.norm == "bn":
+                full = self._bn_boxes[L.key]
+                g, be = self._flat[L.g_off: L.g_off + L.cout], self._flat[L.be_off: L.be_off + L.cout]
+                gg, gbe = self._gflat[L.g_off: L.g_off + L.cout], self._gflat[L.be_off: L.be_off + L.cout]
+                h = L.cout // 2
+                for net, sl in (("netA", slice(0, h)), ("netB", slice(h, L.cout))):
+                    nb = ChainNet._box(self, LayerSpec(f"{net}.{int(L.key[5:]) + 1}", CONV, 4, 2, 2, 1, 1, True, None, ACT_NONE))
+                    nb.weight.data, nb.weight.grad = g[sl], gg[sl]
+                    nb.bias.data, nb.bias.grad = be[sl], gbe[sl]
+                    nb.weight._sgan_seg = (self, L.g_off + sl.start, h)
+                    nb.bias._sgan_seg = (self, L.be_off + sl.start, h)
+                    nb._buffers["running_mean"] = full.running_mean[sl]
+                    nb._buffers["running_var"] = full.running_var[sl]
+
+    def _ensure_grads(self):
+        ChainNet._ensure_grads(self)
+        self._rebind()
+
+    def _apply(self, fn, recurse=True):
+        for box in self._stem_boxes.values():      # not in the module tree: their BatchNorm buffers move with the net all the same
+            for k, buf in box._buffers.items():
+                if buf is not None:
+                    box._buffers[k] = fn(buf)
+        return ChainNet._apply(self, fn, recurse)
+
+    def _default_bias_init(self):
+        ChainNet._default_bias_init(self)
+        for L in self.layers:      # each stem half keeps torch's bound for ITS fan-in (2 / 1 input channels; ndf each)
+            if L.key.startswith("stem."):
+                (_, ba), (_, bb) = self._half_views(self._flat, L)
+                fa, fb = ((2, 1) if L.key == "stem.0" else (L.cin // 2, L.cin // 2))
+                ba.uniform_(-1.0 / math.sqrt(fa * 16), 1.0 / math.sqrt(fa * 16))
+                bb.uniform_(-1.0 / math.sqrt(fb * 16), 1.0 / math.sqrt(fb * 16))
+
+    def _mask_offdiag(self, flat):
+        for L in self.layers:
+            if L.key.startswith("stem."):
+                m = flat[L.w_off: L.w_off + L.k * L.k * L.cout_s * L.cin_s].view(L.k * L.k, L.cout_s, L.cin_s)
+                h = L.cout // 2
+                ca = 2 if L.key == "stem.0" else L.cin // 2
+                m[:, :h, ca:].zero_()
+                m[:, h:, :ca].zero_()
+
+    def run_backward(self, x, outs, stats, dout, need_dx, want_wgrad):
+        dx = ChainNet.run_backward(self, x, outs, stats, dout, need_dx, want_wgrad)
+        if want_wgrad:
+            self._mask_offdiag(self._gflat)      # the dense backward-weight kernels also fill the cross blocks: not parameters
+        return dx
+
+    def forward(self, x):
+        return self._wrap_output(_ChainFn.apply(self, x, *[p for p in self.parameters()]))
+
+
 class _SigmoidFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits):

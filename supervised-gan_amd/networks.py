@@ -8,27 +8,21 @@ hand-written gfx950 kernels (include/sgan_hip.h); normalisation and activations 
 separate passes (they are applied while the consumer conv stages its input) and the whole net is
 one autograd node.
 
-Implemented: which_model_netG in {fcgan, deconv (README alias), unet_128, unet_256, crn, autoencoder, dcgan}, which_model_netD in
-{n_layers, basic}.  Other names raise NotImplementedError like the reference does for unknown
-names (models/networks.py:95,123)."""
+Implemented: every name of the reference's factories -- which_model_netG in {fcgan, deconv (README alias), fcgan_star, unet_128,
+unet_256, crn, autoencoder, dcgan, resnet_6blocks, resnet_9blocks} with their option branches (dropout, batch / instance norm,
+residual, Gaussian noise, skips, upsampling modes), which_model_netD in {n_layers, basic, dcgan, n_layers_sep}.  Unknown names
+raise NotImplementedError like the reference (models/networks.py:95,123).
+
+This module is the import surface (the factories, `weights_init`, `print_network`); the layer-program core lives in chain.py, the
+networks in generators.py / discriminators.py, the losses in losses.py -- re-exported here so that `networks.X` keeps working."""
 from __future__ import annotations
 
-import math
-import os
-from dataclasses import dataclass
-from typing import List, Optional
-
-import numpy as np
 import torch
-import torch.nn as nn
-import torch.nn.functional as F
 
-from . import ops
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, CONV, CONVT, SganError
-from .ops import pad4
+from .ops import pad4      # noqa: F401  (re-export)
 from .chain import (BN_EPS, BN_MOMENTUM, IN_EPS, ChainNet, LayerSpec, _BwdArena, _ChainFn, _dgrad_math, _MultiChainFn,      # noqa: F401
                     _ParamBox, can_group, multi_forward, pack_flat)
-from .discriminators import (DCGANDiscriminator, NLayerDiscriminator, _SigmoidFn, init_gauss_filters,      # noqa: F401
+from .discriminators import (DCGANDiscriminator, NLayerDiscriminator, NLayerDiscriminatorSep, _SigmoidFn, init_gauss_filters,      # noqa: F401
                              matlab_style_gauss2D)
 from .generators import (AutoEncoder, CascadedRefinementNetwork, DCGANGenerator, FCGANGenerator, FCGANGeneratorStar,      # noqa: F401
                          ResnetGenerator, UnetGenerator)
@@ -107,7 +101,8 @@ def define_D(input_nc, ndf, which_model_netD, n_layers_D=3, norm='batch', use_si
             raise NotImplementedError("the dcgan discriminator has no Gaussian pre-filter (the reference fails on scale_factor > 1 too)")
         netD = DCGANDiscriminator(gpu_ids=gpu_ids, nc=input_nc, ndf=ndf)
     elif which_model_netD == 'n_layers_sep':
-        raise NotImplementedError('Discriminator model name [%s] is not on the MI355X path yet' % which_model_netD)
+        netD = NLayerDiscriminatorSep(input_nc, ndf, n_layers=n_layers_D, norm=norm, use_sigmoid=use_sigmoid,
+                                      scale_factor=scale_factor, num_classes=num_classes, gpu_ids=gpu_ids)
     else:
         raise NotImplementedError('Discriminator model name [%s] is not recognized' % which_model_netD)
     netD.apply(weights_init)

@@ -122,6 +122,48 @@ def test_nlayer_d_small(N, golden_dir, s):
                 assert rel(params[name].grad, g[k]) < TOL, name
 
 
+@pytest.mark.parametrize("s", [1, 2])
+def test_nlayer_d_sep_small(N, golden_dir, s):
+    """`--which_model_netD n_layers_sep`: the two stems as one block-diagonal chain (discriminators.NLayerDiscriminatorSep) against
+    the reference golden -- output, loss, image gradient, every parameter gradient under the reference's keys; the cross blocks of
+    the stem weights stay exactly zero in the parameters and in the gradients."""
+    g = load(golden_dir, f"nlayer_d_sep_small_s{s}.npz")
+    D = N.define_D(3, 8, "n_layers_sep", n_layers_D=3, norm="instance", use_sigmoid=True, scale_factor=s, gpu_ids=[0])
+    D.load_state_dict(O.init_nlayer_d_sep(40 + s, 8, 3, s))
+    x = O.np_uniform(240 + s, (1, 3, 128, 128)).cuda().requires_grad_(True)
+    crit = N.GANLoss(use_lsgan=False)
+    p = D.forward(x)
+    assert p.shape == g["p"].shape
+    loss = crit(p, True) * 0.6 + crit(D.forward(x), False) * 0.4
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(p, g["p"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    assert rel(x.grad, g["dx"]) < TOL
+    params = dict(D.named_parameters())
+    assert {k[5:] for k in g.files if k.startswith("grad/")} <= set(params)
+    wscale = {}
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith(".weight"):
+            wscale[k[5:-7]] = np.abs(g[k]).max()
+            assert rel(params[k[5:]].grad, g[k]) < TOL, k
+    for k in g.files:      # biases: those in front of an InstanceNorm have an analytically zero gradient (compared on the weight's scale)
+        if k.startswith("grad/") and k.endswith(".bias"):
+            assert np.abs(params[k[5:]].grad.cpu().numpy() - g[k]).max() < TOL * max(wscale[k[5:-5]], np.abs(g[k]).max()), k
+    for L in D.layers[:2]:
+        for flat in (D._flat, D._gflat):
+            m = flat[L.w_off: L.w_off + 16 * L.cout_s * L.cin_s].view(16, L.cout_s, L.cin_s)
+            h, ca = L.cout // 2, (2 if L.key == "stem.0" else L.cin // 2)
+            assert float(m[:, :h, ca:].abs().max()) == 0.0 and float(m[:, h:, :ca].abs().max()) == 0.0
+    # a second pass (gradients accumulate), and an optimizer over ALL parameters keeps the block structure
+    from supervised_gan_amd.optim import FusedAdam
+    opt = FusedAdam(D.parameters() if s == 1 else [p_ for n_, p_ in D.named_parameters() if not n_.startswith("gauss")], lr=1e-3, betas=(0.5, 0.999))
+    opt.step()
+    L = D.layers[0]
+    m = D._flat[L.w_off: L.w_off + 16 * L.cout_s * L.cin_s].view(16, L.cout_s, L.cin_s)
+    assert float(m[:, :8, 2:].abs().max()) == 0.0 and float(m[:, 8:, :2].abs().max()) == 0.0 and float(m[:, :8, :2].abs().max()) > 0
+
+
 def test_nlayer_d_n4_lsgan(N, golden_dir):
     g = load(golden_dir, "nlayer_d_small_n4_lsgan.npz")
     D = N.define_D(3, 8, "n_layers", n_layers_D=4, norm="instance", use_sigmoid=False, scale_factor=1, gpu_ids=[0])

@@ -106,6 +106,26 @@ def test_nlayer_d_small(golden_dir, s):
             assert rel(sd[k[5:]].grad, g[k]) < TIGHT * 10, k
 
 
+@pytest.mark.parametrize("s", [1, 2])
+def test_nlayer_d_sep_small(golden_dir, s):
+    """`--which_model_netD n_layers_sep` (models/networks.py:851-942) against the reference run with its one broken call patched
+    (oracle/make_golden.py:golden_d_sep)."""
+    g = load(golden_dir, f"nlayer_d_sep_small_s{s}.npz")
+    sd = O.init_nlayer_d_sep(40 + s, 8, 3, s)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = O.np_uniform(240 + s, (1, 3, 128, 128)).requires_grad_(True)
+    p = O.nlayer_d_sep_forward(sd, x, 3, s, True)
+    loss = O.gan_loss(p, True) * 0.6 + O.gan_loss(O.nlayer_d_sep_forward(sd, x, 3, s, True), False) * 0.4
+    loss.backward()
+    assert p.shape == g["p"].shape and rel(p, g["p"]) < TIGHT
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
+    assert rel(x.grad, g["dx"]) < TIGHT * 10
+    for k in g.files:
+        if k.startswith("grad/") and k.endswith(".weight"):
+            assert rel(sd[k[5:]].grad, g[k]) < TIGHT * 10, k
+
+
 def test_nlayer_d_n4_lsgan(golden_dir):
     g = load(golden_dir, "nlayer_d_small_n4_lsgan.npz")
     sd = O.init_nlayer_d(29, 3, 8, 4, 1)

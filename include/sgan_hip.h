@@ -203,6 +203,23 @@ int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* wo
 int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw,
                         int32_t dgrad_math, void* stream);
 
+/* ---- class-weighted cross-entropy on logits, softmax over channels (NHWC maps, <= 16 classes) ---------------------------
+ * sgan_ce_fwd:  loss = sum_p w[y_p] (logsumexp(z_p) - z_p[y_p]) / sum_p w[y_p];  y_p = label[p] (int64 map) or const_label when label
+ *               is NULL; class_w NULL = unit weights; labels outside [0, C) are skipped (torch's ignore_index).  `acc` (2 doubles) and
+ *               `ticket` (1 uint32) are caller-owned scratch that must be ZERO on entry; acc keeps the two sums for sgan_ce_bwd.
+ * sgan_ce_bwd:  dlogits = gout[0] * w[y_p] * (softmax(z_p) - onehot(y_p)) / sum w   (padding channels of dlogits: zeros).
+ * Replaces: nn.CrossEntropyLoss in GANLossMultiClass (models/networks.py:188-202), CrossEntropyLoss2d = NLLLoss2d(log_softmax)
+ * (models/loss.py:6-12) of the segmentation trainers.
+ * sgan_softmax_fwd / _bwd: p = softmax over the C logical channels; dz = p * (dp - sum_c dp_c p_c).  Replaces F.softmax(logit, 1)
+ * (models/segm_model.py:155-160). */
+int sgan_ce_fwd(const float* logits, int32_t ld, int32_t npix, int32_t C, const int64_t* label, int32_t const_label,
+                const float* class_w, double* acc, uint32_t* ticket, float* loss_out, void* stream);
+int sgan_ce_bwd(const float* logits, int32_t ld, int32_t npix, int32_t C, const int64_t* label, int32_t const_label,
+                const float* class_w, const double* acc, const float* gout, float* dlogits, int32_t dld, void* stream);
+int sgan_softmax_fwd(const float* z, int32_t ld, int32_t npix, int32_t C, float* p, int32_t pld, void* stream);
+int sgan_softmax_bwd(const float* dp, int32_t dpld, const float* p, int32_t pld, int32_t npix, int32_t C, float* dz, int32_t dzld,
+                     void* stream);
+
 /* ---- transposed weight copy for backward-data ---------------------------------------------------
  * flat_t[off + tap][ci][co] = flat[off + tap][co][ci] for every conv segment (bias / affine ranges of the flat
  * parameter buffer are not touched).  Run after each optimizer step on the nets whose backward-data is needed. */

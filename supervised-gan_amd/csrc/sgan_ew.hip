@@ -602,6 +602,125 @@ extern "C" int sgan_scale(const float* gout, const float* g, float* dx, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// Class-weighted cross-entropy on logits and softmax over the channel dimension of an NHWC map (round 3; the (f)-row trainers ran
+// these on aten kernels): GANLossMultiClass (models/networks.py:188-202: CrossEntropyLoss of every pixel's class scores against one
+// class), CrossEntropyLoss2d of the segmentation trainers (models/loss.py:6-12: NLLLoss2d(log_softmax), class weights), and the
+// softmax that turns the U-Net's logits into the "fake" label map (models/segm_model.py:155-160).  C <= 16 classes per pixel.
+//   loss = sum_p w[y_p] * (lse_p - z_p[y_p]) / sum_p w[y_p]        (torch's weighted mean)
+// forward: per-workgroup partials (fp64) of the two sums, the last workgroup (ticket) finishes; backward: recomputes the softmax and
+// writes d loss / d z = gout * w[y_p] * (softmax_p - onehot(y_p)) / sum w -- the denominator is read from the forward's sums.
+// ------------------------------------------------------------------------------------------
+#define SG_CE_MAXC 16
+__device__ __forceinline__ float sg_ce_lse(const float* z, int C, float* zs) {
+    float m = -3.4e38f;
+    for (int c = 0; c < C; ++c) { zs[c] = z[c]; m = fmaxf(m, zs[c]); }
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(zs[c] - m);
+    return m + logf(sum);
+}
+
+__global__ __launch_bounds__(256) void sg_ce_fwd_kernel(const float* logits, int ld, int npix, int C, const int64_t* label, int const_label,
+                                                        const float* class_w, double* acc, unsigned* ticket, float* loss_out) {
+    double s_num = 0.0, s_den = 0.0;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        float zs[SG_CE_MAXC];
+        const float lse = sg_ce_lse(logits + (int64_t)p * ld, C, zs);
+        int y = label ? (int)label[p] : const_label;
+        if (y < 0 || y >= C) continue;      // torch's ignore_index (-100) and anything out of range: no contribution
+        const float w = class_w ? class_w[y] : 1.f;
+        float zy = 0.f;
+        for (int c = 0; c < C; ++c) zy = c == y ? zs[c] : zy;
+        s_num += (double)(w * (lse - zy));
+        s_den += (double)w;
+    }
+    __shared__ double red[2][4];
+    for (int o = 32; o > 0; o >>= 1) { s_num += __shfl_xor(s_num, o); s_den += __shfl_xor(s_den, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_num; red[1][threadIdx.x >> 6] = s_den; }
+    SG_SYNC();
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&acc[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {      // every workgroup's sums are in: finish
+            const double num = __hip_atomic_load(&acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double den = __hip_atomic_load(&acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            loss_out[0] = den > 0.0 ? (float)(num / den) : 0.f;
+            ticket[0] = 0u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sg_ce_bwd_kernel(const float* logits, int ld, int npix, int C, const int64_t* label, int const_label,
+                                                        const float* class_w, const double* acc, const float* gout, float* dlogits, int dld) {
+    const double den = acc[1];
+    const float scale = den > 0.0 ? (float)((double)gout[0] / den) : 0.f;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        float zs[SG_CE_MAXC];
+        const float lse = sg_ce_lse(logits + (int64_t)p * ld, C, zs);
+        const int y = label ? (int)label[p] : const_label;
+        const bool ok = y >= 0 && y < C;
+        const float w = ok ? (class_w ? class_w[y] : 1.f) * scale : 0.f;
+        for (int c = 0; c < dld; ++c) dlogits[(int64_t)p * dld + c] = c < C ? w * (expf(zs[c] - lse) - (c == y ? 1.f : 0.f)) : 0.f;
+    }
+}
+
+extern "C" int sgan_ce_fwd(const float* logits, int32_t ld, int32_t npix, int32_t C, const int64_t* label, int32_t const_label,
+                           const float* class_w, double* acc, uint32_t* ticket, float* loss_out, void* stream) {
+    SGAN_CHECK(logits && acc && ticket && loss_out && npix > 0 && C >= 1 && C <= SG_CE_MAXC && ld >= C, "bad argument (1..%d classes)", SG_CE_MAXC);
+    int blocks = ew_cdiv(npix, 256);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(sg_ce_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, ld, npix, C, label, const_label, class_w, acc,
+                       ticket, loss_out);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+extern "C" int sgan_ce_bwd(const float* logits, int32_t ld, int32_t npix, int32_t C, const int64_t* label, int32_t const_label,
+                           const float* class_w, const double* acc, const float* gout, float* dlogits, int32_t dld, void* stream) {
+    SGAN_CHECK(logits && acc && gout && dlogits && npix > 0 && C >= 1 && C <= SG_CE_MAXC && ld >= C && dld >= C, "bad argument");
+    int blocks = ew_cdiv(npix, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sg_ce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, ld, npix, C, label, const_label, class_w, acc,
+                       gout, dlogits, dld);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// softmax over the C logical channels of every pixel (padding channels of the result are written as zeros); backward:
+// dz = p * (dp - sum_c dp_c p_c)
+__global__ __launch_bounds__(256) void sg_softmax_fwd_kernel(const float* z, int ld, int npix, int C, float* p_out, int pld) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        float zs[SG_CE_MAXC];
+        const float lse = sg_ce_lse(z + (int64_t)p * ld, C, zs);
+        for (int c = 0; c < pld; ++c) p_out[(int64_t)p * pld + c] = c < C ? expf(zs[c] - lse) : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void sg_softmax_bwd_kernel(const float* dp, int dpld, const float* pr, int pld, int npix, int C, float* dz, int dzld) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot += dp[(int64_t)p * dpld + c] * pr[(int64_t)p * pld + c];
+        for (int c = 0; c < dzld; ++c) dz[(int64_t)p * dzld + c] = c < C ? pr[(int64_t)p * pld + c] * (dp[(int64_t)p * dpld + c] - dot) : 0.f;
+    }
+}
+extern "C" int sgan_softmax_fwd(const float* z, int32_t ld, int32_t npix, int32_t C, float* p, int32_t pld, void* stream) {
+    SGAN_CHECK(z && p && npix > 0 && C >= 1 && C <= SG_CE_MAXC && ld >= C && pld >= C, "bad argument");
+    int blocks = ew_cdiv(npix, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sg_softmax_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, ld, npix, C, p, pld);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+extern "C" int sgan_softmax_bwd(const float* dp, int32_t dpld, const float* p, int32_t pld, int32_t npix, int32_t C, float* dz, int32_t dzld,
+                                void* stream) {
+    SGAN_CHECK(dp && p && dz && npix > 0 && C >= 1 && C <= SG_CE_MAXC && dpld >= C && pld >= C && dzld >= C, "bad argument");
+    int blocks = ew_cdiv(npix, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sg_softmax_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dp, dpld, p, pld, npix, C, dz, dzld);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // transposed master copy of the conv weights (backward-data wants the reduction channel contiguous)
 // ------------------------------------------------------------------------------------------
 struct SgWtTable { sgan_wt_seg s[64]; int64_t first[65]; int32_t n; };   // first[i]: first 32x32 tile of segment i

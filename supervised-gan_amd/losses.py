@@ -131,9 +131,61 @@ class GANLoss(nn.Module):
                                      *[self._logits_of(i) for i in inputs])
 
 
+class _CEFn(torch.autograd.Function):
+    """Class-weighted cross-entropy of a [1, C, H, W] logits map against an int64 label map [1, H, W] (or one class for every
+    pixel): sgan_ce_fwd / sgan_ce_bwd.  The forward keeps nothing but the two fp64 sums; the backward recomputes the softmax."""
+
+    @staticmethod
+    def forward(ctx, logits, label, const_label, class_w):
+        zb = ops.as_nhwc(logits)
+        acc = ops.stat_arena(3, logits.device)      # [sum w nll, sum w, ticket]; zeroed
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        lab = label.reshape(-1).contiguous() if label is not None else None
+        ops.ce_fwd(zb, logits.shape[1], lab, const_label, class_w, acc, loss)
+        ctx.zb, ctx.lab, ctx.cl, ctx.cw, ctx.acc, ctx.C = zb, lab, const_label, class_w, acc, logits.shape[1]
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        dz = torch.empty_like(ctx.zb)
+        ops.ce_bwd(ctx.zb, ctx.C, ctx.lab, ctx.cl, ctx.cw, ctx.acc, gout.contiguous().float(), dz)
+        return ops.logical_view(dz, ctx.C), None, None, None
+
+
+def cross_entropy_logits(logits, label=None, const_label=0, class_weights=None):
+    """nn.CrossEntropyLoss(weight=class_weights)(logits, label) for a [1, C, H, W] map on the HIP kernel (C <= 16, batch 1); `label`
+    None: every pixel has class `const_label`."""
+    assert logits.dim() == 4 and logits.shape[0] == 1 and logits.shape[1] <= 16, logits.shape
+    cw = class_weights.detach().float().contiguous() if class_weights is not None else None
+    return _CEFn.apply(logits, label, int(const_label), cw)
+
+
+class _SoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits):
+        zb = ops.as_nhwc(logits)
+        pb = torch.empty_like(zb)
+        ops.softmax_fwd(zb, logits.shape[1], pb)
+        ctx.pb, ctx.C = pb, logits.shape[1]
+        return ops.logical_view(pb, logits.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        dz = torch.empty_like(ctx.pb)
+        ops.softmax_bwd(ops.as_nhwc(g), ctx.pb, ctx.C, dz)
+        return ops.logical_view(dz, ctx.C)
+
+
+def softmax_channels(logits):
+    """F.softmax(logits, dim=1) of a [1, C, H, W] map on the HIP kernel (the result is NHWC-backed: the discriminators read it with
+    no layout copy)."""
+    assert logits.dim() == 4 and logits.shape[0] == 1 and logits.shape[1] <= 16, logits.shape
+    return _SoftmaxFn.apply(logits)
+
+
 class GANLossMultiClass(nn.Module):
     """GANLossMultiClass (models/networks.py:188-202): CrossEntropyLoss over the class channel of every pixel of a
-    discriminator map.  The maps are 3 x 67 x 67: the loss runs on PyTorch's own kernels."""
+    discriminator map against one class: one forward and one backward launch (sgan_ce_fwd / sgan_ce_bwd)."""
 
     def __init__(self, use_lsgan=False, num_classes=3, use_gpu=False):
         super().__init__()
@@ -141,11 +193,8 @@ class GANLossMultiClass(nn.Module):
         self.num_classes = num_classes
 
     def __call__(self, input, target_label):
-        flat = input.permute(0, 2, 3, 1).reshape(-1, self.num_classes)
-        tgt = getattr(self, "_tgt", None)
-        if tgt is None or tgt.device != flat.device or tgt.shape[1] != flat.shape[0]:
-            tgt = self._tgt = torch.arange(self.num_classes, device=flat.device).view(-1, 1).expand(-1, flat.shape[0]).contiguous()
-        return F.cross_entropy(flat, tgt[int(target_label)])
+        assert input.shape[1] == self.num_classes
+        return cross_entropy_logits(input, None, int(target_label))
 
 
 class _L1Fn(torch.autograd.Function):

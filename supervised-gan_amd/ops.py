@@ -476,6 +476,30 @@ def l1w_fwd(x, y, Creal, a, weights_dev, nweights, lam, loss_out, g):
                                  _ptr(loss_out), _ptr(_act(g)), g.stride(1), _ptr(ws), IMAGE_LOSS_WS_BYTES, _stream()), "sgan_l1w_fwd")
 
 
+def ce_fwd(logits, Creal, label, const_label, class_w, acc, loss_out):
+    """Class-weighted cross-entropy of an [H, W, Cs] logits buffer (sgan_ce_fwd).  acc: zeroed float64[2 + 1] scratch (sums | ticket)."""
+    H, W, _ = logits.shape
+    L.check(L.lib().sgan_ce_fwd(_ptr(_act(logits)), logits.stride(1), H * W, Creal, _ptr(label), int(const_label), _ptr(class_w),
+                                _ptr(acc), C.c_void_p(acc.data_ptr() + 16), _ptr(loss_out), _stream()), "sgan_ce_fwd")
+
+
+def ce_bwd(logits, Creal, label, const_label, class_w, acc, gout, dlogits):
+    H, W, _ = logits.shape
+    L.check(L.lib().sgan_ce_bwd(_ptr(_act(logits)), logits.stride(1), H * W, Creal, _ptr(label), int(const_label), _ptr(class_w),
+                                _ptr(acc), _ptr(gout), _ptr(_act(dlogits)), dlogits.stride(1), _stream()), "sgan_ce_bwd")
+
+
+def softmax_fwd(z, Creal, p):
+    H, W, _ = z.shape
+    L.check(L.lib().sgan_softmax_fwd(_ptr(_act(z)), z.stride(1), H * W, Creal, _ptr(_act(p)), p.stride(1), _stream()), "sgan_softmax_fwd")
+
+
+def softmax_bwd(dp, p, Creal, dz):
+    H, W, _ = p.shape
+    L.check(L.lib().sgan_softmax_bwd(_ptr(_act(dp)), dp.stride(1), _ptr(_act(p)), p.stride(1), H * W, Creal, _ptr(_act(dz)), dz.stride(1),
+                                     _stream()), "sgan_softmax_bwd")
+
+
 def bce01_fwd(x, t, Creal, loss_out, g):
     H, W, _ = x.shape
     ws = torch.empty(IMAGE_LOSS_WS_BYTES // 8, dtype=torch.float64, device=x.device)

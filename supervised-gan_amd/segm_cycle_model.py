@@ -15,6 +15,7 @@ from .base_model import BaseModel
 from .cgan_cycle_model import CGANCycleModel
 from .image_pool import ImagePool
 from .optim import AdamGroups, FusedAdam
+from .losses import softmax_channels
 from .segm_model import SegmentationModel, _identity
 
 
@@ -108,7 +109,7 @@ class SegmentationCycleModel(CGANCycleModel):
         self.real_A, self.real_B = self.input_A, self.input_B
         self.noise1, self.noise2 = self._draw(1).clone(), self._draw(2).clone()
         self.logit = self.netG1.forward(self.real_A, self.noise1, activation=_identity)
-        self.fake_B = torch.sigmoid(self.logit) if self.use_sigmoid_ss else F.softmax(self.logit, dim=1)
+        self.fake_B = torch.sigmoid(self.logit) if self.use_sigmoid_ss else softmax_channels(self.logit)
         self.fake_A = self.netG2.forward(self.real_B, self.noise2)
         self.recon_A = self.netG2.forward(self.fake_B, self.noise2)
 
@@ -119,7 +120,7 @@ class SegmentationCycleModel(CGANCycleModel):
             self.real_A, self.real_B = self.input_A, self.input_B
             self.noise1 = self._draw(1).clone()
             self.logit = self.netG1.forward(self.real_A, self.noise1, activation=_identity)
-            self.fake_B = torch.sigmoid(self.logit) if self.use_sigmoid_ss else F.softmax(self.logit, dim=1)
+            self.fake_B = torch.sigmoid(self.logit) if self.use_sigmoid_ss else softmax_channels(self.logit)
 
     # ---- losses -----------------------------------------------------------------------------------
     def _d_fake_source(self):

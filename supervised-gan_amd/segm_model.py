@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from . import networks
 from .cgan_model import CGANModel
+from .losses import cross_entropy_logits, softmax_channels
 from .util import compute_Rand_F_scores
 
 
@@ -61,7 +62,7 @@ class SegmentationModel(CGANModel):
         self.real_B = self.input_B
         self.noise = self._draw_noise()
         self.logit = self.netG.forward(self.real_A, self.noise, activation=_identity)                 # :155
-        self.fake_B = torch.sigmoid(self.logit) if self.use_sigmoid_ss else F.softmax(self.logit, dim=1)
+        self.fake_B = torch.sigmoid(self.logit) if self.use_sigmoid_ss else softmax_channels(self.logit)
 
     sample_noise = forward
 
@@ -80,7 +81,7 @@ class SegmentationModel(CGANModel):
             self.loss_G_CE = F.binary_cross_entropy(self.fake_B, self.real_B, weight=wm)
         else:
             w = self.class_weights if (weighted or self.isTrain) else None
-            self.loss_G_CE = F.nll_loss(F.log_softmax(self.logit, dim=1), self.label, weight=w)
+            self.loss_G_CE = cross_entropy_logits(self.logit, self.label, 0, w)      # models/loss.py:6-12 on the HIP kernel
         return self.loss_G_CE
 
     def backward_G(self):

@@ -817,6 +817,44 @@ def L_raw():
     return _lib.lib()
 
 
+@pytest.mark.parametrize("C,H,W,weighted", [(3, 67, 67, False), (3, 35, 19, True), (5, 64, 48, True), (12, 9, 7, False)])
+def test_cross_entropy_and_softmax_kernels(hip, C, H, W, weighted):
+    """sgan_ce_fwd / sgan_ce_bwd against F.cross_entropy (class weights, an int64 label map with ignored pixels, and the one-class
+    form GANLossMultiClass uses), sgan_softmax_fwd / _bwd against F.softmax, through their autograd wrappers (losses.py)."""
+    from supervised_gan_amd.losses import cross_entropy_logits, softmax_channels
+    g = torch.Generator().manual_seed(C * 100 + H)
+    z = (torch.randn(1, C, H, W, generator=g) * 3).requires_grad_(True)
+    lab = torch.randint(0, C, (1, H, W), generator=g)
+    lab[0, 0, :3] = -100                                    # torch's ignore_index
+    cw = (torch.rand(C, generator=g) + 0.5) if weighted else None
+    ref = F.cross_entropy(z, lab, weight=cw)
+    ref.backward()
+    zc = z.detach().cuda().requires_grad_(True)
+    loss = cross_entropy_logits(zc, lab.cuda(), 0, cw.cuda() if cw is not None else None)
+    (loss * 1.7).backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    assert float((zc.grad.cpu() - 1.7 * z.grad).abs().max()) < 1e-6 * float(z.grad.abs().max()) + 1e-9
+    for k in (0, C - 1):                                    # every pixel the same class (the multi-class GAN objective)
+        z2 = z.detach().clone().requires_grad_(True)
+        r2 = F.cross_entropy(z2.permute(0, 2, 3, 1).reshape(-1, C), torch.full((H * W,), k, dtype=torch.long))
+        r2.backward()
+        z2c = z.detach().cuda().requires_grad_(True)
+        l2 = cross_entropy_logits(z2c, None, k)
+        l2.backward()
+        assert abs(float(l2) - float(r2)) < 2e-6 * max(1.0, abs(float(r2)))
+        assert float((z2c.grad.cpu() - z2.grad).abs().max()) < 1e-6 * float(z2.grad.abs().max()) + 1e-9
+    z3 = z.detach().clone().requires_grad_(True)
+    R = torch.randn(1, C, H, W, generator=g)
+    (F.softmax(z3, dim=1) * R).sum().backward()
+    z3c = z.detach().cuda().requires_grad_(True)
+    p = softmax_channels(z3c)
+    (p * R.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert float((p.detach().cpu() - F.softmax(z.detach(), dim=1)).abs().max()) < 1e-6
+    assert float((z3c.grad.cpu() - z3.grad).abs().max()) < 2e-6 * float(z3.grad.abs().max()) + 1e-9
+
+
 GUARD = 4096      # fp32 elements of sentinel behind every operand (16 KB: more than any vector over-read)
 
 

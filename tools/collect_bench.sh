@@ -2,7 +2,7 @@
 # Re-runs only the bench lines (profiles/<round>_pmc_traffic.json from collect_profiles.sh + summarize_profiles.py must exist,
 # bench.py reads the dominant kernel's HBM traffic from it).
 set -o pipefail
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 echo "== bench (default flags)"; timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"

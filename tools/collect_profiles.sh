@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): the bench lines and the rocprofv3 evidence for them.  Everything lands in
 # gpurun_out/<round>/ ; tools/summarize_profiles.py copies the summaries to keep into profiles/.
 set -o pipefail
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

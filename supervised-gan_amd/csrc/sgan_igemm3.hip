@@ -641,34 +641,6 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     const int nunits = ntaps * ncb;
     const int dy0 = G.pdy0[phz], dx0 = G.pdx0[phz];
 
-    // ---- patch staging: item e = 4 * patch pixel + k-group (8 channels = two 16-byte loads -> one hi and one lo chunk) ----
-    const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
-    const int kg = tid & 3;
-    int a_goff[A_IT], a_dst[A_IT];     // a_goff == OOB: outside the input (zero after the transform); a_dst < 0: no such patch pixel
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int p = (tid + it * NT) >> 2;
-        const int pr = p / PW, pc = p - pr * PW;
-        const int iy = ty0 * P.is + dy0 + pr, ix = tx0 * P.is + dx0 + pc;
-        const bool ok = (p < npix) & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
-        a_goff[it] = ok ? ((iy * P.Win + ix) * P.in_ld + kg * 8) << 2 : OOB;
-        const int ldst = S2 ? ((pr & 1) * 2 + (pc & 1)) * PLANE + (pr >> 1) * RS + (pc >> 1) * SG3P_PS : pr * RS + pc * SG3P_PS;
-        a_dst[it] = p < npix ? ldst + kg * 32 : -1;
-    }
-    f32x4 a_reg[A_IT][2];
-    auto issue_a = [&](int cb) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int o = ((a_goff[it] != OOB) & (cb < ncb)) ? a_goff[it] + cb * 128 : OOB;     // past the last block: zeros, never used
-            a_reg[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o, 0, 0));
-            a_reg[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o + 16, 0, 0));
-        }
-    };
-    // The first channel block's patch loads leave HERE, ahead of the tap table, the statistics -> scale / shift arithmetic (two dependent
-    // memory round trips and fp64 math) and the barrier that publishes them: their latency runs under all of that (in-kernel stamps:
-    // 1500 .. 2700 cycles of statistics work per workgroup start, 3000 .. 6000 for the first patch when it started after it).
-    issue_a(0);
-
     SG3P_MARK(5);
     if (tid < SGAN_MAX_TAPS) {
         const bool v = tid < ntaps;
@@ -694,6 +666,29 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
         }
     }
 
+    // ---- patch staging: item e = 4 * patch pixel + k-group (8 channels = two 16-byte loads -> one hi and one lo chunk) ----
+    const float pro_neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
+    const int kg = tid & 3;
+    int a_goff[A_IT], a_dst[A_IT];     // a_goff == OOB: outside the input (zero after the transform); a_dst < 0: no such patch pixel
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int p = (tid + it * NT) >> 2;
+        const int pr = p / PW, pc = p - pr * PW;
+        const int iy = ty0 * P.is + dy0 + pr, ix = tx0 * P.is + dx0 + pc;
+        const bool ok = (p < npix) & ((unsigned)iy < (unsigned)P.Hin) & ((unsigned)ix < (unsigned)P.Win);
+        a_goff[it] = ok ? ((iy * P.Win + ix) * P.in_ld + kg * 8) << 2 : OOB;
+        const int ldst = S2 ? ((pr & 1) * 2 + (pc & 1)) * PLANE + (pr >> 1) * RS + (pc >> 1) * SG3P_PS : pr * RS + pc * SG3P_PS;
+        a_dst[it] = p < npix ? ldst + kg * 32 : -1;
+    }
+    f32x4 a_reg[A_IT][2];
+    auto issue_a = [&](int cb) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int o = ((a_goff[it] != OOB) & (cb < ncb)) ? a_goff[it] + cb * 128 : OOB;     // past the last block: zeros, never used
+            a_reg[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o, 0, 0));
+            a_reg[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o + 16, 0, 0));
+        }
+    };
     auto store_a = [&](int cb) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
@@ -843,6 +838,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     auto prefetch = [&](auto K_) { next_b_addrs(); issue_b(K_); };
     auto maybe = [&](auto K_, int u) { if (u + decltype(K_)::value < nunits) iteration(K_); };
 
+    issue_a(0);
     prefetch(std::integral_constant<int, 0>{}); prefetch(std::integral_constant<int, 1>{});
     if constexpr (NSET == 4) { prefetch(std::integral_constant<int, 2>{}); prefetch(std::integral_constant<int, 3>{}); }
     store_a(0);

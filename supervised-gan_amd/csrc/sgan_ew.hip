@@ -1083,11 +1083,10 @@ __global__ __launch_bounds__(256) void sg_gauss_fwd_kernel(const float* in, int 
     }
     SG_SYNC();
     const int CQ = C >> 2;
-    const int64_t total = (int64_t)Ho * Wo * CQ;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e % CQ) * 4;
-        const int64_t pix = e / CQ;
-        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+    const int total = Ho * Wo * CQ;      // < 2^31 (host-checked): 32-bit index arithmetic (the 64-bit divisions were most of this kernel's time)
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int pix = e / CQ, c = (e - pix * CQ) * 4;
+        const int oy = pix / Wo, ox = pix - oy * Wo;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int ky0 = max(0, pad - oy * s), ky1 = min(k, H + pad - oy * s);
         const int kx0 = max(0, pad - ox * s), kx1 = min(k, W + pad - ox * s);
@@ -1096,7 +1095,7 @@ __global__ __launch_bounds__(256) void sg_gauss_fwd_kernel(const float* in, int 
             for (int kx = kx0; kx < kx1; ++kx)
                 acc += *reinterpret_cast<const f32x4*>(gs + (ky * k + kx) * C + c) * *reinterpret_cast<const f32x4*>(row + (int64_t)kx * in_ld);
         }
-        *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = acc;
+        *reinterpret_cast<f32x4*>(out + (int64_t)pix * out_ld + c) = acc;
     }
 }
 
@@ -1154,20 +1153,33 @@ __global__ __launch_bounds__(256) void sg_gauss_multi_fwd_kernel(const SgGaussTa
     }
     SG_SYNC();
     const int CQ = C >> 2;
-    const int64_t total = (int64_t)Ho * Wo * CQ;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e % CQ) * 4;
-        const int64_t pix = e / CQ;
-        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+    const int total = Ho * Wo * CQ;      // < 2^31 (host-checked): 32-bit index arithmetic (the 64-bit divisions were most of this kernel's time)
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int pix = e / CQ, c = (e - pix * CQ) * 4;
+        const int oy = pix / Wo, ox = pix - oy * Wo;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int ky0 = max(0, pad - oy * s), ky1 = min(k, H + pad - oy * s);
         const int kx0 = max(0, pad - ox * s), kx1 = min(k, W + pad - ox * s);
+        // a row of taps at a time, all its loads in flight before the first is used (round 2 walked the taps one dependent load after
+        // the other behind run-time loop bounds: 81 memory round trips per output of the scale-4 filter); taps outside the image or
+        // beyond k read a clamped address and meet a zero weight
         for (int ky = ky0; ky < ky1; ++ky) {
             const float* row = J.src + ((int64_t)(oy * s + ky - pad) * W + (ox * s - pad)) * J.src_ld + c;
-            for (int kx = kx0; kx < kx1; ++kx)
-                acc += *reinterpret_cast<const f32x4*>(gs + (ky * k + kx) * C + c) * *reinterpret_cast<const f32x4*>(row + (int64_t)kx * J.src_ld);
+            const float* grow = gs + ky * k * C + c;
+            for (int kb = 0; kb < k; kb += 9) {
+                f32x4 v[9], g4[9];
+#pragma unroll
+                for (int u = 0; u < 9; ++u) {
+                    const int kx = kb + u;
+                    const bool ok = (kx >= kx0) & (kx < kx1);
+                    v[u] = *reinterpret_cast<const f32x4*>(row + (int64_t)(ok ? kx : kx0) * J.src_ld);
+                    g4[u] = ok ? *reinterpret_cast<const f32x4*>(grow + kx * C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 9; ++u) acc += g4[u] * v[u];
+            }
         }
-        *reinterpret_cast<f32x4*>(J.dst + pix * J.dst_ld + c) = acc;
+        *reinterpret_cast<f32x4*>(J.dst + (int64_t)pix * J.dst_ld + c) = acc;
     }
 }
 
@@ -1192,30 +1204,37 @@ __global__ __launch_bounds__(256) void sg_gauss_multi_bwd_kernel(const SgGaussTa
     }
     SG_SYNC();
     const int H = T.j[0].Hd, W = T.j[0].Wd, CQ = C >> 2;
-    const int64_t total = (int64_t)H * W * CQ;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e % CQ) * 4;
-        const int64_t pix = e / CQ;
-        const int ix = (int)(pix % W), iy = (int)(pix / W);
+    const int total = H * W * CQ;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int pix = e / CQ, c = (e - pix * CQ) * 4;
+        const int iy = pix / W, ix = pix - iy * W;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int j = 0; j < T.n; ++j) {
             const SgGaussJob& J = T.j[j];
             const int k = J.k, pad = J.pad, s = J.s, Ho = J.Hs, Wo = J.Ws;
             const float* gj = gs + goff[j];
-            for (int ky = (iy + pad) % s; ky < k; ky += s) {
-                const int oy = (iy + pad - ky) / s;          // exact; decreasing in ky
-                if (iy + pad - ky < 0) break;
-                if (oy >= Ho) continue;
-                for (int kx = (ix + pad) % s; kx < k; kx += s) {
-                    const int ox = (ix + pad - kx) / s;
-                    if (ix + pad - kx < 0) break;
-                    if (ox >= Wo) continue;
-                    acc += *reinterpret_cast<const f32x4*>(gj + (ky * k + kx) * C + c) *
-                           *reinterpret_cast<const f32x4*>(J.src + ((int64_t)oy * Wo + ox) * J.src_ld + c);
+            // at most ceil(k / s)^2 <= 3 x 3 taps reach this image pixel (k = 4 sigma + 1, s = 2 sigma): all nine loads leave before the
+            // first is used, invalid ones read a clamped address against a zero weight (host-checked: k <= 3 s)
+            const int kyb = (iy + pad) % s, kxb = (ix + pad) % s;
+            f32x4 v[9], g4[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int ky = kyb + a * s, ny = iy + pad - ky;
+                const int oy = ny / s;          // exact when ny >= 0
+                const bool yok = (ky < k) & (ny >= 0) & (oy < Ho);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int kx = kxb + b * s, nx = ix + pad - kx;
+                    const int ox = nx / s;
+                    const bool ok = yok & (kx < k) & (nx >= 0) & (ox < Wo);
+                    v[a * 3 + b] = *reinterpret_cast<const f32x4*>(J.src + (ok ? ((int64_t)oy * Wo + ox) * J.src_ld : 0) + c);
+                    g4[a * 3 + b] = ok ? *reinterpret_cast<const f32x4*>(gj + (ky * k + kx) * C + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 9; ++u) acc += g4[u] * v[u];
         }
-        f32x4* o = reinterpret_cast<f32x4*>(T.j[0].dst + pix * T.j[0].dst_ld + c);
+        f32x4* o = reinterpret_cast<f32x4*>(T.j[0].dst + (int64_t)pix * T.j[0].dst_ld + c);
         *o = T.accumulate ? *o + acc : acc;
     }
 }
@@ -1240,6 +1259,10 @@ static int sg_fill_gauss(SgGaussTable& T, const sgan_gauss_job* jobs, int n, int
             return sgan_fail(SGAN_ERR_INVALID, "backward jobs must share the image gradient");
     }
     if (lds > 60000) return sgan_fail(SGAN_ERR_UNSUPPORTED, "gauss taps do not fit LDS");
+    for (int i = 0; i < n; ++i) {
+        if ((int64_t)jobs[i].H * jobs[i].W * (C >> 2) >= (1ll << 31)) return sgan_fail(SGAN_ERR_UNSUPPORTED, "gauss image too large (job %d)", i);
+        if (bwd && jobs[i].k > 3 * jobs[i].s) return sgan_fail(SGAN_ERR_UNSUPPORTED, "gauss backward: k <= 3 * stride (job %d)", i);
+    }
     return SGAN_OK;
 }
 
@@ -1823,14 +1846,29 @@ __global__ __launch_bounds__(256) void sg_to_nhwc_kernel(const float* src, int64
 // space): the kernel then IS the host-to-device copy of the batch, on the compute queue of the step's stream.
 __global__ __launch_bounds__(256) void sg_planes_to_nhwc4_kernel(const float* src, int64_t sc, int64_t sh, int H, int W, int Creal,
                                                                  float* dst, int dst_ld) {
-    const int64_t total = (int64_t)H * W;
-    for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (int64_t)gridDim.x * 256) {
-        const int x = (int)(pix % W), y = (int)(pix / W);
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // four consecutive pixels of a row per thread: one 16-byte load per plane (W % 4 == 0 and 16-byte aligned rows: the fast path;
+    // round 2 walked single pixels with 64-bit divisions -- 16 us for a 512 x 512 batch already in HBM), four 16-byte stores
+    const int W4 = W >> 2;
+    const bool fast = (W & 3) == 0 && (sh & 3) == 0 && (sc & 3) == 0 && ((uintptr_t)src & 15) == 0;
+    const int total = fast ? H * W4 : H * W;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        if (fast) {
+            const int y = t / W4, x = (t - y * W4) * 4;
+            f32x4 pl[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c < Creal) v[c] = src[c * sc + y * sh + x];
-        *reinterpret_cast<f32x4*>(dst + pix * dst_ld) = v;
+            for (int c = 0; c < 4; ++c)
+                pl[c] = c < Creal ? *reinterpret_cast<const f32x4*>(src + c * sc + (int64_t)y * sh + x) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            float* o = dst + ((int64_t)y * W + x) * dst_ld;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(o + (int64_t)i * dst_ld) = (f32x4){pl[0][i], pl[1][i], pl[2][i], pl[3][i]};
+        } else {
+            const int y = t / W, x = t - y * W;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < Creal) v[c] = src[c * sc + (int64_t)y * sh + x];
+            *reinterpret_cast<f32x4*>(dst + (int64_t)t * dst_ld) = v;
+        }
     }
 }
 

@@ -220,6 +220,12 @@ int sgan_softmax_fwd(const float* z, int32_t ld, int32_t npix, int32_t C, float*
 int sgan_softmax_bwd(const float* dp, int32_t dpld, const float* p, int32_t pld, int32_t npix, int32_t C, float* dz, int32_t dzld,
                      void* stream);
 
+/* ---- backward pass of a one-channel stride-1 head (the PatchGAN logits conv, models/networks.py:832-835) in one launch: the job
+ * lists of sgan_conv_dgrad_grouped and sgan_conv_wgrad_grouped for the SAME pass (wjobs may be NULL: input gradient only).  Returns 1
+ * when the layer is not of that type (Conv2d, stride 1, k <= 4, stored Cout 4 / logical 1, Cin >= 64, no `accumulate`): the caller
+ * then issues the two generic calls.  Exact fp32. */
+int sgan_conv_head_bwd(const sgan_conv_dgrad_job* djobs, const sgan_conv_wgrad_job* wjobs, int32_t n, void* stream);
+
 /* ---- transposed weight copy for backward-data ---------------------------------------------------
  * flat_t[off + tap][ci][co] = flat[off + tap][co][ci] for every conv segment (bias / affine ranges of the flat
  * parameter buffer are not touched).  Run after each optimizer step on the nets whose backward-data is needed. */

@@ -128,6 +128,7 @@ SIGNATURES = {
     "sgan_sgd_multi": [C.POINTER(AdamSeg), _I, _P, _F, _P],
     "sgan_adam_pack": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _P, _P, _P, _P, _P, C.POINTER(WtSeg), _I, _I, _P],
     "sgan_zero_multi": [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _I, _P],
+    "sgan_conv_head_bwd": [C.POINTER(ConvDgradJob), C.POINTER(ConvWgradJob), _I, _P],
     "sgan_ce_fwd": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "sgan_ce_bwd": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P],
     "sgan_softmax_fwd": [_P, _I, _I, _I, _P, _I, _P],

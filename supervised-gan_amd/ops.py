@@ -324,6 +324,15 @@ def conv_bwd_grouped(djobs, wjobs, dgrad_math=None):
     sgan_conv_bwd_fused covers the layer, the two grouped launches otherwise.  dgrad_math: arithmetic of the backward-data half
     ("f32" / "bf16x3"; None = the current mode)."""
     dm = _DGRAD_MATH if _DGRAD_MATH is not None else (_MATH_NAMES[dgrad_math] if dgrad_math else _math)
+    d0 = djobs[0][0]
+    if d0.Cout == 4 and d0.Cout_logical == 1 and d0.kind == L.CONV and d0.stride == 1 and len(djobs) == len(wjobs) and djobs[0][4] is not None:
+        _check_dgrad_jobs(djobs)
+        _check_wgrad_jobs(wjobs)
+        rc = L.lib().sgan_conv_head_bwd(_dgrad_array(djobs), _wgrad_array(wjobs), len(djobs), _stream())      # the one-channel head: one launch
+        if rc == 0:
+            return True
+        if rc < 0:
+            L.check(rc, "sgan_conv_head_bwd")
     if _math == L.MATH_BF16X3:
         _check_dgrad_jobs(djobs)
         _check_wgrad_jobs(wjobs)

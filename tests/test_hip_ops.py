@@ -817,6 +817,67 @@ def L_raw():
     return _lib.lib()
 
 
+@pytest.mark.parametrize("case", [(256, 4, 2, 10, 12, "in", 2), (64, 3, 1, 21, 19, "bn", 1), (512, 4, 2, 9, 9, "in", 2), (128, 4, 2, 33, 17, None, 2)],
+                         ids=lambda c: f"C{c[0]}_k{c[1]}p{c[2]}_{c[3]}x{c[4]}_{c[5]}")
+def test_head_backward_one_launch(hip, case):
+    """sgan_conv_head_bwd (sg_head_bwd_kernel): backward-data (+ activation derivative, norm-backward sums) and backward-weight / bias of
+    the one-channel stride-1 head in ONE launch, two problems grouped, against torch autograd through norm + activation + conv."""
+    from hip_utils import from_buf, from_master, master_weight, pad_vec, rel, stats_of, to_buf
+    from supervised_gan_amd import _lib
+    ops = hip
+    C, k, p, H, W, norm, act = case
+    g = torch.Generator().manual_seed(C + H)
+    w = (torch.randn(1, C, k, k, generator=g) * 0.05).requires_grad_(True)
+    b = (torch.randn(1, generator=g) * 0.1).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True) if norm == "bn" else None
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True) if norm == "bn" else None
+    wm = master_weight(w.detach(), False)
+    dw, db = torch.zeros_like(wm), torch.zeros(4, device="cuda")
+    djobs, wjobs, refs = [], [], []
+    for (h, w_) in ((H, W), (H + 5, W + 2)):
+        x = (torch.randn(1, C, h, w_, generator=g) * 1.5 + 0.3).requires_grad_(True)
+        a = _norm_act(x, norm, gamma, beta, act, 0.2)
+        out = F.conv2d(a, w, b, stride=1, padding=p)
+        R = torch.randn(out.shape, generator=g)
+        (out * R).sum().backward()
+        ho, wo = out.shape[2:]
+        desc = ops.conv_desc(0, k, 1, p, h, w_, C, ho, wo, 4, C, 1)
+        xb, Rb = to_buf(x.detach()), to_buf(R)
+        nd = ops.norm_desc(stats_of(x.detach()) if norm else None, pad_vec(gamma.detach()) if gamma is not None else None,
+                           pad_vec(beta.detach()) if beta is not None else None, h * w_, 1e-5, act, 0.2)
+        din = torch.full((h, w_, C), float("nan"), device="cuda")
+        sums = torch.zeros(2 * C, dtype=torch.float64, device="cuda") if norm else None
+        djobs.append((desc, Rb, wm._sgan_wt, din, xb, nd, sums, 0, False, True, 0))
+        wjobs.append((desc, xb, nd, Rb, dw, db))
+        refs.append((x, din, xb, nd, sums))
+    assert ops.conv_bwd_grouped(djobs, wjobs) is True
+    assert _lib.lib().sgan_last_kernel().decode() == "sg_head_bwd_kernel"
+    dgam = torch.zeros(C, device="cuda") if norm == "bn" else None
+    dbet = torch.zeros(C, device="cuda") if norm == "bn" else None
+    for x, din, xb, nd, sums in refs:
+        if norm:
+            ops.norm_bwd_apply(din, xb, nd, sums, dgam, dbet)
+    torch.cuda.synchronize()
+    for x, din, xb, nd, sums in refs:
+        assert rel(from_buf(din, C), x.grad) < 2e-5
+    assert rel(from_master(dw, k, C, 1, False), w.grad) < 2e-5
+    assert abs(float(db[0]) - float(b.grad)) < 2e-5 * max(1.0, abs(float(b.grad))) and float(db[1:].abs().max()) == 0.0
+    if norm == "bn":
+        assert rel(dgam, gamma.grad) < 1e-4 and rel(dbet, beta.grad) < 1e-4
+    # the untransposed weight layout and "input gradient only" (the generator step with --skip_wasted_D_wgrad)
+    din2 = torch.full_like(refs[0][1], float("nan"))
+    d0 = djobs[0]
+    from supervised_gan_amd import _lib as LL
+    arr = ops._dgrad_array([(d0[0], d0[1], wm, din2, d0[4], d0[5], None, 0, False, False, 0)])
+    assert LL.lib().sgan_conv_head_bwd(arr, None, 1, ops._stream()) == 0
+    torch.cuda.synchronize()
+    sums0 = torch.zeros(2 * C, dtype=torch.float64, device="cuda") if norm else None
+    din3 = torch.full_like(din2, float("nan"))
+    ops.conv_dgrad(d0[0], d0[1], wm, din3, d0[4], d0[5], sums0)      # the generic kernel, same raw result (before the norm backward)
+    torch.cuda.synchronize()
+    assert rel(din2, din3) < 2e-6
+
+
 @pytest.mark.parametrize("C,H,W,weighted", [(3, 67, 67, False), (3, 35, 19, True), (5, 64, 48, True), (12, 9, 7, False)])
 def test_cross_entropy_and_softmax_kernels(hip, C, H, W, weighted):
     """sgan_ce_fwd / sgan_ce_bwd against F.cross_entropy (class weights, an int64 label map with ignored pixels, and the one-class

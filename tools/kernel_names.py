@@ -21,7 +21,7 @@ def short(name):
     m = re.match(r"(sg_wgrad3_kernel)<(\d+,\d+,\d+,\d+),(?:true|false)>$", n)
     if m:
         return f"{m.group(1)}<{m.group(2)}>"
-    m = re.match(r"sg_bwd_fused_kernel<(\d+),\d+,(?:true|false)>$", n)      # backward-data variant, backward-weight tile, prologue flag
+    m = re.match(r"sg_bwd_fused_kernel<(\d+),\d+,(?:true|false)(?:,(?:true|false))?>$", n)      # backward-data variant, backward-weight tile, prologue flag, fp16 planes
     if m:
         return "sg_bwd_fused_kernel<f32 dgrad>" if m.group(1) == "4" else "sg_bwd_fused_kernel"
     m = re.match(r"(sg_wgrad_kernel)<(.*),(true|false)>$", n)
@@ -30,6 +30,8 @@ def short(name):
     m = re.match(r"sg_conv_c4_kernel<\d+,\d+,(?:true|false)>$", n)      # column blocks, row blocks per wave, full epilogue
     if m:
         return "sg_conv_c4_kernel"
+    if re.match(r"sg_head_bwd_kernel<\d+>$", n):      # kernel size
+        return "sg_head_bwd_kernel"
     m = re.match(r"sg_conv_head_kernel<\d+>$", n)      # tile height
     if m:
         return "sg_conv_head_kernel"

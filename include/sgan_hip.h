@@ -509,6 +509,12 @@ int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev,
  * at dst[(h * W + w) * Cs + c] of a padded NHWC buffer (channels C .. Cs-1 are not touched: zero them once). */
 int sgan_normal_fill_nhwc(float* dst, int32_t C, int32_t H, int32_t W, int32_t Cs, uint64_t seed, uint64_t* offset_dev,
                           int32_t advance, void* stream);
+/* Two latents of the same shape drawn back to back (dst_a first; the values two sgan_normal_fill_nhwc calls give, the stream offset
+ * advanced past both) by one single-block launch that also zeroes `zero` (zero_bytes, a multiple of 16, may be 0): the generator pass
+ * that opens with two latents (FCGANModel.sample_noise_and_prefetch: the reference's sample_noise() of one step, fcgan_model.py:192-193,
+ * and forward() of the next, :179) needs its statistics arena cleared at the same point.  <= 65536 values per latent. */
+int sgan_normal_fill_nhwc_pair(float* dst_a, float* dst_b, int32_t C, int32_t H, int32_t W, int32_t Cs, uint64_t seed,
+                               uint64_t* offset_dev, void* zero, int64_t zero_bytes, void* stream);
 int sgan_rng_advance(uint64_t* offset_dev, uint64_t by, void* stream);
 
 #ifdef __cplusplus

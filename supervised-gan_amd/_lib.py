@@ -135,6 +135,7 @@ SIGNATURES = {
     "sgan_softmax_bwd": [_P, _I, _P, _I, _I, _I, _P, _I, _P],
     "sgan_normal_fill": [_P, _L, C.c_uint64, _P, _I, _P],
     "sgan_normal_fill_nhwc": [_P, _I, _I, _I, _I, C.c_uint64, _P, _I, _P],
+    "sgan_normal_fill_nhwc_pair": [_P, _P, _I, _I, _I, _I, C.c_uint64, _P, _P, C.c_int64, _P],
     "sgan_profile_enable": [_I],
     "sgan_profile_count": [],
     "sgan_profile_mark": [_P],

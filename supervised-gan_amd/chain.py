@@ -77,8 +77,8 @@ class _BwdArena:
     """Zeroed fp64 scratch for the backward sums, carved from the same fill as the forward statistics.  A second
     backward through the same forward (retain_graph) gets a fresh zeroed buffer."""
 
-    def __init__(self, buf, rep=0):
-        self.buf, self.dev = buf, buf.device
+    def __init__(self, buf, rep=0, dev=None):
+        self.buf, self.dev = buf, (buf.device if buf is not None else dev)      # buf None: every backward takes its sums from the step's pool
         self.rep = rep           # replica stride of the forward statistics AND of `buf` (they share one ops.stat_arena)
         self.rep_bwd = rep       # replica stride of what take() handed out last
 
@@ -399,8 +399,23 @@ class ChainNet(nn.Module):
         return self._norm_of(li, stats, count)
 
     # ---- forward / backward programs ----------------------------------------------------------
-    def run_forward(self, x: torch.Tensor, update_running=True):
-        """x: [H, W, Cs] NHWC buffer.  Returns (outs, stats): raw conv outputs and per-layer stats."""
+    def _kept_arena(self, n_stats, device, zeroed=False):
+        """Forward statistics of a KEPT forward (run_forward(keep=True)): their own allocation in the replicated layout of
+        ops.stat_arena, outside the step's arena pool -- begin_step() of the NEXT step must not zero them (forward_pair).
+        zeroed: the caller has cleared `self._kept_full` on this stream already."""
+        full = getattr(self, "_kept_full", None)
+        reps = ops.stat_replicas() if ops._STAT_REPLICATED else 1
+        if full is None or full.numel() != reps * max(n_stats, 1) or full.device != device:
+            assert not zeroed
+            full = self._kept_full = torch.zeros(reps * max(n_stats, 1), dtype=torch.float64, device=device)
+        elif not zeroed:
+            ops.zero_multi([full])
+        return full[:max(n_stats, 1)]
+
+    def run_forward(self, x: torch.Tensor, update_running=True, keep=False):
+        """x: [H, W, Cs] NHWC buffer.  Returns (outs, stats): raw conv outputs and per-layer stats.
+        keep: remember this call's buffers as `self._kept` (input, outputs, statistics in an allocation of their own, backward sums
+        taken from the pool at backward time) so that forward_pair() can later write another forward of this net into them."""
         ops.require_gpu(x, type(self).__name__)
         if self._flat.device != x.device:
             raise SganError(f"module parameters are on {self._flat.device}, input on {x.device}")
@@ -409,8 +424,12 @@ class ChainNet(nn.Module):
         geo = self._geometry(H, W)
         final_act = self._take_call_act()
         n_stats = sum(2 * L.cout_s for L in self.layers if L.norm)
-        # one zero-fill serves the forward statistics and the backward sums (second half, consumed by run_backward)
-        arena = ops.stat_arena(2 * n_stats, x.device)
+        if keep:
+            assert not any(L.drop > 0 for L in self.layers), "a kept forward has no dropout state"
+            arena = self._kept_arena(n_stats, x.device)
+        else:
+            # one zero-fill serves the forward statistics and the backward sums (second half, consumed by run_backward)
+            arena = ops.stat_arena(2 * n_stats, x.device)
         rep = ops.stat_rep(arena)
         stats, o = [], 0
         for L in self.layers:
@@ -419,7 +438,7 @@ class ChainNet(nn.Module):
                 o += 2 * L.cout_s
             else:
                 stats.append(None)
-        stats.append(_BwdArena(arena[n_stats:], rep))
+        stats.append(_BwdArena(None, rep, x.device) if keep else _BwdArena(arena[n_stats:], rep))
         stats[-1].final_act = final_act
         outs = []
         cur = x
@@ -467,6 +486,8 @@ class ChainNet(nn.Module):
                     _, _, _, ho, wo = geo[li]
                     rl.append((stats[li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo, L.cout_s, rep))
             ops.bn_running_update(rl, BN_MOMENTUM)
+        if keep:
+            self._kept = dict(x=x, outs=outs, stats=stats, n_stats=n_stats, final_act=final_act)
         return outs, stats
 
     def run_backward(self, x, outs, stats, dout, need_dx: bool, want_wgrad: bool):
@@ -583,7 +604,8 @@ class _ChainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net: "ChainNet", x_logical, *params):
         xb = net._prepare_input(x_logical)
-        outs, stats = net.run_forward(xb["chain_in"])
+        keep, net._keep_next = getattr(net, "_keep_next", False), False      # one-shot: set by the caller right before forward()
+        outs, stats = net.run_forward(xb["chain_in"], keep=True) if keep else net.run_forward(xb["chain_in"])
         ctx.net, ctx.xb, ctx.outs, ctx.stats = net, xb, outs, stats
         ctx.want_wgrad = net.compute_param_grads and any(ctx.needs_input_grad[2:])
         ctx.need_dx = ctx.needs_input_grad[1]
@@ -601,6 +623,52 @@ class _ChainFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # grouped execution: several chains of the same architecture, one kernel launch per layer
 # ------------------------------------------------------------------------------------------------
+class _AdoptFn(_ChainFn):
+    """Autograd node over the buffers of net._kept after forward_pair() has written a forward of `x_logical` into them: no kernel
+    runs here, the backward is _ChainFn's."""
+
+    @staticmethod
+    def forward(ctx, net: "ChainNet", x_logical, *params):
+        kept = net._kept
+        xb = net._prepare_input(x_logical)
+        assert xb["chain_in"].data_ptr() == kept["x"].data_ptr(), "forward_pair() wrote the kept forward from another input buffer"
+        ctx.net, ctx.xb, ctx.outs, ctx.stats = net, xb, kept["outs"], kept["stats"]
+        ctx.want_wgrad = net.compute_param_grads and any(ctx.needs_input_grad[2:])
+        ctx.need_dx = ctx.needs_input_grad[1]
+        return ops.logical_view(kept["outs"][-1], net.layers[-1].cout)
+
+
+def forward_pair(net: "ChainNet", x_a, x_b, arena_zeroed=False):
+    """(net(x_a), net(x_b)) with ONE launch per layer (the two calls see the same weights: e.g. the re-draw that ends a training step
+    and the forward() that opens the next one, models/fcgan_model.py:178-193).  net(x_a) is computed without autograd.  net(x_b)'s
+    outputs and statistics are written INTO the buffers of the net's kept forward (run_forward(keep=True); x_b must be that call's
+    input buffer) and come back under a fresh autograd node: whatever was built on those buffers -- a hipGraph that captured the
+    backward of that forward -- sees a new forward without one having run on its own.  BatchNorm running statistics are updated for
+    x_a, then for x_b, as two calls in that order would.  arena_zeroed: the caller has already cleared net._kept_full on this stream
+    (ops.normal_fill_nhwc_pair does it in the launch that draws the two latents)."""
+    kept = net._kept
+    xa = net._prepare_input(x_a.detach())["chain_in"]
+    xb = net._prepare_input(x_b.detach())["chain_in"]
+    assert xb.data_ptr() == kept["x"].data_ptr() and tuple(xa.shape) == tuple(xb.shape)
+    arena = net._kept_arena(kept["n_stats"], xb.device, arena_zeroed)      # zeroed here (one launch) unless the caller did
+    stats_b, o = [], 0
+    for L in net.layers:
+        if L.norm:
+            stats_b.append(arena[o: o + 2 * L.cout_s])
+            o += 2 * L.cout_s
+        else:
+            stats_b.append(None)
+    stats_b.append(_BwdArena(None, ops.stat_rep(arena), xb.device))
+    stats_b[-1].final_act = net.final_act
+    stats_b[-1].drop = {}
+    kept["stats"], kept["final_act"] = stats_b, net.final_act
+    with torch.no_grad():
+        outs, _ = _grouped_forward([net, net], [xa, xb], given=[None, (kept["outs"], stats_b)])
+    ya = net._wrap_output(ops.logical_view(outs[0][-1], net.layers[-1].cout))
+    yb = net._wrap_output(_AdoptFn.apply(net, x_b, *list(net.model.parameters())))
+    return ya, yb
+
+
 def _same_architecture(a: "ChainNet", b: "ChainNet") -> bool:
     if len(a.layers) != len(b.layers) or a.final_act != b.final_act or getattr(a, "no_group", False) or getattr(b, "no_group", False):
         return False
@@ -613,18 +681,24 @@ def can_group(nets) -> bool:
     return 1 < len(nets) <= 8 and all(_same_architecture(nets[0], n) for n in nets[1:])
 
 
-def _grouped_forward(nets, xs):
-    """nets[j] applied to xs[j] ([H,W,Cs] buffers); per layer ONE grouped launch.  Returns per-job (outs, stats)."""
+def _grouped_forward(nets, xs, given=None):
+    """nets[j] applied to xs[j] ([H,W,Cs] buffers); per layer ONE grouped launch.  Returns per-job (outs, stats).
+    given[j] = (outs, stats) of job j supplied by the caller (forward_pair: the buffers of a kept forward, statistics zeroed), None = fresh."""
     dev = xs[0].device
     J = len(nets)
+    given = given or [None] * J
     geos = [n._geometry(x.shape[0], x.shape[1]) for n, x in zip(nets, xs)]
     per_job = sum(2 * L.cout_s for L in nets[0].layers if L.norm)
-    arena = ops.stat_arena(2 * per_job * J, dev)   # forward statistics | backward sums, in replicated copies
+    fresh = [j for j in range(J) if given[j] is None]
+    arena = ops.stat_arena(2 * per_job * len(fresh), dev)   # forward statistics | backward sums, in replicated copies
     rep = ops.stat_rep(arena)
-    bwd = _BwdArena(arena[per_job * J:], rep)
+    bwd = _BwdArena(arena[per_job * len(fresh):], rep)
     stats = []
     for j in range(J):
-        st, o = [], j * per_job
+        if given[j] is not None:
+            stats.append(given[j][1])
+            continue
+        st, o = [], fresh.index(j) * per_job
         for L in nets[j].layers:
             if L.norm:
                 st.append(arena[o: o + 2 * L.cout_s])
@@ -641,10 +715,11 @@ def _grouped_forward(nets, xs):
         for j, net in enumerate(nets):
             L = net.layers[li]
             desc, h, w, ho, wo = geos[j][li]
-            out = torch.empty((ho, wo, L.cout_s), dtype=torch.float32, device=dev)
+            out = given[j][0][li] if given[j] is not None else torch.empty((ho, wo, L.cout_s), dtype=torch.float32, device=dev)
+            assert tuple(out.shape) == (ho, wo, L.cout_s)
             in_norm = net._norm_of(li - 1, stats[j], h * w) if li > 0 else None
             wt, b = net._wb(L)
-            jobs.append((desc, cur[j], in_norm, wt, b, out, stats[j][li], 0, rep))
+            jobs.append((desc, cur[j], in_norm, wt, b, out, stats[j][li], 0, stats[j][-1].rep))
             outs[j].append(out)
             cur[j] = out
         ops.conv_fwd_grouped(jobs, nets[0].final_act if li == nL - 1 else ACT_NONE)
@@ -655,7 +730,7 @@ def _grouped_forward(nets, xs):
                 if L.norm == "bn":
                     nb = net._bn_boxes[L.key]
                     _, _, _, ho, wo = geos[j][li]
-                    rl.append((stats[j][li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo, L.cout_s, rep))
+                    rl.append((stats[j][li], nb.running_mean, nb.running_var, nb.num_batches_tracked, L.cout, ho * wo, L.cout_s, stats[j][-1].rep))
             ops.bn_running_update(rl, BN_MOMENTUM)
     return outs, stats
 

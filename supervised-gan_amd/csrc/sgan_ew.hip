@@ -2284,6 +2284,39 @@ __global__ __launch_bounds__(256) void sg_normal_fill_kernel(float* dst, int64_t
 
 __global__ void sg_rng_advance_kernel(uint64_t* offset, uint64_t by) { offset[0] += by; }
 
+// Two small latents drawn back to back (dst_a first: the values two sg_normal_fill_kernel launches give) by ONE block, which also
+// zeroes `zero` (zero_n16 x 16 bytes: the statistics arena of the generator pass that reads the latents) and advances the stream.
+__global__ __launch_bounds__(256) void sg_normal_fill_pair_kernel(float* dst_a, float* dst_b, int64_t n, uint64_t seed, uint64_t* offset,
+                                                                  int hw, int cs, float4* zero, int64_t zero_n16) {
+    const uint64_t off = offset[0];
+    SG_SYNC();
+    const int64_t nq = (n + 3) >> 2;
+    if (threadIdx.x == 0) offset[0] = off + 2 * (uint64_t)nq;
+    for (int64_t i = threadIdx.x; i < zero_n16; i += 256) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t q2 = threadIdx.x; q2 < 2 * nq; q2 += 256) {
+        const uint64_t ctr = off + (uint64_t)q2;
+        float* dst = q2 < nq ? dst_a : dst_b;
+        const int64_t q = q2 < nq ? q2 : q2 - nq;
+        uint32_t r[4];
+        sg_philox((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        float z[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0,1]
+            const float u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);       // [0,1)
+            const float rad = sqrtf(-2.0f * logf(u1));
+            float sn, csn;
+            sincosf(6.28318530717958647692f * u2, &sn, &csn);
+            z[2 * h] = rad * csn;
+            z[2 * h + 1] = rad * sn;
+        }
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = q * 4 + j;
+            if (i < n) dst[cs ? (i % hw) * cs + i / hw : i] = z[j];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sg_dropout_mask_kernel(float* mask, int64_t n, float p, float keep_scale, uint64_t seed,
                                                               const uint64_t* offset) {
     const uint64_t off = offset ? offset[0] : 0;
@@ -2342,6 +2375,18 @@ static int sg_normal_fill_launch(float* dst, int64_t n, int hw, int cs, uint64_t
 extern "C" int sgan_normal_fill(float* dst, int64_t n, uint64_t seed, uint64_t* offset_dev, int32_t advance, void* stream) {
     SGAN_CHECK(dst && n > 0, "bad argument");
     return sg_normal_fill_launch(dst, n, 1, 0, seed, offset_dev, advance, stream);
+}
+
+extern "C" int sgan_normal_fill_nhwc_pair(float* dst_a, float* dst_b, int32_t C, int32_t H, int32_t W, int32_t Cs, uint64_t seed,
+                                          uint64_t* offset_dev, void* zero, int64_t zero_bytes, void* stream) {
+    SGAN_CHECK(dst_a && dst_b && dst_a != dst_b && offset_dev && C > 0 && H > 0 && W > 0 && Cs >= C, "bad argument");
+    const int64_t n = (int64_t)C * H * W;
+    SGAN_CHECK(n <= 65536 && zero_bytes >= 0 && zero_bytes <= (1 << 22) && (zero_bytes % 16) == 0 && (zero || zero_bytes == 0),
+               "one block draws both latents: <= 65536 values each, <= 4 MiB (multiple of 16 bytes) to zero");
+    hipLaunchKernelGGL(sg_normal_fill_pair_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dst_a, dst_b, n, seed, offset_dev, H * W, Cs,
+                       (float4*)zero, zero_bytes / 16);
+    SGAN_LAUNCH_CHECK();
+    return SGAN_OK;
 }
 
 extern "C" int sgan_normal_fill_nhwc(float* dst, int32_t C, int32_t H, int32_t W, int32_t Cs, uint64_t seed, uint64_t* offset_dev,

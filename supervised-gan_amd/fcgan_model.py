@@ -95,15 +95,20 @@ class FCGANModel(BaseModel):
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
 
     # ---- data ---------------------------------------------------------------------------------
-    def _draw_noise(self):
+    def _draw_noise(self, alt=False):
+        """alt: into the second latent buffer (sample_noise_and_prefetch: two latents alive at once)."""
+        if alt and getattr(self, '_noise_buf_alt', None) is None:
+            self._noise_buf_alt = torch.zeros_like(self._noise_buf)
+            self._noise_alt = ops.logical_view(self._noise_buf_alt, self.opt.noise_nc)
+        buf, view = (self._noise_buf_alt, self._noise_alt) if alt else (self._noise_buf, self.noise_)
         if self.noise_source is not None:
             z = self.noise_source()
-            self.noise_.copy_(z)
-        elif self._noise_buf is not None:
-            ops.normal_fill_nhwc(self._noise_buf, self.opt.noise_nc, self._rng_seed, self._rng_offset)
+            view.copy_(z)
+        elif buf is not None:
+            ops.normal_fill_nhwc(buf, self.opt.noise_nc, self._rng_seed, self._rng_offset)
         else:
-            ops.normal_fill(self.noise_, self._rng_seed, self._rng_offset)
-        return self.noise_
+            ops.normal_fill(view, self._rng_seed, self._rng_offset)
+        return view
 
     def set_input(self, input):
         AorB = self.opt.which_direction == 'A'
@@ -129,9 +134,48 @@ class FCGANModel(BaseModel):
     def forward(self):
         self.real = self.input
         self.noise = self._draw_noise()
+        self.netG._keep_next = getattr(self, '_prefetch', False)      # graphed step: forward_pair() refills THIS call's buffers
         self.fake = self.netG.forward(self.noise)
 
-    sample_noise = forward
+    def sample_noise(self):
+        self.real = self.input
+        self.noise = self._draw_noise()
+        self.fake = self.netG.forward(self.noise)
+
+    # ---- the step's last re-draw and the next step's forward() as one pass over the generator (graph_step.GraphedStep) -----------
+    def prefetch_supported(self):
+        """The re-draw after the last G update (fcgan_model.py:192-193) and the forward() that opens the next step (:179) see the same
+        generator weights and independent latents: GraphedStep runs them as ONE two-problem pass (chain.forward_pair) when the
+        generator is a plain chain without dropout state and the latents are drawn on the device."""
+        from .chain import ChainNet
+        o = self.opt
+        return (self.isTrain and o.n_update_G > 1 and o.n_update_D == 1 and self.noise_source is None and self._noise_buf is not None
+                and isinstance(self.netG, ChainNet) and hasattr(self.netG, '_wrap_output') and type(self.netG).__name__ == 'FCGANGenerator'
+                and not any(L.drop > 0 for L in self.netG.layers))
+
+    def sample_noise_and_prefetch(self):
+        """sample_noise() of this step, then forward() of the next one: the same two latents in the same order, one launch per layer.
+        `fake` is the re-drawn sample (what the reference leaves behind after a step); adopt_prefetched() installs the other one."""
+        from .chain import forward_pair
+        if getattr(self, '_noise_buf_alt', None) is None:
+            self._noise_buf_alt = torch.zeros_like(self._noise_buf)
+            self._noise_alt = ops.logical_view(self._noise_buf_alt, self.opt.noise_nc)
+        za, zb = self._noise_alt, self.noise_
+        full = getattr(self.netG, '_kept_full', None)
+        fused = full is not None and full.numel() * 8 <= (1 << 22) and za.numel() <= 65536
+        if fused:      # both latents and the cleared statistics arena of the pass in one launch
+            ops.normal_fill_nhwc_pair(self._noise_buf_alt, self._noise_buf, self.opt.noise_nc, self._rng_seed, self._rng_offset, full)
+        else:
+            self._draw_noise(alt=True)
+            self._draw_noise()
+        self.noise = za
+        self.fake, self._fake_next = forward_pair(self.netG, za, zb, arena_zeroed=fused)
+
+    def adopt_prefetched(self):
+        """What forward() would have done: `noise`, `fake` of the step that starts now (already computed by sample_noise_and_prefetch)."""
+        self.real = self.input
+        self.noise = self.noise_
+        self.fake = self._fake_next
 
     def _pool_source(self):
         return self.fake

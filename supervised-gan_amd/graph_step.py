@@ -11,7 +11,15 @@ The step is therefore captured once into hipGraphs and replayed:
 Everything that changes from step to step lives in device memory the kernels read and advance
 themselves (Adam step counter and LR, Philox offset, BatchNorm num_batches_tracked), so replays are
 faithful.  With data parallelism the gradient all-reduce is not captured: graph B is cut at the
-two/three synchronisation points and RCCL runs between the pieces on the same stream."""
+two/three synchronisation points and RCCL runs between the pieces on the same stream.
+
+Prefetch (fcgan with n_update_G > 1): the re-draw that ends a step and the forward() that opens the next one are two generator
+passes over the same weights, each a chain of launches too small to fill the card (~100 us for 4 GFLOP).  The graphed step runs
+them as ONE two-problem pass at the end of graph B (FCGANModel.sample_noise_and_prefetch -> chain.forward_pair) which writes the
+second problem into the buffers of the forward the captured backward was built on; graph A disappears.  Same latents in the same
+order, same BatchNorm running-statistics updates in the same order.  SGAN_NO_G_PREFETCH=1 switches it off."""
+import os
+
 import torch
 
 from . import ops
@@ -29,6 +37,8 @@ class GraphedStep:
         assert opt.batchSize == 1
         self._captured = False
         self._warmup_steps = warmup_steps
+        self._prefetch = (not hasattr(model, "graph_spec") and hasattr(model, "prefetch_supported") and model.prefetch_supported()
+                          and os.environ.get("SGAN_NO_G_PREFETCH", "0") in ("", "0"))
 
     # the step cut into capturable segments; "sync_D"/"sync_G" are the data-parallel hand-off points
     def _program(self):
@@ -39,6 +49,8 @@ class GraphedStep:
             prog += ["sync_G", [m.optimizer_G.step]]
             if o.n_update_G > 1:
                 prog[-1].append(m.sample_noise)
+        if self._prefetch:
+            prog[-1][-1] = m.sample_noise_and_prefetch
         return prog
 
     def _spec(self):
@@ -52,13 +64,35 @@ class GraphedStep:
         m = self.m
         assert getattr(m, "noise_source", None) is None, "graphed step draws its latents on the device"
         spec = self._spec()
-        for _ in range(self._warmup_steps):   # lazy state (optimizer moments, caches) must exist before capture
+        for _ in range(self._warmup_steps - (1 if self._prefetch else 0)):   # lazy state (optimizer moments, caches) must exist before capture
             m.set_input(example_input)
             m.optimize_parameters()
+        if self._prefetch:
+            # the last warm-up step runs the graph's own program eagerly: the arena pool then holds the sequence of arenas the
+            # capture is going to ask for, and the step ends with the first two-problem pass (the next forward() is in place)
+            # ON the stream the capture will use: autograd runs a node's backward on the stream its forward ran on, and the capture's
+            # first backward walks the node this pass leaves behind (a backward hopping to the default stream mid-capture crashed
+            # hipStreamEndCapture)
+            m._prefetch = True
+            m.set_input(example_input)
+            self._cap_stream = torch.cuda.Stream(device=m.device)
+            self._cap_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._cap_stream):
+                ops.begin_step()
+                m.forward()
+                for item in self._program():
+                    if isinstance(item, list):
+                        for f in item:
+                            f()
+                    elif m.grad_sync is not None:
+                        m.grad_sync(m.optimizer_D if item == "sync_D" else m.optimizer_G)
+            torch.cuda.current_stream().wait_stream(self._cap_stream)
         for name in ("optimizer_D", "optimizer_D1", "optimizer_D2", "optimizer_G"):
             if hasattr(m, name):
                 getattr(m, name).sync_lr()
         torch.cuda.synchronize()
+        if self._prefetch:
+            m.adopt_prefetched()
         self.pools = spec["pools"]
         shapes = [tuple(t.shape) for t in spec["sources"]()]
         self.fake_for_D = [torch.zeros((h, w, ops.pad4(nc)), dtype=torch.float32, device=m.device) for (_, nc, h, w) in shapes]
@@ -70,14 +104,20 @@ class GraphedStep:
         if dist_on:
             torch.distributed.barrier()
             torch.cuda.synchronize()
-        self.gA = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.gA, capture_error_mode=self._mode):
-            ops.begin_step()      # the statistics arenas of the whole step (graph A and every piece of graph B), one launch
-            m.forward()
-            self._fakeA = spec["sources"]()
-        pool = self.gA.pool()
+        if self._prefetch:
+            self.gA = None
+            self._fakeA = spec["sources"]()      # the kept forward's output: every replay's two-problem pass rewrites it in place
+            pool = None
+            merged = [ops.begin_step]
+        else:
+            self.gA = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.gA, capture_error_mode=self._mode):
+                ops.begin_step()      # the statistics arenas of the whole step (graph A and every piece of graph B), one launch
+                m.forward()
+                self._fakeA = spec["sources"]()
+            pool = self.gA.pool()
+            merged = []
         self.segs = []
-        merged = []
         for item in spec["program"]:
             if isinstance(item, tuple):          # ("sync", optimizer): data-parallel hand-off point
                 if m.grad_sync is not None:
@@ -95,13 +135,17 @@ class GraphedStep:
             self.segs.append(("graph", self._capture(merged, pool, self._mode)))
         self._captured = True
         torch.cuda.synchronize()
+        if self._prefetch:
+            self._fake_last = m.fake      # the re-drawn sample of the step just finished: what `fake` is between steps
 
-    @staticmethod
-    def _capture(fns, pool, mode="global"):
+    def _capture(self, fns, pool, mode="global"):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+        if pool is None:
+            pool = getattr(self, "_pool", None)
+        with torch.cuda.graph(g, pool=pool, stream=getattr(self, "_cap_stream", None), capture_error_mode=mode):
             for f in fns:
                 f()
+        self._pool = g.pool()
         return g
 
     def step(self, data=None):
@@ -109,7 +153,10 @@ class GraphedStep:
         m = self.m
         if data is not None:
             m.set_input(data)
-        self.gA.replay()
+        if self._prefetch:
+            m.adopt_prefetched()      # host attributes only: the forward itself ran at the end of the previous step
+        else:
+            self.gA.replay()
         for pool, src, buf in zip(self.pools, self._fakeA, self.fake_for_D):      # the reference's query order
             # a copy KERNEL on the step's stream: Tensor.copy_ of a contiguous tensor is hipMemcpyAsync, which on this stack starts
             # ~100 us after the work queued before it (measured: profiles/r02 timeline), a bubble in every step
@@ -120,6 +167,8 @@ class GraphedStep:
                 obj.replay()
             else:
                 m.grad_sync(obj)
+        if self._prefetch:
+            m.fake, m.noise = self._fake_last, m._noise_alt
 
 
 GraphedFCGANStep = GraphedStep

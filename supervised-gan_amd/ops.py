@@ -727,6 +727,17 @@ def normal_fill_nhwc(buf, C_real, seed, offset_dev=None, advance=True):
                                           int(bool(advance)), _stream()), "sgan_normal_fill_nhwc")
 
 
+def normal_fill_nhwc_pair(buf_a, buf_b, C_real, seed, offset_dev, zero=None):
+    """normal_fill_nhwc(buf_a) then normal_fill_nhwc(buf_b) -- same values, same advance of the stream -- as ONE launch that also
+    zeroes the contiguous tensor `zero` (the statistics arena of the pass that reads the two latents)."""
+    H, W, Cs = buf_a.shape
+    assert buf_a.shape == buf_b.shape and buf_a.is_contiguous() and buf_b.is_contiguous() and buf_a.dtype == buf_b.dtype == torch.float32
+    assert zero is None or zero.is_contiguous()
+    L.check(L.lib().sgan_normal_fill_nhwc_pair(_ptr(buf_a), _ptr(buf_b), int(C_real), H, W, Cs, C.c_uint64(seed & (2 ** 64 - 1)),
+                                               _ptr(offset_dev), _ptr(zero), zero.numel() * zero.element_size() if zero is not None else 0,
+                                               _stream()), "sgan_normal_fill_nhwc_pair")
+
+
 # ------------------------------------------------------------------------------------------------
 # NCHW <-> NHWC boundary.  Tensors handed to user code are logical [1, C, H, W] *views* of our
 # padded NHWC buffers (zero copy); a weak registry lets us recognise such a view (or its .detach())

@@ -250,6 +250,53 @@ def test_grouped_chains_equal_individual_chains(N):
         d.compute_param_grads = True
 
 
+def test_forward_pair_refills_a_kept_forward(N):
+    """chain.forward_pair: G(za) and G(zb) as one two-problem pass, G(zb) written into the buffers of an earlier kept forward and handed
+    back under a fresh autograd node == two separate calls (outputs, parameter gradients, BatchNorm running statistics in call order)."""
+    from supervised_gan_amd import chain, ops
+
+    def make():
+        G = N.define_G(2, 0, 8, "fcgan", "instance", False, n_layers_G=5, use_fcn=True, noise_nc=8, gpu_ids=[0])
+        G.load_state_dict(O.init_fcgan_g(11, 8, 2, 8, 5))
+        return G
+
+    def latent(seed):
+        buf = torch.zeros(2, 2, 8, device="cuda")
+        v = ops.logical_view(buf, 8)
+        v.copy_(O.np_normal(seed, (1, 8, 2, 2)).cuda())
+        return v
+
+    r = O.np_normal(102, (1, 2, 128, 128)).cuda()
+    Gr, Gp = make(), make()
+    # reference: separate calls  z0 | za, zb (+ backward through G(zb)) | zc, zd (+ backward through G(zd))
+    Gr.forward(latent(1))
+    ref = []
+    for sa, sb in ((2, 3), (4, 5)):
+        ya = Gr.forward(latent(sa)).detach().clone()
+        Gr.zero_grad_flat()
+        yb = Gr.forward(latent(sb))
+        (yb * r).sum().backward()
+        torch.cuda.synchronize()
+        ref.append((ya, yb.detach().clone(), Gr._gflat.clone(), {k: v.clone() for k, v in Gr.state_dict().items() if "running" in k or "tracked" in k}))
+    # kept forward + two refills of its buffers
+    zb = latent(1)
+    Gp._keep_next = True
+    y0 = Gp.forward(zb)
+    kept_out = Gp._kept["outs"][-1]
+    for (sa, sb), (ra, rb, rg, rbuf) in zip(((2, 3), (4, 5)), ref):
+        zb.copy_(O.np_normal(sb, (1, 8, 2, 2)).cuda())          # the kept call's input buffer, new latent
+        Gp.zero_grad_flat()
+        ya, yb = chain.forward_pair(Gp, latent(sa), zb)
+        assert yb.data_ptr() == kept_out.data_ptr() and ya.grad_fn is None and yb.grad_fn is not None
+        (yb * r).sum().backward()
+        torch.cuda.synchronize()
+        assert rel(ya, ra) < 1e-4 and rel(yb, rb) < 1e-4
+        assert O.rel_err(Gp._gflat, rg) < 1e-3
+        for k, v in rbuf.items():
+            assert rel(Gp.state_dict()[k].double(), v.double()) < 1e-5, k
+    assert y0.data_ptr() == kept_out.data_ptr()
+
+
 # ------------------------------------------------------------------------------------------------
 # U-Net generator (models/networks.py:318-419)
 # ------------------------------------------------------------------------------------------------

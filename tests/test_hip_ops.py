@@ -525,6 +525,17 @@ def test_normal_fill_nhwc_is_the_flat_fill_in_place(hip):
     assert torch.equal(buf[..., :Cr].permute(2, 0, 1).contiguous().view(-1), flat)
     assert float(buf[..., Cr:].min()) == 7.0 and float(buf[..., Cr:].max()) == 7.0
     assert int(o1) == int(o2) == 11 + (Cr * H * W + 3) // 4
+    # two latents + a cleared arena in one launch == two calls (bit for bit, same advance of the stream)
+    a1, b1 = torch.full((H, W, 8), 7.0, device="cuda"), torch.full((H, W, 8), 7.0, device="cuda")
+    a2, b2 = a1.clone(), b1.clone()
+    z = torch.full((1000,), 3.0, dtype=torch.float64, device="cuda")
+    o3, o4 = o1.clone(), o1.clone()
+    ops.normal_fill_nhwc(a1, Cr, 99, o3)
+    ops.normal_fill_nhwc(b1, Cr, 99, o3)
+    ops.normal_fill_nhwc_pair(a2, b2, Cr, 99, o4, z[:998])
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2) and not torch.equal(a2[..., :Cr], b2[..., :Cr]) and int(o3) == int(o4)
+    assert float(z[:998].abs().max()) == 0.0 and float(z[998:].min()) == 3.0
 
 
 def test_fused_gan_loss_one_kernel(hip):

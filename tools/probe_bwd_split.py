@@ -7,7 +7,9 @@ from supervised_gan_amd import ops, _lib
 from hip_utils import derived_copies
 from bench_thin import timeit
 ops.set_math("bf16x3")
-for (cin, cout, s, sizes) in [(128, 256, 1, [65, 33, 17] * 2), (64, 128, 2, [129, 65, 33] * 2), (128, 256, 1, [65, 33, 17])]:
+CASES = [(128, 256, 1, [65, 33, 17] * 2, True), (64, 128, 2, [129, 65, 33] * 2, True), (128, 256, 1, [65, 33, 17], True),
+         (32, 64, 2, [257, 129, 65] * 2, False), (32, 64, 2, [257, 129, 65], False), (64, 128, 2, [129, 65, 33], True)]
+for (cin, cout, s, sizes, normed) in CASES:
     k, p = 4, 2
     w = torch.randn(k * k * cout * cin, device="cuda") * 0.05
     wm, wt = derived_copies(w, k, cout, cin)
@@ -18,9 +20,9 @@ for (cin, cout, s, sizes) in [(128, 256, 1, [65, 33, 17] * 2), (64, 128, 2, [129
         desc = ops.conv_desc(0, k, s, p, H, H, cin, Ho, Ho, cout)
         x = torch.randn(H, H, cin, device="cuda"); dy = torch.randn(Ho, Ho, cout, device="cuda"); din = torch.empty(H, H, cin, device="cuda")
         st = torch.zeros(2 * cin, dtype=torch.float64, device="cuda"); st[cin:] = H * H
-        sums = ops.stat_arena(2 * cin, "cuda")
-        nd = ops.norm_desc(st, None, None, H * H, 1e-5, 2, 0.2)
-        dj.append((desc, dy, wt, din, x, nd, sums, 0, False, True, ops.stat_rep(sums)))
+        sums = ops.stat_arena(2 * cin, "cuda") if normed else None
+        nd = ops.norm_desc(st if normed else None, None, None, H * H, 1e-5, 2, 0.2)
+        dj.append((desc, dy, wt, din, x, nd, sums, 0, False, True, ops.stat_rep(sums) if normed else 0))
         wj.append((desc, x, nd, dy, dw, db))
         keep.append((x, dy, din, st, sums, nd, desc))
     gf = sum(2.0 * d[0].Hout * d[0].Wout * cin * cout * 16 for d in dj) / 1e9

@@ -223,3 +223,178 @@ extern "C" int sgan_conv_head_bwd(const sgan_conv_dgrad_job* djobs, const sgan_c
     sg_prof_end(st, g_sgan_last_kernel);
     return SGAN_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Forward of the same head (and of any one-channel stride-1 Conv2d with k 3 or 4 on >= 64 channels: the CRN output conv) in the
+// shape of the backward kernel above.  sg_conv_head_kernel (sgan_igemm.hip) walks the channels in blocks of 32 through one LDS
+// patch with two barriers per block -- a chain of 16 barrier-separated phases that a launch of ~230 workgroups cannot overlap
+// (22 us for 0.1 GFLOP).  Here a thread owns one CHANNEL and the input is the stationary operand: a wave walks the
+// (R + K - 1) x (16 + K - 1) input patch of an R x 16 tile of result pixels for its 64 channels, every loaded value is normalised /
+// activated once and feeds the up to K * K results it reaches (R * 16 accumulators in registers, every index a compile-time constant),
+// the next patch row's loads are in flight while this row is computed, and there is no barrier until the end: the 64 lanes'
+// accumulators are folded with a butterfly (31 or 63 shuffles), the waves' sums meet in LDS atomics, one thread per pixel writes.
+// A workgroup = 4 waves = all channel chunks of one tile (C = 256: one chunk each) or, with fewer chunks than waves, several
+// row groups.  Exact fp32.  Reference op: the last nn.Conv2d of NLayerDiscriminator (models/networks.py:832-835) forward.
+// ------------------------------------------------------------------------------------------
+#define SGF_TW 16
+template <int K, int R>
+__global__ __launch_bounds__(256) void sg_conv_head2_kernel(const SgIgemmParams G, const int pad, const int nrg) {
+    sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();
+    constexpr int PC = SGF_TW + K - 1, PR = R + K - 1, NV = R * SGF_TW;
+    __shared__ float osum[4 * NV];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int g = 0;
+    for (int gi = 1; gi < G.nprob; ++gi)
+        if ((int)blockIdx.x >= G.q[gi].tile0[0]) g = gi;
+    const SgLocal P = sg_local(G, g);
+    const int tile = blockIdx.x - G.q[g].tile0[0], tiles_x = G.q[g].tile0[1];
+    const int TY = R * nrg;                                   // result rows per workgroup
+    const int oy0 = (tile / tiles_x) * TY, ox0 = (tile % tiles_x) * SGF_TW;
+    const int Ck = P.Ck, wpr = 4 / nrg;                       // waves per row group = channel chunks in flight
+    const int rg = wave / wpr, ch0 = wave % wpr;
+    const int nch = (Ck + 63) >> 6;
+    for (int i = tid; i < 4 * NV; i += 256) osum[i] = 0.f;
+    const bool pnorm = P.pro.stats != nullptr;
+    const float neg = P.pro.act == SGAN_ACT_NONE ? 1.f : (P.pro.act == SGAN_ACT_RELU ? 0.f : P.pro.slope);
+    const int ry0 = oy0 + rg * R;                             // first result row of this wave
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.in), 0, 0x7FFFFFFF, 0x00020000);
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    if (ry0 < P.Hout) {
+        for (int ch = ch0; ch < nch; ch += wpr) {
+            const int c = ch * 64 + lane;
+            const bool cok = c < Ck;
+            const int cc = cok ? c : Ck - 1;
+            // unconditional loads from clamped addresses, masked afterwards (a load under a branch is waited for at the join)
+            float wv[K * K];
+#pragma unroll
+            for (int t = 0; t < K * K; ++t) {
+                const float wl = P.w[G.taps[G.tap0[0] + t].w_off + cc];
+                wv[t] = cok ? wl : 0.f;
+            }
+            float sc = 1.f, sh = 0.f;
+            if (pnorm) {
+                float mean, rstd;
+                sg_mean_rstd(P.pro, Ck, cc, mean, rstd);
+                const float gm = P.pro.gamma ? P.pro.gamma[cc] : 1.f;
+                const float bt = P.pro.beta ? P.pro.beta[cc] : 0.f;
+                sc = gm * rstd;
+                sh = bt - mean * sc;
+            }
+            // buffer loads: per patch column one 32-bit lane offset (fixed for the tile), per patch row one scalar offset
+            float xs[PC], xn[PC];
+            int voff[PC];
+#pragma unroll
+            for (int pc = 0; pc < PC; ++pc) voff[pc] = (min(max(ox0 - pad + pc, 0), P.Win - 1) * P.in_ld + cc) << 2;
+            auto load_row = [&](int pr, float (&dst)[PC]) {
+                const int iy = min(max(ry0 - pad + pr, 0), P.Hin - 1);
+                const int soff = __builtin_amdgcn_readfirstlane(iy * P.Win * P.in_ld * 4);
+#pragma unroll
+                for (int pc = 0; pc < PC; ++pc) dst[pc] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff[pc], soff, 0));
+            };
+            load_row(0, xs);
+#pragma unroll
+            for (int pr = 0; pr < PR; ++pr) {
+                if (pr + 1 < PR) load_row(pr + 1, xn);
+                const int iy = ry0 - pad + pr;
+                const bool rok = cok && (unsigned)iy < (unsigned)P.Hin;
+#pragma unroll
+                for (int pc = 0; pc < PC; ++pc) {
+                    const int ix = ox0 - pad + pc;
+                    const float y = xs[pc] * sc + sh;
+                    float a = y > 0.f ? y : y * neg;
+                    a = (rok && (unsigned)ix < (unsigned)P.Win) ? a : 0.f;      // zero padding applies AFTER norm + activation
+#pragma unroll
+                    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) {
+                            const int r = pr - ky, q = pc - kx;      // result (row, column) this (input pixel, tap) feeds
+                            if (r >= 0 && r < R && q >= 0 && q < SGF_TW) acc[r * SGF_TW + q] = fmaf(a, wv[ky * K + kx], acc[r * SGF_TW + q]);
+                        }
+                }
+                if (pr + 1 < PR) {
+#pragma unroll
+                    for (int pc = 0; pc < PC; ++pc) xs[pc] = xn[pc];
+                }
+            }
+        }
+    }
+    // fold the 64 lanes: at each step a lane keeps half of its values and adds the partner's copies of them; after log2(NV) steps
+    // every lane holds ONE result (value index = the lane bits used so far), summed over the lanes that differ in the remaining bits
+    int idx = 0;
+    {
+        int n = NV;
+        float* v = acc;
+#pragma unroll
+        for (int off = 32; off >= 1 && n > 1; off >>= 1) {
+            const bool hi = lane & off;
+            n >>= 1;
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                const float send = hi ? v[i] : v[i + n];
+                const float keep = hi ? v[i + n] : v[i];
+                v[i] = keep + __shfl_xor(send, off);
+            }
+            idx = idx * 2 + (hi ? 1 : 0);
+        }
+    }
+    float tot = acc[0];
+    if constexpr (NV == 32) tot += __shfl_xor(tot, 1);        // 32 values on 64 lanes: lanes l and l ^ 1 hold halves of the same result
+    // value index: the first step split [0, NV/2) | [NV/2, NV) by its lane bit, the next split each half, ... : idx read as a binary number
+    SG_SYNC();      // osum zeroed
+    if (NV == 64 || !(lane & 1)) atomicAdd(&osum[rg * NV + idx], tot);
+    SG_SYNC();
+    for (int i = tid; i < TY * SGF_TW; i += 256) {
+        const int oy = oy0 + i / SGF_TW, ox = ox0 + (i % SGF_TW);
+        if (oy >= P.Hout || ox >= P.Wout) continue;
+        float v = osum[i] + (P.bias ? P.bias[0] : 0.f);
+        if (P.out_act == SGAN_ACT_TANH) v = tanhf(v);
+        f32x4 o4 = (f32x4){v, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 1; n < 4; ++n) {       // padding channels carry the bias like the generic kernels (zero in practice)
+            float b = P.bias ? P.bias[n] : 0.f;
+            if (P.out_act == SGAN_ACT_TANH) b = tanhf(b);
+            o4[n] = b;
+        }
+        *reinterpret_cast<f32x4*>(P.out + ((int64_t)oy * P.Wout + ox) * P.out_ld) = o4;
+    }
+}
+
+// 0: launched; 1: not covered (the caller goes on to sg_conv_head_kernel); called after sg_head_plan() accepted the launch
+int sg_launch_head2(SgIgemmParams& P, hipStream_t st) {
+    static const int off = getenv("SGAN_NO_HEAD2") ? 1 : 0;
+    if (off || P.Ck < 64 || P.nphase != 1 || P.is != 1 || P.os != 1 || P.w_ks != 1) return 1;
+    const int nt = P.ntaps[0];
+    const int K = nt == 16 ? 4 : nt == 9 ? 3 : 0;
+    if (!K) return 1;
+    const int dy0 = P.taps[P.tap0[0]].dy, dx0 = P.taps[P.tap0[0]].dx;
+    if (dy0 != dx0 || dy0 > 0 || -dy0 >= K) return 1;
+    for (int t = 0; t < nt; ++t) {      // row-major k x k taps
+        const SgTap& tp = P.taps[P.tap0[0] + t];
+        if (tp.dy != dy0 + t / K || tp.dx != dx0 + t % K) return 1;
+    }
+    const int pad = -dy0;
+    const int nch = (P.Ck + 63) / 64;
+    const int nrg = nch >= 3 ? 1 : nch == 2 ? 2 : 4;      // row groups per workgroup: waves that have no channel chunk of their own take rows
+    static const int r_env = getenv("SGAN_HEAD2_R") ? atoi(getenv("SGAN_HEAD2_R")) : 0;      // tuning knob: 2 or 4 result rows per wave
+    const int R = r_env == 4 ? 4 : 2;
+    int t = 0;
+    for (int g = 0; g < P.nprob; ++g) {
+        const int tx = (P.q[g].Wout + SGF_TW - 1) / SGF_TW, ty = (P.q[g].Hout + R * nrg - 1) / (R * nrg);
+        P.q[g].tile0[0] = t;
+        P.q[g].tile0[1] = tx;
+        t += tx * ty;
+    }
+    if (t == 0) return SGAN_OK;
+    sg_prof_begin(st);
+    if (K == 4 && R == 2) hipLaunchKernelGGL((sg_conv_head2_kernel<4, 2>), dim3(t), dim3(256), 0, st, P, pad, nrg);
+    else if (K == 4) hipLaunchKernelGGL((sg_conv_head2_kernel<4, 4>), dim3(t), dim3(256), 0, st, P, pad, nrg);
+    else if (R == 2) hipLaunchKernelGGL((sg_conv_head2_kernel<3, 2>), dim3(t), dim3(256), 0, st, P, pad, nrg);
+    else hipLaunchKernelGGL((sg_conv_head2_kernel<3, 4>), dim3(t), dim3(256), 0, st, P, pad, nrg);
+    SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = "sg_conv_head2_kernel";
+    sg_prof_end(st, g_sgan_last_kernel);
+    return SGAN_OK;
+}

@@ -121,6 +121,8 @@ int sg_igemm3_eligible(const SgIgemmParams& P);
 int sg_launch_igemm3(SgIgemmParams& P, hipStream_t st, float* ws, int64_t ws_bytes);
 int64_t sg_igemm3_workspace_need(const SgIgemmParams& P);
 
+int sg_launch_head2(SgIgemmParams& P, hipStream_t st);      // sgan_head.hip: one-channel stride-1 head forward; 1 = not covered
+
 // ---- one launch for a layer's backward-data and backward-weight (sgan_fused.hip) ----
 int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out);
 int sg_build_dgrad_params(const sgan_conv_dgrad_job* jobs, int32_t n, SgIgemmParams& P, bool allow_f16 = true);   // sgan_igemm.hip: the argument checks + parameter block of sgan_conv_dgrad_grouped

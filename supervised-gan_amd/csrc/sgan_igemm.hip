@@ -1580,7 +1580,10 @@ static int sg_dispatch_igemm(SgIgemmParams& P, hipStream_t st, float* ws, int64_
     P.slab_stride = 0;
     if (sg_use_small_n(P)) {   // skinny result: direct kernels
         if (sg_use_scatter4(P)) return sg_launch_scatter4(P, st);
-        if (sg_head_plan(P)) return sg_launch_head(P, st);
+        if (sg_head_plan(P)) {
+            const int r2 = sg_launch_head2(P, st);      // sgan_head.hip: channel-per-thread form (k 3 / 4, >= 64 channels)
+            return r2 != 1 ? r2 : sg_launch_head(P, st);
+        }
         const int ktot = sg_max_k(P);
         if (ktot >= 2048) return sg_launch_small_n<64, 1, 8>(P, st);
         if (ktot >= 256) return sg_launch_small_n<16, 2, 4>(P, st);

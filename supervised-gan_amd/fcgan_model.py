@@ -265,7 +265,7 @@ class FCGANModel(BaseModel):
         return self._each_D[self.n_netD:].sum()
 
     def optimize_parameters(self):
-        ops.begin_step()      # one launch zeroes every statistics arena of the step
+        ops.begin_step(self.optimizer_D.take_zeroing())      # one launch zeroes every statistics arena of the step and D's gradients
         self.forward()
         for _ in range(self.opt.n_update_D):
             self.optimizer_D.zero_grad()

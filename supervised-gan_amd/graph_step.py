@@ -53,6 +53,11 @@ class GraphedStep:
             prog[-1][-1] = m.sample_noise_and_prefetch
         return prog
 
+    def _begin(self):
+        """Start of a step: the arenas' zeroing launch, which also clears the gradient buffers optimizer_D.zero_grad() is about to."""
+        opt_d = getattr(self.m, "optimizer_D", None)
+        ops.begin_step(opt_d.take_zeroing() if (hasattr(opt_d, "take_zeroing") and not hasattr(self.m, "graph_spec")) else ())
+
     def _spec(self):
         m = self.m
         if hasattr(m, "graph_spec"):
@@ -78,7 +83,7 @@ class GraphedStep:
             self._cap_stream = torch.cuda.Stream(device=m.device)
             self._cap_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._cap_stream):
-                ops.begin_step()
+                self._begin()
                 m.forward()
                 for item in self._program():
                     if isinstance(item, list):
@@ -108,11 +113,11 @@ class GraphedStep:
             self.gA = None
             self._fakeA = spec["sources"]()      # the kept forward's output: every replay's two-problem pass rewrites it in place
             pool = None
-            merged = [ops.begin_step]
+            merged = [self._begin]
         else:
             self.gA = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.gA, capture_error_mode=self._mode):
-                ops.begin_step()      # the statistics arenas of the whole step (graph A and every piece of graph B), one launch
+                self._begin()      # the statistics arenas of the whole step (graph A and every piece of graph B), one launch
                 m.forward()
                 self._fakeA = spec["sources"]()
             pool = self.gA.pool()

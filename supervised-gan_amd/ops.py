@@ -172,10 +172,16 @@ class _ArenaPool:
     def __init__(self):
         self.slots, self.clean, self.cur = [], [], 0
 
-    def begin_step(self):
+    def begin_step(self, also_zero=()):
         dirty = [i for i, c in enumerate(self.clean) if not c]
-        if dirty:
-            zero_multi([self.slots[i] for i in dirty])
+        extra = []
+        for t in also_zero:      # e.g. the discriminators' gradient arena: cleared by the same launch instead of a fill of its own
+            if t.is_contiguous() and t.data_ptr() % 16 == 0 and (t.numel() * t.element_size()) % 16 == 0:
+                extra.append(t)
+            else:
+                t.zero_()
+        if dirty or extra:
+            zero_multi([self.slots[i] for i in dirty] + extra)
             for i in dirty:
                 self.clean[i] = True
         self.cur = 0
@@ -203,10 +209,11 @@ _NO_ARENA_POOL = __import__("os").environ.get("SGAN_NO_ARENA_POOL", "0") not in 
 _ARENAS = _ArenaPool()
 
 
-def begin_step():
+def begin_step(also_zero=()):
     """Call at the start of a training step (the trainers' optimize_parameters and the captured graph do): one launch zeroes every
-    statistics arena the step is going to use."""
-    _ARENAS.begin_step()
+    statistics arena the step is going to use -- and the tensors in `also_zero` (FusedAdam.take_zeroing(): the gradient buffers an
+    optimizer would otherwise clear with a fill of its own in zero_grad())."""
+    _ARENAS.begin_step(also_zero)
 
 
 def stat_arena(n, device):

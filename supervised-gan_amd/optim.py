@@ -83,6 +83,14 @@ class FusedAdam:
         for _, ag, off, n in self._segs:
             ag[off: off + n].zero_()
 
+    def take_zeroing(self):
+        """The gradient buffers the next zero_grad() would clear, for a caller that clears them itself RIGHT NOW on this stream
+        (ops.begin_step(also_zero=...): the step's one zeroing launch); that zero_grad() then does nothing."""
+        if self._grads_clean:
+            return []
+        self._grads_clean = True
+        return [ag[off: off + n] for _, ag, off, n in self._segs]
+
     def _fused_plan(self):
         """(nets, conv ranges relative to the segment, derived buffers) when the whole optimizer is ONE arena segment whose networks
         keep their derived weight copies at the arena's offsets -- then Adam, the three copies and the gradient zeroing are one launch
@@ -195,6 +203,9 @@ class AdamGroups:
     def zero_grad(self, set_to_none=False):
         for o in self.optimizers:
             o.zero_grad()
+
+    def take_zeroing(self):
+        return [t for o in self.optimizers for t in o.take_zeroing()]
 
     def step(self):
         for o in self.optimizers:

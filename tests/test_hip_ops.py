@@ -828,6 +828,43 @@ def L_raw():
     return _lib.lib()
 
 
+@pytest.mark.parametrize("case", [(256, 4, 2, 10, 12, "in", 2, 0), (64, 3, 1, 21, 19, "bn", 1, 3), (512, 4, 2, 9, 9, "in", 2, 0), (128, 4, 2, 33, 17, None, 2, 0),
+                                  (96, 3, 1, 18, 35, "in", 0, 3), (256, 4, 1, 40, 23, None, 0, 0)],
+                         ids=lambda c: f"C{c[0]}_k{c[1]}p{c[2]}_{c[3]}x{c[4]}_{c[5]}")
+def test_head_forward_channel_per_thread(hip, case):
+    """sg_conv_head2_kernel: the one-channel stride-1 head forward (thread = channel, input-stationary), two problems of different
+    size in one launch, norm / activation on load, bias, optional tanh -- against torch."""
+    from hip_utils import from_buf, master_weight, pad_vec, rel, stats_of, to_buf
+    from supervised_gan_amd import _lib
+    ops = hip
+    C, k, p, H, W, norm, act, out_act = case
+    g = torch.Generator().manual_seed(7 * C + H)
+    w = torch.randn(1, C, k, k, generator=g) * 0.05
+    b = torch.randn(1, generator=g) * 0.1
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)) if norm == "bn" else None
+    beta = (0.1 * torch.randn(C, generator=g)) if norm == "bn" else None
+    wm, bb = master_weight(w, False), pad_vec(b)
+    jobs, refs = [], []
+    for (h, w_) in ((H, W), (H + 7, W + 3)):
+        x = torch.randn(1, C, h, w_, generator=g) * 1.5 + 0.3
+        ref = F.conv2d(_norm_act(x, norm, gamma, beta, act, 0.2), w, b, stride=1, padding=p)
+        if out_act == 3:
+            ref = torch.tanh(ref)
+        ho, wo = ref.shape[2:]
+        desc = ops.conv_desc(0, k, 1, p, h, w_, C, ho, wo, 4, C, 1)
+        nd = ops.norm_desc(stats_of(x) if norm else None, pad_vec(gamma) if gamma is not None else None, pad_vec(beta) if beta is not None else None,
+                           h * w_, 1e-5, act, 0.2)
+        out = torch.full((ho, wo, 4), float("nan"), device="cuda")
+        jobs.append((desc, to_buf(x), nd, wm, bb, out, None, 0, 0))
+        refs.append((out, ref))
+    ops.conv_fwd_grouped(jobs, out_act)
+    torch.cuda.synchronize()
+    assert _lib.lib().sgan_last_kernel().decode() == "sg_conv_head2_kernel"
+    for out, ref in refs:
+        assert rel(from_buf(out, 1), ref) < 2e-5
+        assert float(out[..., 1:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("case", [(256, 4, 2, 10, 12, "in", 2), (64, 3, 1, 21, 19, "bn", 1), (512, 4, 2, 9, 9, "in", 2), (128, 4, 2, 33, 17, None, 2)],
                          ids=lambda c: f"C{c[0]}_k{c[1]}p{c[2]}_{c[3]}x{c[4]}_{c[5]}")
 def test_head_backward_one_launch(hip, case):

@@ -189,7 +189,9 @@ FLIPS_ALLOWED = {
     "fcgan_step_full.npz": [_D_FIRST],
     "fcgan_step_full_nug1.npz": [_D_FIRST],
     "cgan_step_full.npz": [_D_FIRST, r"(step1|probeG)/gradD_0/model\.(2|8)\.weight"],
-    "twostage_full.npz": [_D_FIRST, r"probe/gradD2_1/model\.11\.weight"],
+    # (model.5: two sampled elements moved when the CRN's one-channel output conv changed kernels (sg_conv_head2_kernel, 1e-7-level
+    # differences in fake_B); with SGAN_NO_HEAD2=1 the tensor is back inside the strict bound)
+    "twostage_full.npz": [_D_FIRST, r"probe/gradD2_1/model\.(5|11)\.weight"],
     "twostage_small.npz": [_D_FIRST], "twostage_factd_small.npz": [_D_FIRST], "twostage_multiclass_small.npz": [_D_FIRST],
     "twostage_nocycle_small.npz": [_D_FIRST],
     "cgan_cycle_small.npz": [_D_FIRST], "cgan_cycle_small_d34.npz": [_D_FIRST],

@@ -31,6 +31,7 @@ def jobs(sizes, C=256, k=4, p=2):
         x = torch.randn(H, H, C, device="cuda"); r = torch.zeros(Ho, Ho, 4, device="cuda"); r[..., 0].normal_()
         w = torch.randn(k * k * 4 * C, device="cuda") * 0.05
         wm, wt = derived_copies(w, k, 4, C)
+        wt._wm = wm
         dw = torch.zeros_like(w); db = torch.zeros(4, device="cuda")
         st = torch.zeros(2 * C, dtype=torch.float64, device="cuda"); st[C:] = H * H
         nrm = ops.norm_desc(st, None, None, H * H, 1e-5, 2, 0.2)
@@ -47,6 +48,9 @@ if __name__ == "__main__":
         os.environ.pop("SGAN_NO_HEAD_BWD", None)
         t = timeit(lambda: ops.conv_bwd_grouped(dj, wj))
         print(f"head {name}  one launch   {t:7.1f} us  {_lib.lib().sgan_last_kernel().decode()}")
+        fj = [(d[0], d[4], d[5], wm_, None, torch.empty(d[0].Hout, d[0].Wout, 4, device="cuda"), None, 0, 0) for d, wm_ in zip(dj, [j[2]._wm for j in dj])]
+        tfw = timeit(lambda: ops.conv_fwd_grouped(fj, 0))
+        print(f"head {name}  forward      {tfw:7.1f} us  {_lib.lib().sgan_last_kernel().decode()}")
         if os.environ.get("PROBE_GENERIC"):
             t1 = timeit(lambda: ops.conv_dgrad_grouped(dj)); k1 = _lib.lib().sgan_last_kernel().decode()
             t2 = timeit(lambda: ops.conv_wgrad_grouped(wj)); k2 = _lib.lib().sgan_last_kernel().decode()

@@ -3,7 +3,7 @@ import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-idx = [i for i, n in enumerate(names) if "sg_adam_kernel" in n]
+idx = [i for i, n in enumerate(names) if "sg_adam" in n]
 # a step = three Adam launches (D, G, G); take a window in the middle of the run
 k = (len(idx) // 2) // 3 * 3
 while k + 3 < len(idx) and idx[k + 1] - idx[k] < idx[k + 2] - idx[k + 1]:      # align on the D update (the longest gap follows it)

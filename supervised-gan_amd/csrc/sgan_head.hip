@@ -213,6 +213,17 @@ extern "C" int sgan_conv_head_bwd(const sgan_conv_dgrad_job* djobs, const sgan_c
         tiles += Q.tiles_x * ((d->Hin + SGH_TY - 1) / SGH_TY);
     }
     if (tiles == 0) return SGAN_OK;
+    // Every tile adds its dW with same-address fp32 atomics (~75 ns each, serial per cache line): fine for the PatchGAN heads (2 x 45
+    // tiles per weight tensor: 19 us against 36 for the two generic launches), break-even at ~150 tiles (131 x 131 map: 42 us against
+    // 44), hopeless on a full-size map (CRN output conv, 64 -> 1 on 512 x 512 = 2048 tiles: 300 us against ~70).  Past the limit the
+    // caller runs the generic pair.
+    static const int max_tiles = getenv("SGAN_HEAD_BWD_MAX_TILES") ? atoi(getenv("SGAN_HEAD_BWD_MAX_TILES")) : 128;
+    for (int g = 0; g < n && wjobs; ++g) {
+        int per_dw = 0;
+        for (int h = 0; h < n; ++h)
+            if (P.q[h].dw == P.q[g].dw) per_dw += P.q[h].tiles_x * ((P.q[h].H + SGH_TY - 1) / SGH_TY);
+        if (P.q[g].dw && per_dw > max_tiles) return 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     sg_prof_begin(st);
     const dim3 grid(tiles, (P.C + SGH_CH - 1) / SGH_CH);

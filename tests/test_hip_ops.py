@@ -926,6 +926,25 @@ def test_head_backward_one_launch(hip, case):
     assert rel(din2, din3) < 2e-6
 
 
+def test_head_backward_declines_full_size_maps(hip):
+    """Past ~128 tiles per weight tensor the same-address atomics of sg_head_bwd_kernel cost more than the two generic launches
+    (CRN output conv on 512 x 512: 300 us against 70): sgan_conv_head_bwd answers 1 and conv_bwd_grouped runs the generic pair."""
+    from hip_utils import master_weight
+    from supervised_gan_amd import _lib
+    ops = hip
+    C, k, p, H, W = 64, 3, 1, 160, 160
+    wm = master_weight(torch.randn(1, C, k, k) * 0.05, False)
+    x, R = torch.randn(H, W, C, device="cuda"), torch.randn(H, W, 4, device="cuda")
+    desc = ops.conv_desc(0, k, 1, p, H, W, C, H, W, 4, C, 1)
+    nd = ops.norm_desc(None, None, None, H * W, 1e-5, 1, 0.0)
+    din, dw, db = torch.empty(H, W, C, device="cuda"), torch.zeros_like(wm), torch.zeros(4, device="cuda")
+    dj, wj = [(desc, R, wm._sgan_wt, din, x, nd, None, 0, False, True, 0)], [(desc, x, nd, R, dw, db)]
+    assert _lib.lib().sgan_conv_head_bwd(ops._dgrad_array(dj), ops._wgrad_array(wj), 1, ops._stream()) == 1
+    ops.conv_bwd_grouped(dj, wj)
+    torch.cuda.synchronize()
+    assert _lib.lib().sgan_last_kernel().decode() != "sg_head_bwd_kernel" and float(dw.abs().max()) > 0
+
+
 @pytest.mark.parametrize("C,H,W,weighted", [(3, 67, 67, False), (3, 35, 19, True), (5, 64, 48, True), (12, 9, 7, False)])
 def test_cross_entropy_and_softmax_kernels(hip, C, H, W, weighted):
     """sgan_ce_fwd / sgan_ce_bwd against F.cross_entropy (class weights, an int64 label map with ignored pixels, and the one-class

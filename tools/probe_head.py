@@ -43,8 +43,13 @@ def jobs(sizes, C=256, k=4, p=2):
 
 
 if __name__ == "__main__":
-    for name, sizes in (("n=6", [66, 34, 18] * 2), ("n=3", [66, 34, 18])):
-        dj, wj = jobs(sizes)
+    C = int(os.environ.get("PROBE_C", "256"))
+    cases = (("n=6", [66, 34, 18] * 2), ("n=3", [66, 34, 18]))
+    if os.environ.get("PROBE_SIZES"):      # e.g. PROBE_SIZES=66,66,34,34
+        sz = [int(v) for v in os.environ["PROBE_SIZES"].split(",")]
+        cases = ((f"C{C} {sz}", sz),)
+    for name, sizes in cases:
+        dj, wj = jobs(sizes, C)
         os.environ.pop("SGAN_NO_HEAD_BWD", None)
         t = timeit(lambda: ops.conv_bwd_grouped(dj, wj))
         print(f"head {name}  one launch   {t:7.1f} us  {_lib.lib().sgan_last_kernel().decode()}")

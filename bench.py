@@ -477,6 +477,7 @@ def main():
     dt = time.perf_counter() - t0
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
+    gs_bytes, gs_calls = getattr(getattr(model, "grad_sync", None), "bytes", 0), getattr(getattr(model, "grad_sync", None), "calls", 0)      # of the timed steps
     # the same steps with the batches in pinned host memory (round 2's headline regime: the input gather reads over PCIe inside the step)
     host_ring = synthetic_ring(8, rank, device, where="host")
     kh = min(args.steps, 100)
@@ -510,8 +511,8 @@ def main():
         gsync = model.grad_sync
         rccl = {"backend": torch.distributed.get_backend(), "rccl_ranks": int(round(float(one.item()))),
                 "world_size": torch.distributed.get_world_size(),
-                "allreduce_bytes_per_step": int(getattr(gsync, "bytes", 0) / max(args.steps, 1)),
-                "allreduce_calls_per_step": getattr(gsync, "calls", 0) / max(args.steps, 1)}
+                "allreduce_bytes_per_step": int(gs_bytes / max(args.steps, 1)),
+                "allreduce_calls_per_step": gs_calls / max(args.steps, 1)}
 
     if rank == 0:
         from supervised_gan_amd import ops as _ops

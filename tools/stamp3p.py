@@ -59,6 +59,18 @@ if op in ("s2fwd1", "s2fwd2"):      # the stride-2 PatchGAN layers (32 -> 64 fro
         nrm = ops.norm_desc(st_in, None, None, H * H, 1e-5, 2, 0.2)
         desc = ops.conv_desc(0, k, s, p, H, H, cin, Ho, Ho, cout)
         jf.append((desc, x, nrm, wm, b, y, st_out, 0, ops.stat_rep(st_out))); keep.append((x, y, st_in, st_out, nrm, desc))
+if op == "d1dgrad":      # backward-data INTO the first PatchGAN layer's output (32 channels, LeakyReLU, no norm) on the patch kernel: SGAN_PATCH_N32=1
+    k, s, p, cin, cout = 4, 2, 2, 32, 64
+    sizes = [257, 129, 65] * (nprob // 3)
+    w = torch.randn(k * k * cout * cin, device="cuda") * 0.05
+    wm, wt = derived_copies(w, k, cout, cin)
+    jd = []
+    for H in sizes:
+        Ho = (H + 2 * p - k) // s + 1
+        x = torch.randn(H, H, cin, device="cuda"); r = torch.randn(Ho, Ho, cout, device="cuda"); dx = torch.empty(H, H, cin, device="cuda")
+        nrm = ops.norm_desc(None, None, None, H * H, 1e-5, 2, 0.2)
+        desc = ops.conv_desc(0, k, s, p, H, H, cin, Ho, Ho, cout)
+        jd.append((desc, r, wt, dx, x, nrm, None, 0, False, True)); keep.append((x, r, dx, nrm, desc))
 fn = (lambda: ops.conv_fwd_grouped(jf)) if op in ("fwd", "gfwd", "s2fwd1", "s2fwd2") else (lambda: ops.conv_dgrad_grouped(jd))
 for _ in range(5):
     fn()

@@ -594,9 +594,14 @@ extern "C" int sgan_debug_stamps(void* dst, int n) {
 // patch: tap (ty, tx) of result pixel (py, px) reads patch pixel (2 py + ty, 2 px + tx) = plane (ty & 1, tx & 1) at (py + (ty >> 1),
 // px + (tx >> 1)) -- the same lane addressing as stride 1 plus a per-tap constant, so the fragment reads stay conflict free and the
 // loop body does not change.  Each input element is staged (18 / 8)^2 = 5 times for a 4 x 4 kernel instead of 16 (sg_igemm3_kernel).
-template <int BN, int A_IT, bool PRO, bool F16, bool S2 = false>
+// KW: wave groups per workgroup (256 threads each).  KW = 2: the two groups take the two halves of the channel blocks of the SAME tile,
+// each with its own patch and weight buffers, in lockstep (every barrier is the whole workgroup's); group 1 hands its accumulators to
+// group 0 through LDS at the end.  For launches of 64 - 256 workgroups (the generator at batch 1): the serial chain of a tile
+// halves and the CU runs two waves per SIMD instead of one.
+template <int BN, int A_IT, bool PRO, bool F16, bool S2 = false, int KW = 1>
 __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* smem, const int bid, const int nblocks) {
     constexpr int NT = 256, WGN = 2, WTM = 32, WTN = BN / WGN, MB = 1, NB = WTN / 32;
+    static_assert(KW == 1 || KW == 2, "wave groups");
     constexpr int B_IT = BN * 8 / NT;
     // weight-tile register ring (even: the LDS buffer of a step is its slot's parity).  BN = 128 (wave tile 32 x 64, ring of 2)
     // compiles but measured slower on every layer tried (D 128 -> 256 @65^2 x 6: dgrad 73 us against 63.5): the halved workgroup
@@ -608,7 +613,8 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
 #ifdef SG3P_STAMP
     if (threadIdx.x == 0 && blockIdx.x < 4096) sg3p_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int kgp = KW > 1 ? (int)threadIdx.x >> 8 : 0;               // wave group
+    const int tid = KW > 1 ? (int)threadIdx.x & 255 : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;      // index inside the group
     const int wm = wid / WGN, wn = wid % WGN;
     const int ntn = (G.N + BN - 1) / BN;
     const int item = sg_xcd_remap(bid, nblocks);
@@ -624,9 +630,10 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     const int PLANE = S2 ? ((PH + 1) >> 1) * RS : 0;         // bytes of one parity plane
     const int npix = PH * PW;
 
-    char* Ap = smem;                                         // [PH][RS] patch of the current channel block (S2: four parity planes)
-    char* Bs = smem + (((S2 ? 4 * PLANE : PH * RS) + 255) & ~255);              // [2][BN * 128]
-    double* red = reinterpret_cast<double*>(Bs + 2 * BN * 128);            // [2 * BN]
+    const int patch_bytes = ((S2 ? 4 * PLANE : PH * RS) + 255) & ~255;
+    char* Ap = smem + kgp * patch_bytes;                     // [PH][RS] patch of the current channel block (S2: four parity planes), one per wave group
+    char* Bs = smem + KW * patch_bytes + kgp * (2 * BN * 128);              // [2][BN * 128], one per wave group
+    double* red = reinterpret_cast<double*>(smem + KW * patch_bytes + KW * (2 * BN * 128));            // [2 * BN]
     int4* ttab = reinterpret_cast<int4*>(red + 2 * BN);                    // per tap {patch byte offset, -, -, weight slab offset}
     float* pscale = reinterpret_cast<float*>(ttab + SGAN_MAX_TAPS);        // [Ck]
     float* pshift = pscale + G.Ck;
@@ -637,7 +644,8 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     const int oa = G.oa[phz], ob = G.ob[phz];
     const int Ck = P.Ck, N = P.N;
     const int ntaps = G.ntaps[phz];
-    const int ncb = Ck >> 5;
+    const int ncb = (Ck >> 5) / KW;          // channel blocks of THIS wave group (the launcher made the count a multiple of KW) ...
+    const int cb_base = kgp * ncb;           // ... starting here
     const int nunits = ntaps * ncb;
     const int dy0 = G.pdy0[phz], dx0 = G.pdx0[phz];
 
@@ -684,7 +692,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     auto issue_a = [&](int cb) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int o = ((a_goff[it] != OOB) & (cb < ncb)) ? a_goff[it] + cb * 128 : OOB;     // past the last block: zeros, never used
+            const int o = ((a_goff[it] != OOB) & (cb < ncb)) ? a_goff[it] + (cb + cb_base) * 128 : OOB;     // past the last block: zeros, never used
             a_reg[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o, 0, 0));
             a_reg[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, o + 16, 0, 0));
         }
@@ -694,7 +702,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
         for (int it = 0; it < A_IT; ++it) {
             f32x4 v0 = a_reg[it][0], v1 = a_reg[it][1];
             if constexpr (PRO) {   // zero padding applies AFTER norm + activation (see sg_igemm3_kernel)
-                const int c = cb * 32 + kg * 8;
+                const int c = (cb + cb_base) * 32 + kg * 8;
                 const f32x4 sc0 = *reinterpret_cast<const f32x4*>(pscale + c), sc1 = *reinterpret_cast<const f32x4*>(pscale + c + 4);
                 const f32x4 sh0 = *reinterpret_cast<const f32x4*>(pshift + c), sh1 = *reinterpret_cast<const f32x4*>(pshift + c + 4);
                 const float okf = a_goff[it] != OOB ? 1.f : 0.f;
@@ -733,7 +741,7 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
     int w_pref = 0;            // set behind the barrier that publishes the tap table
     auto next_b_addrs = [&]() {
         const bool in_range = ld_cb < ncb;
-        const int woff = w_pref + ld_cb * 32;
+        const int woff = w_pref + (ld_cb + cb_base) * 32;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) b_off_n[it] = (b_rowok[it] & in_range) ? (b_base[it] + woff) << 2 : OOB;
         ++ld_tap;
@@ -877,6 +885,24 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
         if constexpr (NSET == 4) { maybe(std::integral_constant<int, 1>{}, u); maybe(std::integral_constant<int, 2>{}, u); }
     }
     SG3P_MARK(3);
+    if constexpr (KW > 1) {      // the last iteration ended on a barrier: every patch / weight buffer is free; group 1 -> LDS -> group 0
+        float* xch = reinterpret_cast<float*>(smem);       // [NB * 16][256]
+        if (kgp == 1) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 256 + tid] = acc[0][j][r];
+        }
+        SG_SYNC();
+        if (kgp == 1) {
+            if (P.stats != nullptr) SG_SYNC();      // the barrier inside group 0's epilogue
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][j][r] += xch[(j * 16 + r) * 256 + tid];
+    }
 
     sg3_epilogue<BN, WTM, WTN, MB, NB, F16>(P, acc, red, 0, n0, wm, wn, tid, (unsigned)bid, epi_const, [&](int row) -> int64_t {
         const int py = ty0 + (row >> 3), px = tx0 + (row & 7);
@@ -889,11 +915,11 @@ __device__ __forceinline__ void sg_igemm3p_body(const SgIgemmParams& G, char* sm
 #endif
 }
 
-template <int BN, int A_IT, bool PRO, bool F16, bool S2 = false>
-__global__ __launch_bounds__(256) void sg_igemm3p_kernel(const SgIgemmParams G) {
+template <int BN, int A_IT, bool PRO, bool F16, bool S2 = false, int KW = 1>
+__global__ __launch_bounds__(256 * KW) void sg_igemm3p_kernel(const SgIgemmParams G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();
-    sg_igemm3p_body<BN, A_IT, PRO, F16, S2>(G, smem, blockIdx.x, gridDim.x);
+    sg_igemm3p_body<BN, A_IT, PRO, F16, S2, KW>(G, smem, blockIdx.x, gridDim.x);
 }
 
 #ifndef SG_KERNELS_ONLY      // sgan_fused.hip includes this file for the kernel bodies only
@@ -1045,12 +1071,29 @@ static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {   /
     P.slab = nullptr;
     P.slab_stride = 0;
     dim3 grid(t * sg3_cdiv(P.N, BN), 1, 1);
-    const size_t lds = (size_t)maxlds + (size_t)2 * BN * 128 + (size_t)4 * BN * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
+    // two wave groups per workgroup (the channel blocks split between them) where the grid leaves most SIMDs with one wave or none
+    static const int kw_max_wgs = getenv("SGAN_PATCH_KW_MAX") ? atoi(getenv("SGAN_PATCH_KW_MAX")) : 256;      // tuning knob; 0 = never
+    const int ncb = P.Ck >> 5;
+    const bool kw2 = !S2 && A_IT == 2 && BN == 64 && (long)grid.x <= kw_max_wgs && (ncb & 1) == 0 && ncb >= 2;
+    const int KWr = kw2 ? 2 : 1;
+    const size_t lds = (size_t)KWr * ((size_t)maxlds + (size_t)2 * BN * 128) + (size_t)4 * BN * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
     if (lds > 160 * 1024) return sgan_fail(SGAN_ERR_UNSUPPORTED, "LDS %zu too large", lds);
     bool pro = P.pro_act != SGAN_ACT_NONE;
     for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
     sg_prof_begin(st);
-    if (P.planes_f16) {
+    if constexpr (!S2 && A_IT == 2 && BN == 64) {
+        if (kw2) {
+            if (P.planes_f16) {
+                if (pro) hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, true, true, false, 2>), grid, dim3(512), lds, st, P);
+                else hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, false, true, false, 2>), grid, dim3(512), lds, st, P);
+            } else {
+                if (pro) hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, true, false, false, 2>), grid, dim3(512), lds, st, P);
+                else hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, false, false, false, 2>), grid, dim3(512), lds, st, P);
+            }
+        }
+    }
+    if (kw2) { /* launched above */ }
+    else if (P.planes_f16) {
         if (pro) hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, true, true, S2>), grid, dim3(256), lds, st, P);
         else hipLaunchKernelGGL((sg_igemm3p_kernel<BN, A_IT, false, true, S2>), grid, dim3(256), lds, st, P);
     } else {

@@ -282,9 +282,11 @@ def test_fused_backward_equals_the_two_launches(ops, shape, dmath):
     print("fused launch:", fused)
     _FUSED_SEEN[(shape, dmath)] = fused
     for (da, sa), (df, sf) in zip(res["apart"][0], res["fused"][0]):
-        assert torch.equal(da, df)
+        # the same arithmetic; bit-equal unless the stand-alone launch is small enough for two wave groups per workgroup
+        # (sg_igemm3p_kernel<..., KW = 2>: the two halves of the channel blocks are added at the end, another rounding order)
+        assert torch.equal(da, df) or rel(df, da) < 4e-6
         if sa is not None:
-            assert rel(sf, sa) < 1e-12
+            assert rel(sf, sa) < (1e-12 if torch.equal(da, df) else 4e-6)
     assert rel(res["fused"][1], res["apart"][1]) < 2e-6 and rel(res["fused"][2], res["apart"][2]) < 2e-6
 
 

@@ -1213,8 +1213,11 @@ static void sg_launch_c4_rb(SgIgemmParams& P, int tiles, hipStream_t st) {
 }
 
 static int sg_launch_c4(SgIgemmParams& P, hipStream_t st) {
-    static const int rb = getenv("SGAN_C4_RB") ? atoi(getenv("SGAN_C4_RB")) : 4;      // tuning knob: 1, 2 or 4 row blocks per wave
-    const int RB = (rb == 1 || rb == 2) ? rb : 4;
+    static const int rb = getenv("SGAN_C4_RB") ? atoi(getenv("SGAN_C4_RB")) : 0;      // tuning knob: 1, 2 or 4 row blocks per wave (0: by grid size)
+    // four row blocks per wave unless that leaves the chip with under ~1.5 workgroups per CU (three-problem first PatchGAN conv: 340
+    // workgroups, 11.4 us; with two row blocks 680 workgroups, 9.8 us; the six-problem launch keeps four: 16.7 us either way)
+    int RB = (rb == 1 || rb == 2 || rb == 4) ? rb : 4;
+    if (!rb && sg_fill_tiles(P, 64 * 4) <= 400) RB = 2;
     const int tiles = sg_fill_tiles(P, 64 * RB);
     if (tiles == 0) return SGAN_OK;
     sg_prof_begin(st);

@@ -250,6 +250,33 @@ def test_grouped_chains_equal_individual_chains(N):
         d.compute_param_grads = True
 
 
+def test_begin_step_clears_the_gradients_zero_grad_was_about_to(N):
+    """ops.begin_step(also_zero=FusedAdam.take_zeroing()): the step's one zeroing launch clears the optimizer's gradient arena and the
+    zero_grad() that follows does nothing (once); an optimizer whose step() already zeroed its gradients hands over nothing."""
+    from supervised_gan_amd import ops
+    from supervised_gan_amd.optim import FusedAdam
+    D = N.define_D(2, 8, "n_layers", n_layers_D=3, norm="instance", use_sigmoid=True, scale_factor=1, gpu_ids=[0])
+    opt = FusedAdam(list(D.model.parameters()), lr=2e-4, betas=(0.5, 0.999))
+    D._gflat.fill_(3.0)
+    bufs = opt.take_zeroing()
+    assert bufs and sum(b.numel() for b in bufs) == D._gflat.numel()      # the padded flat arena, not just the logical parameters
+    ops.begin_step(bufs)
+    torch.cuda.synchronize()
+    assert float(D._gflat.abs().max()) == 0.0
+    D._gflat.fill_(5.0)
+    opt.zero_grad()          # the one the caller took over: a no-op
+    assert float(D._gflat.min()) == 5.0
+    opt.zero_grad()          # the next one clears again
+    torch.cuda.synchronize()
+    assert float(D._gflat.abs().max()) == 0.0
+    G = N.define_G(2, 0, 8, "fcgan", "instance", False, n_layers_G=5, use_fcn=True, noise_nc=8, gpu_ids=[0])
+    og = FusedAdam(list(G.parameters()), lr=2e-4, betas=(0.5, 0.999), zero_grads_in_step=True)
+    G._gflat.fill_(1e-3)
+    og.step()                # zeroes what it consumed
+    torch.cuda.synchronize()
+    assert float(G._gflat.abs().max()) == 0.0 and og.take_zeroing() == []
+
+
 def test_forward_pair_refills_a_kept_forward(N):
     """chain.forward_pair: G(za) and G(zb) as one two-problem pass, G(zb) written into the buffers of an earlier kept forward and handed
     back under a fresh autograd node == two separate calls (outputs, parameter gradients, BatchNorm running statistics in call order)."""

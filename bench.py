@@ -173,6 +173,18 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
         pix = desc.Hout * desc.Wout if desc.kind == 0 else desc.Hin * desc.Win
         return 2.0 * pix * cin * cout * desc.k * desc.k
 
+    def abytes(desc, kind, has_x=True):
+        """Algorithmic HBM bytes of one problem: every operand tensor once (stored channels, fp32).  fwd: in + out; dgrad: dOut + dX
+        (+ the forward tensor its activation derivative reads); wgrad: x + dOut; bwd (one fused launch): dOut + x + dX."""
+        i, o = 4.0 * desc.Hin * desc.Win * desc.Cin, 4.0 * desc.Hout * desc.Wout * desc.Cout
+        if kind == "fwd":
+            return i + o
+        if kind == "dgrad":
+            return o + i + (i if has_x else 0.0)
+        if kind == "wgrad":
+            return i + o
+        return o + 2.0 * i
+
     depth = [0]      # conv_fwd / conv_dgrad may delegate to their grouped form: record the outermost call only
 
     def wrap(name, grouped):
@@ -181,7 +193,9 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
         def f(first, *a, **k):
             if depth[0] == 0:
                 fl = sum(flops(j[0]) for j in first) if grouped else flops(first)
-                calls.append((orig, (first,) + a, k, fl))
+                kd = "fwd" if "fwd" in name else ("dgrad" if "dgrad" in name else "wgrad")
+                ab = sum(abytes(j[0], kd, kd != "dgrad" or j[4] is not None) for j in first) if grouped else abytes(first, kd)
+                calls.append((orig, (first,) + a, k, fl, ab))
             depth[0] += 1
             try:
                 return orig(first, *a, **k)
@@ -198,7 +212,8 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
                 return orig(djobs, wjobs, *a, **k)
             fused = orig(djobs, wjobs, *a, **k)
             if fused:
-                calls.append((orig, (djobs, wjobs) + a, k, sum(flops(j[0]) for j in djobs) + sum(flops(j[0]) for j in wjobs)))
+                calls.append((orig, (djobs, wjobs) + a, k, sum(flops(j[0]) for j in djobs) + sum(flops(j[0]) for j in wjobs),
+                              sum(abytes(j[0], "bwd") for j in djobs)))
             return fused
         setattr(ops, name, f)
         return orig
@@ -225,7 +240,7 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
         # event-pair overhead from per-launch events and came out 6 % optimistic).
         NREP = 8
         agg, per_call = {}, []
-        for fn, a, k, fl in calls:
+        for fn, a, k, fl, ab in calls:
             fn(*a, **k)
             nm = lib.sgan_last_kernel().decode()
             torch.cuda.synchronize()
@@ -244,14 +259,15 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / NREP)      # ms per call
             del g
-            a_ = agg.setdefault(nm, [0, 0.0, 0.0])
+            a_ = agg.setdefault(nm, [0, 0.0, 0.0, 0.0])
             a_[0] += reps
             a_[1] += best * reps
             a_[2] += fl * reps
+            a_[3] += ab * reps
             per_call.append((nm, best * 1e3))
         if os.environ.get("SGAN_BENCH_CALLS"):     # tuning aid: one line per conv call of the step
             with open(os.environ["SGAN_BENCH_CALLS"], "w") as f:
-                for ci, ((fn, a, k, fl), (nm, us)) in enumerate(zip(calls, per_call)):
+                for ci, ((fn, a, k, fl, ab), (nm, us)) in enumerate(zip(calls, per_call)):
                     first = a[0]
                     descs = [j[0] for j in first] if isinstance(first, list) else [first]
                     shape = " ".join(f"{'T' if d.kind else 'C'}k{d.k}s{d.stride} {d.Cin}->{d.Cout} {d.Hin}x{d.Win}->{d.Hout}x{d.Wout}" for d in descs[:2])
@@ -260,7 +276,8 @@ def profile_kernels(model, ring, reps=3, workload="fcgan"):
         model._streams = saved_streams
     calls.clear()
     return {k: {"launches_per_step": v[0] / reps, "avg_us": 1e3 * v[1] / v[0], "ms_per_step": v[1] / reps,
-                "tflops": v[2] / (v[1] * 1e-3) / 1e12, "gflop_per_launch": v[2] / v[0] / 1e9} for k, v in agg.items()}
+                "tflops": v[2] / (v[1] * 1e-3) / 1e12, "gflop_per_launch": v[2] / v[0] / 1e9,
+                "algorithmic_bytes_per_launch": int(v[3] / v[0])} for k, v in agg.items()}
 
 
 def _cpu_model():
@@ -562,6 +579,7 @@ def main():
             issued = useful * (3.0 if split else 1.0)
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": useful, "peak": peak,
                                "unit": "TFLOP/s", "frac": useful / peak, "traffic": traffic,
+                               "traffic_algorithmic": kern[dom].get("algorithmic_bytes_per_launch"),      # every operand tensor of a launch once
                                "achieved_useful": useful, "achieved_issued": issued, "frac_issued": issued / peak,
                                "mfma_flops_issued_per_useful_flop": 3 if split else 1,
                                "frac_of_fp32_matrix_peak": kern[dom]["tflops"] / 157.3,

@@ -20,7 +20,7 @@
 // WV: 1 = backward-weight 64 x 64 tiles, 2 = 32 x 128
 // F16: the backward-data half on fp16 planes (every job brought the maximum of its gradient tensor); the backward-weight half is bf16
 template <int DV, int WV, bool WPRO, bool F16>
-__global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G, const SgWgradParams W, int ndg, int wx, int wy) {
+__global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G, const SgWgradParams W, int ndg, int wx, int wy, int wmode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     sg_warm_kernargs<(int)(sizeof(SgIgemmParams) + sizeof(SgWgradParams))>();
     const int b = blockIdx.x;
@@ -31,7 +31,15 @@ __global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G
         else if constexpr (DV == 5) sg_igemm3p_body<64, 6, false, F16, true>(G, smem, b, ndg);
         else sg_igemm3_body<128, 32, 4, 1, false, F16, false>(G, smem, b, ndg, 0);
     } else {
-        const int w = b - ndg;
+        // wmode 1 (SGAN_FUSED_WXCD=1, off by default): the backward-weight workgroups start at a multiple of 8 and every XCD takes a
+        // CONTIGUOUS range of the pixel-range-major order, so that an L2 holds a few pixel ranges of dOut / x instead of all of them.
+        // Measured stand-alone (tools/probe_bwd_split.py): 32 -> 64, six problems (36 ranges) 70.6 -> 64.8 us, but 128 -> 256 (8 ranges
+        // of unequal work on eight XCDs) 130 -> 140 us and, three problems (4 ranges), 65 -> 85 us; inside the training step the
+        // 32 -> 64 launches moved by 0-3 us.  Equal-work ranges would need the pixel split cut across problem boundaries.
+        const int ndp = wmode ? (ndg + 7) & ~7 : ndg;
+        if (b < ndp) return;
+        int w = b - ndp;
+        if (wmode) w = sg_xcd_remap(w, (int)gridDim.x - ndp);
         const int bx = w % wx, by = (w / wx) % wy, bz = w / (wx * wy);
         if constexpr (WV == 1) sg_wgrad3_body<64, 64, 2, 2, WPRO, false>(W, smem, bx, by, bz);
         else sg_wgrad3_body<32, 128, 1, 4, WPRO, false>(W, smem, bx, by, bz);
@@ -40,17 +48,18 @@ __global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G
 
 template <int DV, int WV>
 static void sg_fused_launch(const SgIgemmParams& P, const SgWgradParams& W, const SgFusePlan& pd, const SgFusePlan& pw, hipStream_t st) {
-    const dim3 grid(pd.nblocks + pw.nblocks);
+    static const int wmode = getenv("SGAN_FUSED_WXCD") ? (atoi(getenv("SGAN_FUSED_WXCD")) != 0) : 0;      // tuning knob (see the kernel)
+    const dim3 grid((wmode ? ((pd.nblocks + 7) & ~7) : pd.nblocks) + pw.nblocks);
     const size_t lds = pd.lds > pw.lds ? pd.lds : pw.lds;
     if constexpr (DV == 6) {       // fp16 planes are asked for where they matter: backward-data into a layer without a normalisation
         if (P.planes_f16) {
-            if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
-            else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
+            if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode);
+            else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode);
             return;
         }
     }
-    if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
-    else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy);
+    if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode);
+    else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode);
 }
 
 // 0: launched; 1: this pair is not covered (launch sgan_conv_dgrad_grouped and sgan_conv_wgrad_grouped instead); < 0: error

@@ -892,6 +892,13 @@ def multi_forward(jobs):
             n, x = jobs[grp[0]]
             results[grp[0]] = n.forward(x)
             continue
+        # largest problem first: the workgroups of a grouped launch are dealt out problem by problem, and where their durations differ
+        # (backward-weight pixel ranges: 68 / 37 / 11 chunks for the three PatchGAN scales) the long ones should not start last
+        def _work(i):
+            n_, x_ = jobs[i]
+            sf = float(getattr(n_, "scale_factor", 1) or 1)
+            return -(x_.shape[-1] * x_.shape[-2]) / (sf * sf)
+        grp = sorted(grp, key=_work)      # stable: equal sizes keep the caller's order
         nets = [jobs[i][0] for i in grp]
         params, seen = [], set()
         for n in nets:

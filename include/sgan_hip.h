@@ -202,6 +202,12 @@ int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t n, void* wo
  * backward-weight: DESIGN.md R2.3); the backward-weight half must be SGAN_MATH_BF16X3. */
 int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw,
                         int32_t dgrad_math, void* stream);
+/* The same with a workspace: a pair whose backward-data half is a deep reduction on a small map (generator 256 -> 128 at 32 x 32, the
+ * inner U-Net levels) keeps its split-K inside the fused launch -- the partial tiles go to `workspace`, a second kernel sums them and
+ * runs the backward-data epilogue.  workspace_bytes == -1: query, returns the KiB the pair wants (0: none) and launches nothing.
+ * Without enough workspace such a pair answers 1 (the caller issues the two grouped calls), as sgan_conv_bwd_fused does. */
+int sgan_conv_bwd_fused_ws(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw,
+                           int32_t dgrad_math, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- class-weighted cross-entropy on logits, softmax over channels (NHWC maps, <= 16 classes) ---------------------------
  * sgan_ce_fwd:  loss = sum_p w[y_p] (logsumexp(z_p) - z_p[y_p]) / sum_p w[y_p];  y_p = label[p] (int64 map) or const_label when label

@@ -116,7 +116,7 @@ struct SgPhase {
 };
 
 // what one half of a fused backward launch needs to know about the other (sgan_fused.hip)
-struct SgFusePlan { int variant; int nblocks; int gx, gy, gz; size_t lds; bool pro; const char* name; };
+struct SgFusePlan { int variant; int nblocks; int gx, gy, gz; size_t lds; bool pro; const char* name; int ks; };      // ks: split-K of the backward-data half (variant 3), 1 = none
 
 struct SgNorm {  // device-side copy of sgan_norm_desc
     const double* stats;

@@ -20,14 +20,14 @@
 // WV: 1 = backward-weight 64 x 64 tiles, 2 = 32 x 128
 // F16: the backward-data half on fp16 planes (every job brought the maximum of its gradient tensor); the backward-weight half is bf16
 template <int DV, int WV, bool WPRO, bool F16>
-__global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G, const SgWgradParams W, int ndg, int wx, int wy, int wmode) {
+__global__ __launch_bounds__(256) void sg_bwd_fused_kernel(const SgIgemmParams G, const SgWgradParams W, int ndg, int wx, int wy, int wmode, int dks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     sg_warm_kernargs<(int)(sizeof(SgIgemmParams) + sizeof(SgWgradParams))>();
     const int b = blockIdx.x;
     if (b < ndg) {
         if constexpr (DV == 1) sg_igemm3p_body<64, 2, false, F16>(G, smem, b, ndg);
         else if constexpr (DV == 2) sg_igemm3p_body<64, 4, false, F16>(G, smem, b, ndg);
-        else if constexpr (DV == 3) sg_igemm3_body<64, 64, 2, 2, false, F16, true>(G, smem, b, ndg, 0);
+        else if constexpr (DV == 3) sg_igemm3_body<64, 64, 2, 2, false, F16, true>(G, smem, b % (ndg / dks), ndg / dks, b / (ndg / dks));      // (tile, k split)
         else if constexpr (DV == 5) sg_igemm3p_body<64, 6, false, F16, true>(G, smem, b, ndg);
         else sg_igemm3_body<128, 32, 4, 1, false, F16, false>(G, smem, b, ndg, 0);
     } else {
@@ -53,32 +53,44 @@ static void sg_fused_launch(const SgIgemmParams& P, const SgWgradParams& W, cons
     const size_t lds = pd.lds > pw.lds ? pd.lds : pw.lds;
     if constexpr (DV == 6) {       // fp16 planes are asked for where they matter: backward-data into a layer without a normalisation
         if (P.planes_f16) {
-            if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode);
-            else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode);
+            if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode, pd.ks);
+            else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false, true>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode, pd.ks);
             return;
         }
     }
-    if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode);
-    else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode);
+    if (pw.pro) hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, true, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode, pd.ks);
+    else hipLaunchKernelGGL((sg_bwd_fused_kernel<DV, WV, false, false>), grid, dim3(256), lds, st, P, W, pd.nblocks, pw.gx, pw.gy, wmode, pd.ks);
 }
 
-// 0: launched; 1: this pair is not covered (launch sgan_conv_dgrad_grouped and sgan_conv_wgrad_grouped instead); < 0: error
+// 0: launched; 1: this pair is not covered (launch sgan_conv_dgrad_grouped and sgan_conv_wgrad_grouped instead); < 0: error.
+// workspace_bytes == -1: query -- KiB of workspace the pair wants (0: none), nothing is launched.
+static int sg_conv_bwd_fused_impl(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw,
+                                  int32_t dgrad_math, void* workspace, int64_t workspace_bytes, void* stream);
 extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw,
                                    int32_t dgrad_math, void* stream) {
+    return sg_conv_bwd_fused_impl(djobs, nd, wjobs, nw, dgrad_math, nullptr, 0, stream);
+}
+extern "C" int sgan_conv_bwd_fused_ws(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw,
+                                      int32_t dgrad_math, void* workspace, int64_t workspace_bytes, void* stream) {
+    return sg_conv_bwd_fused_impl(djobs, nd, wjobs, nw, dgrad_math, workspace, workspace_bytes, stream);
+}
+static int sg_conv_bwd_fused_impl(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw,
+                                  int32_t dgrad_math, void* workspace, int64_t workspace_bytes, void* stream) {
+    const bool query = workspace_bytes == -1;
     static const int off = getenv("SGAN_NO_BWD_FUSION") ? 1 : 0;
-    if (off) return 1;
+    if (off) return query ? 0 : 1;
     SgIgemmParams P;
     SgWgradParams W;
     int rc = sg_build_dgrad_params(djobs, nd, P, true);      // fp16 planes when every job brought its gradient's maximum
     if (rc) return rc;
     rc = sg_build_wgrad_params(wjobs, nw, W, false);         // the backward-weight half of a fused launch stays on bf16 planes
     if (rc) return rc;
-    if (wjobs[0].d->math != SGAN_MATH_BF16X3 || sg_dgrad_is_skinny(P)) return 1;
+    if (wjobs[0].d->math != SGAN_MATH_BF16X3 || sg_dgrad_is_skinny(P)) return query ? 0 : 1;
     if (dgrad_math >= 0) P.math = dgrad_math;      // the two job lists may share descriptors: the backward-data mode comes apart
     const int e3 = sg_igemm3_eligible(P);
     if (e3 < 0) return e3;
     SgFusePlan pd, pw;
-    if (e3 == 0) return 1;      // exact-fp32 backward-data (tiny maps, SGAN_MATH_F32): the two grouped calls
+    if (e3 == 0) return query ? 0 : 1;      // exact-fp32 backward-data (tiny maps, SGAN_MATH_F32): the two grouped calls
     sg_igemm3_fuse_plan(P, &pd);
     if (pd.variant != 6 && P.planes_f16) {      // only variant 6 is instantiated with fp16 planes: the others run this pair on bf16 planes
         rc = sg_build_dgrad_params(djobs, nd, P, false);
@@ -86,10 +98,17 @@ extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd,
         if (dgrad_math >= 0) P.math = dgrad_math;
         sg_igemm3_fuse_plan(P, &pd);
     }
-    if (pd.variant == 0 || pd.nblocks == 0) return 1;
+    if (pd.variant == 0 || pd.nblocks == 0) return query ? 0 : 1;
     sg_wgrad3_fuse_plan(W, &pw);
-    if (pw.variant == 0 || pw.nblocks == 0) return 1;
-    if ((pd.lds > pw.lds ? pd.lds : pw.lds) > 160 * 1024) return 1;     // the CU's LDS (the split kernels with two k-tiles per barrier take a little over 64 KB)
+    if (pw.variant == 0 || pw.nblocks == 0) return query ? 0 : 1;
+    if ((pd.lds > pw.lds ? pd.lds : pw.lds) > 160 * 1024) return query ? 0 : 1;     // the CU's LDS (the split kernels with two k-tiles per barrier take a little over 64 KB)
+    const int64_t slab = (int64_t)P.q[0].Hout * P.q[0].Wout * P.N;
+    const int64_t need = pd.ks > 1 ? (int64_t)pd.ks * slab * 4 : 0;
+    if (query) return (int)((need + 1023) >> 10);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return 1;      // a split backward-data half needs its slabs: the caller runs the two grouped calls
+    P.ksplit = pd.ks;
+    P.slab = pd.ks > 1 ? (float*)workspace : nullptr;
+    P.slab_stride = slab;
     hipStream_t st = (hipStream_t)stream;
     sg_prof_begin(st);
     switch (pd.variant * 10 + pw.variant) {
@@ -107,5 +126,6 @@ extern "C" int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd,
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = "sg_bwd_fused_kernel";
     sg_prof_end(st, g_sgan_last_kernel);
+    if (pd.ks > 1) return sg_launch_splitk_epilogue(P, st);      // sum of the slabs + the backward-data epilogue (activation derivative, norm-backward sums)
     return SGAN_OK;
 }

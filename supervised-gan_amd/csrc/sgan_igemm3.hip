@@ -1110,6 +1110,7 @@ static int sg3p_launch(SgIgemmParams& P, hipStream_t st, const char* name) {   /
 // below do and says which body runs it.  variant 0: not one of the bodies the fused kernel carries (the caller launches separately).
 int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out) {
     out->variant = 0;
+    out->ks = 1;
     if (P.pro_act != SGAN_ACT_NONE) return 0;
     for (int g = 0; g < P.nprob; ++g)
         if (P.q[g].pro_stats) return 0;
@@ -1144,11 +1145,18 @@ int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out) {
     }
     // a launch that would have been split-K on its own runs unsplit here when the split is shallow: the backward-weight
     // workgroups of the same grid fill the CUs the split was there to fill (SGAN_FUSE_MAX_KS: tuning knob)
-    static const int max_ks = getenv("SGAN_FUSE_MAX_KS") ? atoi(getenv("SGAN_FUSE_MAX_KS")) : 1;
-    if (tl.BM != 64 || tl.BN != 64 || sg_plan_ksplit(P, 64, 64) > max_ks) return 0;
+    // A launch that would have been split-K on its own: the split stays (its slabs go to the caller's workspace and
+    // sg_splitk_epilogue_kernel finishes them after the fused launch) -- the deep, narrow layers (generator 256 -> 128 at 32 x 32,
+    // the inner U-Net levels) are exactly the ones whose two halves leave the chip idle one after the other.  SGAN_FUSE_MAX_KS caps the
+    // split a fused launch accepts (0: only unsplit launches fuse, as in round 2).
+    static const int max_ks = getenv("SGAN_FUSE_MAX_KS") ? atoi(getenv("SGAN_FUSE_MAX_KS")) : 64;
+    if (tl.BM != 64 || tl.BN != 64) return 0;
+    const int ks = sg_plan_ksplit(P, 64, 64);
+    if (ks > 1 && ks > max_ks) return 0;
     const int tiles = sg_fill_tiles(P, 64);
     out->variant = 3;
-    out->nblocks = tiles * sg3_cdiv(P.N, 64);
+    out->ks = ks;
+    out->nblocks = tiles * sg3_cdiv(P.N, 64) * ks;
     out->lds = (size_t)4 * (64 + 64) * 128 + (size_t)4 * 64 * 4 + SGAN_MAX_TAPS * 16 + (size_t)2 * P.Ck * 4;
     out->name = "sg_igemm3_kernel<64,64,2,2>";
     return 0;

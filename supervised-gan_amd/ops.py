@@ -343,11 +343,13 @@ def conv_bwd_grouped(djobs, wjobs, dgrad_math=None):
     if _math == L.MATH_BF16X3:
         _check_dgrad_jobs(djobs)
         _check_wgrad_jobs(wjobs)
-        rc = L.lib().sgan_conv_bwd_fused(_dgrad_array(djobs), len(djobs), _wgrad_array(wjobs), len(wjobs), dm, _stream())
+        da, wa = _dgrad_array(djobs), _wgrad_array(wjobs)
+        ws = _workspace(L.lib().sgan_conv_bwd_fused_ws(da, len(djobs), wa, len(wjobs), dm, None, -1, None), djobs[0][1].device)
+        rc = L.lib().sgan_conv_bwd_fused_ws(da, len(djobs), wa, len(wjobs), dm, _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream())
         if rc == 0:
             return True
         if rc < 0:
-            L.check(rc, "sgan_conv_bwd_fused")
+            L.check(rc, "sgan_conv_bwd_fused_ws")
     conv_wgrad_grouped(wjobs)
     with math_scope(dgrad_math):
         conv_dgrad_grouped(djobs)

@@ -231,6 +231,50 @@ def test_igemm3_grouped_and_splitk(ops, tile):
     assert rel(got["bf16x3"][0], got["f32"][0]) < 3e-5 and rel(got["bf16x3"][1], got["f32"][1]) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [("convT", 4, 2, 1, 256, 128, 32, 32, "bn", 1), ("convT", 4, 2, 1, 256, 256, 16, 16, "bn", 1),
+                                   ("conv", 4, 2, 1, 512, 512, 32, 32, "in", 2), ("convT", 4, 2, 1, 512, 256, 16, 16, "in", 1)],
+                         ids=lambda c: f"{c[0]}_{c[4]}to{c[5]}_{c[6]}x{c[7]}")
+def test_fused_backward_with_a_split_k_half(ops, shape):
+    """Deep reductions on small maps (one problem): the backward-data half keeps its split-K INSIDE the fused launch
+    (sgan_conv_bwd_fused_ws: slabs in the caller's workspace, sg_splitk_epilogue_kernel afterwards) -- same results as the two
+    grouped calls."""
+    from hip_utils import master_weight, pad_vec, rel, stats_of, to_buf
+    from supervised_gan_amd import _lib
+    kind, k, s, p, cin, cout, H, W, norm, act = shape
+    tr = kind == "convT"
+    _select_tile("auto")
+    ops.set_math("bf16x3")
+    g = torch.Generator().manual_seed(23)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    wm = master_weight(torch.randn(*wshape, generator=g) * 0.05, tr)
+    x = torch.randn(1, cin, H, W, generator=g) * 1.5 + 0.3
+    ho, wo = ((H - 1) * s - 2 * p + k, (W - 1) * s - 2 * p + k) if tr else ((H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1)
+    desc = ops.conv_desc(1 if tr else 0, k, s, p, H, W, cin, ho, wo, cout, cin, cout)
+    gam = pad_vec(1 + 0.2 * torch.randn(cin, generator=g)) if norm == "bn" else None
+    bet = pad_vec(0.1 * torch.randn(cin, generator=g)) if norm == "bn" else None
+    nd = ops.norm_desc(stats_of(x), gam, bet, H * W, 1e-5, act, 0.2)
+    xb, rb = to_buf(x), to_buf(torch.randn(1, cout, ho, wo, generator=g))
+    res = {}
+    for mode in ("apart", "fused"):
+        din = torch.full((H, W, cin), float("nan"), device="cuda")
+        sums = torch.zeros(2 * cin, dtype=torch.float64, device="cuda")
+        dw, db = torch.zeros_like(wm), torch.zeros(cout, device="cuda")
+        dj, wj = [(desc, rb, wm._sgan_wt, din, xb, nd, sums, 0, False, True, 0)], [(desc, xb, nd, rb, dw, db)]
+        if mode == "apart":
+            ops.conv_wgrad_grouped(wj)
+            ops.conv_dgrad_grouped(dj)
+            apart_kernel = _lib.lib().sgan_last_kernel().decode()      # sg_igemm3_kernel<64,64,2,2> (split-K) on the ConvTranspose cases
+        else:
+            assert ops.conv_bwd_grouped(dj, wj) is True
+            assert _lib.lib().sgan_last_kernel().decode() == "sg_bwd_fused_kernel"
+        torch.cuda.synchronize()
+        res[mode] = (din, sums, dw, db)
+    a, f = res["apart"], res["fused"]
+    assert torch.isfinite(f[0]).all()
+    assert torch.equal(a[0], f[0]) or rel(f[0], a[0]) < 4e-6
+    assert rel(f[1], a[1]) < 1e-6 and rel(f[2], a[2]) < 2e-6 and rel(f[3], a[3]) < 2e-6
+
+
 @pytest.mark.parametrize("dmath", [None, "f16"])
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"{c[0]}_k{c[1]}s{c[2]}_{c[4]}to{c[5]}_{c[6]}x{c[7]}" for c in SHAPES])
 def test_fused_backward_equals_the_two_launches(ops, shape, dmath):

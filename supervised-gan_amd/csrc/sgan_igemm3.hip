@@ -1151,9 +1151,19 @@ int sg_igemm3_fuse_plan(SgIgemmParams& P, SgFusePlan* out) {
     // split a fused launch accepts (0: only unsplit launches fuse, as in round 2).
     static const int max_ks = getenv("SGAN_FUSE_MAX_KS") ? atoi(getenv("SGAN_FUSE_MAX_KS")) : 64;
     if (tl.BM != 64 || tl.BN != 64) return 0;
-    const int ks = sg_plan_ksplit(P, 64, 64);
+    int ks = sg_plan_ksplit(P, 64, 64);
     if (ks > 1 && ks > max_ks) return 0;
     const int tiles = sg_fill_tiles(P, 64);
+    if (ks > 1) {      // beside the backward-weight workgroups ~128 backward-data workgroups are enough (measured on the generator's two deep
+        // layers: 256 -> 128, 64 tiles: split 2 28.6 us, split 8 34 us; 256 -> 256, 16 tiles: split 8 23.6 us, split 32 31.5 us, split 2 34.9 us)
+        static const int want = getenv("SGAN_FUSE_KS_WGS") ? atoi(getenv("SGAN_FUSE_KS_WGS")) : 128;
+        const int cap = max(1, want / max(1, tiles * sg3_cdiv(P.N, 64)));
+        if (ks > cap) {
+            const int nkt = sg3_cdiv(sg_max_k(P), 32);
+            const int per = sg3_cdiv(nkt, cap);
+            ks = sg3_cdiv(nkt, per);      // every split non-empty
+        }
+    }
     out->variant = 3;
     out->ks = ks;
     out->nblocks = tiles * sg3_cdiv(P.N, 64) * ks;

@@ -413,12 +413,13 @@ extern "C" int sgan_debug_stamps_thin(void* dst, int n) {
 // 2 x SG_THIN_U steps in flight per wave, the eight partials of a workgroup meet in LDS and the workgroup adds its tile to dW with
 // fp32 atomics whose 64 lanes cover 256 CONTIGUOUS bytes (lane -> (row, thin channel) of one tap: the full-rate form of
 // MI355X_MICROARCH.md "Global float atomics"; round 2's direct-atomic experiment scattered 16-byte pieces 512 B apart).
-template <int MB, bool PRO, bool SWAP>
-__global__ __launch_bounds__(64 * SG_THIN_NW) void sg_wgrad_thin_kernel(const SgWgradParams G, int nbias_z0) {
-    sg_warm_kernargs<(int)sizeof(SgWgradParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
-    constexpr int ROWS = 16 * MB, COLS = 64, NB = 4, NW = SG_THIN_NW, NT = 64 * NW;
+// (body: workgroup coordinates come in as `by`, `bz` so that sg_bwd_thin_pair_kernel can run it on a slice of its grid; NW = 4 there --
+// a 256-thread workgroup like its partner's, whose waves are the SIMDs' second instruction stream)
+template <int MB, bool PRO, bool SWAP, int NW>
+__device__ __forceinline__ void sg_wgrad_thin_body(const SgWgradParams& G, const int nbias_z0, char* smem, const int by, const int bz) {
+    constexpr int ROWS = 16 * MB, COLS = 64, NB = 4, NT = 64 * NW;
     static_assert(MB == 1 || MB == 2 || MB == 4, "operand widths");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
     float* red = reinterpret_cast<float*>(smem);   // [4 slots][ROWS][COLS]: waves w and w + 4 share slot w
     float* redb = red + 4 * ROWS * COLS;           // [4 slots][ROWS]
     float* pss = redb + 4 * ROWS;                  // [2 * Cin] prologue scale | shift
@@ -427,10 +428,10 @@ __global__ __launch_bounds__(64 * SG_THIN_NW) void sg_wgrad_thin_kernel(const Sg
     const int fr = lane & 15, fq = lane >> 4;
     SGT_MARK(0); SGT_MARK(6);
     if constexpr (SWAP) {
-        if ((int)blockIdx.z >= nbias_z0) {   // bias gradient of a thin-Cout layer: sum of dOut over its pixels (<= 4 channels), few workgroups
-            const SgWgradProb& Q = G.q[(blockIdx.z - nbias_z0) >> 2];
-            if (!Q.dbias || blockIdx.y != 0) return;
-            const int npix = Q.Hout * Q.Wout, part = (blockIdx.z - nbias_z0) & 3;
+        if (bz >= nbias_z0) {   // bias gradient of a thin-Cout layer: sum of dOut over its pixels (<= 4 channels), few workgroups
+            const SgWgradProb& Q = G.q[(bz - nbias_z0) >> 2];
+            if (!Q.dbias || by != 0) return;
+            const int npix = Q.Hout * Q.Wout, part = (bz - nbias_z0) & 3;
             f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
             for (int p = part * NT + tid; p < npix; p += 4 * NT) s4 += *reinterpret_cast<const f32x4*>(Q.dout + (int64_t)p * Q.dout_ld);
 #pragma unroll
@@ -450,14 +451,14 @@ __global__ __launch_bounds__(64 * SG_THIN_NW) void sg_wgrad_thin_kernel(const Sg
     }
     int g = 0;
     for (int gi = 1; gi < G.nprob; ++gi)
-        if ((int)blockIdx.z >= G.q[gi].z0) g = gi;
+        if (bz >= G.q[gi].z0) g = gi;
     const SgWgradProb& Q = G.q[g];
-    const int zl = blockIdx.z - Q.z0;
+    const int zl = bz - Q.z0;
     const int phz = zl / Q.nsplit, split = zl % Q.nsplit;
     const int Hp = Q.Hp[phz], Wp = Q.Wp[phz], M = Hp * Wp;
     if (M == 0) return;
     const int rows_total = SWAP ? G.Cin : G.Cout;
-    const int r0 = blockIdx.y * ROWS;
+    const int r0 = by * ROWS;
     // this wave's pixel range: the workgroup's share of M, cut into NW (multiples of 4 pixels)
     const int per_wg = ((M + Q.nsplit - 1) / Q.nsplit + 4 * NW - 1) / (4 * NW) * (4 * NW);
     const int per_wave = per_wg / NW;
@@ -626,9 +627,13 @@ __global__ __launch_bounds__(64 * SG_THIN_NW) void sg_wgrad_thin_kernel(const Sg
         }
     };
     SGT_MARK(2);
-    if (wid >= 4) stash(false);
-    SG_SYNC();
-    if (wid < 4) stash(true);
+    if constexpr (NW == 8) {
+        if (wid >= 4) stash(false);
+        SG_SYNC();
+        if (wid < 4) stash(true);
+    } else {
+        stash(false);
+    }
     SG_SYNC();
     SGT_MARK(3);
     // fp32 atomics, 64 consecutive lanes -> 64 consecutive floats of dW:
@@ -648,6 +653,13 @@ __global__ __launch_bounds__(64 * SG_THIN_NW) void sg_wgrad_thin_kernel(const Sg
     if (tid < ROWS && do_bias && r0 + tid < rows_total)
         atomicAdd(Q.dbias + r0 + tid, (redb[tid] + redb[ROWS + tid]) + (redb[2 * ROWS + tid] + redb[3 * ROWS + tid]));
     SGT_MARK(4); SGT_MARK(7);
+}
+
+template <int MB, bool PRO, bool SWAP>
+__global__ __launch_bounds__(64 * SG_THIN_NW) void sg_wgrad_thin_kernel(const SgWgradParams G, int nbias_z0) {
+    sg_warm_kernargs<(int)sizeof(SgWgradParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sg_wgrad_thin_body<MB, PRO, SWAP, SG_THIN_NW>(G, nbias_z0, smem, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 template <int MB, bool SWAP>

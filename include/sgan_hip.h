@@ -209,6 +209,12 @@ int sgan_conv_bwd_fused(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan
 int sgan_conv_bwd_fused_ws(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw,
                            int32_t dgrad_math, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* A layer with a 4-channel side (the generator's output ConvTranspose2d(ngf, 2), models/networks.py:528-533; the first PatchGAN conv
+ * Conv2d(2, ndf) in a generator update, :815-817): its backward-data and backward-weight launches in ONE grid
+ * (sg_bwd_thin_pair_kernel).  Same job lists as sgan_conv_dgrad_grouped / sgan_conv_wgrad_grouped, same results.  Returns 1 when the
+ * pair is not one of the two shapes (the caller issues the two grouped calls). */
+int sgan_conv_bwd_thin_pair(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw, void* stream);
+
 /* ---- class-weighted cross-entropy on logits, softmax over channels (NHWC maps, <= 16 classes) ---------------------------
  * sgan_ce_fwd:  loss = sum_p w[y_p] (logsumexp(z_p) - z_p[y_p]) / sum_p w[y_p];  y_p = label[p] (int64 map) or const_label when label
  *               is NULL; class_w NULL = unit weights; labels outside [0, C) are skipped (torch's ignore_index).  `acc` (2 doubles) and

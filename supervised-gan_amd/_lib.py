@@ -85,6 +85,7 @@ SIGNATURES = {
     "sgan_conv_dgrad_grouped": [C.POINTER(ConvDgradJob), _I, _P, _L, _P],
     "sgan_conv_wgrad_grouped": [C.POINTER(ConvWgradJob), _I, _P, _L, _P],
     "sgan_conv_bwd_fused": [C.POINTER(ConvDgradJob), _I, C.POINTER(ConvWgradJob), _I, _I, _P],
+    "sgan_conv_bwd_thin_pair": [C.POINTER(ConvDgradJob), _I, C.POINTER(ConvWgradJob), _I, _P],
     "sgan_conv_bwd_fused_ws": [C.POINTER(ConvDgradJob), _I, C.POINTER(ConvWgradJob), _I, _I, _P, C.c_int64, _P],
     "sgan_norm_bwd_apply": [_P, _I, _P, _I, _I, _I, C.POINTER(NormDesc), _P, _I, _P, _P, _P],
     "sgan_norm_bwd_apply_multi": [C.POINTER(NormBwdJob), _I, _P],

@@ -768,7 +768,8 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
         norms = [nets[j]._norm_of(li - 1, stats[j], geos[j][li][1] * geos[j][li][2]) if li > 0 else None for j in range(J)]
         wj = [j for j in range(J) if want_wgrad[j]]
         wjobs = [(geos[j][li][0], srcs[j], norms[j], dcur[j]) + nets[j]._gwb(nets[j].layers[li]) for j in wj]
-        if wjobs and li == 0:
+        pair0 = li == 0 and bool(wjobs) and wj == [j for j in range(J) if need_dx[j]]      # first layer, both gradients of the same jobs:
+        if wjobs and li == 0 and not pair0:                                                  # one launch below (ops.conv_bwd_grouped)
             ops.conv_wgrad_grouped(wjobs)
         if li > 0:
             jobs, dins = [], []
@@ -806,7 +807,10 @@ def _grouped_backward(nets, xs, outs, stats, douts, need_dx, want_wgrad):
                     desc, h, w, ho, wo = geos[j][0]
                     dxs[j] = torch.empty((h, w, L.cin_s), dtype=torch.float32, device=dev)
                     jobs.append((desc, dcur[j], nets[j]._wt(L), dxs[j], None, None, None, 0, False, True))
-                ops.conv_dgrad_grouped(jobs)
+                if pair0:
+                    ops.conv_bwd_grouped(jobs, wjobs)
+                else:
+                    ops.conv_dgrad_grouped(jobs)
     return dxs
 
 

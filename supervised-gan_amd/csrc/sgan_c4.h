@@ -130,7 +130,7 @@ __device__ __forceinline__ void sg_conv_scatter4_body(const SgIgemmParams& G, ch
     }
 }
 
-__global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmParams G) {
+static __global__ __launch_bounds__(256) void sg_conv_scatter4_kernel(const SgIgemmParams G) {      // (static: this header is in two translation units)
     sg_warm_kernargs<(int)sizeof(SgIgemmParams)>();      // sgan_common.h: the scalar-cache misses of the parameter block, taken together
     extern __shared__ __attribute__((aligned(16))) char smem[];
     sg_conv_scatter4_body(G, smem, (int)blockIdx.x);
@@ -348,6 +348,14 @@ static void sg_launch_c4_rb(SgIgemmParams& P, int tiles, hipStream_t st) {
     else hipLaunchKernelGGL((sg_conv_c4_kernel<4, RB, false>), dim3(tiles), dim3(256), 0, st, P);
 }
 
+// row blocks per wave of a c4 launch (see sg_launch_c4)
+static int sg_c4_pick_rb(SgIgemmParams& P) {
+    static const int rb = getenv("SGAN_C4_RB") ? atoi(getenv("SGAN_C4_RB")) : 0;
+    int RB = (rb == 1 || rb == 2 || rb == 4) ? rb : 4;
+    if (!rb && sg_fill_tiles(P, 64 * 4) <= 400) RB = 2;
+    return RB;
+}
+
 static int sg_launch_c4(SgIgemmParams& P, hipStream_t st) {
     static const int rb = getenv("SGAN_C4_RB") ? atoi(getenv("SGAN_C4_RB")) : 0;      // tuning knob: 1, 2 or 4 row blocks per wave (0: by grid size)
     // four row blocks per wave unless that leaves the chip with under ~1.5 workgroups per CU (three-problem first PatchGAN conv: 340
@@ -377,7 +385,8 @@ static bool sg_use_scatter4(const SgIgemmParams& P) {
     return true;
 }
 
-static int sg_launch_scatter4(SgIgemmParams& P, hipStream_t st) {
+// tile table of a scatter4 launch (first workgroup and tiles per row of every problem); returns the workgroup count
+static int sg_scatter4_plan(SgIgemmParams& P, size_t* lds) {
     int t = 0;
     for (int g = 0; g < P.nprob; ++g) {
         int hp = 0, wp = 0;
@@ -387,8 +396,14 @@ static int sg_launch_scatter4(SgIgemmParams& P, hipStream_t st) {
         P.q[g].tile0[1] = tx;
         t += tx * ty;
     }
+    *lds = (size_t)256 * SG_SC_LDZ * 4 + (size_t)2 * P.Ck * 4;
+    return t;
+}
+
+static int sg_launch_scatter4(SgIgemmParams& P, hipStream_t st) {
+    size_t lds;
+    const int t = sg_scatter4_plan(P, &lds);
     if (t == 0) return SGAN_OK;
-    const size_t lds = (size_t)256 * SG_SC_LDZ * 4 + (size_t)2 * P.Ck * 4;
     sg_prof_begin(st);
     hipLaunchKernelGGL(sg_conv_scatter4_kernel, dim3(t), dim3(256), lds, st, P);
     SGAN_LAUNCH_CHECK();

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "sgan_wgrad.h"
+#include "sgan_c4.h"      // the 4-channel backward-data bodies the thin-pair launch runs beside the thin backward-weight body
 
 // PRO: the forward input gets the producer's norm + activation applied while it is staged
 template <int BCO, int BKC, int WGC, int WGK, bool PRO>
@@ -662,20 +663,19 @@ __global__ __launch_bounds__(64 * SG_THIN_NW) void sg_wgrad_thin_kernel(const Sg
     sg_wgrad_thin_body<MB, PRO, SWAP, SG_THIN_NW>(G, nbias_z0, smem, (int)blockIdx.y, (int)blockIdx.z);
 }
 
+struct SgThinPlan { int nrb, z, zgrid; size_t lds; bool pro; };
+
+// pixel split per problem (nsplit, z0) for ~`want_wgs` workgroups over the launch; false: nothing to do
 template <int MB, bool SWAP>
-static int sg_launch_wgrad_thin(SgWgradParams& P, hipStream_t st, const char* name, void* workspace, int64_t workspace_bytes) {
+static bool sg_thin_plan(SgWgradParams& P, double want_wgs, SgThinPlan* out) {
     constexpr int ROWS = 16 * MB, COLS = 64, PS = ROWS * COLS + ROWS;
-    (void)workspace;
-    if (workspace_bytes == -1) return 0;      // single pass since round 3: no workspace
     const int nrb = sgw_cdiv(SWAP ? P.Cin : P.Cout, ROWS);
-    // one eight-wave workgroup per CU over the whole launch, >= 256 pixels per workgroup
     long pix_total = 0;
     for (int g = 0; g < P.nprob; ++g)
         for (int i = 0; i < P.nphase; ++i) pix_total += (long)P.q[g].Hp[i] * P.q[g].Wp[i];
-    if (pix_total == 0) return SGAN_OK;
-    const char* want_env = getenv("SGAN_THIN_WANT");        // tuning knobs
+    if (pix_total == 0) return false;
     const int min_pix = getenv("SGAN_THIN_MINPIX") ? atoi(getenv("SGAN_THIN_MINPIX")) : 256;
-    const double want = (want_env ? atof(want_env) : 256.0) / (double)nrb;
+    const double want = want_wgs / (double)nrb;
     int z = 0;
     for (int g = 0; g < P.nprob; ++g) {
         long pg = 0;
@@ -692,13 +692,27 @@ static int sg_launch_wgrad_thin(SgWgradParams& P, hipStream_t st, const char* na
         P.q[g].z0 = z;
         z += P.nphase * nsplit;
     }
-    dim3 grid(1, nrb, z + (SWAP ? 4 * P.nprob : 0));      // SWAP: four bias workgroups per problem behind the tiles
-    const size_t lds = (size_t)(4 * PS + 2 * P.Cin + 16) * 4;
-    bool pro = P.pro_act != SGAN_ACT_NONE;
-    for (int g = 0; g < P.nprob; ++g) pro = pro || P.q[g].pro_stats != nullptr;
+    out->nrb = nrb;
+    out->z = z;
+    out->zgrid = z + (SWAP ? 4 * P.nprob : 0);      // SWAP: four bias workgroups per problem behind the tiles
+    out->lds = (size_t)(4 * PS + 2 * P.Cin + 16) * 4;
+    out->pro = P.pro_act != SGAN_ACT_NONE;
+    for (int g = 0; g < P.nprob; ++g) out->pro = out->pro || P.q[g].pro_stats != nullptr;
+    return true;
+}
+
+template <int MB, bool SWAP>
+static int sg_launch_wgrad_thin(SgWgradParams& P, hipStream_t st, const char* name, void* workspace, int64_t workspace_bytes) {
+    (void)workspace;
+    if (workspace_bytes == -1) return 0;      // single pass since round 3: no workspace
+    // one eight-wave workgroup per CU over the whole launch, >= 256 pixels per workgroup
+    const char* want_env = getenv("SGAN_THIN_WANT");        // tuning knob
+    SgThinPlan pl;
+    if (!sg_thin_plan<MB, SWAP>(P, want_env ? atof(want_env) : 256.0, &pl)) return SGAN_OK;
+    dim3 grid(1, pl.nrb, pl.zgrid);
     sg_prof_begin(st);
-    if (pro) hipLaunchKernelGGL((sg_wgrad_thin_kernel<MB, true, SWAP>), grid, dim3(64 * SG_THIN_NW), lds, st, P, z);
-    else hipLaunchKernelGGL((sg_wgrad_thin_kernel<MB, false, SWAP>), grid, dim3(64 * SG_THIN_NW), lds, st, P, z);
+    if (pl.pro) hipLaunchKernelGGL((sg_wgrad_thin_kernel<MB, true, SWAP>), grid, dim3(64 * SG_THIN_NW), pl.lds, st, P, pl.z);
+    else hipLaunchKernelGGL((sg_wgrad_thin_kernel<MB, false, SWAP>), grid, dim3(64 * SG_THIN_NW), pl.lds, st, P, pl.z);
     SGAN_LAUNCH_CHECK();
     g_sgan_last_kernel = name;
     sg_prof_end(st, g_sgan_last_kernel);
@@ -812,6 +826,98 @@ extern "C" int sgan_conv_wgrad_grouped(const sgan_conv_wgrad_job* jobs, int32_t 
     if (d0->Cout <= 16) return sg_launch_wgrad<16, 128, 1, 4>(P, st);
     if (d0->Cout <= 32) return sg_launch_wgrad<32, 64, 1, 4>(P, st);
     return sg_launch_wgrad<64, 64, 2, 2>(P, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// The two backward launches of a layer with a 4-channel side in ONE grid: the generator's output layer (ConvT 32 -> 2: backward-data
+// on sg_conv_c4_body, backward-weight on the thin kernel, 15 + 19 us apart) and the first PatchGAN conv in a generator update
+// (4 -> 32: sg_conv_scatter4_body + the thin kernel, 19 + 16 us).  Neither feeds the other, each leaves most of the chip waiting on
+// its own memory round trips, and a hipGraph replays kernel nodes one after the other -- the same argument as sg_bwd_fused_kernel.
+// The first `ndg` workgroups run the backward-data body, the rest the thin backward-weight body with four waves per workgroup
+// (a 256-thread workgroup like its partner's).  DK: 0 = c4 (full epilogue, <= 32 result channels), 1 = scatter4.
+// ------------------------------------------------------------------------------------------
+template <int DK, int RB, int MB, bool WPRO, bool SWAP>
+__global__ __launch_bounds__(256) void sg_bwd_thin_pair_kernel(const SgIgemmParams G, const SgWgradParams W, int ndg, int dgx, int wy, int nbias_z0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    sg_warm_kernargs<(int)(sizeof(SgIgemmParams) + sizeof(SgWgradParams))>();
+    const int b = blockIdx.x;
+    if (b < ndg) {
+        if constexpr (DK == 0) sg_conv_c4_body<2, RB, true>(G, b % dgx, b / dgx);
+        else sg_conv_scatter4_body(G, smem, b);
+    } else {
+        const int w = b - ndg;
+        sg_wgrad_thin_body<MB, WPRO, SWAP, 4>(W, nbias_z0, smem, w % wy, w / wy);
+    }
+}
+
+// 0: launched; 1: not such a pair (the caller issues the two grouped calls); < 0: error
+extern "C" int sgan_conv_bwd_thin_pair(const sgan_conv_dgrad_job* djobs, int32_t nd, const sgan_conv_wgrad_job* wjobs, int32_t nw, void* stream) {
+    static const int off = getenv("SGAN_NO_THIN_PAIR") ? 1 : 0;
+    if (off || getenv("SGAN_NO_THIN_WGRAD")) return 1;
+    SgIgemmParams P;
+    SgWgradParams W;
+    int rc = sg_build_dgrad_params(djobs, nd, P, false);
+    if (rc) return rc;
+    rc = sg_build_wgrad_params(wjobs, nw, W, false);
+    if (rc) return rc;
+    const sgan_conv_desc* d0 = wjobs[0].d;
+    if (d0->k * d0->k > 16 || djobs[0].d->kind != d0->kind || djobs[0].d->Cin != d0->Cin || djobs[0].d->Cout != d0->Cout) return 1;
+    bool swap;
+    if (d0->Cin == 4 && W.nphase == 1 && d0->Cout > 16 && d0->Cout <= 32) {      // conv-form gather of a 4-channel image, MB = 2
+        swap = false;
+        W.thin_real = (d0->Cin_logical > 0 && d0->Cin_logical < 4) ? d0->Cin_logical : 4;
+    } else if (d0->Cout == 4 && d0->Cin >= 16 && d0->Cin <= 32 && (d0->kind == SGAN_CONVT || d0->stride == 1)) {
+        swap = true;
+        sg_thin_swap_geometry(W, d0, wjobs, nw);
+        W.thin_real = (d0->Cout_logical > 0 && d0->Cout_logical < 4) ? d0->Cout_logical : 4;
+    } else {
+        return 1;
+    }
+    // the backward-data half: where sg_dispatch_igemm (sgan_igemm.hip) would have sent it
+    P.ksplit = 1;
+    P.slab = nullptr;
+    P.slab_stride = 0;
+    bool skinny = P.N == 4;
+    for (int g = 0; g < P.nprob; ++g)
+        if (P.q[g].xref || P.q[g].stats || (P.q[g].out_ld & 3) || P.q[g].accum) skinny = false;
+    int dk, ndg, dgx = 1, RB = 4;
+    size_t lds_d = 0;
+    if (skinny && sg_use_scatter4(P)) {
+        dk = 1;
+        ndg = sg_scatter4_plan(P, &lds_d);
+    } else if (P.N > 4 && P.N <= 32 && sg_igemm3_eligible(P) == 0 && sg_use_c4(P) && sg_c4_needs_epi(P)) {
+        dk = 0;
+        RB = sg_c4_pick_rb(P);
+        if (RB == 1) RB = 2;
+        dgx = sg_fill_tiles(P, 64 * RB);
+        ndg = dgx * ((P.N + 31) / 32);
+    } else {
+        return 1;
+    }
+    if (ndg == 0 || (dk == 1) != !swap) return 1;      // (the two pairs of the fcgan step: scatter4 + cin4, c4 + cout4)
+    static const double want = getenv("SGAN_THIN_PAIR_WANT") ? atof(getenv("SGAN_THIN_PAIR_WANT")) : 512.0;      // four-wave workgroups
+    SgThinPlan pl;
+    const bool ok = swap ? sg_thin_plan<2, true>(W, want, &pl) : sg_thin_plan<2, false>(W, want, &pl);
+    if (!ok) return 1;
+    const size_t lds = lds_d > pl.lds ? lds_d : pl.lds;
+    if (lds > 64 * 1024 && lds_d <= 64 * 1024 && pl.lds <= 64 * 1024) return 1;
+    const dim3 grid(ndg + pl.nrb * pl.zgrid);
+    hipStream_t st = (hipStream_t)stream;
+    sg_prof_begin(st);
+    if (dk == 1) {
+        if (pl.pro) hipLaunchKernelGGL((sg_bwd_thin_pair_kernel<1, 4, 2, true, false>), grid, dim3(256), lds, st, P, W, ndg, dgx, pl.nrb, pl.z);
+        else hipLaunchKernelGGL((sg_bwd_thin_pair_kernel<1, 4, 2, false, false>), grid, dim3(256), lds, st, P, W, ndg, dgx, pl.nrb, pl.z);
+    } else if (RB == 2) {
+        if (pl.pro) hipLaunchKernelGGL((sg_bwd_thin_pair_kernel<0, 2, 2, true, true>), grid, dim3(256), lds, st, P, W, ndg, dgx, pl.nrb, pl.z);
+        else hipLaunchKernelGGL((sg_bwd_thin_pair_kernel<0, 2, 2, false, true>), grid, dim3(256), lds, st, P, W, ndg, dgx, pl.nrb, pl.z);
+    } else {
+        if (pl.pro) hipLaunchKernelGGL((sg_bwd_thin_pair_kernel<0, 4, 2, true, true>), grid, dim3(256), lds, st, P, W, ndg, dgx, pl.nrb, pl.z);
+        else hipLaunchKernelGGL((sg_bwd_thin_pair_kernel<0, 4, 2, false, true>), grid, dim3(256), lds, st, P, W, ndg, dgx, pl.nrb, pl.z);
+    }
+    SGAN_LAUNCH_CHECK();
+    g_sgan_last_kernel = "sg_bwd_thin_pair_kernel";
+    sg_prof_end(st, g_sgan_last_kernel);
+    return SGAN_OK;
 }
 
 extern "C" int sgan_conv_wgrad(const sgan_conv_desc* d, const float* in, int32_t in_ld, const sgan_norm_desc* in_norm,

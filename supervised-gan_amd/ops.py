@@ -350,6 +350,15 @@ def conv_bwd_grouped(djobs, wjobs, dgrad_math=None):
             return True
         if rc < 0:
             L.check(rc, "sgan_conv_bwd_fused_ws")
+    if min(d0.Cin, d0.Cout) == 4 and len(djobs) == len(wjobs):      # a layer with a 4-channel side: its two launches in one grid
+        _check_dgrad_jobs(djobs)
+        _check_wgrad_jobs(wjobs)
+        with math_scope(dgrad_math):
+            rc = L.lib().sgan_conv_bwd_thin_pair(_dgrad_array(djobs), len(djobs), _wgrad_array(wjobs), len(wjobs), _stream())
+        if rc == 0:
+            return True
+        if rc < 0:
+            L.check(rc, "sgan_conv_bwd_thin_pair")
     conv_wgrad_grouped(wjobs)
     with math_scope(dgrad_math):
         conv_dgrad_grouped(djobs)

@@ -926,6 +926,55 @@ def test_head_backward_one_launch(hip, case):
     assert rel(din2, din3) < 2e-6
 
 
+@pytest.mark.parametrize("case", [("convT", 4, 2, 1, 32, 2, [(64, 64)], "bn", 1), ("convT", 4, 2, 1, 32, 2, [(37, 50)], "bn", 1),
+                                  ("conv", 4, 2, 2, 2, 32, [(130, 130), (66, 66), (34, 34)], None, 0), ("conv", 4, 2, 2, 2, 32, [(257, 131)], None, 0)],
+                         ids=lambda c: f"{c[0]}_{c[4]}to{c[5]}_n{len(c[6])}_{c[6][0][0]}x{c[6][0][1]}")
+def test_thin_pair_backward(hip, case, math_mode):
+    """sgan_conv_bwd_thin_pair (sg_bwd_thin_pair_kernel): backward-data and backward-weight of a layer with a 4-channel side in one grid --
+    the generator's output ConvTranspose2d (32 -> 2) and the first PatchGAN conv (2 -> 32) -- against the two grouped calls."""
+    from hip_utils import master_weight, pad_vec, rel, stats_of, to_buf
+    from supervised_gan_amd import _lib
+    from supervised_gan_amd.ops import pad4
+    ops = hip
+    kind, k, s_, p, cin, cout, sizes, norm, act = case
+    tr = kind == "convT"
+    g = torch.Generator().manual_seed(41 + cin)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    wm = master_weight(torch.randn(*wshape, generator=g) * 0.05, tr)
+    gam = pad_vec(1 + 0.2 * torch.randn(cin, generator=g)) if norm == "bn" else None
+    bet = pad_vec(0.1 * torch.randn(cin, generator=g)) if norm == "bn" else None
+    probs = []
+    for (H, W) in sizes:
+        x = torch.randn(1, cin, H, W, generator=g) * 1.5 + 0.3
+        ho, wo = ((H - 1) * s_ - 2 * p + k, (W - 1) * s_ - 2 * p + k) if tr else ((H + 2 * p - k) // s_ + 1, (W + 2 * p - k) // s_ + 1)
+        desc = ops.conv_desc(1 if tr else 0, k, s_, p, H, W, pad4(cin), ho, wo, pad4(cout), cin, cout)
+        nd = ops.norm_desc(stats_of(x), gam, bet, H * W, 1e-5, act, 0.2) if norm else None
+        probs.append((desc, to_buf(x), nd, to_buf(torch.randn(1, cout, ho, wo, generator=g)), H, W))
+    res = {}
+    for mode in ("apart", "pair"):
+        dw, db = torch.zeros_like(wm), torch.zeros(pad4(cout), device="cuda")
+        dj, wj, keep = [], [], []
+        for desc, xb, nd, rb, H, W in probs:
+            din = torch.full((H, W, pad4(cin)), float("nan"), device="cuda")
+            sums = torch.zeros(2 * pad4(cin), dtype=torch.float64, device="cuda") if norm else None
+            dj.append((desc, rb, wm._sgan_wt, din, xb if norm else None, nd, sums, 0, False, True, 0))
+            wj.append((desc, xb, nd, rb, dw, db))
+            keep.append((din, sums))
+        if mode == "apart":
+            ops.conv_wgrad_grouped(wj)
+            ops.conv_dgrad_grouped(dj)
+        else:
+            assert ops.conv_bwd_grouped(dj, wj) is True
+            assert _lib.lib().sgan_last_kernel().decode() == "sg_bwd_thin_pair_kernel"
+        torch.cuda.synchronize()
+        res[mode] = (keep, dw, db)
+    for (da, sa), (dp, sp) in zip(res["apart"][0], res["pair"][0]):
+        assert torch.isfinite(dp).all() and rel(dp, da) < 2e-6
+        if sa is not None:
+            assert rel(sp, sa) < 1e-6
+    assert rel(res["pair"][1], res["apart"][1]) < 3e-6 and rel(res["pair"][2], res["apart"][2]) < 3e-6
+
+
 def test_head_backward_declines_full_size_maps(hip):
     """Past ~128 tiles per weight tensor the same-address atomics of sg_head_bwd_kernel cost more than the two generic launches
     (CRN output conv on 512 x 512: 300 us against 70): sgan_conv_head_bwd answers 1 and conv_bwd_grouped runs the generic pair."""

@@ -30,6 +30,8 @@ def short(name):
     m = re.match(r"sg_conv_c4_kernel<\d+,\d+,(?:true|false)>$", n)      # column blocks, row blocks per wave, full epilogue
     if m:
         return "sg_conv_c4_kernel"
+    if re.match(r"sg_bwd_thin_pair_kernel<.*>$", n):      # backward-data body, row blocks, thin operand width, prologue flag, operand swap
+        return "sg_bwd_thin_pair_kernel"
     if re.match(r"sg_head_bwd_kernel<\d+>$", n):      # kernel size
         return "sg_head_bwd_kernel"
     m = re.match(r"sg_conv_head_kernel<\d+>$", n)      # tile height
